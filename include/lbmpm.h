@@ -1,0 +1,157 @@
+/*
+ * lbmpm.h -- C ABI of liblbmpm_hip.so, the MI355X (gfx950) replacement for the GPU
+ * collision-streaming path of PorousMediaSimulation/openLBMPM.
+ *
+ * The reference has no FFI: its "operator interface" is a set of Numba @cuda.jit kernel
+ * objects launched from Python drivers, one launch per algebraic step
+ * (e.g. RKCG2D/RKD2Q9.py:1295-1490, 20 launches per time step).  This header is what a
+ * maintainer binds instead (ctypes stub in INTEGRATION.md).  Two levels:
+ *
+ *   (1) FUSED solvers (performance path).  One context per simulation; the library owns
+ *       the device memory (dense SoA lattice, q-major) and advances whole time steps in
+ *       fused HIP kernels.  Host arrays cross the boundary in the reference's own dense
+ *       result layout (the arrays its drivers write to HDF5: [ny][nx] and [ny][nx][9]
+ *       float64, zeros at solid nodes; RKD2Q9.py:902-957).
+ *
+ *   (2) KERNEL-LEVEL entry points (drop-in path): one C function per reference kernel on
+ *       the reference's sparse arrays (declared in lbmpm_kernels.h).
+ *
+ * Conventions: every function returns 0 on success or a negative lbmpm_status; the text
+ * of the last failure on the calling thread is available from lbmpm_last_error().
+ * All floating point is IEEE binary64.  No function takes or returns a C++/torch type.
+ * A context is not re-entrant; distinct contexts are independent (one per GPU/process).
+ */
+#ifndef LBMPM_H
+#define LBMPM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum lbmpm_status {
+    LBMPM_OK = 0,
+    LBMPM_ERR_INVALID = -1,     /* bad argument / configuration               */
+    LBMPM_ERR_HIP = -2,         /* a HIP runtime call failed                   */
+    LBMPM_ERR_NOMEM = -3,       /* device or host allocation failed            */
+    LBMPM_ERR_STATE = -4,       /* call not valid in the context's state       */
+    LBMPM_ERR_UNSUPPORTED = -5  /* option exists in the reference but not here */
+} lbmpm_status;
+
+const char *lbmpm_last_error(void);
+/* "liblbmpm_hip <version> gfx950" */
+const char *lbmpm_version(void);
+/* number of visible HIP devices, or a negative status */
+int lbmpm_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Colour-gradient D2Q9 two-phase solver with continuum-surface-force (CSF) tension.
+ * Replaces the kernel sequence of RKColorGradientLBM.runRKColorGradient2DCSF
+ * (RKCG2D/RKD2Q9.py:1225-1490) = the @cuda.jit kernels of RKCG2D/AcceleratedRKGPU2D.py:
+ *   constantTotalVelocityInlet :2348, ghostPointsConstantVelocityRK :607,
+ *   calConstPressureInletGPU :925, ghostPointsConstPressureInletRK :968,
+ *   calConstPressureLowerGPUTotal :2560, ghostPointsConstPressureLowerRK :1045,
+ *   convectiveOutletGPU/Ghost2GPU/Ghost3GPU :700/:731/:762,
+ *   calTotalFluidPDF :1414, calPhysicalVelocityRKGPU2DNew1 :2634, calPhaseFieldPhi :1348,
+ *   calColorValueOnSolid :1560, calRKInitialGradient :1584,
+ *   updateColorGradientOnWetting :1639 / ...New :2430,
+ *   calForceTermInColorGradient2D :1686 / ...New2D :2499,
+ *   calRKCollision1TotalGPU2DSRTM :1804 + calPerturbationFromForce2D :1743,
+ *   calRKCollision1TotalGPU2DMRTM :1938 + calPerturbationFromForce2DMRT :2027,
+ *   calRecoloringProcessM :1857, calStreaming1GPU :340, calStreaming2GPU :409,
+ *   calMacroDensityRKGPU2D :103
+ * and the host set-up of RKD2Q9.py:657-892 (compaction, neighbour tables, wetting lists,
+ * solid normals), which becomes implicit in the dense mask.
+ * ---------------------------------------------------------------------------------- */
+
+enum { LBMPM_RELAX_SRT = 0, LBMPM_RELAX_MRT = 1 };
+enum { LBMPM_INLET_VELOCITY = 0,      /* BoundaryTypeInlet 'Neumann'   */
+       LBMPM_INLET_PRESSURE = 1 };    /* BoundaryTypeInlet 'Dirichlet' */
+enum { LBMPM_OUTLET_PRESSURE = 0,     /* BoundaryTypeOutlet 'Dirichlet'  */
+       LBMPM_OUTLET_CONVECTIVE = 1 }; /* BoundaryTypeOutlet 'Convective' */
+
+typedef struct lbmpm_rk2d_config {
+    int64_t nx, ny;            /* xDomain, yDomain (incl. ghost rows 0 and ny-1)            */
+    double surface_tension;    /* [SurfaceTension] SurfaceTensionValue                      */
+    double contact_angle_deg;  /* [SurfaceTension] ContactAngle                             */
+    int32_t wetting_type;      /* [SurfaceTension] WettingType 1 (Xu 2017) | 2 (Akai 2018)  */
+    double beta;               /* [RKParameters] BetaThickness                              */
+    double delta;              /* [RKParameters] DeltaValue                                 */
+    double tau_r, tau_b;       /* [FluidParameters] TauR, TauB                              */
+    int32_t tau_type;          /* [FluidParameters] TauType 1 | 2                           */
+    int32_t relaxation;        /* [RelaxationType] Type: LBMPM_RELAX_*                      */
+    int32_t inlet_type;        /* LBMPM_INLET_*                                             */
+    int32_t outlet_type;       /* LBMPM_OUTLET_*                                            */
+    double inlet_velocity_y;   /* VelocityYR + VelocityYB (RKD2Q9.py:1300)                  */
+    double inlet_rho_r;        /* densityRH                                                 */
+    double inlet_rho_b;        /* densityBH                                                 */
+    double outlet_rho_total;   /* densityBL + densityRL (RKD2Q9.py:1344)                    */
+    int32_t device;            /* HIP device ordinal                                        */
+    int32_t variant;           /* 0 = default kernel schedule; see DESIGN.md                */
+} lbmpm_rk2d_config;
+
+typedef struct lbmpm_rk2d lbmpm_rk2d;
+
+/* Field ids for lbmpm_rk2d_get_field.  "current" fields describe the lattice exactly as
+ * the reference's device arrays hold it after the last completed time step. */
+typedef enum lbmpm_rk2d_field {
+    LBMPM_RK_PDF_R = 0,   /* [ny][nx][9] post-streaming f_R  (deviceFluidPDFR)      */
+    LBMPM_RK_PDF_B = 1,   /* [ny][nx][9] post-streaming f_B  (deviceFluidPDFB)      */
+    LBMPM_RK_RHO_R = 2,   /* [ny][nx]   sum_i f_R            (deviceFluidRhoR)      */
+    LBMPM_RK_RHO_B = 3,   /* [ny][nx]                         (deviceFluidRhoB)      */
+    LBMPM_RK_VX = 4,      /* [ny][nx]   u of the last step   (devicePhysicalVX)     */
+    LBMPM_RK_VY = 5,      /*                                  (devicePhysicalVY)     */
+    LBMPM_RK_PHI = 6,     /* [ny][nx]   phase field           (deviceColorValue)     */
+    LBMPM_RK_GX = 7,      /* [ny][nx]   colour gradient       (deviceGradientX)      */
+    LBMPM_RK_GY = 8,
+    LBMPM_RK_FX = 9,      /* [ny][nx]   CSF force             (deviceForceX)         */
+    LBMPM_RK_FY = 10,
+    LBMPM_RK_K = 11,      /* [ny][nx]   curvature             (deviceKValue)         */
+    /* what resultInHDF5 (RKD2Q9.py:938-957) would record at the START of the next step
+     * (after that step's boundary kernels, velocity and phase field): */
+    LBMPM_RK_REC_PDF_R = 20, LBMPM_RK_REC_PDF_B = 21, LBMPM_RK_REC_RHO_R = 22,
+    LBMPM_RK_REC_RHO_B = 23, LBMPM_RK_REC_VX = 24, LBMPM_RK_REC_VY = 25
+} lbmpm_rk2d_field;
+
+/* is_domain: host [ny][nx] uint8, 1 = void/fluid, 0 = solid (isDomain, RKD2Q9.py:417-443). */
+int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is_domain,
+                      lbmpm_rk2d **out);
+void lbmpm_rk2d_destroy(lbmpm_rk2d *ctx);
+
+/* Initial (or restart) state: dense host arrays [ny][nx][9] as fluidPDFR/fluidPDFB
+ * (RKD2Q9.py:449-450); values at solid nodes are ignored.  Resets the step counter. */
+int lbmpm_rk2d_set_pdf(lbmpm_rk2d *ctx, const double *pdf_r, const double *pdf_b);
+/* Same from densities and velocity through f = rho w (1 + 3eu + 4.5(eu)^2 - 1.5u^2)
+ * (RKD2Q9.py:577-601).  vx/vy may be NULL (= 0). */
+int lbmpm_rk2d_set_macro(lbmpm_rk2d *ctx, const double *rho_r, const double *rho_b,
+                         const double *vx, const double *vy);
+
+/* Advance nsteps time steps (asynchronous on the context's stream). */
+int lbmpm_rk2d_step(lbmpm_rk2d *ctx, int64_t nsteps);
+/* Same, bracketed by HIP events on the context's stream; *ms_total = elapsed device time,
+ * *ms_dominant = summed duration of the dominant (collision-streaming) kernel only. */
+int lbmpm_rk2d_step_timed(lbmpm_rk2d *ctx, int64_t nsteps, double *ms_total,
+                          double *ms_dominant);
+int lbmpm_rk2d_sync(lbmpm_rk2d *ctx);
+/* Diagnostics (u and curvature of the last step of each lbmpm_rk2d_step call are kept
+ * for LBMPM_RK_VX/VY/K).  Off by default: costs three extra stores per node on that step. */
+int lbmpm_rk2d_enable_diagnostics(lbmpm_rk2d *ctx, int on);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream); NULL = library stream. */
+int lbmpm_rk2d_set_stream(lbmpm_rk2d *ctx, void *hip_stream);
+
+/* Copy a field to a dense host array (synchronises).  out must hold ny*nx (or ny*nx*9)
+ * doubles.  Solid nodes read 0. */
+int lbmpm_rk2d_get_field(lbmpm_rk2d *ctx, int field, double *out);
+int64_t lbmpm_rk2d_num_fluid_nodes(const lbmpm_rk2d *ctx);
+int64_t lbmpm_rk2d_steps_done(const lbmpm_rk2d *ctx);
+/* Name of the dominant kernel as it appears in rocprofv3 --kernel-trace output. */
+const char *lbmpm_rk2d_dominant_kernel(const lbmpm_rk2d *ctx);
+/* Device bytes held by the context. */
+int64_t lbmpm_rk2d_device_bytes(const lbmpm_rk2d *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBMPM_H */

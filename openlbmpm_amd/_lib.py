@@ -1,0 +1,82 @@
+"""ctypes binding of liblbmpm_hip.so (the C ABI declared in include/lbmpm.h).
+
+The library is the product: there is NO CPU fallback.  If it is missing or cannot be
+loaded this module raises immediately (build it with `python -m openlbmpm_amd.build`).
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liblbmpm_hip.so")
+
+F64P = C.POINTER(C.c_double)
+U8P = C.POINTER(C.c_uint8)
+I64P = C.POINTER(C.c_int64)
+
+
+class LbmpmError(RuntimeError):
+    pass
+
+
+class RK2DConfig(C.Structure):
+    # mirrors struct lbmpm_rk2d_config (include/lbmpm.h)
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64),
+                ("surface_tension", C.c_double), ("contact_angle_deg", C.c_double),
+                ("wetting_type", C.c_int32),
+                ("beta", C.c_double), ("delta", C.c_double),
+                ("tau_r", C.c_double), ("tau_b", C.c_double),
+                ("tau_type", C.c_int32), ("relaxation", C.c_int32),
+                ("inlet_type", C.c_int32), ("outlet_type", C.c_int32),
+                ("inlet_velocity_y", C.c_double), ("inlet_rho_r", C.c_double),
+                ("inlet_rho_b", C.c_double), ("outlet_rho_total", C.c_double),
+                ("device", C.c_int32), ("variant", C.c_int32)]
+
+
+_lib = None
+
+# every symbol include/lbmpm.h declares (checked by tests/test_abi.py)
+_SIGNATURES = {
+    "lbmpm_last_error": (C.c_char_p, []),
+    "lbmpm_version": (C.c_char_p, []),
+    "lbmpm_device_count": (C.c_int, []),
+    "lbmpm_rk2d_create": (C.c_int, [C.POINTER(RK2DConfig), U8P, C.POINTER(C.c_void_p)]),
+    "lbmpm_rk2d_destroy": (None, [C.c_void_p]),
+    "lbmpm_rk2d_set_pdf": (C.c_int, [C.c_void_p, F64P, F64P]),
+    "lbmpm_rk2d_set_macro": (C.c_int, [C.c_void_p, F64P, F64P, F64P, F64P]),
+    "lbmpm_rk2d_step": (C.c_int, [C.c_void_p, C.c_int64]),
+    "lbmpm_rk2d_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),
+    "lbmpm_rk2d_sync": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk2d_enable_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
+    "lbmpm_rk2d_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lbmpm_rk2d_get_field": (C.c_int, [C.c_void_p, C.c_int, F64P]),
+    "lbmpm_rk2d_num_fluid_nodes": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk2d_steps_done": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk2d_dominant_kernel": (C.c_char_p, [C.c_void_p]),
+    "lbmpm_rk2d_device_bytes": (C.c_int64, [C.c_void_p]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raise LbmpmError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LbmpmError("%s is missing: the HIP library is the only compute path "
+                         "(no CPU fallback). Build it: python -m openlbmpm_amd.build" % LIB_PATH)
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise LbmpmError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().lbmpm_last_error().decode("utf-8", "replace")
+        raise LbmpmError("%s failed (status %d): %s" % (what or "lbmpm call", rc, msg))

@@ -1,0 +1,45 @@
+"""Build recipe for liblbmpm_hip.so (hipcc, gfx950 only, in-tree so it travels with gpurun).
+
+    python -m openlbmpm_amd.build [--force]
+"""
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "liblbmpm_hip.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: keep the reference's evaluation order (no FMA contraction); the
+# kernels are HBM-bound, so this costs nothing measurable and tightens parity.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+        glob.glob(os.path.join(os.path.dirname(PKG), "include", "*.h")) + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB]
+    if verbose:
+        print("[openlbmpm_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,886 @@
+// rk2d.hip -- colour-gradient D2Q9 (CSF) time stepper for gfx950.
+//
+// Replaces the 20-launch Numba-CUDA step of RKColorGradientLBM.runRKColorGradient2DCSF
+// (RKCG2D/RKD2Q9.py:1295-1490, kernels in RKCG2D/AcceleratedRKGPU2D.py) -- see
+// include/lbmpm.h for the kernel-by-kernel list and DESIGN.md for the data layout.
+//
+// Layout (HBM): dense grid, structure of arrays, direction-major:
+//     f[c][q][y*pitch + x]   c in {R,B}, q in 0..8, float64, two ping-pong buffers
+//     solidnbr[y*pitch + x]  uint8, bit (i-1) set <=> node + e_i is NOT fluid (periodic wrap)
+//     flags[y*pitch + x]     uint8, bit0 = fluid
+//     F[2][..]   CSF force of the last step (the reference's velocity lags it by one step)
+//     ns[2][..]  unit normal of the solid surface on fluid nodes that touch solid
+// State between steps = POST-COLLISION populations stored at their own node; a step
+// starts by PULLING them (f_i(x) <- f*_i(x - e_i), or f*_opp(i)(x) when x - e_i is solid:
+// identical to the reference's push + in-place half-way bounce-back,
+// AcceleratedRKGPU2D.py:340-417).
+#include "lbmpm_common.h"
+
+#include <cmath>
+
+namespace {
+
+using lbmpm::set_error;
+
+struct RKDev {
+    int nx, ny, pitch;
+    size_t plane;
+    const uint8_t *flags;
+    const uint8_t *solidnbr;
+    const double *fin;
+    double *fout;
+    double *F;         // [2][plane]
+    const double *ns;  // [2][plane]
+    double *phi;       // [plane]
+    double *G;         // [2][plane]
+    double *diag;      // [3][plane] vx, vy, K  (nullptr = off)
+    double sigma, cosT, sinT, beta, delta, tauR, tauB, vyIn, pInB, pInR, pOut;
+    int wetting, tautype, inlet, outlet;
+};
+
+__device__ __forceinline__ int wrapi(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
+
+// ---------------------------------------------------------------- streaming (pull)
+// AcceleratedRKGPU2D.py:340-417 calStreaming1GPU + calStreaming2GPU, in pull form.
+template <bool FIRST>
+__device__ __forceinline__ void pull_node(const RKDev &p, int x, int y, double fR[9], double fB[9])
+{
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY, OPP[9] = LBMPM_D2Q9_OPP;
+    const size_t idx = (size_t)y * p.pitch + x;
+    const double *fr = p.fin;
+    const double *fb = p.fin + 9 * p.plane;
+    if (FIRST) {   // initial state is already "post-streaming" (RKD2Q9.py:1243-1247)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { fR[i] = fr[i * p.plane + idx]; fB[i] = fb[i * p.plane + idx]; }
+        return;
+    }
+    const unsigned sn = p.solidnbr[idx];
+    fR[0] = fr[idx];
+    fB[0] = fb[idx];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int o = OPP[i];
+        if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
+            fR[i] = fr[o * p.plane + idx];
+            fB[i] = fb[o * p.plane + idx];
+        } else {
+            const int xs = wrapi(x - EX[i], p.nx), ys = wrapi(y - EY[i], p.ny);
+            const size_t s = (size_t)ys * p.pitch + xs;
+            fR[i] = fr[i * p.plane + s];
+            fB[i] = fb[i * p.plane + s];
+        }
+    }
+}
+
+__device__ __forceinline__ double sum9(const double f[9])
+{   // accumulation order of calMacroDensityRKGPU2D (A:103-120) and of the ghost kernels
+    double r = 0.;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r += f[i];
+    return r;
+}
+
+// ---------------------------------------------------------------- boundary rows
+// constantTotalVelocityInlet, A:2348-2412 (ratioB evaluated after rhoR was overwritten)
+__device__ __forceinline__ void bc_inlet_velocity(double v, double fR[9], double fB[9], double &rhoR, double &rhoB)
+{
+    const double t0 = fR[0] + fB[0], t1 = fR[1] + fB[1], t2 = fR[2] + fB[2], t3 = fR[3] + fB[3];
+    const double t5 = fR[5] + fB[5], t6 = fR[6] + fB[6];
+    const double rho = (t0 + t1 + t3 + 2. * (t2 + t5 + t6)) / (1. + v);
+    const double eq2 = rho * 1. / 9. * (1. + 3. * (1. * v) + 4.5 * (0. + 1. * v) * (0. + 1. * v) - 1.5 * (v * v));
+    const double eq4 = rho * 1. / 9. * (1. + 3. * (-1. * v) + 4.5 * (0. + (-1.) * v) * (0. + (-1.) * v) - 1.5 * (v * v));
+    const double t4 = eq4 + (t2 - eq2);
+    const double eq5 = rho * 1. / 36. * (1. + 3. * (1. * v + 1. * 0.) + 4.5 * (1. * v + 1. * 0.) * (1. * v + 1. * 0.) - 1.5 * (v * v));
+    const double eq7 = rho * 1. / 36. * (1. + 3. * ((-1.) * v + (-1.) * 0.) + 4.5 * ((-1.) * v + (-1.) * 0.) * ((-1.) * v + (-1.) * 0.) - 1.5 * (v * v));
+    const double t7 = eq7 + (t5 - eq5);
+    const double eq6 = rho * 1. / 36. * (1. + 3. * ((1.) * v + (-1.) * 0.) + 4.5 * ((1.) * v + (-1.) * 0.) * (1. * v + (-1.) * 0.) - 1.5 * (v * v));
+    const double eq8 = rho * 1. / 36. * (1. + 3. * ((-1.) * v + (1.) * 0.) + 4.5 * ((-1.) * v + 1. * 0.) * ((-1.) * v + 1. * 0.) - 1.5 * (v * v));
+    const double t8 = eq8 + (t6 - eq6);
+    const double ratioR = rhoR / (rhoR + rhoB);
+    rhoR = ratioR * rho;
+    fR[4] = ratioR * t4; fR[7] = ratioR * t7; fR[8] = ratioR * t8;
+    const double ratioB = rhoB / (rhoR + rhoB);     // reference quirk: uses the NEW rhoR
+    rhoB = ratioB * rho;
+    fB[4] = ratioB * t4; fB[7] = ratioB * t7; fB[8] = ratioB * t8;
+}
+
+// calConstPressureInletGPU, A:925-962 (Zou-He pressure per colour)
+__device__ __forceinline__ void bc_inlet_pressure_one(double pc, double f[9], double &rho)
+{
+    const double v = -1. + (f[0] + f[1] + f[3] + 2. * (f[2] + f[5] + f[6])) / pc;
+    f[4] = f[2] - 2. / 3. * pc * v;
+    f[7] = f[5] + 1. / 2. * (f[1] - f[3]) - 1. / 6. * pc * v;
+    f[8] = f[6] - 1. / 2. * (f[1] - f[3]) - 1. / 6. * pc * v;
+    rho = pc;
+}
+
+// calConstPressureLowerGPUTotal, A:2560-2590
+__device__ __forceinline__ void bc_outlet_pressure(double pL, double fR[9], double fB[9], double rhoR, double rhoB)
+{
+    const double t0 = fR[0] + fB[0], t1 = fR[1] + fB[1], t3 = fR[3] + fB[3], t4 = fR[4] + fB[4];
+    const double t7 = fR[7] + fB[7], t8 = fR[8] + fB[8];
+    const double v = 1. - 1. / pL * (t0 + t1 + t3 + 2. * (t4 + t7 + t8));
+    const double t2 = t4 + 2. / 3. * (pL * v);
+    const double t5 = t7 + 0.5 * (t3 - t1) + 1. / 6. * pL * v;
+    const double t6 = t8 + 0.5 * (t1 - t3) + 1. / 6. * pL * v;
+    const double ratioR = rhoR / (rhoR + rhoB);
+    fR[2] = ratioR * t2; fR[5] = ratioR * t5; fR[6] = ratioR * t6;
+    const double ratioB = rhoB / (rhoR + rhoB);
+    fB[2] = ratioB * t2; fB[5] = ratioB * t5; fB[6] = ratioB * t6;
+}
+
+// State of node (x,y) as the reference holds it after the boundary kernels of a step
+// (RKD2Q9.py:1299-1352): post-streaming populations + densities.
+//   inlet 'Neumann'  : row ny-2 velocity BC, ghost row ny-1 = copy of it with rho re-summed
+//                      (ghostPointsConstantVelocityRK, A:607-650)
+//   inlet 'Dirichlet': row ny-2 Zou-He pressure, ghost row copies f and rho (A:968-1002)
+//   outlet 'Dirichlet': row 1 Zou-He pressure on f_tot, ghost row 0 copies f and rho
+//                      (ghostPointsConstPressureLowerRK, A:1045-1081; the reference tests the
+//                       COMPACT index < nx, which is row 0 whenever row 0 is all fluid)
+//   outlet 'Convective': rows 2,1,0 <- row 3, rho re-summed (A:700-784)
+template <bool FIRST, bool WITH_BC>
+__device__ __forceinline__ void node_state(const RKDev &p, int x, int y, double fR[9], double fB[9],
+                                           double &rhoR, double &rhoB)
+{
+    int ys = y;
+    if (WITH_BC) {
+        if (y == p.ny - 1) ys = p.ny - 2;
+        if (p.outlet == LBMPM_OUTLET_PRESSURE) { if (y == 0) ys = 1; }
+        else { if (y <= 2) ys = 3; }
+    }
+    pull_node<FIRST>(p, x, ys, fR, fB);
+    rhoR = sum9(fR);
+    rhoB = sum9(fB);
+    if (!WITH_BC) return;
+    if (ys == p.ny - 2) {
+        if (p.inlet == LBMPM_INLET_VELOCITY) {
+            bc_inlet_velocity(p.vyIn, fR, fB, rhoR, rhoB);
+            if (y == p.ny - 1) { rhoR = sum9(fR); rhoB = sum9(fB); }
+        } else {
+            bc_inlet_pressure_one(p.pInB, fB, rhoB);
+            bc_inlet_pressure_one(p.pInR, fR, rhoR);
+        }
+    }
+    if (p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1) bc_outlet_pressure(p.pOut, fR, fB, rhoR, rhoB);
+}
+
+// ---------------------------------------------------------------- collision pieces
+// tau(phi): A:1967-1981 (same text in A:1815-1827, A:2052-2066, A:1755-1767)
+__device__ __forceinline__ double tau_of(const RKDev &p, double Phi, double rR, double rB)
+{
+    double tau = 1.;
+    if (Phi > p.delta) tau = p.tauR;
+    else if (Phi < -p.delta) tau = p.tauB;
+    else if (fabs(Phi) <= p.delta) {
+        if (p.tautype == 1) {
+            tau = 0.5 + 1. / ((1. + Phi) / (2. * (p.tauR - 0.5)) + (1. - Phi) / (2. * (p.tauB - 0.5)));
+        } else if (p.tautype == 2) {
+            const double ratioR = rR / (rR + rB), ratioB = rB / (rR + rB);
+            const double miuR = 3. / (p.tauR - 0.5), miuB = 3. / (p.tauB - 0.5);
+            const double miu = 1. / (ratioR * miuR + ratioB * miuB);
+            tau = 3. * miu + 0.5;
+        }
+    }
+    return tau;
+}
+
+// A:170-176 calEquilibriumRK2D
+__device__ __forceinline__ double feq(double rho, double w, double ex, double ey, double vx, double vy)
+{
+    return rho * w * (1 + (3. * (ex * vx + ey * vy) + 4.5 * (ex * vx + ey * vy) * (ex * vx + ey * vy) -
+                           1.5 * (vx * vx + vy * vy)));
+}
+
+// Lallemand-Luo moment basis exactly as assembled in RKD2Q9.py:308-336; its rows are
+// mutually orthogonal, so M^-1 = M^T diag(1/|row|^2) (the reference inverts numerically).
+__device__ __forceinline__ void to_moments(const double d[9], double m[9])
+{
+    constexpr int M[9][9] = {{1, 1, 1, 1, 1, 1, 1, 1, 1},      {-4, -1, -1, -1, -1, 2, 2, 2, 2},
+                             {4, -2, -2, -2, -2, 1, 1, 1, 1},  {0, 1, 0, -1, 0, 1, -1, -1, 1},
+                             {0, -2, 0, 2, 0, 1, -1, -1, 1},   {0, 0, 1, 0, -1, 1, 1, -1, -1},
+                             {0, 0, -2, 0, 2, 1, 1, -1, -1},   {0, 1, -1, 1, -1, 0, 0, 0, 0},
+                             {0, 0, 0, 0, 0, 1, -1, 1, -1}};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double t = 0.;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (M[i][j] != 0) t += (double)M[i][j] * d[j];
+        m[i] = t;
+    }
+}
+
+__device__ __forceinline__ void from_moments(const double m[9], double d[9])
+{
+    constexpr int M[9][9] = {{1, 1, 1, 1, 1, 1, 1, 1, 1},      {-4, -1, -1, -1, -1, 2, 2, 2, 2},
+                             {4, -2, -2, -2, -2, 1, 1, 1, 1},  {0, 1, 0, -1, 0, 1, -1, -1, 1},
+                             {0, -2, 0, 2, 0, 1, -1, -1, 1},   {0, 0, 1, 0, -1, 1, 1, -1, -1},
+                             {0, 0, -2, 0, 2, 1, 1, -1, -1},   {0, 1, -1, 1, -1, 0, 0, 0, 0},
+                             {0, 0, 0, 0, 0, 1, -1, 1, -1}};
+    constexpr double INV_N2[9] = {1. / 9., 1. / 36., 1. / 36., 1. / 6., 1. / 12., 1. / 6., 1. / 12., 1. / 4., 1. / 4.};
+    double s[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s[j] = m[j] * INV_N2[j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double t = 0.;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (M[j][i] != 0) t += (double)M[j][i] * s[j];
+        d[i] = t;
+    }
+}
+
+// Collision + Guo forcing on f_tot.
+//   SRT: calRKCollision1TotalGPU2DSRTM A:1804-1848, calPerturbationFromForce2D A:1743-1798
+//   MRT: calRKCollision1TotalGPU2DMRTM A:1938-2017, calPerturbationFromForce2DMRT A:2027-2113
+//        S = diag(0,1.64,1.54,0,1.9,0,1.9,1/tau,1/tau) with tau evaluated per node.
+template <bool MRT>
+__device__ __forceinline__ void collide(const RKDev &p, double fT[9], double rhoR, double rhoB, double phi,
+                                        double vx, double vy, double Fx, double Fy)
+{
+    constexpr double W[9] = LBMPM_D2Q9_W;
+    constexpr int EXi[9] = LBMPM_D2Q9_EX, EYi[9] = LBMPM_D2Q9_EY;
+    const double tau = tau_of(p, phi, rhoR, rhoB);
+    if (!MRT) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double ex = EXi[i], ey = EYi[i];
+            const double eT = feq(rhoR, W[i], ex, ey, vx, vy) + feq(rhoB, W[i], ex, ey, vx, vy);
+            double f = -1. / tau * (fT[i] - eT) + fT[i];
+            const double src = W[i] * ((3. * (ex - vx) + 9. * ex * (ex * vx + ey * vy)) * Fx +
+                                       (3. * (ey - vy) + 9. * ey * (ex * vx + ey * vy)) * Fy) *
+                               (1. - 1. / (2. * tau));
+            fT[i] = f + src;
+        }
+    } else {
+        double d[9], src[9], m[9], ms[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double ex = EXi[i], ey = EYi[i];
+            d[i] = fT[i] - (feq(rhoR, W[i], ex, ey, vx, vy) + feq(rhoB, W[i], ex, ey, vx, vy));
+            const double t1 = ex * Fx * 3.;
+            const double t2 = ey * Fy * 3.;
+            const double t3 = (ex * ex - 1. / 3.) * vx * Fx * 9.;
+            const double t4 = ex * ey * vy * Fx * 9.;
+            const double t5 = ey * ex * vx * Fy * 9.;
+            const double t6 = (ey * ey - 1. / 3.) * vy * Fy * 9.;
+            src[i] = W[i] * (t1 + t2 + t3 + t4 + t5 + t6);
+        }
+        to_moments(d, m);
+        to_moments(src, ms);
+        const double S[9] = {0., 1.64, 1.54, 0., 1.9, 0., 1.9, 1. / tau, 1. / tau};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m[i] = (1. - 0.5 * S[i]) * ms[i] - S[i] * m[i];
+        from_moments(m, d);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fT[i] += d[i];
+    }
+}
+
+// calRecoloringProcessM, A:1857-1899
+__device__ __forceinline__ void recolor(double beta, const double fT[9], double rhoR, double rhoB, double gx,
+                                        double gy, double fR[9], double fB[9])
+{
+    constexpr double W[9] = LBMPM_D2Q9_W;
+    constexpr int EXi[9] = LBMPM_D2Q9_EX, EYi[9] = LBMPM_D2Q9_EY;
+    const double gn = sqrt(gx * gx + gy * gy);
+    const double tot = rhoR + rhoB;
+    const double SQ2 = sqrt(2.);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const double ex = EXi[i], ey = EYi[i];
+        const double un = (i == 0) ? 0. : (i < 5 ? 1. : SQ2);
+        double c = 0.;
+        if (gn > 1.0e-8 && un > 1.0e-8) c = (ex * gx + ey * gy) / (un * gn);
+        const double a = beta * rhoR * rhoB / tot * W[i] * c * un;
+        fR[i] = rhoR / tot * fT[i] + a;
+        fB[i] = rhoB / tot * fT[i] - a;
+    }
+}
+
+// ---------------------------------------------------------------- gradient / wetting / force
+// updateColorGradientOnWetting (type 1, A:1639-1679) and ...New (type 2, A:2430-2492)
+__device__ __forceinline__ void wetting_fix(const RKDev &p, double nsx, double nsy, double &gx, double &gy)
+{
+    const double nrm = sqrt(gx * gx + gy * gy);
+    if (p.wetting == 1) {
+        const double n1x = nsx * p.cosT - nsy * p.sinT, n1y = nsy * p.cosT + nsx * p.sinT;
+        const double n2x = nsx * p.cosT + nsy * p.sinT, n2y = nsy * p.cosT - nsx * p.sinT;
+        double ux = 0., uy = 0.;
+        if (nrm > 1.0e-8) { ux = gx / nrm; uy = gy / nrm; }
+        const double dx1 = ux - n1x, dy1 = uy - n1y, dx2 = ux - n2x, dy2 = uy - n2y;
+        const double d1 = sqrt(dx1 * dx1 + dy1 * dy1), d2 = sqrt(dx2 * dx2 + dy2 * dy2);
+        double mx = 0., my = 0.;
+        if (d1 < d2) { mx = n1x; my = n1y; }
+        else if (d1 > d2) { mx = n2x; my = n2y; }
+        else if (d1 == d2) { mx = nsx; my = nsy; }
+        gx = nrm * mx; gy = nrm * my;
+    } else if (p.wetting == 2) {
+        double ux = 0., uy = 0.;
+        if (nrm > 1.0e-8) { ux = -gx / nrm; uy = -gy / nrm; }
+        const double ang = ux * nsx + uy * nsy;
+        const double th = acos(ang);
+        const double sth = sin(th), cth = cos(th);
+        double c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
+        if (fabs(sth) > 1.0e-9) {
+            c1 = p.sinT * cth / sth;
+            c2 = p.sinT / sth;
+            c3 = -p.sinT * cth / sth;
+            c4 = -p.sinT / sth;
+        }
+        const double nx1 = (p.cosT - c1) * nsx + c2 * ux, ny1 = (p.cosT - c1) * nsy + c2 * uy;
+        const double nx2 = (p.cosT - c3) * nsx + c4 * ux, ny2 = (p.cosT - c3) * nsy + c4 * uy;
+        const double dx1 = nx1 - ux, dy1 = ny1 - uy, dx2 = nx2 - ux, dy2 = ny2 - uy;
+        const double d1 = sqrt(dx1 * dx1 + dy1 * dy1), d2 = sqrt(dx2 * dx2 + dy2 * dy2);
+        if (d1 < d2) { gx = -nrm * nx1; gy = -nrm * ny1; }
+        else if (d1 > d2) { gx = -nrm * nx2; gy = -nrm * ny2; }
+    }
+}
+
+// unit normal used by the curvature stencil: type 2 -> -G/|G| above 1e-8 (A:2512-2520),
+// type 1 -> +G/|G| above 0 (A:1703-1708)
+__device__ __forceinline__ void unit_normal(int wetting, double gx, double gy, double &ux, double &uy)
+{
+    const double n = sqrt(gx * gx + gy * gy);
+    ux = 0.; uy = 0.;
+    if (wetting == 2) { if (n > 1.0e-8) { ux = -gx / n; uy = -gy / n; } }
+    else { if (n > 0.) { ux = gx / n; uy = gy / n; } }
+}
+
+// ---------------------------------------------------------------- kernels (split schedule)
+constexpr int BX = 64, BY = 4;
+
+// K1: phase field of the post-streaming, post-BC state (calPhaseFieldPhi A:1348)
+template <bool FIRST>
+__global__ __launch_bounds__(BX *BY) void rk2d_phase_field(RKDev p)
+{
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    double fR[9], fB[9], rR, rB;
+    node_state<FIRST, true>(p, x, y, fR, fB, rR, rB);
+    p.phi[idx] = (rR - rB) / (rR + rB);
+}
+
+// K2: colour gradient with wetting correction
+//   calColorValueOnSolid A:1560-1581 (evaluated on the fly for solid neighbours),
+//   calRKInitialGradient A:1584-1634, updateColorGradientOnWetting[New]
+__global__ __launch_bounds__(BX *BY) void rk2d_gradient(RKDev p)
+{
+    constexpr double W[9] = LBMPM_D2Q9_W;
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    const unsigned sn = p.solidnbr[idx];
+    double gx = 0., gy = 0.;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int xn = wrapi(x + EX[i], p.nx), yn = wrapi(y + EY[i], p.ny);
+        const size_t nidx = (size_t)yn * p.pitch + xn;
+        double v;
+        if (!((sn >> (i - 1)) & 1u)) {
+            v = p.phi[nidx];
+        } else {   // wetting solid: weighted mean of phi over its fluid neighbours
+            const unsigned ss = p.solidnbr[nidx];
+            double sum = 0., sw = 0.;
+#pragma unroll
+            for (int j = 1; j < 9; ++j) {
+                if (!((ss >> (j - 1)) & 1u)) {
+                    const int x2 = wrapi(xn + EX[j], p.nx), y2 = wrapi(yn + EY[j], p.ny);
+                    sum += W[j] * p.phi[(size_t)y2 * p.pitch + x2];
+                    sw += W[j];
+                }
+            }
+            v = sum / sw;
+        }
+        gx += W[i] * v * (double)EX[i];
+        gy += W[i] * v * (double)EY[i];
+    }
+    gx = 3. * gx; gy = 3. * gy;
+    if (sn != 0) wetting_fix(p, p.ns[idx], p.ns[p.plane + idx], gx, gy);
+    p.G[idx] = gx;
+    p.G[p.plane + idx] = gy;
+}
+
+// K3: everything else of the step (dominant kernel): stream+BC, u, curvature + CSF force,
+// collision + forcing, recolouring, store post-collision populations.
+template <bool FIRST, bool MRT, bool DIAG>
+__global__ __launch_bounds__(BX *BY) void rk2d_collide_stream(RKDev p)
+{
+    constexpr double W[9] = LBMPM_D2Q9_W;
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    double fR[9], fB[9], rR, rB;
+    node_state<FIRST, true>(p, x, y, fR, fB, rR, rB);
+    double fT[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fT[i] = fR[i] + fB[i];          // calTotalFluidPDF A:1414
+    // calPhysicalVelocityRKGPU2DNew1 A:2634-2654 (force of the PREVIOUS step)
+    const double rs = rB + rR;
+    const double vx = (fT[1] - fT[3] + fT[5] - fT[6] - fT[7] + fT[8] + 0.5 * p.F[idx]) / rs;
+    const double vy = (fT[2] - fT[4] + fT[5] + fT[6] - fT[7] - fT[8] + 0.5 * p.F[p.plane + idx]) / rs;
+    const double phi = (rR - rB) / (rR + rB);
+    // calForceTermInColorGradient[New]2D A:1686-1736 / A:2499-2551
+    const double gx = p.G[idx], gy = p.G[p.plane + idx];
+    double ux, uy;
+    unit_normal(p.wetting, gx, gy, ux, uy);
+    const unsigned sn = p.solidnbr[idx];
+    double pyx = 0., pxy = 0., px = 0., py = 0.;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        if ((sn >> (i - 1)) & 1u) continue;
+        const int xn = wrapi(x + EX[i], p.nx), yn = wrapi(y + EY[i], p.ny);
+        const size_t nidx = (size_t)yn * p.pitch + xn;
+        double qx, qy;
+        unit_normal(p.wetting, p.G[nidx], p.G[p.plane + nidx], qx, qy);
+        pyx += 3. * W[i] * qy * (double)EX[i];
+        pxy += 3. * W[i] * qx * (double)EY[i];
+        px += 3. * W[i] * qx * (double)EX[i];
+        py += 3. * W[i] * qy * (double)EY[i];
+    }
+    const double K = ux * uy * (pyx + pxy) - uy * uy * px - ux * ux * py;
+    const double sgn = (p.wetting == 2) ? -0.5 : 0.5;
+    const double Fx = sgn * p.sigma * K * gx, Fy = sgn * p.sigma * K * gy;
+    p.F[idx] = Fx;
+    p.F[p.plane + idx] = Fy;
+    if (DIAG) { p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K; }
+    collide<MRT>(p, fT, rR, rB, phi, vx, vy, Fx, Fy);
+    recolor(p.beta, fT, rR, rB, gx, gy, fR, fB);
+    double *fr = p.fout, *fb = p.fout + 9 * p.plane;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { fr[i * p.plane + idx] = fR[i]; fb[i * p.plane + idx] = fB[i]; }
+}
+
+// Observation kernels: populations/densities as the reference's device arrays hold them
+// after the last completed step (WITH_BC=false), or as resultInHDF5 records them at the
+// start of the next step (WITH_BC=true: + velocity, RKD2Q9.py:1382-1393).
+template <bool FIRST, bool WITH_BC>
+__global__ __launch_bounds__(BX *BY) void rk2d_observe(RKDev p, double *out /*[22][plane]*/)
+{
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    double fR[9], fB[9], rR, rB;
+    node_state<FIRST, WITH_BC>(p, x, y, fR, fB, rR, rB);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { out[i * p.plane + idx] = fR[i]; out[(9 + i) * p.plane + idx] = fB[i]; }
+    out[18 * p.plane + idx] = rR;
+    out[19 * p.plane + idx] = rB;
+    double fT[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fT[i] = fR[i] + fB[i];
+    const double rs = rB + rR;
+    out[20 * p.plane + idx] = (fT[1] - fT[3] + fT[5] - fT[6] - fT[7] + fT[8] + 0.5 * p.F[idx]) / rs;
+    out[21 * p.plane + idx] = (fT[2] - fT[4] + fT[5] + fT[6] - fT[7] - fT[8] + 0.5 * p.F[p.plane + idx]) / rs;
+}
+
+// ---------------------------------------------------------------- set-up kernels
+// bit (i-1) of solidnbr <=> node + e_i is not fluid, periodic wrap on all four edges
+// (the wrap of fillNeighboringNodes, A:25-28).
+__global__ void rk2d_setup_solidnbr(int nx, int ny, int pitch, const uint8_t *flags, uint8_t *solidnbr)
+{
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= nx || y >= ny) return;
+    unsigned b = 0;
+    for (int i = 1; i < 9; ++i) {
+        const int xn = wrapi(x + EX[i], nx), yn = wrapi(y + EY[i], ny);
+        if (!(flags[(size_t)yn * pitch + xn] & 1)) b |= 1u << (i - 1);
+    }
+    solidnbr[(size_t)y * pitch + x] = (uint8_t)b;
+}
+
+// calVectorNormaltoSolid, RKD2Q9.py:768-892: 24-point iso-8 stencil over the solid mask.
+__global__ void rk2d_setup_normals(int nx, int ny, int pitch, size_t plane, const uint8_t *flags,
+                                   const uint8_t *solidnbr, double *ns)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= nx || y >= ny) return;
+    const size_t idx = (size_t)y * pitch + x;
+    if (!(flags[idx] & 1) || solidnbr[idx] == 0) return;
+    // reference accumulation order (dx, dy, weight)
+    constexpr int DX[24] = {1, 0, -1, 0, 1, -1, -1, 1, 2, 0, -2, 0, 2, 1, -1, -2, -2, -1, 1, 2, 2, -2, -2, 2};
+    constexpr int DY[24] = {0, 1, 0, -1, 1, 1, -1, -1, 0, 2, 0, -2, 1, 2, 2, 1, -1, -2, -2, -1, 2, 2, -2, -2};
+    constexpr double WW[24] = {4. / 21., 4. / 21., 4. / 21., 4. / 21., 4. / 45., 4. / 45., 4. / 45., 4. / 45.,
+                               1. / 60., 1. / 60., 1. / 60., 1. / 60., 2. / 315., 2. / 315., 2. / 315., 2. / 315.,
+                               2. / 315., 2. / 315., 2. / 315., 2. / 315., 1. / 5040., 1. / 5040., 1. / 5040., 1. / 5040.};
+    double sx = 0., sy = 0.;
+    for (int k = 0; k < 24; ++k) {
+        int xn = x + DX[k], yn = y + DY[k];
+        xn = xn < 0 ? xn + nx : (xn >= nx ? xn - nx : xn);
+        yn = yn < 0 ? yn + ny : (yn >= ny ? yn - ny : yn);
+        if (!(flags[(size_t)yn * pitch + xn] & 1)) {
+            sx += WW[k] * 1. * (double)DX[k];
+            sy += WW[k] * 1. * (double)DY[k];
+        }
+    }
+    const double n = sqrt(sx * sx + sy * sy);
+    ns[idx] = sx / n;
+    ns[plane + idx] = sy / n;
+}
+
+}  // namespace
+
+// ====================================================================== host side
+struct lbmpm_rk2d {
+    lbmpm_rk2d_config cfg;
+    int nx, ny, pitch;
+    size_t plane;
+    int64_t nfluid = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint8_t *flags = nullptr, *solidnbr = nullptr;
+    double *fA = nullptr, *fB = nullptr;   // ping-pong [2][9][plane]; fA holds the current state
+    double *F = nullptr, *ns = nullptr, *phi = nullptr, *G = nullptr, *diag = nullptr, *obs = nullptr;
+    std::vector<uint8_t> h_domain;
+    bool streamed = false;    // false: fA holds the initial (already "post-streaming") state
+    bool diag_valid = false;
+    int64_t steps = 0;
+    int64_t bytes = 0;
+    lbmpm::EventPool pool;
+};
+
+namespace {
+
+RKDev make_dev(const lbmpm_rk2d *c)
+{
+    RKDev p;
+    p.nx = c->nx; p.ny = c->ny; p.pitch = c->pitch; p.plane = c->plane;
+    p.flags = c->flags; p.solidnbr = c->solidnbr;
+    p.fin = c->fA; p.fout = c->fB; p.F = c->F; p.ns = c->ns; p.phi = c->phi; p.G = c->G; p.diag = c->diag;
+    const double th = c->cfg.contact_angle_deg / 180. * M_PI;
+    p.sigma = c->cfg.surface_tension; p.cosT = cos(th); p.sinT = sin(th);
+    p.beta = c->cfg.beta; p.delta = c->cfg.delta; p.tauR = c->cfg.tau_r; p.tauB = c->cfg.tau_b;
+    p.vyIn = c->cfg.inlet_velocity_y; p.pInB = c->cfg.inlet_rho_b; p.pInR = c->cfg.inlet_rho_r;
+    p.pOut = c->cfg.outlet_rho_total;
+    p.wetting = c->cfg.wetting_type; p.tautype = c->cfg.tau_type;
+    p.inlet = c->cfg.inlet_type; p.outlet = c->cfg.outlet_type;
+    return p;
+}
+
+dim3 grid_of(const lbmpm_rk2d *c) { return dim3((c->nx + BX - 1) / BX, (c->ny + BY - 1) / BY); }
+
+template <bool FIRST>
+int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
+{
+    RKDev p = make_dev(c);
+    const dim3 g = grid_of(c), b(BX, BY);
+    rk2d_phase_field<FIRST><<<g, b, 0, c->stream>>>(p);
+    rk2d_gradient<<<g, b, 0, c->stream>>>(p);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool ev = timed && c->pool.take(&e0, &e1);
+    if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+    const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
+    if (mrt) {
+        if (diag) rk2d_collide_stream<FIRST, true, true><<<g, b, 0, c->stream>>>(p);
+        else rk2d_collide_stream<FIRST, true, false><<<g, b, 0, c->stream>>>(p);
+    } else {
+        if (diag) rk2d_collide_stream<FIRST, false, true><<<g, b, 0, c->stream>>>(p);
+        else rk2d_collide_stream<FIRST, false, false><<<g, b, 0, c->stream>>>(p);
+    }
+    if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
+    LBMPM_HIP_TRY(hipGetLastError());
+    std::swap(c->fA, c->fB);
+    c->streamed = true;
+    c->diag_valid = diag;
+    c->steps += 1;
+    return LBMPM_OK;
+}
+
+int run_steps(lbmpm_rk2d *c, int64_t n, bool timed)
+{
+    for (int64_t k = 0; k < n; ++k) {
+        const bool diag = (c->diag != nullptr) && (k == n - 1);
+        const int rc = c->streamed ? launch_step<false>(c, diag, timed) : launch_step<true>(c, diag, timed);
+        if (rc != LBMPM_OK) return rc;
+    }
+    return LBMPM_OK;
+}
+
+template <typename T>
+int dev_alloc(lbmpm_rk2d *c, T **ptr, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, count * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return LBMPM_ERR_NOMEM;
+    }
+    e = hipMemset(v, 0, count * sizeof(T));
+    if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
+    *ptr = static_cast<T *>(v);
+    c->bytes += (int64_t)(count * sizeof(T));
+    return LBMPM_OK;
+}
+
+}  // namespace
+
+extern "C" int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is_domain, lbmpm_rk2d **out)
+{
+    LBMPM_REQUIRE(cfg && is_domain && out, "lbmpm_rk2d_create: null argument");
+    LBMPM_REQUIRE(cfg->nx >= 4 && cfg->ny >= 8 && cfg->nx < (1 << 30) && cfg->ny < (1 << 30),
+                  "lbmpm_rk2d_create: domain %lld x %lld out of range", (long long)cfg->nx, (long long)cfg->ny);
+    LBMPM_REQUIRE(cfg->wetting_type == 1 || cfg->wetting_type == 2, "WettingType must be 1 or 2 (got %d)", cfg->wetting_type);
+    LBMPM_REQUIRE(cfg->tau_type == 1 || cfg->tau_type == 2, "TauType must be 1 or 2 (got %d)", cfg->tau_type);
+    LBMPM_REQUIRE(cfg->relaxation == LBMPM_RELAX_SRT || cfg->relaxation == LBMPM_RELAX_MRT, "bad relaxation %d", cfg->relaxation);
+    LBMPM_REQUIRE(cfg->inlet_type == 0 || cfg->inlet_type == 1, "bad inlet_type %d", cfg->inlet_type);
+    LBMPM_REQUIRE(cfg->outlet_type == 0 || cfg->outlet_type == 1, "bad outlet_type %d", cfg->outlet_type);
+    LBMPM_REQUIRE(cfg->tau_r > 0.5 && cfg->tau_b > 0.5, "TauR/TauB must exceed 0.5");
+    LBMPM_HIP_TRY(hipSetDevice(cfg->device));
+    lbmpm_rk2d *c = new (std::nothrow) lbmpm_rk2d();
+    if (!c) { set_error("out of host memory"); return LBMPM_ERR_NOMEM; }
+    c->cfg = *cfg;
+    c->nx = (int)cfg->nx; c->ny = (int)cfg->ny;
+    c->pitch = (c->nx + 31) / 32 * 32;           // rows start on 256-byte boundaries
+    c->plane = (size_t)c->pitch * c->ny;
+    c->h_domain.assign(is_domain, is_domain + (size_t)c->nx * c->ny);
+    std::vector<uint8_t> hflags(c->plane, 0);
+    for (int y = 0; y < c->ny; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            const uint8_t v = is_domain[(size_t)y * c->nx + x] == 1 ? 1 : 0;
+            hflags[(size_t)y * c->pitch + x] = v;
+            c->nfluid += v;
+        }
+    int rc = LBMPM_OK;
+#define TRY_RC(e) do { rc = (e); if (rc != LBMPM_OK) { lbmpm_rk2d_destroy(c); return rc; } } while (0)
+    {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return LBMPM_ERR_HIP; }
+        c->own_stream = true;
+    }
+    TRY_RC(dev_alloc(c, &c->flags, c->plane));
+    TRY_RC(dev_alloc(c, &c->solidnbr, c->plane));
+    TRY_RC(dev_alloc(c, &c->fA, 18 * c->plane));
+    TRY_RC(dev_alloc(c, &c->fB, 18 * c->plane));
+    TRY_RC(dev_alloc(c, &c->F, 2 * c->plane));
+    TRY_RC(dev_alloc(c, &c->ns, 2 * c->plane));
+    TRY_RC(dev_alloc(c, &c->phi, c->plane));
+    TRY_RC(dev_alloc(c, &c->G, 2 * c->plane));
+    {
+        hipError_t e = hipMemcpy(c->flags, hflags.data(), c->plane, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_error("hipMemcpy(flags) failed: %s", hipGetErrorString(e)); lbmpm_rk2d_destroy(c); return LBMPM_ERR_HIP; }
+    }
+    const dim3 b(64, 4), g((c->nx + 63) / 64, (c->ny + 3) / 4);
+    rk2d_setup_solidnbr<<<g, b, 0, c->stream>>>(c->nx, c->ny, c->pitch, c->flags, c->solidnbr);
+    rk2d_setup_normals<<<g, b, 0, c->stream>>>(c->nx, c->ny, c->pitch, c->plane, c->flags, c->solidnbr, c->ns);
+    {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { set_error("set-up kernels failed: %s", hipGetErrorString(e)); lbmpm_rk2d_destroy(c); return LBMPM_ERR_HIP; }
+    }
+#undef TRY_RC
+    *out = c;
+    return LBMPM_OK;
+}
+
+extern "C" void lbmpm_rk2d_destroy(lbmpm_rk2d *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *ptr : {(void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->F,
+                      (void *)c->ns, (void *)c->phi, (void *)c->G, (void *)c->diag, (void *)c->obs})
+        if (ptr) (void)hipFree(ptr);
+    c->pool.destroy();
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int lbmpm_rk2d_set_stream(lbmpm_rk2d *c, void *hip_stream)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hip_stream == nullptr) {
+        if (!c->own_stream) {
+            LBMPM_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+        return LBMPM_OK;
+    }
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk2d_set_pdf(lbmpm_rk2d *c, const double *pdf_r, const double *pdf_b)
+{
+    LBMPM_REQUIRE(c && pdf_r && pdf_b, "lbmpm_rk2d_set_pdf: null argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    std::vector<double> h(18 * c->plane, 0.0);
+    for (int y = 0; y < c->ny; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            const size_t s = ((size_t)y * c->nx + x) * 9, d = (size_t)y * c->pitch + x;
+            if (c->h_domain[(size_t)y * c->nx + x] != 1) continue;
+            for (int i = 0; i < 9; ++i) {
+                h[i * c->plane + d] = pdf_r[s + i];
+                h[(9 + i) * c->plane + d] = pdf_b[s + i];
+            }
+        }
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    LBMPM_HIP_TRY(hipMemcpy(c->fA, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    LBMPM_HIP_TRY(hipMemset(c->F, 0, 2 * c->plane * sizeof(double)));
+    c->streamed = false;
+    c->diag_valid = false;
+    c->steps = 0;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk2d_set_macro(lbmpm_rk2d *c, const double *rho_r, const double *rho_b, const double *vx,
+                                    const double *vy)
+{
+    LBMPM_REQUIRE(c && rho_r && rho_b, "lbmpm_rk2d_set_macro: null argument");
+    static const double EXd[9] = LBMPM_D2Q9_EX, EYd[9] = LBMPM_D2Q9_EY, Wd[9] = LBMPM_D2Q9_W;
+    const size_t n = (size_t)c->nx * c->ny;
+    std::vector<double> fr(9 * n, 0.0), fb(9 * n, 0.0);
+    for (size_t k = 0; k < n; ++k) {
+        if (c->h_domain[k] != 1) continue;
+        const double ux = vx ? vx[k] : 0.0, uy = vy ? vy[k] : 0.0;
+        for (int i = 0; i < 9; ++i) {   // RKD2Q9.py:577-601
+            const double eu = EXd[i] * ux + EYd[i] * uy;
+            const double t = 1 + (3. * eu + 4.5 * eu * eu - 1.5 * (ux * ux + uy * uy));
+            fr[9 * k + i] = rho_r[k] * Wd[i] * t;
+            fb[9 * k + i] = rho_b[k] * Wd[i] * t;
+        }
+    }
+    return lbmpm_rk2d_set_pdf(c, fr.data(), fb.data());
+}
+
+extern "C" int lbmpm_rk2d_step(lbmpm_rk2d *c, int64_t nsteps)
+{
+    LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_rk2d_step: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    return run_steps(c, nsteps, false);
+}
+
+extern "C" int lbmpm_rk2d_step_timed(lbmpm_rk2d *c, int64_t nsteps, double *ms_total, double *ms_dominant)
+{
+    LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_rk2d_step_timed: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t pairs = (size_t)(nsteps < 4096 ? nsteps : 4096);
+    if (c->pool.reserve(pairs + 1) != LBMPM_OK) { set_error("hipEventCreate failed"); return LBMPM_ERR_HIP; }
+    c->pool.reset();
+    hipEvent_t t0, t1;
+    c->pool.take(&t0, &t1);
+    LBMPM_HIP_TRY(hipEventRecord(t0, c->stream));
+    const int rc = run_steps(c, nsteps, true);
+    if (rc != LBMPM_OK) return rc;
+    LBMPM_HIP_TRY(hipEventRecord(t1, c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    LBMPM_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+    if (ms_total) *ms_total = ms;
+    if (ms_dominant) {
+        const size_t timed_launches = c->pool.used / 2 - 1;
+        double s = 0.0;
+        for (size_t k = 2; k + 1 < c->pool.used; k += 2) {
+            float m = 0.f;
+            LBMPM_HIP_TRY(hipEventElapsedTime(&m, c->pool.ev[k], c->pool.ev[k + 1]));
+            s += m;
+        }
+        // scale to all launches when more steps than pooled event pairs were run
+        *ms_dominant = timed_launches ? s * (double)nsteps / (double)timed_launches : 0.0;
+    }
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk2d_sync(lbmpm_rk2d *c)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk2d_enable_diagnostics(lbmpm_rk2d *c, int on)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (on && !c->diag) { const int rc = dev_alloc(c, &c->diag, 3 * c->plane); if (rc) return rc; }
+    if (!on && c->diag) {
+        LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->diag); c->diag = nullptr; c->diag_valid = false;
+        c->bytes -= (int64_t)(3 * c->plane * sizeof(double));
+    }
+    return LBMPM_OK;
+}
+
+namespace {
+
+int copy_plane(lbmpm_rk2d *c, const double *dev, double *out, int ncomp)
+{   // device SoA [ncomp][plane] -> host dense AoS [ny][nx][ncomp], zeros at solid
+    std::vector<double> h((size_t)ncomp * c->plane);
+    LBMPM_HIP_TRY(hipMemcpy(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int y = 0; y < c->ny; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            const size_t k = (size_t)y * c->nx + x, d = (size_t)y * c->pitch + x;
+            const bool fluid = c->h_domain[k] == 1;
+            for (int i = 0; i < ncomp; ++i) out[k * ncomp + i] = fluid ? h[i * c->plane + d] : 0.0;
+        }
+    return LBMPM_OK;
+}
+
+}  // namespace
+
+extern "C" int lbmpm_rk2d_get_field(lbmpm_rk2d *c, int field, double *out)
+{
+    LBMPM_REQUIRE(c && out, "lbmpm_rk2d_get_field: null argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    const bool rec = field >= LBMPM_RK_REC_PDF_R && field <= LBMPM_RK_REC_VY;
+    const bool cur_obs = field >= LBMPM_RK_PDF_R && field <= LBMPM_RK_RHO_B;
+    if (rec || cur_obs) {
+        if (!c->obs) { const int rc = dev_alloc(c, &c->obs, 22 * c->plane); if (rc) return rc; }
+        RKDev p = make_dev(c);
+        const dim3 g = grid_of(c), b(BX, BY);
+        if (rec) {
+            if (c->streamed) rk2d_observe<false, true><<<g, b, 0, c->stream>>>(p, c->obs);
+            else rk2d_observe<true, true><<<g, b, 0, c->stream>>>(p, c->obs);
+        } else {
+            if (c->streamed) rk2d_observe<false, false><<<g, b, 0, c->stream>>>(p, c->obs);
+            else rk2d_observe<true, false><<<g, b, 0, c->stream>>>(p, c->obs);
+        }
+        LBMPM_HIP_TRY(hipGetLastError());
+        LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+        const int f = rec ? field - LBMPM_RK_REC_PDF_R : field;
+        switch (f) {
+            case 0: return copy_plane(c, c->obs, out, 9);
+            case 1: return copy_plane(c, c->obs + 9 * c->plane, out, 9);
+            case 2: return copy_plane(c, c->obs + 18 * c->plane, out, 1);
+            case 3: return copy_plane(c, c->obs + 19 * c->plane, out, 1);
+            case 4: return copy_plane(c, c->obs + 20 * c->plane, out, 1);
+            case 5: return copy_plane(c, c->obs + 21 * c->plane, out, 1);
+        }
+    }
+    switch (field) {
+        case LBMPM_RK_PHI: return copy_plane(c, c->phi, out, 1);
+        case LBMPM_RK_GX: return copy_plane(c, c->G, out, 1);
+        case LBMPM_RK_GY: return copy_plane(c, c->G + c->plane, out, 1);
+        case LBMPM_RK_FX: return copy_plane(c, c->F, out, 1);
+        case LBMPM_RK_FY: return copy_plane(c, c->F + c->plane, out, 1);
+        case LBMPM_RK_VX: case LBMPM_RK_VY: case LBMPM_RK_K:
+            if (!c->diag || !c->diag_valid) {
+                set_error("field %d needs lbmpm_rk2d_enable_diagnostics(ctx, 1) before the last lbmpm_rk2d_step", field);
+                return LBMPM_ERR_STATE;
+            }
+            return copy_plane(c, c->diag + (field == LBMPM_RK_VX ? 0 : field == LBMPM_RK_VY ? 1 : 2) * c->plane, out, 1);
+        default: break;
+    }
+    set_error("lbmpm_rk2d_get_field: unknown field id %d", field);
+    return LBMPM_ERR_INVALID;
+}
+
+extern "C" int64_t lbmpm_rk2d_num_fluid_nodes(const lbmpm_rk2d *c) { return c ? c->nfluid : 0; }
+extern "C" int64_t lbmpm_rk2d_steps_done(const lbmpm_rk2d *c) { return c ? c->steps : 0; }
+extern "C" int64_t lbmpm_rk2d_device_bytes(const lbmpm_rk2d *c) { return c ? c->bytes : 0; }
+extern "C" const char *lbmpm_rk2d_dominant_kernel(const lbmpm_rk2d *c)
+{
+    (void)c;
+    return "rk2d_collide_stream";
+}
