@@ -56,6 +56,30 @@ _SIGNATURES = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP/HSA
+    runtimes in one process cannot both open the GPU, so when torch is installed we make its
+    copies the process-wide ones BEFORE liblbmpm_hip.so resolves its DT_NEEDED entries (same
+    SONAMEs), whether or not torch itself has been imported yet.  Without torch the system
+    ROCm runtime under /opt/rocm is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load (once) and return the shared library; raise LbmpmError if unavailable."""
     global _lib
@@ -64,6 +88,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise LbmpmError("%s is missing: the HIP library is the only compute path "
                          "(no CPU fallback). Build it: python -m openlbmpm_amd.build" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:
