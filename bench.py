@@ -30,12 +30,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.m
 B_ALG = {"c2": 288.0}        # algorithmic bytes per lattice update
 
 
-def build_c2(nx, ny, device):
+def build_c2(nx, ny, device, variant=0):
     from openlbmpm_amd.rk2d import RK2DSolver
     from openlbmpm_amd.geometry import simple_geometry, initial_densities_rk
     dom = simple_geometry(nx, ny)
     rR, rB = initial_densities_rk(dom, False, 10, mode="intrusion")
-    s = RK2DSolver(dom, dict(relax="MRT"), device=device)
+    s = RK2DSolver(dom, dict(relax="MRT"), device=device, variant=variant)
     s.set_macro(rR, rB)
     return s, dom, rR, rB
 
@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("NX", "NY"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="0 fused (default), 1 split-3 schedule")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +87,7 @@ def main():
     nx, ny = args.size if args.size else (1024, 1024)
     if args.workload != "c2":
         raise SystemExit("unknown workload %r" % args.workload)
-    solver, dom, _, _ = build_c2(nx, ny, local_rank)
+    solver, dom, rR0, rB0 = build_c2(nx, ny, local_rank, args.variant)
     nfluid = solver.num_fluid_nodes
 
     def barrier():
@@ -107,8 +108,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     # sanity: the state must still be finite after the timed steps
-    rho = solver.get("rhoR")
+    rho = solver.get("rhoR") + solver.get("rhoB")
     assert np.isfinite(rho).all(), "non-finite density after the timed run"
+    m0 = float((rR0 + rB0).sum())
+    assert abs(float(rho.sum()) - m0) / m0 < 1e-2, "mass drifted: the timed run did not do real work"
 
     if rank == 0:
         mlups = nfluid * args.steps * world / wall / 1e6
@@ -124,7 +127,7 @@ def main():
                                    "red intruding from the top quarter)" % (nx, ny),
                        "fluid_nodes": nfluid, "lattice_nodes": nx * ny,
                        "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
-                       "kernel_schedule": "split-3",
+                       "kernel_schedule": "fused" if args.variant == 0 else "split-3",
                        "device_ms_per_step_hip_events": round(ms_total / args.steps, 6)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

@@ -458,6 +458,208 @@ __global__ __launch_bounds__(BX *BY) void rk2d_collide_stream(RKDev p)
     for (int i = 0; i < 9; ++i) { fr[i * p.plane + idx] = fR[i]; fb[i * p.plane + idx] = fB[i]; }
 }
 
+// ---------------------------------------------------------------- fused schedule
+// One kernel per time step.  A workgroup owns a TW x TH tile and recomputes the phase
+// field on the tile + 3-node halo (the CSF force at a node needs n^ at distance 1, hence G,
+// hence phi / phi_solid at distance 2, hence phi at distance 3 next to wetting solids):
+//   A  every fluid node of tile+halo: pull + boundary rows -> rhoR, rhoB -> phi -> LDS
+//      (owners of interior nodes keep f_tot, rhoR, rhoB in registers)
+//   B  solid nodes of tile+2: phi_s = weighted mean over fluid neighbours -> LDS (in place)
+//   C  fluid nodes of tile+1: G (+ wetting fix), unit normal n^ -> LDS
+//   D  interior: curvature, CSF force, u, collision + forcing, recolouring, store.
+// The halo re-reads hit the XCD's L2 (tiles are handed to XCDs in contiguous bands).
+template <int TH_, int NT_>
+struct FusedShape {
+    static constexpr int TW = 64, TH = TH_, NT = NT_, H = 3;
+    static constexpr int TY = TH / NT;            // thread rows
+    static constexpr int THREADS = TW * TY;
+    static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;
+};
+
+__device__ __forceinline__ int wrapm(int v, int n)
+{
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+
+template <bool FIRST, bool MRT, bool DIAG, typename SH>
+__global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
+{
+    constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
+    constexpr int RW = SH::RW, RH = SH::RH;
+    constexpr double W[9] = LBMPM_D2Q9_W;
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    __shared__ double s_phi[RH * RW];
+    __shared__ double s_ux[RH * RW];
+    __shared__ double s_uy[RH * RW];
+    __shared__ uint8_t s_fluid[RH * RW];
+
+    // XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch order);
+    // give every XCD a contiguous band of tiles so halo rows are shared inside one L2.
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, k = b & 7, j = b >> 3;
+    const int t = k * q + (k < r ? k : r) + j;
+    const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
+    const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
+
+    // fluid mask of the region
+    bool any_solid = false;
+    for (int n = tid; n < RH * RW; n += THREADS) {
+        const int rx = n % RW, ry = n / RW;
+        const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
+        const uint8_t fl = p.flags[(size_t)y * p.pitch + x] & 1;
+        s_fluid[n] = fl;
+        if (!fl && rx >= 1 && rx < RW - 1 && ry >= 1 && ry < RH - 1) any_solid = true;
+    }
+    const bool need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
+
+    // ---- phase A: interior nodes (owner keeps f_tot, rho in registers)
+    double fT[NT][9], rR[NT], rB[NT];
+    unsigned sn[NT];
+    bool act[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        const int x = tx0 + lx, y = ty0 + ly + m * TY;
+        const int ri = (H + ly + m * TY) * RW + H + lx;
+        act[m] = (x < p.nx) && (y < p.ny) && s_fluid[ri];
+        sn[m] = 0;
+        if (act[m]) {
+            double fR[9], fB[9];
+            node_state<FIRST, true>(p, x, y, fR, fB, rR[m], rB[m]);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fT[m][i] = fR[i] + fB[i];
+            s_phi[ri] = (rR[m] - rB[m]) / (rR[m] + rB[m]);
+            sn[m] = p.solidnbr[(size_t)y * p.pitch + x];
+        } else if (s_fluid[ri]) {
+            // fluid node beyond the lattice edge of a partial tile: it is the periodic image
+            // of a real node and serves as halo for the valid part of the tile
+            const int xw = wrapm(x, p.nx), yw = wrapm(y, p.ny);
+            double fR[9], fB[9], a, c;
+            node_state<FIRST, true>(p, xw, yw, fR, fB, a, c);
+            s_phi[ri] = (a - c) / (a + c);
+        }
+    }
+    // ---- phase A: halo nodes (phi only)
+    constexpr int NHALO = 2 * H * RW + 2 * H * TH;
+    for (int n = tid; n < NHALO; n += THREADS) {
+        int rx, ry, mloc = n;
+        if (mloc < H * RW) { ry = mloc / RW; rx = mloc % RW; }
+        else if ((mloc -= H * RW) < H * RW) { ry = RH - H + mloc / RW; rx = mloc % RW; }
+        else { mloc -= H * RW; ry = H + mloc / (2 * H); const int c = mloc % (2 * H); rx = c < H ? c : RW - 2 * H + c; }
+        const int ri = ry * RW + rx;
+        if (!s_fluid[ri]) continue;
+        if (!need3 && (rx == 0 || rx == RW - 1 || ry == 0 || ry == RH - 1)) continue;
+        const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
+        double fR[9], fB[9], a, c;
+        node_state<FIRST, true>(p, x, y, fR, fB, a, c);
+        s_phi[ri] = (a - c) / (a + c);
+    }
+    __syncthreads();
+
+    // ---- phase B: colour value on wetting solids (calColorValueOnSolid A:1560-1581)
+    if (need3) {
+        for (int n = tid; n < (RH - 2) * (RW - 2); n += THREADS) {
+            const int rx = 1 + n % (RW - 2), ry = 1 + n / (RW - 2);
+            const int ri = ry * RW + rx;
+            if (s_fluid[ri]) continue;
+            double sum = 0., sw = 0.;
+#pragma unroll
+            for (int i = 1; i < 9; ++i) {
+                const int rn = ri + EY[i] * RW + EX[i];
+                if (s_fluid[rn]) { sum += W[i] * s_phi[rn]; sw += W[i]; }
+            }
+            if (sw > 0.) s_phi[ri] = sum / sw;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase C: colour gradient, wetting correction, unit normal
+    auto gradient_at = [&](int ri, int x, int y, double &gx, double &gy) {
+        double ax = 0., ay = 0.;
+        bool solid_nb = false;
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            const int rn = ri + EY[i] * RW + EX[i];
+            const double v = s_phi[rn];
+            solid_nb |= !s_fluid[rn];
+            ax += W[i] * v * (double)EX[i];
+            ay += W[i] * v * (double)EY[i];
+        }
+        gx = 3. * ax; gy = 3. * ay;
+        if (solid_nb) {
+            const size_t idx = (size_t)y * p.pitch + x;
+            wetting_fix(p, p.ns[idx], p.ns[p.plane + idx], gx, gy);
+        }
+        double ux, uy;
+        unit_normal(p.wetting, gx, gy, ux, uy);
+        s_ux[ri] = ux; s_uy[ri] = uy;
+    };
+    double gx[NT], gy[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        const int ri = (H + ly + m * TY) * RW + H + lx;
+        gx[m] = 0.; gy[m] = 0.;
+        if (s_fluid[ri]) {
+            const int x = wrapm(tx0 + lx, p.nx), y = wrapm(ty0 + ly + m * TY, p.ny);
+            gradient_at(ri, x, y, gx[m], gy[m]);
+        }
+    }
+    constexpr int NRING = 2 * (TW + 2) + 2 * TH;
+    for (int n = tid; n < NRING; n += THREADS) {
+        int rx, ry, mloc = n;
+        if (mloc < TW + 2) { ry = H - 1; rx = H - 1 + mloc; }
+        else if ((mloc -= TW + 2) < TW + 2) { ry = H + TH; rx = H - 1 + mloc; }
+        else { mloc -= TW + 2; ry = H + mloc / 2; rx = (mloc & 1) ? H + TW : H - 1; }
+        const int ri = ry * RW + rx;
+        if (!s_fluid[ri]) continue;
+        const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
+        double a, c;
+        gradient_at(ri, x, y, a, c);
+    }
+    __syncthreads();
+
+    // ---- phase D: force, velocity, collision, recolouring, store
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        if (!act[m]) continue;
+        const int x = tx0 + lx, y = ty0 + ly + m * TY;
+        const size_t idx = (size_t)y * p.pitch + x;
+        const int ri = (H + ly + m * TY) * RW + H + lx;
+        const double ux = s_ux[ri], uy = s_uy[ri];
+        double pyx = 0., pxy = 0., px = 0., py = 0.;
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            if ((sn[m] >> (i - 1)) & 1u) continue;
+            const int rn = ri + EY[i] * RW + EX[i];
+            const double qx = s_ux[rn], qy = s_uy[rn];
+            pyx += 3. * W[i] * qy * (double)EX[i];
+            pxy += 3. * W[i] * qx * (double)EY[i];
+            px += 3. * W[i] * qx * (double)EX[i];
+            py += 3. * W[i] * qy * (double)EY[i];
+        }
+        const double K = ux * uy * (pyx + pxy) - uy * uy * px - ux * ux * py;
+        const double sgn = (p.wetting == 2) ? -0.5 : 0.5;
+        const double Fx = sgn * p.sigma * K * gx[m], Fy = sgn * p.sigma * K * gy[m];
+        const double rs = rB[m] + rR[m];
+        double *f = fT[m];
+        const double vx = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8] + 0.5 * p.F[idx]) / rs;
+        const double vy = (f[2] - f[4] + f[5] + f[6] - f[7] - f[8] + 0.5 * p.F[p.plane + idx]) / rs;
+        const double phi = (rR[m] - rB[m]) / (rR[m] + rB[m]);
+        p.F[idx] = Fx;
+        p.F[p.plane + idx] = Fy;
+        if (DIAG) {
+            p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K;
+            p.phi[idx] = phi; p.G[idx] = gx[m]; p.G[p.plane + idx] = gy[m];
+        }
+        collide<MRT>(p, f, rR[m], rB[m], phi, vx, vy, Fx, Fy);
+        double fR[9], fB[9];
+        recolor(p.beta, f, rR[m], rB[m], gx[m], gy[m], fR, fB);
+        double *fr = p.fout, *fb = p.fout + 9 * p.plane;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { fr[i * p.plane + idx] = fR[i]; fb[i * p.plane + idx] = fB[i]; }
+    }
+}
+
 // Observation kernels: populations/densities as the reference's device arrays hold them
 // after the last completed step (WITH_BC=false), or as resultInHDF5 records them at the
 // start of the next step (WITH_BC=true: + velocity, RKD2Q9.py:1382-1393).
@@ -568,9 +770,39 @@ RKDev make_dev(const lbmpm_rk2d *c)
 
 dim3 grid_of(const lbmpm_rk2d *c) { return dim3((c->nx + BX - 1) / BX, (c->ny + BY - 1) / BY); }
 
+using FusedDefault = FusedShape<16, 2>;
+
+template <bool FIRST>
+int launch_fused(lbmpm_rk2d *c, bool diag, bool timed)
+{
+    using SH = FusedDefault;
+    RKDev p = make_dev(c);
+    const int tiles_x = (c->nx + SH::TW - 1) / SH::TW, tiles_y = (c->ny + SH::TH - 1) / SH::TH;
+    const dim3 g(tiles_x * tiles_y), b(SH::THREADS);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool ev = timed && c->pool.take(&e0, &e1);
+    if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+    const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
+    if (mrt) {
+        if (diag) rk2d_fused<FIRST, true, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+        else rk2d_fused<FIRST, true, false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+    } else {
+        if (diag) rk2d_fused<FIRST, false, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+        else rk2d_fused<FIRST, false, false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+    }
+    if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
+    LBMPM_HIP_TRY(hipGetLastError());
+    std::swap(c->fA, c->fB);
+    c->streamed = true;
+    c->diag_valid = diag;
+    c->steps += 1;
+    return LBMPM_OK;
+}
+
 template <bool FIRST>
 int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
 {
+    if (c->cfg.variant == 0) return launch_fused<FIRST>(c, diag, timed);
     RKDev p = make_dev(c);
     const dim3 g = grid_of(c), b(BX, BY);
     rk2d_phase_field<FIRST><<<g, b, 0, c->stream>>>(p);
@@ -614,8 +846,10 @@ int dev_alloc(lbmpm_rk2d *c, T **ptr, size_t count)
         set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
         return LBMPM_ERR_NOMEM;
     }
-    e = hipMemset(v, 0, count * sizeof(T));
-    if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
+    // zero on the context's own stream: a null-stream memset is not ordered against the
+    // non-blocking solver stream and could land after a kernel that already wrote the buffer
+    e = hipMemsetAsync(v, 0, count * sizeof(T), c->stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
     *ptr = static_cast<T *>(v);
     c->bytes += (int64_t)(count * sizeof(T));
     return LBMPM_OK;
@@ -634,6 +868,7 @@ extern "C" int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is
     LBMPM_REQUIRE(cfg->inlet_type == 0 || cfg->inlet_type == 1, "bad inlet_type %d", cfg->inlet_type);
     LBMPM_REQUIRE(cfg->outlet_type == 0 || cfg->outlet_type == 1, "bad outlet_type %d", cfg->outlet_type);
     LBMPM_REQUIRE(cfg->tau_r > 0.5 && cfg->tau_b > 0.5, "TauR/TauB must exceed 0.5");
+    LBMPM_REQUIRE(cfg->variant == 0 || cfg->variant == 1, "variant must be 0 (fused) or 1 (split), got %d", cfg->variant);
     LBMPM_HIP_TRY(hipSetDevice(cfg->device));
     lbmpm_rk2d *c = new (std::nothrow) lbmpm_rk2d();
     if (!c) { set_error("out of host memory"); return LBMPM_ERR_NOMEM; }
@@ -665,7 +900,10 @@ extern "C" int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is
     TRY_RC(dev_alloc(c, &c->phi, c->plane));
     TRY_RC(dev_alloc(c, &c->G, 2 * c->plane));
     {
-        hipError_t e = hipMemcpy(c->flags, hflags.data(), c->plane, hipMemcpyHostToDevice);
+        // every transfer goes through the context's stream: the null stream is not ordered
+        // against it (hipStreamNonBlocking)
+        hipError_t e = hipMemcpyAsync(c->flags, hflags.data(), c->plane, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { set_error("hipMemcpy(flags) failed: %s", hipGetErrorString(e)); lbmpm_rk2d_destroy(c); return LBMPM_ERR_HIP; }
     }
     const dim3 b(64, 4), g((c->nx + 63) / 64, (c->ny + 3) / 4);
@@ -724,9 +962,9 @@ extern "C" int lbmpm_rk2d_set_pdf(lbmpm_rk2d *c, const double *pdf_r, const doub
                 h[(9 + i) * c->plane + d] = pdf_b[s + i];
             }
         }
+    LBMPM_HIP_TRY(hipMemcpyAsync(c->fA, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    LBMPM_HIP_TRY(hipMemsetAsync(c->F, 0, 2 * c->plane * sizeof(double), c->stream));
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
-    LBMPM_HIP_TRY(hipMemcpy(c->fA, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
-    LBMPM_HIP_TRY(hipMemset(c->F, 0, 2 * c->plane * sizeof(double)));
     c->streamed = false;
     c->diag_valid = false;
     c->steps = 0;
@@ -816,7 +1054,8 @@ namespace {
 int copy_plane(lbmpm_rk2d *c, const double *dev, double *out, int ncomp)
 {   // device SoA [ncomp][plane] -> host dense AoS [ny][nx][ncomp], zeros at solid
     std::vector<double> h((size_t)ncomp * c->plane);
-    LBMPM_HIP_TRY(hipMemcpy(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    LBMPM_HIP_TRY(hipMemcpyAsync(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     for (int y = 0; y < c->ny; ++y)
         for (int x = 0; x < c->nx; ++x) {
             const size_t k = (size_t)y * c->nx + x, d = (size_t)y * c->pitch + x;
@@ -858,6 +1097,11 @@ extern "C" int lbmpm_rk2d_get_field(lbmpm_rk2d *c, int field, double *out)
             case 5: return copy_plane(c, c->obs + 21 * c->plane, out, 1);
         }
     }
+    if (c->cfg.variant == 0 && field >= LBMPM_RK_PHI && field <= LBMPM_RK_GY && !(c->diag && c->diag_valid)) {
+        set_error("field %d needs lbmpm_rk2d_enable_diagnostics(ctx, 1) before the last lbmpm_rk2d_step "
+                  "(the fused schedule keeps phi and G on chip)", field);
+        return LBMPM_ERR_STATE;
+    }
     switch (field) {
         case LBMPM_RK_PHI: return copy_plane(c, c->phi, out, 1);
         case LBMPM_RK_GX: return copy_plane(c, c->G, out, 1);
@@ -881,6 +1125,5 @@ extern "C" int64_t lbmpm_rk2d_steps_done(const lbmpm_rk2d *c) { return c ? c->st
 extern "C" int64_t lbmpm_rk2d_device_bytes(const lbmpm_rk2d *c) { return c ? c->bytes : 0; }
 extern "C" const char *lbmpm_rk2d_dominant_kernel(const lbmpm_rk2d *c)
 {
-    (void)c;
-    return "rk2d_collide_stream";
+    return (c && c->cfg.variant == 0) ? "rk2d_fused" : "rk2d_collide_stream";
 }

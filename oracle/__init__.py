@@ -22,8 +22,39 @@ def build(force=False):
     return so
 
 
-def lib():
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the host's cores inside a quota-limited container, and an OpenMP
+    team larger than the quota spins itself to a crawl)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:    # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                quota = int(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                period = int(fh.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def lib(threads=None):
+    """Load the oracle; OpenMP team = min(usable cores, LBMPM_ORACLE_THREADS or 16)."""
     global _LIB
     if _LIB is None:
         _LIB = ctypes.CDLL(build())
+        cap = int(os.environ.get("LBMPM_ORACLE_THREADS", "16"))
+        _LIB.rk_oracle_set_threads(ctypes.c_int(min(usable_cores(), cap)))
+    if threads is not None:
+        _LIB.rk_oracle_set_threads(ctypes.c_int(int(threads)))
     return _LIB

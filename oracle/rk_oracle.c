@@ -750,6 +750,16 @@ void rk_csf_run(rk_sim *s, i64 nsteps)
     for (i64 k = 0; k < nsteps; ++k) rk_csf_step(s);
 }
 
+void rk_oracle_set_threads(int n)
+{
+#if defined(_OPENMP)
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int rk_oracle_threads(void)
 {
 #if defined(_OPENMP)
