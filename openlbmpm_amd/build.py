@@ -14,7 +14,8 @@ LIB = os.path.join(PKG, "liblbmpm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: keep the reference's evaluation order (no FMA contraction); the
 # kernels are HBM-bound, so this costs nothing measurable and tightens parity.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-ffp-contract=" + os.environ.get("LBMPM_FP_CONTRACT", "off"),
          "-Wall", "-Wno-unused-function"]
 
 

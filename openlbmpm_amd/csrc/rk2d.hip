@@ -17,6 +17,7 @@
 #include "lbmpm_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -36,38 +37,41 @@ struct RKDev {
     double *diag;      // [3][plane] vx, vy, K  (nullptr = off)
     double sigma, cosT, sinT, beta, delta, tauR, tauB, vyIn, pInB, pInR, pOut;
     int wetting, tautype, inlet, outlet;
+    int first;         // 1: fin holds the initial (already post-streaming) state
 };
 
 __device__ __forceinline__ int wrapi(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
 
 // ---------------------------------------------------------------- streaming (pull)
 // AcceleratedRKGPU2D.py:340-417 calStreaming1GPU + calStreaming2GPU, in pull form.
-template <bool FIRST>
 __device__ __forceinline__ void pull_node(const RKDev &p, int x, int y, double fR[9], double fB[9])
 {
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY, OPP[9] = LBMPM_D2Q9_OPP;
     const size_t idx = (size_t)y * p.pitch + x;
     const double *fr = p.fin;
     const double *fb = p.fin + 9 * p.plane;
-    if (FIRST) {   // initial state is already "post-streaming" (RKD2Q9.py:1243-1247)
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { fR[i] = fr[i * p.plane + idx]; fB[i] = fb[i * p.plane + idx]; }
-        return;
-    }
-    const unsigned sn = p.solidnbr[idx];
+    // p.first: the initial state is already "post-streaming" (RKD2Q9.py:1243-1247) -> read in place
+    const bool first = p.first != 0;
+    const unsigned sn = first ? 0u : p.solidnbr[idx];
+    // All 18 loads are issued without waiting for the solid-neighbour byte (solid nodes hold
+    // finite junk that is never used); the rare bounce-back links are patched afterwards.
     fR[0] = fr[idx];
     fB[0] = fb[idx];
 #pragma unroll
     for (int i = 1; i < 9; ++i) {
-        const int o = OPP[i];
-        if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
-            fR[i] = fr[o * p.plane + idx];
-            fB[i] = fb[o * p.plane + idx];
-        } else {
-            const int xs = wrapi(x - EX[i], p.nx), ys = wrapi(y - EY[i], p.ny);
-            const size_t s = (size_t)ys * p.pitch + xs;
-            fR[i] = fr[i * p.plane + s];
-            fB[i] = fb[i * p.plane + s];
+        const int xs = wrapi(x - EX[i], p.nx), ys = wrapi(y - EY[i], p.ny);
+        const size_t s = first ? idx : (size_t)ys * p.pitch + xs;
+        fR[i] = fr[i * p.plane + s];
+        fB[i] = fb[i * p.plane + s];
+    }
+    if (sn != 0) {
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            const int o = OPP[i];
+            if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
+                fR[i] = fr[o * p.plane + idx];
+                fB[i] = fb[o * p.plane + idx];
+            }
         }
     }
 }
@@ -138,7 +142,7 @@ __device__ __forceinline__ void bc_outlet_pressure(double pL, double fR[9], doub
 //                      (ghostPointsConstPressureLowerRK, A:1045-1081; the reference tests the
 //                       COMPACT index < nx, which is row 0 whenever row 0 is all fluid)
 //   outlet 'Convective': rows 2,1,0 <- row 3, rho re-summed (A:700-784)
-template <bool FIRST, bool WITH_BC>
+template <bool WITH_BC>
 __device__ __forceinline__ void node_state(const RKDev &p, int x, int y, double fR[9], double fB[9],
                                            double &rhoR, double &rhoB)
 {
@@ -148,7 +152,7 @@ __device__ __forceinline__ void node_state(const RKDev &p, int x, int y, double 
         if (p.outlet == LBMPM_OUTLET_PRESSURE) { if (y == 0) ys = 1; }
         else { if (y <= 2) ys = 3; }
     }
-    pull_node<FIRST>(p, x, ys, fR, fB);
+    pull_node(p, x, ys, fR, fB);
     rhoR = sum9(fR);
     rhoB = sum9(fB);
     if (!WITH_BC) return;
@@ -191,111 +195,87 @@ __device__ __forceinline__ double feq(double rho, double w, double ex, double ey
                            1.5 * (vx * vx + vy * vy)));
 }
 
-// Lallemand-Luo moment basis exactly as assembled in RKD2Q9.py:308-336; its rows are
-// mutually orthogonal, so M^-1 = M^T diag(1/|row|^2) (the reference inverts numerically).
-__device__ __forceinline__ void to_moments(const double d[9], double m[9])
-{
-    constexpr int M[9][9] = {{1, 1, 1, 1, 1, 1, 1, 1, 1},      {-4, -1, -1, -1, -1, 2, 2, 2, 2},
-                             {4, -2, -2, -2, -2, 1, 1, 1, 1},  {0, 1, 0, -1, 0, 1, -1, -1, 1},
-                             {0, -2, 0, 2, 0, 1, -1, -1, 1},   {0, 0, 1, 0, -1, 1, 1, -1, -1},
-                             {0, 0, -2, 0, 2, 1, 1, -1, -1},   {0, 1, -1, 1, -1, 0, 0, 0, 0},
-                             {0, 0, 0, 0, 0, 1, -1, 1, -1}};
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        double t = 0.;
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            if (M[i][j] != 0) t += (double)M[i][j] * d[j];
-        m[i] = t;
-    }
-}
-
-__device__ __forceinline__ void from_moments(const double m[9], double d[9])
-{
-    constexpr int M[9][9] = {{1, 1, 1, 1, 1, 1, 1, 1, 1},      {-4, -1, -1, -1, -1, 2, 2, 2, 2},
-                             {4, -2, -2, -2, -2, 1, 1, 1, 1},  {0, 1, 0, -1, 0, 1, -1, -1, 1},
-                             {0, -2, 0, 2, 0, 1, -1, -1, 1},   {0, 0, 1, 0, -1, 1, 1, -1, -1},
-                             {0, 0, -2, 0, 2, 1, 1, -1, -1},   {0, 1, -1, 1, -1, 0, 0, 0, 0},
-                             {0, 0, 0, 0, 0, 1, -1, 1, -1}};
-    constexpr double INV_N2[9] = {1. / 9., 1. / 36., 1. / 36., 1. / 6., 1. / 12., 1. / 6., 1. / 12., 1. / 4., 1. / 4.};
-    double s[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s[j] = m[j] * INV_N2[j];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        double t = 0.;
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            if (M[j][i] != 0) t += (double)M[j][i] * s[j];
-        d[i] = t;
-    }
-}
-
 // Collision + Guo forcing on f_tot.
 //   SRT: calRKCollision1TotalGPU2DSRTM A:1804-1848, calPerturbationFromForce2D A:1743-1798
 //   MRT: calRKCollision1TotalGPU2DMRTM A:1938-2017, calPerturbationFromForce2DMRT A:2027-2113
 //        S = diag(0,1.64,1.54,0,1.9,0,1.9,1/tau,1/tau) with tau evaluated per node.
+// The reference multiplies (f - f_eq) and the source term by M, S and M^-1 as dense 9x9
+// loops; here the same algebra is done in moment space: M f_eq and M src are known in
+// closed form for this basis (verified against the matrices in tests/test_lattice.py),
+//   m_eq  = rho (1, -2+3u^2, 1-3u^2, ux, -ux, uy, -uy, ux^2-uy^2, ux uy)
+//   m_src = (0, 6u.F, -6u.F, Fx, -Fx, Fy, -Fy, 2(uxFx-uyFy), uxFy+uyFx)
+// and M^-1 = M^T diag(1/|row|^2).  Differences to the dense form are rounding-level.
 template <bool MRT>
 __device__ __forceinline__ void collide(const RKDev &p, double fT[9], double rhoR, double rhoB, double phi,
                                         double vx, double vy, double Fx, double Fy)
 {
-    constexpr double W[9] = LBMPM_D2Q9_W;
-    constexpr int EXi[9] = LBMPM_D2Q9_EX, EYi[9] = LBMPM_D2Q9_EY;
     const double tau = tau_of(p, phi, rhoR, rhoB);
+    const double rho = rhoR + rhoB;
+    const double usq = vx * vx + vy * vy;
     if (!MRT) {
+        constexpr double W[9] = LBMPM_D2Q9_W;
+        constexpr int EXi[9] = LBMPM_D2Q9_EX, EYi[9] = LBMPM_D2Q9_EY;
+        const double om = 1. / tau, sf = 1. - 1. / (2. * tau);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const double ex = EXi[i], ey = EYi[i];
-            const double eT = feq(rhoR, W[i], ex, ey, vx, vy) + feq(rhoB, W[i], ex, ey, vx, vy);
-            double f = -1. / tau * (fT[i] - eT) + fT[i];
-            const double src = W[i] * ((3. * (ex - vx) + 9. * ex * (ex * vx + ey * vy)) * Fx +
-                                       (3. * (ey - vy) + 9. * ey * (ex * vx + ey * vy)) * Fy) *
-                               (1. - 1. / (2. * tau));
-            fT[i] = f + src;
+            const double eu = ex * vx + ey * vy;
+            const double eT = rho * W[i] * (1. + (3. * eu + 4.5 * eu * eu - 1.5 * usq));
+            const double src = W[i] * ((3. * (ex - vx) + 9. * ex * eu) * Fx + (3. * (ey - vy) + 9. * ey * eu) * Fy) * sf;
+            fT[i] = (fT[i] - om * (fT[i] - eT)) + src;
         }
     } else {
-        double d[9], src[9], m[9], ms[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const double ex = EXi[i], ey = EYi[i];
-            d[i] = fT[i] - (feq(rhoR, W[i], ex, ey, vx, vy) + feq(rhoB, W[i], ex, ey, vx, vy));
-            const double t1 = ex * Fx * 3.;
-            const double t2 = ey * Fy * 3.;
-            const double t3 = (ex * ex - 1. / 3.) * vx * Fx * 9.;
-            const double t4 = ex * ey * vy * Fx * 9.;
-            const double t5 = ey * ex * vx * Fy * 9.;
-            const double t6 = (ey * ey - 1. / 3.) * vy * Fy * 9.;
-            src[i] = W[i] * (t1 + t2 + t3 + t4 + t5 + t6);
-        }
-        to_moments(d, m);
-        to_moments(src, ms);
-        const double S[9] = {0., 1.64, 1.54, 0., 1.9, 0., 1.9, 1. / tau, 1. / tau};
-#pragma unroll
-        for (int i = 0; i < 9; ++i) m[i] = (1. - 0.5 * S[i]) * ms[i] - S[i] * m[i];
-        from_moments(m, d);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) fT[i] += d[i];
+        const double f0 = fT[0], f1 = fT[1], f2 = fT[2], f3 = fT[3], f4 = fT[4], f5 = fT[5], f6 = fT[6],
+                     f7 = fT[7], f8 = fT[8];
+        const double sa = (f1 + f2) + (f3 + f4), sd = (f5 + f6) + (f7 + f8);
+        // non-conserved moments of f_tot (rows 1,2,4,6,7,8 of M; rows 0,3,5 carry S = 0)
+        const double m1 = -4. * f0 - sa + 2. * sd;
+        const double m2 = 4. * f0 - 2. * sa + sd;
+        const double m4 = -2. * (f1 - f3) + ((f5 - f6) - (f7 - f8));
+        const double m6 = -2. * (f2 - f4) + ((f5 + f6) - (f7 + f8));
+        const double m7 = (f1 - f2) + (f3 - f4);
+        const double m8 = (f5 - f6) + (f7 - f8);
+        const double uF = vx * Fx + vy * Fy;
+        const double s7 = 1. / tau;
+        // r = -S (m - m_eq) + (1 - S/2) m_src, pre-divided by |row|^2
+        const double r1 = ((1. - 0.5 * 1.64) * (6. * uF) - 1.64 * (m1 - rho * (-2. + 3. * usq))) * (1. / 36.);
+        const double r2 = ((1. - 0.5 * 1.54) * (-6. * uF) - 1.54 * (m2 - rho * (1. - 3. * usq))) * (1. / 36.);
+        const double r3 = Fx * (1. / 6.);
+        const double r4 = ((1. - 0.5 * 1.9) * (-Fx) - 1.9 * (m4 + rho * vx)) * (1. / 12.);
+        const double r5 = Fy * (1. / 6.);
+        const double r6 = ((1. - 0.5 * 1.9) * (-Fy) - 1.9 * (m6 + rho * vy)) * (1. / 12.);
+        const double r7 = ((1. - 0.5 * s7) * (2. * (vx * Fx - vy * Fy)) - s7 * (m7 - rho * (vx * vx - vy * vy))) * 0.25;
+        const double r8 = ((1. - 0.5 * s7) * (vx * Fy + vy * Fx) - s7 * (m8 - rho * (vx * vy))) * 0.25;
+        // f += M^T r
+        const double a = -r1 - 2. * r2, d = 2. * r1 + r2;
+        fT[0] = f0 + (-4. * r1 + 4. * r2);
+        fT[1] = f1 + (a + r3 - 2. * r4 + r7);
+        fT[2] = f2 + (a + r5 - 2. * r6 - r7);
+        fT[3] = f3 + (a - r3 + 2. * r4 + r7);
+        fT[4] = f4 + (a - r5 + 2. * r6 - r7);
+        fT[5] = f5 + (d + r3 + r4 + r5 + r6 + r8);
+        fT[6] = f6 + (d - r3 - r4 + r5 + r6 - r8);
+        fT[7] = f7 + (d - r3 - r4 - r5 - r6 + r8);
+        fT[8] = f8 + (d + r3 + r4 - r5 - r6 - r8);
     }
 }
 
-// calRecoloringProcessM, A:1857-1899
+// calRecoloringProcessM, A:1857-1899.  cos(phi_i)|e_i| = (e_i . G)/|G| for every direction
+// (the |e_i| factors cancel), so one reciprocal replaces the reference's eight divisions.
 __device__ __forceinline__ void recolor(double beta, const double fT[9], double rhoR, double rhoB, double gx,
                                         double gy, double fR[9], double fB[9])
 {
     constexpr double W[9] = LBMPM_D2Q9_W;
     constexpr int EXi[9] = LBMPM_D2Q9_EX, EYi[9] = LBMPM_D2Q9_EY;
     const double gn = sqrt(gx * gx + gy * gy);
-    const double tot = rhoR + rhoB;
-    const double SQ2 = sqrt(2.);
+    const double itot = 1. / (rhoR + rhoB);
+    const double kR = rhoR * itot, kB = rhoB * itot;
+    const double A = (gn > 1.0e-8) ? beta * rhoR * rhoB * itot / gn : 0.;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const double ex = EXi[i], ey = EYi[i];
-        const double un = (i == 0) ? 0. : (i < 5 ? 1. : SQ2);
-        double c = 0.;
-        if (gn > 1.0e-8 && un > 1.0e-8) c = (ex * gx + ey * gy) / (un * gn);
-        const double a = beta * rhoR * rhoB / tot * W[i] * c * un;
-        fR[i] = rhoR / tot * fT[i] + a;
-        fB[i] = rhoB / tot * fT[i] - a;
+        const double a = A * W[i] * ((double)EXi[i] * gx + (double)EYi[i] * gy);
+        fR[i] = kR * fT[i] + a;
+        fB[i] = kB * fT[i] - a;
     }
 }
 
@@ -344,15 +324,14 @@ __device__ __forceinline__ void unit_normal(int wetting, double gx, double gy, d
 {
     const double n = sqrt(gx * gx + gy * gy);
     ux = 0.; uy = 0.;
-    if (wetting == 2) { if (n > 1.0e-8) { ux = -gx / n; uy = -gy / n; } }
-    else { if (n > 0.) { ux = gx / n; uy = gy / n; } }
+    if (wetting == 2) { if (n > 1.0e-8) { const double r = -1. / n; ux = gx * r; uy = gy * r; } }
+    else { if (n > 0.) { const double r = 1. / n; ux = gx * r; uy = gy * r; } }
 }
 
 // ---------------------------------------------------------------- kernels (split schedule)
 constexpr int BX = 64, BY = 4;
 
 // K1: phase field of the post-streaming, post-BC state (calPhaseFieldPhi A:1348)
-template <bool FIRST>
 __global__ __launch_bounds__(BX *BY) void rk2d_phase_field(RKDev p)
 {
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
@@ -360,7 +339,7 @@ __global__ __launch_bounds__(BX *BY) void rk2d_phase_field(RKDev p)
     const size_t idx = (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
     double fR[9], fB[9], rR, rB;
-    node_state<FIRST, true>(p, x, y, fR, fB, rR, rB);
+    node_state<true>(p, x, y, fR, fB, rR, rB);
     p.phi[idx] = (rR - rB) / (rR + rB);
 }
 
@@ -408,7 +387,7 @@ __global__ __launch_bounds__(BX *BY) void rk2d_gradient(RKDev p)
 
 // K3: everything else of the step (dominant kernel): stream+BC, u, curvature + CSF force,
 // collision + forcing, recolouring, store post-collision populations.
-template <bool FIRST, bool MRT, bool DIAG>
+template <bool MRT>
 __global__ __launch_bounds__(BX *BY) void rk2d_collide_stream(RKDev p)
 {
     constexpr double W[9] = LBMPM_D2Q9_W;
@@ -418,7 +397,7 @@ __global__ __launch_bounds__(BX *BY) void rk2d_collide_stream(RKDev p)
     const size_t idx = (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
     double fR[9], fB[9], rR, rB;
-    node_state<FIRST, true>(p, x, y, fR, fB, rR, rB);
+    node_state<true>(p, x, y, fR, fB, rR, rB);
     double fT[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) fT[i] = fR[i] + fB[i];          // calTotalFluidPDF A:1414
@@ -450,7 +429,7 @@ __global__ __launch_bounds__(BX *BY) void rk2d_collide_stream(RKDev p)
     const double Fx = sgn * p.sigma * K * gx, Fy = sgn * p.sigma * K * gy;
     p.F[idx] = Fx;
     p.F[p.plane + idx] = Fy;
-    if (DIAG) { p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K; }
+    if (p.diag) { p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K; }
     collide<MRT>(p, fT, rR, rB, phi, vx, vy, Fx, Fy);
     recolor(p.beta, fT, rR, rB, gx, gy, fR, fB);
     double *fr = p.fout, *fb = p.fout + 9 * p.plane;
@@ -482,7 +461,7 @@ __device__ __forceinline__ int wrapm(int v, int n)
     return v < 0 ? v + n : v;
 }
 
-template <bool FIRST, bool MRT, bool DIAG, typename SH>
+template <bool MRT, typename SH>
 __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
 {
     constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
@@ -502,7 +481,8 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
 
-    // fluid mask of the region
+    // fluid mask of the region (issued first so that the wait for it leaves the population
+    // loads below in flight)
     bool any_solid = false;
     for (int n = tid; n < RH * RW; n += THREADS) {
         const int rx = n % RW, ry = n / RW;
@@ -511,34 +491,35 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
         s_fluid[n] = fl;
         if (!fl && rx >= 1 && rx < RW - 1 && ry >= 1 && ry < RH - 1) any_solid = true;
     }
-    const bool need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
 
     // ---- phase A: interior nodes (owner keeps f_tot, rho in registers)
-    double fT[NT][9], rR[NT], rB[NT];
+    double fT[NT][9], rR[NT], rB[NT], Fpx[NT], Fpy[NT];
     unsigned sn[NT];
     bool act[NT];
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
         const int x = tx0 + lx, y = ty0 + ly + m * TY;
         const int ri = (H + ly + m * TY) * RW + H + lx;
-        act[m] = (x < p.nx) && (y < p.ny) && s_fluid[ri];
-        sn[m] = 0;
-        if (act[m]) {
+        const bool inside = (x < p.nx) && (y < p.ny);
+        // nodes beyond the lattice edge of a partial tile are periodic images of real nodes
+        // and serve as halo for the valid part of the tile
+        const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);
+        const size_t idx = (size_t)yw * p.pitch + xw;
+        const bool fluid = p.flags[idx] & 1;
+        act[m] = inside && fluid;
+        sn[m] = 0; Fpx[m] = 0.; Fpy[m] = 0.;
+        if (fluid) {
             double fR[9], fB[9];
-            node_state<FIRST, true>(p, x, y, fR, fB, rR[m], rB[m]);
+            sn[m] = p.solidnbr[idx];
+            Fpx[m] = p.F[idx];
+            Fpy[m] = p.F[p.plane + idx];
+            node_state<true>(p, xw, yw, fR, fB, rR[m], rB[m]);
 #pragma unroll
             for (int i = 0; i < 9; ++i) fT[m][i] = fR[i] + fB[i];
             s_phi[ri] = (rR[m] - rB[m]) / (rR[m] + rB[m]);
-            sn[m] = p.solidnbr[(size_t)y * p.pitch + x];
-        } else if (s_fluid[ri]) {
-            // fluid node beyond the lattice edge of a partial tile: it is the periodic image
-            // of a real node and serves as halo for the valid part of the tile
-            const int xw = wrapm(x, p.nx), yw = wrapm(y, p.ny);
-            double fR[9], fB[9], a, c;
-            node_state<FIRST, true>(p, xw, yw, fR, fB, a, c);
-            s_phi[ri] = (a - c) / (a + c);
         }
     }
+    const bool need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
     // ---- phase A: halo nodes (phi only)
     constexpr int NHALO = 2 * H * RW + 2 * H * TH;
     for (int n = tid; n < NHALO; n += THREADS) {
@@ -551,7 +532,7 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
         if (!need3 && (rx == 0 || rx == RW - 1 || ry == 0 || ry == RH - 1)) continue;
         const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
         double fR[9], fB[9], a, c;
-        node_state<FIRST, true>(p, x, y, fR, fB, a, c);
+        node_state<true>(p, x, y, fR, fB, a, c);
         s_phi[ri] = (a - c) / (a + c);
     }
     __syncthreads();
@@ -642,12 +623,12 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
         const double Fx = sgn * p.sigma * K * gx[m], Fy = sgn * p.sigma * K * gy[m];
         const double rs = rB[m] + rR[m];
         double *f = fT[m];
-        const double vx = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8] + 0.5 * p.F[idx]) / rs;
-        const double vy = (f[2] - f[4] + f[5] + f[6] - f[7] - f[8] + 0.5 * p.F[p.plane + idx]) / rs;
+        const double vx = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8] + 0.5 * Fpx[m]) / rs;
+        const double vy = (f[2] - f[4] + f[5] + f[6] - f[7] - f[8] + 0.5 * Fpy[m]) / rs;
         const double phi = (rR[m] - rB[m]) / (rR[m] + rB[m]);
         p.F[idx] = Fx;
         p.F[p.plane + idx] = Fy;
-        if (DIAG) {
+        if (p.diag) {
             p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K;
             p.phi[idx] = phi; p.G[idx] = gx[m]; p.G[p.plane + idx] = gy[m];
         }
@@ -663,7 +644,7 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
 // Observation kernels: populations/densities as the reference's device arrays hold them
 // after the last completed step (WITH_BC=false), or as resultInHDF5 records them at the
 // start of the next step (WITH_BC=true: + velocity, RKD2Q9.py:1382-1393).
-template <bool FIRST, bool WITH_BC>
+template <bool WITH_BC>
 __global__ __launch_bounds__(BX *BY) void rk2d_observe(RKDev p, double *out /*[22][plane]*/)
 {
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
@@ -671,7 +652,7 @@ __global__ __launch_bounds__(BX *BY) void rk2d_observe(RKDev p, double *out /*[2
     const size_t idx = (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
     double fR[9], fB[9], rR, rB;
-    node_state<FIRST, WITH_BC>(p, x, y, fR, fB, rR, rB);
+    node_state<WITH_BC>(p, x, y, fR, fB, rR, rB);
 #pragma unroll
     for (int i = 0; i < 9; ++i) { out[i * p.plane + idx] = fR[i]; out[(9 + i) * p.plane + idx] = fB[i]; }
     out[18 * p.plane + idx] = rR;
@@ -743,6 +724,7 @@ struct lbmpm_rk2d {
     double *fA = nullptr, *fB = nullptr;   // ping-pong [2][9][plane]; fA holds the current state
     double *F = nullptr, *ns = nullptr, *phi = nullptr, *G = nullptr, *diag = nullptr, *obs = nullptr;
     std::vector<uint8_t> h_domain;
+    int shape = 0;            // fused tile shape (LBMPM_RK2D_SHAPE, tuning only)
     bool streamed = false;    // false: fA holds the initial (already "post-streaming") state
     bool diag_valid = false;
     int64_t steps = 0;
@@ -765,60 +747,48 @@ RKDev make_dev(const lbmpm_rk2d *c)
     p.pOut = c->cfg.outlet_rho_total;
     p.wetting = c->cfg.wetting_type; p.tautype = c->cfg.tau_type;
     p.inlet = c->cfg.inlet_type; p.outlet = c->cfg.outlet_type;
+    p.first = c->streamed ? 0 : 1;
     return p;
 }
 
 dim3 grid_of(const lbmpm_rk2d *c) { return dim3((c->nx + BX - 1) / BX, (c->ny + BY - 1) / BY); }
 
-using FusedDefault = FusedShape<16, 2>;
-
-template <bool FIRST>
-int launch_fused(lbmpm_rk2d *c, bool diag, bool timed)
+template <typename SH>
+void launch_fused_shape(lbmpm_rk2d *c, const RKDev &p)
 {
-    using SH = FusedDefault;
-    RKDev p = make_dev(c);
     const int tiles_x = (c->nx + SH::TW - 1) / SH::TW, tiles_y = (c->ny + SH::TH - 1) / SH::TH;
     const dim3 g(tiles_x * tiles_y), b(SH::THREADS);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool ev = timed && c->pool.take(&e0, &e1);
-    if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
-    const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
-    if (mrt) {
-        if (diag) rk2d_fused<FIRST, true, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
-        else rk2d_fused<FIRST, true, false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
-    } else {
-        if (diag) rk2d_fused<FIRST, false, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
-        else rk2d_fused<FIRST, false, false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
-    }
-    if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
-    LBMPM_HIP_TRY(hipGetLastError());
-    std::swap(c->fA, c->fB);
-    c->streamed = true;
-    c->diag_valid = diag;
-    c->steps += 1;
-    return LBMPM_OK;
+    if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2d_fused<true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+    else rk2d_fused<false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
 }
 
-template <bool FIRST>
 int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
 {
-    if (c->cfg.variant == 0) return launch_fused<FIRST>(c, diag, timed);
     RKDev p = make_dev(c);
-    const dim3 g = grid_of(c), b(BX, BY);
-    rk2d_phase_field<FIRST><<<g, b, 0, c->stream>>>(p);
-    rk2d_gradient<<<g, b, 0, c->stream>>>(p);
+    p.first = c->streamed ? 0 : 1;
+    if (!diag) p.diag = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool ev = timed && c->pool.take(&e0, &e1);
-    if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
-    const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
-    if (mrt) {
-        if (diag) rk2d_collide_stream<FIRST, true, true><<<g, b, 0, c->stream>>>(p);
-        else rk2d_collide_stream<FIRST, true, false><<<g, b, 0, c->stream>>>(p);
+    if (c->cfg.variant == 0) {
+        const bool ev = timed && c->pool.take(&e0, &e1);
+        if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+        switch (c->shape) {
+            // tile-shape sweep on MI355X (1024^2): 64x8 / 1 node per thread is the
+            // default; the others stay selectable for tuning (LBMPM_RK2D_SHAPE)
+            case 1: launch_fused_shape<FusedShape<16, 2>>(c, p); break;
+            case 2: launch_fused_shape<FusedShape<16, 1>>(c, p); break;
+            default: launch_fused_shape<FusedShape<8, 1>>(c, p); break;
+        }
+        if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     } else {
-        if (diag) rk2d_collide_stream<FIRST, false, true><<<g, b, 0, c->stream>>>(p);
-        else rk2d_collide_stream<FIRST, false, false><<<g, b, 0, c->stream>>>(p);
+        const dim3 g = grid_of(c), b(BX, BY);
+        rk2d_phase_field<<<g, b, 0, c->stream>>>(p);
+        rk2d_gradient<<<g, b, 0, c->stream>>>(p);
+        const bool ev = timed && c->pool.take(&e0, &e1);
+        if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+        if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2d_collide_stream<true><<<g, b, 0, c->stream>>>(p);
+        else rk2d_collide_stream<false><<<g, b, 0, c->stream>>>(p);
+        if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     }
-    if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     LBMPM_HIP_TRY(hipGetLastError());
     std::swap(c->fA, c->fB);
     c->streamed = true;
@@ -831,7 +801,7 @@ int run_steps(lbmpm_rk2d *c, int64_t n, bool timed)
 {
     for (int64_t k = 0; k < n; ++k) {
         const bool diag = (c->diag != nullptr) && (k == n - 1);
-        const int rc = c->streamed ? launch_step<false>(c, diag, timed) : launch_step<true>(c, diag, timed);
+        const int rc = launch_step(c, diag, timed);
         if (rc != LBMPM_OK) return rc;
     }
     return LBMPM_OK;
@@ -873,6 +843,7 @@ extern "C" int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is
     lbmpm_rk2d *c = new (std::nothrow) lbmpm_rk2d();
     if (!c) { set_error("out of host memory"); return LBMPM_ERR_NOMEM; }
     c->cfg = *cfg;
+    if (const char *e = getenv("LBMPM_RK2D_SHAPE")) c->shape = atoi(e);
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny;
     c->pitch = (c->nx + 31) / 32 * 32;           // rows start on 256-byte boundaries
     c->plane = (size_t)c->pitch * c->ny;
@@ -1078,13 +1049,8 @@ extern "C" int lbmpm_rk2d_get_field(lbmpm_rk2d *c, int field, double *out)
         if (!c->obs) { const int rc = dev_alloc(c, &c->obs, 22 * c->plane); if (rc) return rc; }
         RKDev p = make_dev(c);
         const dim3 g = grid_of(c), b(BX, BY);
-        if (rec) {
-            if (c->streamed) rk2d_observe<false, true><<<g, b, 0, c->stream>>>(p, c->obs);
-            else rk2d_observe<true, true><<<g, b, 0, c->stream>>>(p, c->obs);
-        } else {
-            if (c->streamed) rk2d_observe<false, false><<<g, b, 0, c->stream>>>(p, c->obs);
-            else rk2d_observe<true, false><<<g, b, 0, c->stream>>>(p, c->obs);
-        }
+        if (rec) rk2d_observe<true><<<g, b, 0, c->stream>>>(p, c->obs);
+        else rk2d_observe<false><<<g, b, 0, c->stream>>>(p, c->obs);
         LBMPM_HIP_TRY(hipGetLastError());
         LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
         const int f = rec ? field - LBMPM_RK_REC_PDF_R : field;

@@ -19,12 +19,12 @@ def main():
         print("%-110s %8d %14.3f %12.3f %8.2f" % (name[:110], calls, total, avg, pct))
     if "--pmc" in sys.argv:
         try:
+            # pmc_events holds one row per (dispatch, counter, hardware instance); sum the
+            # instances of a dispatch, then average over dispatches of the same kernel
             rows = list(c.execute(
-                "select k.name, p.name, count(*), avg(e.value), sum(e.value) "
-                "from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
-                "join rocpd_kernel_dispatch d on e.event_id = d.event_id "
-                "join rocpd_info_kernel_symbol k on d.kernel_id = k.id "
-                "group by k.name, p.name order by k.name"))
+                "select name, counter_name, count(*), avg(v), sum(v) from "
+                "(select name, counter_name, dispatch_id, sum(counter_value) as v from pmc_events "
+                " group by name, counter_name, dispatch_id) group by name, counter_name order by name"))
         except sqlite3.Error as ex:
             rows = []
             print("# pmc query failed: %s" % ex)
