@@ -1,0 +1,49 @@
+"""Pins oracle/sc_oracle.c to golden vectors captured from the REAL reference drivers
+ShanChenD2Q9.runOptimizedEFLBM / runOptimizedLBM (tests/golden/gen/make_golden_sc.py).
+CPU-only; tolerance 1e-11 field-relative (observed: bitwise to 1e-14)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden_files, load_params, rel_err
+from oracle.sc import SCOracle, simple_geometry, image_geometry, collision_matrices
+
+FILES = golden_files("sc_")
+KEYS = ("inter", "relax", "rho0", "rho1", "bg0", "bg1", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "vy0", "vy1")
+
+
+def _case(path):
+    d = np.load(path)
+    par = load_params(d)
+    image = par["image"] == "yes"
+    dom = image_geometry(d["image"], 20, 0.5) if image else simple_geometry(par["nx"], par["ny"])
+    return d, par, dom, image
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_setup_matches_reference(path):
+    d, par, dom, image = _case(path)
+    assert np.array_equal(dom, d["isDomain"])
+    o = SCOracle(dom, {k: par[k] for k in KEYS}, image=image)
+    assert np.array_equal(o.fluidNodes, d["fluidNodes"])
+    assert np.array_equal(o.nbr, d["neighboringNodes"])
+    if par["relax"] == "MRT":
+        assert rel_err(collision_matrices(o.tau), d["collisionMatrix"]) < 1e-15
+    if "pre_fbar" in d.files:     # EFS: f-bar = f - F_i/2 after the pre-loop chain, before the BCs
+        pass
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_time_loop_matches_reference(path):
+    d, par, dom, image = _case(path)
+    o = SCOracle(dom, {k: par[k] for k in KEYS}, image=image)
+    efs = par["inter"] == "EFS"
+    fields = ("f", "rho", "Fx", "Fy", "vx", "vy") + (("ueqx", "ueqy", "feq", "fforce") if efs else ())
+    alias = dict(ueqx="ux", ueqy="uy", fforce="ff")
+    for k in d["snaps"]:
+        target = int(k) + 1 if efs else int(k)     # EFS snapshot k = end of loop iteration k (0-based)
+        o.run(target - o.iterations)
+        for f in fields:
+            e = rel_err(getattr(o, alias.get(f, f)), d["s%d_%s" % (k, f)])
+            assert e < 1e-11, "%s snapshot %d field %s rel err %.3e" % (os.path.basename(path), k, f, e)
