@@ -151,6 +151,70 @@ const char *lbmpm_rk2d_dominant_kernel(const lbmpm_rk2d *ctx);
 /* Device bytes held by the context. */
 int64_t lbmpm_rk2d_device_bytes(const lbmpm_rk2d *ctx);
 
+/* ------------------------------------------------------------------------------------
+ * Two-component Shan-Chen D2Q9 solver: original Shan-Chen (velocity-shift forcing) and the
+ * explicit forcing scheme "EFS" (Porter et al. 2012), SRT or MRT.
+ * Replaces the kernel sequences of ShanChenD2Q9.runOptimizedLBM (ShanChen2D/ShanChenD2Q9.py
+ * :1433-1629) and ShanChenD2Q9.runOptimizedEFLBM (:1631-2087), i.e. the @cuda.jit kernels
+ *   ShanChen2D/OptimizedD2Q9GPU.py: savePDFLastStep :70, calFluidRhoGPU :84,
+ *     calFluidPotentialGPUEql :99, calPhysicalVelocity :156, calMacroWholeVelocity :336,
+ *     calStreaming1GPU :452, calStreaming2GPU :539, constantPressureZouHeBoundaryLower :555,
+ *     ghostPointsConstantVelocityInlet :710, ghostPointsConstantPressureOutlet :743,
+ *     constantVelocityZouHeBoundaryHigher :839, convectiveOutletGPU/Ghost2GPU/Ghost3GPU
+ *     :960/:988/:1016, convectiveOutletEachGPU/Each2GPU/Each3GPU :1044/:1070/:1098,
+ *     interactionCollisionProcess :1274
+ *   ShanChen2D/ExplicitD2Q9GPU.py: calExplicit4thOrderScheme :51, calEquilibriumFuncEFGPU :227,
+ *     calForceDistrGPU :255, transformPDFGPU :278, calCollisionEXGPU :294,
+ *     calEquilibriumVEFGPU :340, transformPDFandEquil :1379, transfromForceTerm :1404,
+ *     transformEquilibriumVelocity :1426, calAfterCollisionMRT :1457
+ * Two fluids (NumberOfFluids = 2, like every shipped ini and the reference's outlet kernel),
+ * potential psi = rho ('Simple'), ExplicitScheme = 4, inlet 'Neumann'/'ZouHe'.
+ * ---------------------------------------------------------------------------------- */
+enum { LBMPM_SC_MODEL_SHANCHEN = 0, LBMPM_SC_MODEL_EFS = 1 };
+
+typedef struct lbmpm_sc2d_config {
+    int64_t nx, ny;
+    int32_t model;             /* [InterType] InteractionType: LBMPM_SC_MODEL_*           */
+    int32_t relaxation;        /* [RelaxationType] Type: LBMPM_RELAX_* (MRT: EFS only)     */
+    double tau[2];             /* [FluidProperties] FluidsTau                              */
+    double g_fluid;            /* InteractionFluid (G_01 = G_10; G_kk = 0)                 */
+    double g_solid[2];         /* InteractionSolid                                         */
+    int32_t outlet_type;       /* LBMPM_OUTLET_PRESSURE ('Dirichlet': densities 1.0/0.02 as
+                                  hard-coded in OptimizedD2Q9GPU.py:560) | _CONVECTIVE    */
+    double inlet_velocity_y[2];/* [VelocityBoundary] velocityY                             */
+    int32_t device;
+    int32_t variant;           /* 0 = default                                              */
+} lbmpm_sc2d_config;
+
+typedef struct lbmpm_sc2d lbmpm_sc2d;
+
+/* Fields describe the lattice as the reference's device arrays hold it at the END of the last
+ * completed loop iteration (EFS: after lbmpm_sc2d_step(n) the iterations 0..n-1 are complete). */
+typedef enum lbmpm_sc2d_field {
+    LBMPM_SC_PDF0 = 0, LBMPM_SC_PDF1 = 1,    /* [ny][nx][9]  deviceFluidPDF[k]             */
+    LBMPM_SC_RHO0 = 2, LBMPM_SC_RHO1 = 3,    /* [ny][nx]     deviceFluidRho[k]             */
+    LBMPM_SC_VX = 4, LBMPM_SC_VY = 5,        /* devicePhysicalVX/VY                        */
+    LBMPM_SC_FX0 = 6, LBMPM_SC_FX1 = 7, LBMPM_SC_FY0 = 8, LBMPM_SC_FY1 = 9, /* deviceForceX/Y[k] */
+    LBMPM_SC_UEQX = 10, LBMPM_SC_UEQY = 11   /* EFS: deviceEquilibriumVX/VY                */
+} lbmpm_sc2d_field;
+
+int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is_domain, lbmpm_sc2d **out);
+void lbmpm_sc2d_destroy(lbmpm_sc2d *ctx);
+/* dense host arrays [ny][nx][9] per component (fluidPDF[k], ShanChenD2Q9.py:738) */
+int lbmpm_sc2d_set_pdf(lbmpm_sc2d *ctx, const double *pdf0, const double *pdf1);
+/* f_k = w rho_k (ShanChenD2Q9.py:757-766) */
+int lbmpm_sc2d_set_density(lbmpm_sc2d *ctx, const double *rho0, const double *rho1);
+int lbmpm_sc2d_step(lbmpm_sc2d *ctx, int64_t nsteps);
+int lbmpm_sc2d_step_timed(lbmpm_sc2d *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
+int lbmpm_sc2d_sync(lbmpm_sc2d *ctx);
+/* keep forces / velocities of every step for lbmpm_sc2d_get_field (off by default) */
+int lbmpm_sc2d_enable_diagnostics(lbmpm_sc2d *ctx, int on);
+int lbmpm_sc2d_get_field(lbmpm_sc2d *ctx, int field, double *out);
+int64_t lbmpm_sc2d_num_fluid_nodes(const lbmpm_sc2d *ctx);
+int64_t lbmpm_sc2d_steps_done(const lbmpm_sc2d *ctx);
+const char *lbmpm_sc2d_dominant_kernel(const lbmpm_sc2d *ctx);
+int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,14 @@ class RK2DConfig(C.Structure):
                 ("device", C.c_int32), ("variant", C.c_int32)]
 
 
+class SC2DConfig(C.Structure):
+    # mirrors struct lbmpm_sc2d_config (include/lbmpm.h)
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("model", C.c_int32), ("relaxation", C.c_int32),
+                ("tau", C.c_double * 2), ("g_fluid", C.c_double), ("g_solid", C.c_double * 2),
+                ("outlet_type", C.c_int32), ("inlet_velocity_y", C.c_double * 2),
+                ("device", C.c_int32), ("variant", C.c_int32)]
+
+
 _lib = None
 
 # every symbol include/lbmpm.h declares (checked by tests/test_abi.py)
@@ -53,6 +61,19 @@ _SIGNATURES = {
     "lbmpm_rk2d_steps_done": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk2d_dominant_kernel": (C.c_char_p, [C.c_void_p]),
     "lbmpm_rk2d_device_bytes": (C.c_int64, [C.c_void_p]),
+    "lbmpm_sc2d_create": (C.c_int, [C.POINTER(SC2DConfig), U8P, C.POINTER(C.c_void_p)]),
+    "lbmpm_sc2d_destroy": (None, [C.c_void_p]),
+    "lbmpm_sc2d_set_pdf": (C.c_int, [C.c_void_p, F64P, F64P]),
+    "lbmpm_sc2d_set_density": (C.c_int, [C.c_void_p, F64P, F64P]),
+    "lbmpm_sc2d_step": (C.c_int, [C.c_void_p, C.c_int64]),
+    "lbmpm_sc2d_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),
+    "lbmpm_sc2d_sync": (C.c_int, [C.c_void_p]),
+    "lbmpm_sc2d_enable_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
+    "lbmpm_sc2d_get_field": (C.c_int, [C.c_void_p, C.c_int, F64P]),
+    "lbmpm_sc2d_num_fluid_nodes": (C.c_int64, [C.c_void_p]),
+    "lbmpm_sc2d_steps_done": (C.c_int64, [C.c_void_p]),
+    "lbmpm_sc2d_dominant_kernel": (C.c_char_p, [C.c_void_p]),
+    "lbmpm_sc2d_device_bytes": (C.c_int64, [C.c_void_p]),
 }
 
 

@@ -1,0 +1,72 @@
+// d2q9_device.h -- device helpers shared by the D2Q9 solvers (gfx950).
+#pragma once
+#include "lbmpm_common.h"
+
+namespace lbmpm_dev {
+
+__device__ __forceinline__ int wrapi(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
+
+__device__ __forceinline__ int wrapm(int v, int n)
+{
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+
+// Pull-streaming of two D2Q9 lattices stored as f[c][q][y*pitch + x] (c = 0,1).
+// Equivalent to the reference's push + in-place half-way bounce-back
+// (AcceleratedRKGPU2D.py:340-417, OptimizedD2Q9GPU.py:452-550).  P needs the members
+// nx, ny, pitch, plane, solidnbr, fin, first.
+template <typename P>
+__device__ __forceinline__ void pull_node(const P &p, int x, int y, double f0[9], double f1[9])
+{
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY, OPP[9] = LBMPM_D2Q9_OPP;
+    const size_t idx = (size_t)y * p.pitch + x;
+    const double *fr = p.fin;
+    const double *fb = p.fin + 9 * p.plane;
+    // p.first: the state is already "post-streaming" (initial condition) -> read in place
+    const bool first = p.first != 0;
+    const unsigned sn = first ? 0u : p.solidnbr[idx];
+    // All 18 loads are issued without waiting for the solid-neighbour byte (solid nodes hold
+    // finite junk that is never used); the rare bounce-back links are patched afterwards.
+    f0[0] = fr[idx];
+    f1[0] = fb[idx];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int xs = wrapi(x - EX[i], p.nx), ys = wrapi(y - EY[i], p.ny);
+        const size_t s = first ? idx : (size_t)ys * p.pitch + xs;
+        f0[i] = fr[i * p.plane + s];
+        f1[i] = fb[i * p.plane + s];
+    }
+    if (sn != 0) {
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            const int o = OPP[i];
+            if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
+                f0[i] = fr[o * p.plane + idx];
+                f1[i] = fb[o * p.plane + idx];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double sum9(const double f[9])
+{   // accumulation order of calMacroDensityRKGPU2D / calFluidRhoGPU and of the ghost kernels
+    double r = 0.;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r += f[i];
+    return r;
+}
+
+// bit (i-1) of solidnbr <=> node + e_i is not fluid, periodic wrap on all four edges
+// (the wrap of fillNeighboringNodes, AcceleratedRKGPU2D.py:25-28).
+__global__ void setup_solidnbr(int nx, int ny, int pitch, const uint8_t *flags, uint8_t *solidnbr);
+
+// XCD-aware tile index: workgroup b runs on XCD b % 8 (observed dispatch order); every XCD
+// gets a contiguous band of tiles so halo rows are shared inside one L2.
+__device__ __forceinline__ int xcd_tile(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7, k = b & 7, j = b >> 3;
+    return k * q + (k < r ? k : r) + j;
+}
+
+}  // namespace lbmpm_dev

@@ -1,5 +1,6 @@
 // lbmpm_common.hip -- error state, version, event pool.
 #include "lbmpm_common.h"
+#include "d2q9_device.h"
 
 namespace lbmpm {
 
@@ -65,3 +66,20 @@ extern "C" int lbmpm_device_count(void)
     }
     return n;
 }
+
+namespace lbmpm_dev {
+
+__global__ void setup_solidnbr(int nx, int ny, int pitch, const uint8_t *flags, uint8_t *solidnbr)
+{
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= nx || y >= ny) return;
+    unsigned b = 0;
+    for (int i = 1; i < 9; ++i) {
+        const int xn = wrapi(x + EX[i], nx), yn = wrapi(y + EY[i], ny);
+        if (!(flags[(size_t)yn * pitch + xn] & 1)) b |= 1u << (i - 1);
+    }
+    solidnbr[(size_t)y * pitch + x] = (uint8_t)b;
+}
+
+}  // namespace lbmpm_dev

@@ -15,6 +15,7 @@
 // identical to the reference's push + in-place half-way bounce-back,
 // AcceleratedRKGPU2D.py:340-417).
 #include "lbmpm_common.h"
+#include "d2q9_device.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -22,6 +23,7 @@
 namespace {
 
 using lbmpm::set_error;
+using namespace lbmpm_dev;
 
 struct RKDev {
     int nx, ny, pitch;
@@ -39,50 +41,6 @@ struct RKDev {
     int wetting, tautype, inlet, outlet;
     int first;         // 1: fin holds the initial (already post-streaming) state
 };
-
-__device__ __forceinline__ int wrapi(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
-
-// ---------------------------------------------------------------- streaming (pull)
-// AcceleratedRKGPU2D.py:340-417 calStreaming1GPU + calStreaming2GPU, in pull form.
-__device__ __forceinline__ void pull_node(const RKDev &p, int x, int y, double fR[9], double fB[9])
-{
-    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY, OPP[9] = LBMPM_D2Q9_OPP;
-    const size_t idx = (size_t)y * p.pitch + x;
-    const double *fr = p.fin;
-    const double *fb = p.fin + 9 * p.plane;
-    // p.first: the initial state is already "post-streaming" (RKD2Q9.py:1243-1247) -> read in place
-    const bool first = p.first != 0;
-    const unsigned sn = first ? 0u : p.solidnbr[idx];
-    // All 18 loads are issued without waiting for the solid-neighbour byte (solid nodes hold
-    // finite junk that is never used); the rare bounce-back links are patched afterwards.
-    fR[0] = fr[idx];
-    fB[0] = fb[idx];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) {
-        const int xs = wrapi(x - EX[i], p.nx), ys = wrapi(y - EY[i], p.ny);
-        const size_t s = first ? idx : (size_t)ys * p.pitch + xs;
-        fR[i] = fr[i * p.plane + s];
-        fB[i] = fb[i * p.plane + s];
-    }
-    if (sn != 0) {
-#pragma unroll
-        for (int i = 1; i < 9; ++i) {
-            const int o = OPP[i];
-            if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
-                fR[i] = fr[o * p.plane + idx];
-                fB[i] = fb[o * p.plane + idx];
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ double sum9(const double f[9])
-{   // accumulation order of calMacroDensityRKGPU2D (A:103-120) and of the ghost kernels
-    double r = 0.;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r += f[i];
-    return r;
-}
 
 // ---------------------------------------------------------------- boundary rows
 // constantTotalVelocityInlet, A:2348-2412 (ratioB evaluated after rhoR was overwritten)
@@ -455,12 +413,6 @@ struct FusedShape {
     static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;
 };
 
-__device__ __forceinline__ int wrapm(int v, int n)
-{
-    v %= n;
-    return v < 0 ? v + n : v;
-}
-
 template <bool MRT, typename SH>
 __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
 {
@@ -475,9 +427,7 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
 
     // XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch order);
     // give every XCD a contiguous band of tiles so halo rows are shared inside one L2.
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int q = nb >> 3, r = nb & 7, k = b & 7, j = b >> 3;
-    const int t = k * q + (k < r ? k : r) + j;
+    const int t = xcd_tile(blockIdx.x, gridDim.x);
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
 
@@ -666,21 +616,6 @@ __global__ __launch_bounds__(BX *BY) void rk2d_observe(RKDev p, double *out /*[2
 }
 
 // ---------------------------------------------------------------- set-up kernels
-// bit (i-1) of solidnbr <=> node + e_i is not fluid, periodic wrap on all four edges
-// (the wrap of fillNeighboringNodes, A:25-28).
-__global__ void rk2d_setup_solidnbr(int nx, int ny, int pitch, const uint8_t *flags, uint8_t *solidnbr)
-{
-    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= nx || y >= ny) return;
-    unsigned b = 0;
-    for (int i = 1; i < 9; ++i) {
-        const int xn = wrapi(x + EX[i], nx), yn = wrapi(y + EY[i], ny);
-        if (!(flags[(size_t)yn * pitch + xn] & 1)) b |= 1u << (i - 1);
-    }
-    solidnbr[(size_t)y * pitch + x] = (uint8_t)b;
-}
-
 // calVectorNormaltoSolid, RKD2Q9.py:768-892: 24-point iso-8 stencil over the solid mask.
 __global__ void rk2d_setup_normals(int nx, int ny, int pitch, size_t plane, const uint8_t *flags,
                                    const uint8_t *solidnbr, double *ns)
@@ -878,7 +813,7 @@ extern "C" int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is
         if (e != hipSuccess) { set_error("hipMemcpy(flags) failed: %s", hipGetErrorString(e)); lbmpm_rk2d_destroy(c); return LBMPM_ERR_HIP; }
     }
     const dim3 b(64, 4), g((c->nx + 63) / 64, (c->ny + 3) / 4);
-    rk2d_setup_solidnbr<<<g, b, 0, c->stream>>>(c->nx, c->ny, c->pitch, c->flags, c->solidnbr);
+    setup_solidnbr<<<g, b, 0, c->stream>>>(c->nx, c->ny, c->pitch, c->flags, c->solidnbr);
     rk2d_setup_normals<<<g, b, 0, c->stream>>>(c->nx, c->ny, c->pitch, c->plane, c->flags, c->solidnbr, c->ns);
     {
         hipError_t e = hipStreamSynchronize(c->stream);

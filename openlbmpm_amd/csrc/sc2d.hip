@@ -1,0 +1,780 @@
+// sc2d.hip -- two-component Shan-Chen D2Q9 time stepper for gfx950: original Shan-Chen
+// (velocity-shift forcing) and the explicit forcing scheme (EFS), SRT / MRT.
+//
+// Replaces the per-kernel loops of ShanChenD2Q9.runOptimizedLBM / runOptimizedEFLBM
+// (ShanChen2D/ShanChenD2Q9.py:1433-1629, :1631-2087) -- see include/lbmpm.h for the kernel
+// list.  "O:" = ShanChen2D/OptimizedD2Q9GPU.py, "E:" = ShanChen2D/ExplicitD2Q9GPU.py,
+// "D:" = ShanChen2D/ShanChenD2Q9.py.
+//
+// Layout: dense SoA f[k][q][y*pitch+x] (k = component), ping-pong; solidnbr / flags bytes as
+// in rk2d.hip.  State between steps = post-collision populations at their own node.
+// One fused kernel per time step: a 64x8 tile + 1-node halo recomputes rho_k (= psi_k) of the
+// streamed, boundary-corrected lattice into LDS, then every node evaluates the
+// pseudopotential force from the LDS tile, collides and stores.
+#include "lbmpm_common.h"
+#include "d2q9_device.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace {
+
+using lbmpm::set_error;
+using namespace lbmpm_dev;
+
+struct SCDev {
+    int nx, ny, pitch;
+    size_t plane;
+    const uint8_t *flags;
+    const uint8_t *solidnbr;
+    const double *fin;
+    double *fout;
+    double *F;               // [4][plane] Fx0, Fx1, Fy0, Fy1 of the last iteration
+    const double *fold_in;   // [18][3][pitch] pre-collision f-bar of rows 0..2 (EFS convective outlet)
+    double *fold_out;
+    double *diag;            // [28][plane] or nullptr
+    double *psi;             // [2][plane]   (initialisation only)
+    double *scrA, *scrB;     // [18][plane]  (initialisation only): f_eq, F_i
+    double tau[2], G, Gs[2], vyIn[2];
+    int model, mrt, outlet, first, keep_force;
+};
+
+constexpr int D_RHO = 18, D_VX = 20, D_VY = 21, D_FX = 22, D_FY = 24, D_UEQ = 26, D_PLANES = 28;
+
+// O:839-863 constantVelocityZouHeBoundaryHigher (one component)
+__device__ __forceinline__ void bc_inlet(double v, double g[9])
+{
+    const double rho = (g[0] + g[1] + g[3] + 2. * (g[2] + g[5] + g[6])) / (1. + v);
+    g[4] = g[2] - 2. / 3. * rho * v;
+    g[7] = g[5] + (g[1] - g[3]) / 2. - 1. / 6. * rho * v;
+    g[8] = g[6] - (g[1] - g[3]) / 2. - 1. / 6. * rho * v;
+}
+
+// O:555-585 constantPressureZouHeBoundaryLower: density hard-coded per component
+__device__ __forceinline__ void bc_outlet(double d, double g[9])
+{
+    const double v = 1. - (g[0] + g[1] + g[3] + 2. * (g[4] + g[7] + g[8])) / d;
+    g[2] = g[4] + 2. / 3. * v * d;
+    g[5] = g[7] + 1. / 2. * (g[3] - g[1]) + 1. / 6. * d * v;
+    g[6] = g[8] - 1. / 2. * (g[3] - g[1]) + 1. / 6. * d * v;
+}
+
+__device__ __forceinline__ double mom_x(const double g[9]) { return g[1] - g[3] + g[5] - g[6] - g[7] + g[8]; }
+__device__ __forceinline__ double mom_y(const double g[9]) { return g[2] - g[4] + g[5] + g[6] - g[7] - g[8]; }
+
+// Lattice state of node (x,y) as the reference holds it when the force chain starts:
+//   EFS (D:1897-2024): streamed f-bar, outlet BC, inlet BC + ghost rows, rho = sum f.
+//   SC  (D:1592-1622, :1523-1539, :1579): streamed f, outlet copy rows, [INLET: inlet BC +
+//        ghost row], rho = sum f.
+// INLET=false gives the SC end-of-iteration view (what calPhysicalVelocity :1626 sees).
+template <bool INLET>
+__device__ __forceinline__ void node_state(const SCDev &p, int x, int y, double f0[9], double f1[9],
+                                           double &r0, double &r1)
+{
+    int ys = y;
+    if (INLET && y == p.ny - 1) ys = p.ny - 2;
+    const bool stream = !p.first;
+    if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2 && stream) {
+        pull_node(p, x, 3, f0, f1);
+        if (p.model == LBMPM_SC_MODEL_EFS) {
+            // O:1044-1120 convectiveOutletEach{,2,3}GPU: rows 2,1,0 in sequence,
+            // f = (f_old + |vy(row 3)| f(row above)) / (1 + |vy(row 3)|)
+            const size_t i3 = (size_t)3 * p.pitch + x;
+            const double q0 = sum9(f0), q1 = sum9(f1);
+            double ty = 0., tr = 0.;
+            ty += (mom_y(f0) + 1. / 2. * p.F[2 * p.plane + i3]); tr += q0;
+            ty += (mom_y(f1) + 1. / 2. * p.F[3 * p.plane + i3]); tr += q1;
+            const double v = fabs(ty / tr);
+            for (int r = 2; r >= y; --r) {
+                const size_t o = (size_t)r * p.pitch + x;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    f0[j] = (p.fold_in[(size_t)j * 3 * p.pitch + o] + v * f0[j]) / (1. + v);
+                    f1[j] = (p.fold_in[(size_t)(9 + j) * 3 * p.pitch + o] + v * f1[j]) / (1. + v);
+                }
+            }
+        }
+        // SC: O:960-1038 plain copies of row 3 into rows 2,1,0
+    } else {
+        if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_PRESSURE && y == 0) ys = 1;
+        pull_node(p, x, ys, f0, f1);
+        if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1) {
+            bc_outlet(1.0, f0);
+            bc_outlet(0.02, f1);
+        }
+    }
+    if (INLET && ys == p.ny - 2) { bc_inlet(p.vyIn[0], f0); bc_inlet(p.vyIn[1], f1); }
+    r0 = sum9(f0);
+    r1 = sum9(f1);
+}
+
+// Pseudopotential force on both components from psi of the 8 neighbours (nb0/nb1 = psi_0/psi_1
+// at x + e_i, i = 1..8; sn = solid-neighbour bits).
+//   EFS: E:51-216, weights 1/3, 1/12 (D:1675):  F_k = -6 psi_k sum_j G_kj sum_i w_i (psi_j(x+e_i) - psi_j(x)) e_i
+//                                                     + sum_{solid i} -w_i Gs_k psi_k e_i
+//   SC : O:1295-1392, weights 1/9, 1/36:         F_k = sum_i -w_i G_kj psi_k psi_j(x+e_i) e_i  (+ same solid term)
+__device__ __forceinline__ void sc_force(const SCDev &p, unsigned sn, const double psi[2], const double nb0[9],
+                                         const double nb1[9], double Fx[2], double Fy[2])
+{
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    const bool efs = p.model == LBMPM_SC_MODEL_EFS;
+    const double wa = efs ? 1. / 3. : 1. / 9., wd = efs ? 1. / 12. : 1. / 36.;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        double gx = 0., gy = 0., sx = 0., sy = 0.;
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            const double w = (i < 5) ? wa : wd;
+            const double ex = EX[i], ey = EY[i];
+            if (!((sn >> (i - 1)) & 1u)) {
+                const double other = (k == 0) ? nb1[i] : nb0[i];      // G_kk = 0
+                if (efs) {
+                    const double d = other - psi[1 - k];
+                    if (EX[i] != 0) gx += w * d * ex * p.G;
+                    if (EY[i] != 0) gy += w * d * ey * p.G;
+                } else {
+                    if (EX[i] != 0) gx += -w * p.G * psi[k] * other * ex;
+                    if (EY[i] != 0) gy += -w * p.G * psi[k] * other * ey;
+                }
+            } else {
+                if (EX[i] != 0) sx += -w * p.Gs[k] * psi[k] * ex;
+                if (EY[i] != 0) sy += -w * p.Gs[k] * psi[k] * ey;
+            }
+        }
+        if (efs) {
+            Fx[k] = -6.0 * psi[k] * gx + sx;
+            Fy[k] = -6.0 * psi[k] * gy + sy;
+        } else {
+            Fx[k] = gx + sx;
+            Fy[k] = gy + sy;
+        }
+    }
+}
+
+// EFS MRT: out = M^-1 S M d with S = diag(1,.6,1.5,1,1.2,1,1.2,1/tau,1/tau) (D:99-106, :484-496);
+// M from SimpleD2Q9.py:107-124 (rows mutually orthogonal => M^-1 = M^T diag(1/|row|^2)).
+__device__ __forceinline__ void mrt_relax(const double d[9], double itau, double out[9])
+{
+    constexpr int M[9][9] = {{1, 1, 1, 1, 1, 1, 1, 1, 1},      {-4, -1, -1, -1, -1, 2, 2, 2, 2},
+                             {4, -2, -2, -2, -2, 1, 1, 1, 1},  {0, 1, 0, -1, 0, 1, -1, -1, 1},
+                             {0, -2, 0, 2, 0, 1, -1, -1, 1},   {0, 0, 1, 0, -1, 1, 1, -1, -1},
+                             {0, 0, -2, 0, 2, 1, 1, -1, -1},   {0, 1, -1, 1, -1, 0, 0, 0, 0},
+                             {0, 0, 0, 0, 0, 1, -1, 1, -1}};
+    constexpr double INV_N2[9] = {1. / 9., 1. / 36., 1. / 36., 1. / 6., 1. / 12., 1. / 6., 1. / 12., 1. / 4., 1. / 4.};
+    const double S[9] = {1., 0.6, 1.5, 1., 1.2, 1., 1.2, itau, itau};
+    double m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double t = 0.;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (M[i][j] != 0) t += (double)M[i][j] * d[j];
+        m[i] = t * (S[i] * INV_N2[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double t = 0.;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (M[j][i] != 0) t += (double)M[j][i] * m[j];
+        out[i] = t;
+    }
+}
+
+// Force chain + collision of one node, both components; f0/f1 updated in place.
+//   EFS: u_eq E:340-363 (SRT) / E:1426-1449 (MRT), f_eq E:227-247, F_i E:255-271,
+//        collision E:294-304 (SRT) / E:1379-1469 (MRT)
+//   SC : fused force + velocity shift + BGK, O:1274-1449
+template <bool MRT>
+__device__ __forceinline__ void chain_collide(const SCDev &p, double f0[9], double f1[9], const double rho[2],
+                                              const double Fx[2], const double Fy[2], double &ueqx, double &ueqy)
+{
+    constexpr double W[9] = LBMPM_D2Q9_W;
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    double *f[2] = {f0, f1};
+    if (p.model == LBMPM_SC_MODEL_EFS) {
+        double mx = 0., my = 0., rt = 0.;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double ex = mom_x(f[k]) + 1. / 2. * Fx[k], ey = mom_y(f[k]) + 1. / 2. * Fy[k];
+            if (MRT) { mx += ex * 1.; my += ey * 1.; rt += rho[k] * 1.; }
+            else { mx += ex / p.tau[k]; my += ey / p.tau[k]; rt = rt + rho[k] / p.tau[k]; }
+        }
+        const double ux = mx / rt, uy = my / rt;
+        ueqx = ux; ueqy = uy;
+        const double usq = ux * ux + uy * uy;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double d[9], ff[9];
+            const double ics = 1. / (1. / 3. * rho[k]);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const double eu = (double)EX[j] * ux + (double)EY[j] * uy;
+                const double feq = W[j] * rho[k] * (1. + 3. * eu + 9. / 2. * (eu * eu) - 3. / 2. * usq);
+                ff[j] = ((Fx[k] * ((double)EX[j] - ux)) + (Fy[k] * ((double)EY[j] - uy))) * feq * ics;
+                d[j] = feq - f[k][j] - 1. / 2. * ff[j];
+            }
+            if (MRT) {
+                double rl[9];
+                mrt_relax(d, 1. / p.tau[k], rl);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) f[k][j] = f[k][j] + rl[j] + 1. * ff[j];
+            } else {
+                const double om = 1. / p.tau[k];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) f[k][j] = f[k][j] + om * d[j] + 1. * ff[j];
+            }
+        }
+    } else {
+        double vxt = 0., vyt = 0., rt = 0.;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            vxt += mom_x(f[k]) / p.tau[k];
+            vyt += mom_y(f[k]) / p.tau[k];
+            rt += rho[k] / p.tau[k];
+        }
+        const double pvx = vxt / rt, pvy = vyt / rt;
+        ueqx = pvx; ueqy = pvy;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double ux = pvx + p.tau[k] * Fx[k] / rho[k], uy = pvy + p.tau[k] * Fy[k] / rho[k];
+            const double usq = ux * ux + uy * uy;
+            const double keep = 1. - 1. / p.tau[k], rw = rho[k] / p.tau[k];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const double eu = (double)EX[j] * ux + (double)EY[j] * uy;
+                f[k][j] = keep * f[k][j] + W[j] * rw * (1. + 3. * eu + 4.5 * (eu * eu) - 1.5 * usq);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fused step kernel
+constexpr int TW = 64, TH = 8, HALO = 1, RW = TW + 2 * HALO, RH = TH + 2 * HALO, THREADS = TW * TH;
+
+template <bool MRT>
+__global__ __launch_bounds__(THREADS) void sc2d_fused(SCDev p, int tiles_x)
+{
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    __shared__ double s_psi0[RH * RW];
+    __shared__ double s_psi1[RH * RW];
+    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
+    const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
+
+    // phase A: own node
+    const int x = tx0 + lx, y = ty0 + ly;
+    const bool inside = (x < p.nx) && (y < p.ny);
+    const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);
+    const size_t idx = (size_t)yw * p.pitch + xw;
+    const bool fluid = p.flags[idx] & 1;
+    const bool act = inside && fluid;
+    const int ri = (HALO + ly) * RW + HALO + lx;
+    double f0[9], f1[9], rho[2] = {0., 0.}, Fpx[2] = {0., 0.}, Fpy[2] = {0., 0.};
+    unsigned sn = 0;
+    if (fluid) {
+        sn = p.solidnbr[idx];
+        if (p.keep_force) {
+            Fpx[0] = p.F[idx]; Fpx[1] = p.F[p.plane + idx];
+            Fpy[0] = p.F[2 * p.plane + idx]; Fpy[1] = p.F[3 * p.plane + idx];
+        }
+        node_state<true>(p, xw, yw, f0, f1, rho[0], rho[1]);
+        s_psi0[ri] = rho[0];            // O:99-106 calFluidPotentialGPUEql: psi = rho
+        s_psi1[ri] = rho[1];
+    }
+    // phase A: halo ring (psi only)
+    constexpr int NHALO = 2 * RW + 2 * TH;
+    for (int n = tid; n < NHALO; n += THREADS) {
+        int rx, ry;
+        if (n < RW) { ry = 0; rx = n; }
+        else if (n < 2 * RW) { ry = RH - 1; rx = n - RW; }
+        else { const int m = n - 2 * RW; ry = 1 + m / 2; rx = (m & 1) ? RW - 1 : 0; }
+        const int hx = wrapm(tx0 - HALO + rx, p.nx), hy = wrapm(ty0 - HALO + ry, p.ny);
+        if (!(p.flags[(size_t)hy * p.pitch + hx] & 1)) continue;
+        double g0[9], g1[9], a, b;
+        node_state<true>(p, hx, hy, g0, g1, a, b);
+        s_psi0[ry * RW + rx] = a;
+        s_psi1[ry * RW + rx] = b;
+    }
+    __syncthreads();
+    if (!act) return;
+
+    // phase D: force chain, collision, store
+    double nb0[9], nb1[9];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int rn = ri + EY[i] * RW + EX[i];
+        nb0[i] = s_psi0[rn];
+        nb1[i] = s_psi1[rn];
+    }
+    double Fx[2], Fy[2], ueqx, ueqy;
+    sc_force(p, sn, rho, nb0, nb1, Fx, Fy);
+    if (p.diag) {     // end-of-iteration view of the EFS loop (D:2022-2087)
+        double tx = 0., ty = 0., tr = 0.;
+        tx += (mom_x(f0) + 1. / 2. * Fpx[0]); ty += (mom_y(f0) + 1. / 2. * Fpy[0]); tr += rho[0];
+        tx += (mom_x(f1) + 1. / 2. * Fpx[1]); ty += (mom_y(f1) + 1. / 2. * Fpy[1]); tr += rho[1];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { p.diag[j * p.plane + idx] = f0[j]; p.diag[(9 + j) * p.plane + idx] = f1[j]; }
+        p.diag[D_RHO * p.plane + idx] = rho[0]; p.diag[(D_RHO + 1) * p.plane + idx] = rho[1];
+        p.diag[D_VX * p.plane + idx] = tx / tr; p.diag[D_VY * p.plane + idx] = ty / tr;
+        p.diag[D_FX * p.plane + idx] = Fx[0]; p.diag[(D_FX + 1) * p.plane + idx] = Fx[1];
+        p.diag[D_FY * p.plane + idx] = Fy[0]; p.diag[(D_FY + 1) * p.plane + idx] = Fy[1];
+    }
+    if (p.keep_force || (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_CONVECTIVE && y == 3)) {
+        p.F[idx] = Fx[0]; p.F[p.plane + idx] = Fx[1];
+        p.F[2 * p.plane + idx] = Fy[0]; p.F[3 * p.plane + idx] = Fy[1];
+    }
+    if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2) {
+        const size_t o = (size_t)y * p.pitch + x;     // savePDFLastStep O:70-80, rows 0..2 only
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            p.fold_out[(size_t)j * 3 * p.pitch + o] = f0[j];
+            p.fold_out[(size_t)(9 + j) * 3 * p.pitch + o] = f1[j];
+        }
+    }
+    chain_collide<MRT>(p, f0, f1, rho, Fx, Fy, ueqx, ueqy);
+    if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
+    double *o0 = p.fout, *o1 = p.fout + 9 * p.plane;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { o0[j * p.plane + idx] = f0[j]; o1[j * p.plane + idx] = f1[j]; }
+}
+
+// SC end-of-iteration view (D:1624-1629): streamed populations + outlet copies, rho, u with the
+// force of that iteration.
+__global__ __launch_bounds__(256) void sc2d_observe(SCDev p, double *out)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    double f0[9], f1[9], r0, r1;
+    node_state<false>(p, x, y, f0, f1, r0, r1);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { out[j * p.plane + idx] = f0[j]; out[(9 + j) * p.plane + idx] = f1[j]; }
+    out[D_RHO * p.plane + idx] = r0; out[(D_RHO + 1) * p.plane + idx] = r1;
+    double tx = 0., ty = 0., tr = 0.;
+    tx += (mom_x(f0) + 1. / 2. * p.F[idx]); ty += (mom_y(f0) + 1. / 2. * p.F[2 * p.plane + idx]); tr += r0;
+    tx += (mom_x(f1) + 1. / 2. * p.F[p.plane + idx]); ty += (mom_y(f1) + 1. / 2. * p.F[3 * p.plane + idx]); tr += r1;
+    out[D_VX * p.plane + idx] = tx / tr; out[D_VY * p.plane + idx] = ty / tr;
+    for (int c = 0; c < 4; ++c) out[(D_FX + c) * p.plane + idx] = p.F[c * p.plane + idx];
+}
+
+// ---------------------------------------------------------------- EFS initialisation (D:1714-1849 + first collision)
+__global__ __launch_bounds__(256) void sc2d_init_psi(SCDev p)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    double a = 0., b = 0.;
+    for (int j = 0; j < 9; ++j) { a += p.fin[j * p.plane + idx]; b += p.fin[(9 + j) * p.plane + idx]; }
+    p.psi[idx] = a; p.psi[p.plane + idx] = b;
+}
+
+// psi -> F -> u_eq (from the untransformed f) -> f_eq -> F_i -> f-bar = f - F_i/2
+template <bool MRT>
+__global__ __launch_bounds__(256) void sc2d_init_chain(SCDev p)
+{
+    constexpr double W[9] = LBMPM_D2Q9_W;
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    const unsigned sn = p.solidnbr[idx];
+    double f0[9], f1[9], nb0[9], nb1[9];
+    for (int j = 0; j < 9; ++j) { f0[j] = p.fin[j * p.plane + idx]; f1[j] = p.fin[(9 + j) * p.plane + idx]; }
+    const double rho[2] = {p.psi[idx], p.psi[p.plane + idx]};
+    for (int i = 1; i < 9; ++i) {
+        const size_t n = (size_t)wrapi(y + EY[i], p.ny) * p.pitch + wrapi(x + EX[i], p.nx);
+        nb0[i] = p.psi[n]; nb1[i] = p.psi[p.plane + n];
+    }
+    double Fx[2], Fy[2];
+    sc_force(p, sn, rho, nb0, nb1, Fx, Fy);
+    p.F[idx] = Fx[0]; p.F[p.plane + idx] = Fx[1]; p.F[2 * p.plane + idx] = Fy[0]; p.F[3 * p.plane + idx] = Fy[1];
+    double *f[2] = {f0, f1};
+    double mx = 0., my = 0., rt = 0.;
+    for (int k = 0; k < 2; ++k) {
+        const double ex = mom_x(f[k]) + 1. / 2. * Fx[k], ey = mom_y(f[k]) + 1. / 2. * Fy[k];
+        if (MRT) { mx += ex * 1.; my += ey * 1.; rt += rho[k] * 1.; }
+        else { mx += ex / p.tau[k]; my += ey / p.tau[k]; rt = rt + rho[k] / p.tau[k]; }
+    }
+    const double ux = mx / rt, uy = my / rt, usq = ux * ux + uy * uy;
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 9; ++j) {
+            const double eu = (double)EX[j] * ux + (double)EY[j] * uy;
+            const double feq = W[j] * rho[k] * (1. + 3. * eu + 9. / 2. * (eu * eu) - 3. / 2. * usq);
+            const double ff = ((Fx[k] * ((double)EX[j] - ux)) + (Fy[k] * ((double)EY[j] - uy))) * feq / (1. / 3. * rho[k]);
+            const size_t o = (size_t)(9 * k + j) * p.plane + idx;
+            p.scrA[o] = feq;
+            p.scrB[o] = ff;
+            p.fout[o] = f[k][j] - 1. / 2. * ff;          // transformPDFGPU E:278-288
+        }
+}
+
+// pre-loop boundary kernels (inlet + ghost, then Dirichlet outlet + ghost; D:1772-1849) applied
+// on the fly to f-bar, then the collision of loop iteration 0 with the pre-loop f_eq / F_i.
+// Reads the f-bar buffer (fin here), writes fout.
+template <bool MRT>
+__global__ __launch_bounds__(256) void sc2d_init_collide(SCDev p)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    int ys = y;
+    if (y == p.ny - 1) ys = p.ny - 2;
+    if (p.outlet == LBMPM_OUTLET_PRESSURE && y == 0) ys = 1;
+    const size_t s = (size_t)ys * p.pitch + x;
+    double f0[9], f1[9];
+    for (int j = 0; j < 9; ++j) { f0[j] = p.fin[j * p.plane + s]; f1[j] = p.fin[(9 + j) * p.plane + s]; }
+    if (ys == p.ny - 2) { bc_inlet(p.vyIn[0], f0); bc_inlet(p.vyIn[1], f1); }
+    if (p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1) { bc_outlet(1.0, f0); bc_outlet(0.02, f1); }
+    if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2) {
+        const size_t o = (size_t)y * p.pitch + x;
+        for (int j = 0; j < 9; ++j) {
+            p.fold_out[(size_t)j * 3 * p.pitch + o] = f0[j];
+            p.fold_out[(size_t)(9 + j) * 3 * p.pitch + o] = f1[j];
+        }
+    }
+    double *f[2] = {f0, f1};
+    for (int k = 0; k < 2; ++k) {
+        double d[9], ff[9];
+        for (int j = 0; j < 9; ++j) {
+            const size_t o = (size_t)(9 * k + j) * p.plane + idx;
+            ff[j] = p.scrB[o];
+            d[j] = p.scrA[o] - f[k][j] - 1. / 2. * ff[j];
+        }
+        if (MRT) {
+            double rl[9];
+            mrt_relax(d, 1. / p.tau[k], rl);
+            for (int j = 0; j < 9; ++j) p.fout[(size_t)(9 * k + j) * p.plane + idx] = f[k][j] + rl[j] + 1. * ff[j];
+        } else {
+            const double om = 1. / p.tau[k];
+            for (int j = 0; j < 9; ++j) p.fout[(size_t)(9 * k + j) * p.plane + idx] = f[k][j] + om * d[j] + 1. * ff[j];
+        }
+    }
+}
+
+}  // namespace
+
+// ====================================================================== host side
+struct lbmpm_sc2d {
+    lbmpm_sc2d_config cfg;
+    int nx, ny, pitch;
+    size_t plane;
+    int64_t nfluid = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *flags = nullptr, *solidnbr = nullptr;
+    double *fA = nullptr, *fB = nullptr, *F = nullptr, *foldA = nullptr, *foldB = nullptr, *diag = nullptr,
+           *obs = nullptr;
+    std::vector<uint8_t> h_domain;
+    bool streamed = false, initialised = false, diag_valid = false, keep_force = false;
+    int64_t steps = 0, bytes = 0;
+    lbmpm::EventPool pool;
+};
+
+namespace {
+
+SCDev make_dev(const lbmpm_sc2d *c)
+{
+    SCDev p{};
+    p.nx = c->nx; p.ny = c->ny; p.pitch = c->pitch; p.plane = c->plane;
+    p.flags = c->flags; p.solidnbr = c->solidnbr; p.fin = c->fA; p.fout = c->fB; p.F = c->F;
+    p.fold_in = c->foldA; p.fold_out = c->foldB; p.diag = nullptr; p.psi = nullptr; p.scrA = p.scrB = nullptr;
+    p.tau[0] = c->cfg.tau[0]; p.tau[1] = c->cfg.tau[1]; p.G = c->cfg.g_fluid;
+    p.Gs[0] = c->cfg.g_solid[0]; p.Gs[1] = c->cfg.g_solid[1];
+    p.vyIn[0] = c->cfg.inlet_velocity_y[0]; p.vyIn[1] = c->cfg.inlet_velocity_y[1];
+    p.model = c->cfg.model; p.mrt = c->cfg.relaxation == LBMPM_RELAX_MRT; p.outlet = c->cfg.outlet_type;
+    p.first = c->streamed ? 0 : 1; p.keep_force = c->keep_force ? 1 : 0;
+    return p;
+}
+
+template <typename T>
+int dev_alloc(lbmpm_sc2d *c, T **ptr, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, count * sizeof(T));
+    if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e)); return LBMPM_ERR_NOMEM; }
+    e = hipMemsetAsync(v, 0, count * sizeof(T), c->stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
+    *ptr = static_cast<T *>(v);
+    c->bytes += (int64_t)(count * sizeof(T));
+    return LBMPM_OK;
+}
+
+// EFS: everything the reference does before its loop plus the collision of iteration 0.
+int efs_initialise(lbmpm_sc2d *c)
+{
+    double *psi = nullptr, *scrA = nullptr, *scrB = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &psi, 2 * c->plane)) || (rc = dev_alloc(c, &scrA, 18 * c->plane)) ||
+        (rc = dev_alloc(c, &scrB, 18 * c->plane))) return rc;
+    SCDev p = make_dev(c);
+    p.psi = psi; p.scrA = scrA; p.scrB = scrB;
+    const dim3 g((c->nx + 63) / 64, (c->ny + 3) / 4), b(64, 4);
+    const bool mrt = p.mrt;
+    sc2d_init_psi<<<g, b, 0, c->stream>>>(p);                       // fA -> psi
+    if (mrt) sc2d_init_chain<true><<<g, b, 0, c->stream>>>(p);      // fA -> fB (f-bar), scrA, scrB, F
+    else sc2d_init_chain<false><<<g, b, 0, c->stream>>>(p);
+    SCDev q = p;
+    q.fin = c->fB; q.fout = c->fA; q.fold_out = c->foldA;           // fB -> fA (post-collision), fold -> foldA
+    if (mrt) sc2d_init_collide<true><<<g, b, 0, c->stream>>>(q);
+    else sc2d_init_collide<false><<<g, b, 0, c->stream>>>(q);
+    LBMPM_HIP_TRY(hipGetLastError());
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(psi); (void)hipFree(scrA); (void)hipFree(scrB);
+    c->bytes -= (int64_t)(38 * c->plane * sizeof(double));
+    c->streamed = true;
+    c->initialised = true;
+    return LBMPM_OK;
+}
+
+int launch_step(lbmpm_sc2d *c, bool diag, bool timed)
+{
+    if (c->cfg.model == LBMPM_SC_MODEL_EFS && !c->initialised) { const int rc = efs_initialise(c); if (rc) return rc; }
+    SCDev p = make_dev(c);
+    p.diag = diag ? c->diag : nullptr;
+    const int tiles_x = (c->nx + TW - 1) / TW, tiles_y = (c->ny + TH - 1) / TH;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool ev = timed && c->pool.take(&e0, &e1);
+    if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+    if (p.mrt) sc2d_fused<true><<<dim3(tiles_x * tiles_y), dim3(THREADS), 0, c->stream>>>(p, tiles_x);
+    else sc2d_fused<false><<<dim3(tiles_x * tiles_y), dim3(THREADS), 0, c->stream>>>(p, tiles_x);
+    if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
+    LBMPM_HIP_TRY(hipGetLastError());
+    std::swap(c->fA, c->fB);
+    std::swap(c->foldA, c->foldB);
+    c->streamed = true;
+    c->diag_valid = diag;
+    c->steps += 1;
+    return LBMPM_OK;
+}
+
+int run_steps(lbmpm_sc2d *c, int64_t n, bool timed)
+{
+    for (int64_t k = 0; k < n; ++k) {
+        const bool diag = (c->diag != nullptr) && (k == n - 1);
+        const int rc = launch_step(c, diag, timed);
+        if (rc != LBMPM_OK) return rc;
+    }
+    return LBMPM_OK;
+}
+
+int copy_plane(lbmpm_sc2d *c, const double *dev, double *out, int ncomp)
+{
+    std::vector<double> h((size_t)ncomp * c->plane);
+    LBMPM_HIP_TRY(hipMemcpyAsync(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < c->ny; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            const size_t k = (size_t)y * c->nx + x, d = (size_t)y * c->pitch + x;
+            const bool fluid = c->h_domain[k] == 1;
+            for (int i = 0; i < ncomp; ++i) out[k * ncomp + i] = fluid ? h[i * c->plane + d] : 0.0;
+        }
+    return LBMPM_OK;
+}
+
+}  // namespace
+
+extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is_domain, lbmpm_sc2d **out)
+{
+    LBMPM_REQUIRE(cfg && is_domain && out, "lbmpm_sc2d_create: null argument");
+    LBMPM_REQUIRE(cfg->nx >= 4 && cfg->ny >= 8 && cfg->nx < (1 << 30) && cfg->ny < (1 << 30),
+                  "lbmpm_sc2d_create: domain %lld x %lld out of range", (long long)cfg->nx, (long long)cfg->ny);
+    LBMPM_REQUIRE(cfg->model == LBMPM_SC_MODEL_SHANCHEN || cfg->model == LBMPM_SC_MODEL_EFS, "bad model %d", cfg->model);
+    LBMPM_REQUIRE(cfg->relaxation == LBMPM_RELAX_SRT || cfg->relaxation == LBMPM_RELAX_MRT, "bad relaxation %d", cfg->relaxation);
+    if (cfg->model == LBMPM_SC_MODEL_SHANCHEN && cfg->relaxation == LBMPM_RELAX_MRT) {
+        set_error("the original Shan-Chen path is SRT only in the reference (ShanChenD2Q9.py:1584)");
+        return LBMPM_ERR_UNSUPPORTED;
+    }
+    LBMPM_REQUIRE(cfg->outlet_type == 0 || cfg->outlet_type == 1, "bad outlet_type %d", cfg->outlet_type);
+    LBMPM_REQUIRE(cfg->tau[0] > 0.5 && cfg->tau[1] > 0.5, "FluidsTau must exceed 0.5");
+    LBMPM_REQUIRE(cfg->variant == 0, "variant must be 0");
+    LBMPM_HIP_TRY(hipSetDevice(cfg->device));
+    lbmpm_sc2d *c = new (std::nothrow) lbmpm_sc2d();
+    if (!c) { set_error("out of host memory"); return LBMPM_ERR_NOMEM; }
+    c->cfg = *cfg;
+    c->nx = (int)cfg->nx; c->ny = (int)cfg->ny;
+    c->pitch = (c->nx + 31) / 32 * 32;
+    c->plane = (size_t)c->pitch * c->ny;
+    c->h_domain.assign(is_domain, is_domain + (size_t)c->nx * c->ny);
+    std::vector<uint8_t> hflags(c->plane, 0);
+    for (int y = 0; y < c->ny; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            const uint8_t v = is_domain[(size_t)y * c->nx + x] == 1 ? 1 : 0;
+            hflags[(size_t)y * c->pitch + x] = v;
+            c->nfluid += v;
+        }
+    {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return LBMPM_ERR_HIP; }
+    }
+    int rc = LBMPM_OK;
+#define TRY_RC(e) do { rc = (e); if (rc != LBMPM_OK) { lbmpm_sc2d_destroy(c); return rc; } } while (0)
+    TRY_RC(dev_alloc(c, &c->flags, c->plane));
+    TRY_RC(dev_alloc(c, &c->solidnbr, c->plane));
+    TRY_RC(dev_alloc(c, &c->fA, 18 * c->plane));
+    TRY_RC(dev_alloc(c, &c->fB, 18 * c->plane));
+    TRY_RC(dev_alloc(c, &c->F, 4 * c->plane));
+    TRY_RC(dev_alloc(c, &c->foldA, (size_t)18 * 3 * c->pitch));
+    TRY_RC(dev_alloc(c, &c->foldB, (size_t)18 * 3 * c->pitch));
+#undef TRY_RC
+    hipError_t e = hipMemcpyAsync(c->flags, hflags.data(), c->plane, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { set_error("flags upload failed: %s", hipGetErrorString(e)); lbmpm_sc2d_destroy(c); return LBMPM_ERR_HIP; }
+    const dim3 b(64, 4), g((c->nx + 63) / 64, (c->ny + 3) / 4);
+    setup_solidnbr<<<g, b, 0, c->stream>>>(c->nx, c->ny, c->pitch, c->flags, c->solidnbr);
+    e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { set_error("set-up kernel failed: %s", hipGetErrorString(e)); lbmpm_sc2d_destroy(c); return LBMPM_ERR_HIP; }
+    *out = c;
+    return LBMPM_OK;
+}
+
+extern "C" void lbmpm_sc2d_destroy(lbmpm_sc2d *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *ptr : {(void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->F,
+                      (void *)c->foldA, (void *)c->foldB, (void *)c->diag, (void *)c->obs})
+        if (ptr) (void)hipFree(ptr);
+    c->pool.destroy();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int lbmpm_sc2d_set_pdf(lbmpm_sc2d *c, const double *pdf0, const double *pdf1)
+{
+    LBMPM_REQUIRE(c && pdf0 && pdf1, "lbmpm_sc2d_set_pdf: null argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    std::vector<double> h(18 * c->plane, 0.0);
+    for (int y = 0; y < c->ny; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            if (c->h_domain[(size_t)y * c->nx + x] != 1) continue;
+            const size_t s = ((size_t)y * c->nx + x) * 9, d = (size_t)y * c->pitch + x;
+            for (int i = 0; i < 9; ++i) { h[i * c->plane + d] = pdf0[s + i]; h[(9 + i) * c->plane + d] = pdf1[s + i]; }
+        }
+    LBMPM_HIP_TRY(hipMemcpyAsync(c->fA, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    LBMPM_HIP_TRY(hipMemsetAsync(c->F, 0, 4 * c->plane * sizeof(double), c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->streamed = false; c->initialised = false; c->diag_valid = false; c->steps = 0;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_sc2d_set_density(lbmpm_sc2d *c, const double *rho0, const double *rho1)
+{
+    LBMPM_REQUIRE(c && rho0 && rho1, "lbmpm_sc2d_set_density: null argument");
+    static const double Wd[9] = LBMPM_D2Q9_W;
+    const size_t n = (size_t)c->nx * c->ny;
+    std::vector<double> a(9 * n, 0.0), b(9 * n, 0.0);
+    for (size_t k = 0; k < n; ++k)
+        for (int i = 0; i < 9; ++i) { a[9 * k + i] = Wd[i] * rho0[k]; b[9 * k + i] = Wd[i] * rho1[k]; }
+    return lbmpm_sc2d_set_pdf(c, a.data(), b.data());
+}
+
+extern "C" int lbmpm_sc2d_step(lbmpm_sc2d *c, int64_t nsteps)
+{
+    LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_sc2d_step: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    return run_steps(c, nsteps, false);
+}
+
+extern "C" int lbmpm_sc2d_step_timed(lbmpm_sc2d *c, int64_t nsteps, double *ms_total, double *ms_dominant)
+{
+    LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_sc2d_step_timed: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (c->cfg.model == LBMPM_SC_MODEL_EFS && !c->initialised) { const int rc = efs_initialise(c); if (rc) return rc; }
+    const size_t pairs = (size_t)(nsteps < 4096 ? nsteps : 4096);
+    if (c->pool.reserve(pairs + 1) != LBMPM_OK) { set_error("hipEventCreate failed"); return LBMPM_ERR_HIP; }
+    c->pool.reset();
+    hipEvent_t t0, t1;
+    c->pool.take(&t0, &t1);
+    LBMPM_HIP_TRY(hipEventRecord(t0, c->stream));
+    const int rc = run_steps(c, nsteps, true);
+    if (rc != LBMPM_OK) return rc;
+    LBMPM_HIP_TRY(hipEventRecord(t1, c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    LBMPM_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+    if (ms_total) *ms_total = ms;
+    if (ms_dominant) {
+        const size_t timed_launches = c->pool.used / 2 - 1;
+        double s = 0.0;
+        for (size_t k = 2; k + 1 < c->pool.used; k += 2) {
+            float m = 0.f;
+            LBMPM_HIP_TRY(hipEventElapsedTime(&m, c->pool.ev[k], c->pool.ev[k + 1]));
+            s += m;
+        }
+        *ms_dominant = timed_launches ? s * (double)nsteps / (double)timed_launches : 0.0;
+    }
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_sc2d_sync(lbmpm_sc2d *c)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_sc2d_enable_diagnostics(lbmpm_sc2d *c, int on)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (on && !c->diag) { const int rc = dev_alloc(c, &c->diag, D_PLANES * c->plane); if (rc) return rc; }
+    if (!on && c->diag) {
+        LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->diag); c->diag = nullptr; c->diag_valid = false;
+        c->bytes -= (int64_t)(D_PLANES * c->plane * sizeof(double));
+    }
+    c->keep_force = on != 0;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_sc2d_get_field(lbmpm_sc2d *c, int field, double *out)
+{
+    LBMPM_REQUIRE(c && out, "lbmpm_sc2d_get_field: null argument");
+    LBMPM_REQUIRE(field >= LBMPM_SC_PDF0 && field <= LBMPM_SC_UEQY, "unknown field id %d", field);
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->keep_force) {
+        set_error("lbmpm_sc2d_get_field needs lbmpm_sc2d_enable_diagnostics(ctx, 1) before stepping");
+        return LBMPM_ERR_STATE;
+    }
+    const double *src = nullptr;
+    if (c->cfg.model == LBMPM_SC_MODEL_EFS) {
+        if (!c->diag || !c->diag_valid) { set_error("no completed step with diagnostics yet"); return LBMPM_ERR_STATE; }
+        src = c->diag;
+    } else {
+        LBMPM_REQUIRE(field < LBMPM_SC_UEQX, "u_eq is an EFS field");
+        if (!c->obs) { const int rc = dev_alloc(c, &c->obs, D_PLANES * c->plane); if (rc) return rc; }
+        SCDev p = make_dev(c);
+        const dim3 b(64, 4), g((c->nx + 63) / 64, (c->ny + 3) / 4);
+        sc2d_observe<<<g, b, 0, c->stream>>>(p, c->obs);
+        LBMPM_HIP_TRY(hipGetLastError());
+        LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+        src = c->obs;
+    }
+    switch (field) {
+        case LBMPM_SC_PDF0: return copy_plane(c, src, out, 9);
+        case LBMPM_SC_PDF1: return copy_plane(c, src + 9 * c->plane, out, 9);
+        case LBMPM_SC_RHO0: return copy_plane(c, src + D_RHO * c->plane, out, 1);
+        case LBMPM_SC_RHO1: return copy_plane(c, src + (D_RHO + 1) * c->plane, out, 1);
+        case LBMPM_SC_VX: return copy_plane(c, src + D_VX * c->plane, out, 1);
+        case LBMPM_SC_VY: return copy_plane(c, src + D_VY * c->plane, out, 1);
+        case LBMPM_SC_FX0: return copy_plane(c, src + D_FX * c->plane, out, 1);
+        case LBMPM_SC_FX1: return copy_plane(c, src + (D_FX + 1) * c->plane, out, 1);
+        case LBMPM_SC_FY0: return copy_plane(c, src + D_FY * c->plane, out, 1);
+        case LBMPM_SC_FY1: return copy_plane(c, src + (D_FY + 1) * c->plane, out, 1);
+        case LBMPM_SC_UEQX: return copy_plane(c, src + D_UEQ * c->plane, out, 1);
+        case LBMPM_SC_UEQY: return copy_plane(c, src + (D_UEQ + 1) * c->plane, out, 1);
+    }
+    return LBMPM_ERR_INVALID;
+}
+
+extern "C" int64_t lbmpm_sc2d_num_fluid_nodes(const lbmpm_sc2d *c) { return c ? c->nfluid : 0; }
+extern "C" int64_t lbmpm_sc2d_steps_done(const lbmpm_sc2d *c) { return c ? c->steps : 0; }
+extern "C" int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *c) { return c ? c->bytes : 0; }
+extern "C" const char *lbmpm_sc2d_dominant_kernel(const lbmpm_sc2d *c) { (void)c; return "sc2d_fused"; }
