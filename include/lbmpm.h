@@ -215,6 +215,65 @@ int64_t lbmpm_sc2d_steps_done(const lbmpm_sc2d *ctx);
 const char *lbmpm_sc2d_dominant_kernel(const lbmpm_sc2d *ctx);
 int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
 
+/* ------------------------------------------------------------------------------------
+ * D3Q19 colour-gradient solver (perturbation operator), z-slab capable.
+ * The reference ships only IniFiles/RKtwophasesetup3D.ini for this model (main.py:22 imports a
+ * module that is not in the tree), so there is no reference interface to mirror: the model
+ * is the D3Q19 extension of the 2-D kernels AcceleratedRKGPU2D.py:1125 (BGK), :1169
+ * (gradient + perturbation + recolouring), :657/:1008 (Zou-He per colour), :607/:1045 (ghost
+ * planes), :340/:409 (streaming).  PARITY UNPINNED.
+ * A context owns the planes [z_offset, z_offset + nz_local) of a global lattice of
+ * nz_global planes plus one halo plane on each side.  One time step of a slab is
+ *     pack_halo -> [caller moves F_SEND_* to the neighbours' F_RECV_*] -> unpack_halo
+ *     -> phase_field -> [caller moves PHI_SEND_* to the neighbours' PHI_RECV_*] -> collide
+ * (the first step after set_density needs no population exchange).  With a single slab
+ * lbmpm_rk3d_step does all of it.
+ * ---------------------------------------------------------------------------------- */
+typedef struct lbmpm_rk3d_config {
+    int64_t nx, ny, nz_local, nz_global, z_offset;
+    double ak_r, ak_b;          /* [RKParameters] AkR, AkB                         */
+    double beta;                /* BetaThickness                                   */
+    double tau_r, tau_b;        /* [FluidParameters] TauR, TauB                    */
+    double solid_phi;           /* (SolidRhoR-SolidRhoB)/(SolidRhoR+SolidRhoB)     */
+    double inlet_vz_r, inlet_vz_b;     /* [BoundaryCondition] velocityZR, velocityZB */
+    double outlet_rho_r, outlet_rho_b; /* densityRL, densityBL                     */
+    int32_t device;
+    int32_t variant;
+} lbmpm_rk3d_config;
+
+typedef struct lbmpm_rk3d lbmpm_rk3d;
+
+enum { LBMPM_RK3D_PHI = 0, LBMPM_RK3D_RHO_R = 1, LBMPM_RK3D_RHO_B = 2, LBMPM_RK3D_VX = 3,
+       LBMPM_RK3D_VY = 4, LBMPM_RK3D_VZ = 5 };
+enum { LBMPM_RK3D_BUF_F_SEND_UP = 0, LBMPM_RK3D_BUF_F_SEND_DOWN = 1,
+       LBMPM_RK3D_BUF_F_RECV_FROM_BELOW = 2, LBMPM_RK3D_BUF_F_RECV_FROM_ABOVE = 3,
+       LBMPM_RK3D_BUF_PHI_SEND_UP = 4, LBMPM_RK3D_BUF_PHI_SEND_DOWN = 5,
+       LBMPM_RK3D_BUF_PHI_RECV_FROM_BELOW = 6, LBMPM_RK3D_BUF_PHI_RECV_FROM_ABOVE = 7 };
+
+/* is_domain_with_halo: host [nz_local + 2][ny][nx] uint8 (1 = fluid): the owned planes plus
+ * the plane below and above them; planes outside the global lattice must be 0. */
+int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is_domain_with_halo, lbmpm_rk3d **out);
+void lbmpm_rk3d_destroy(lbmpm_rk3d *ctx);
+int lbmpm_rk3d_set_stream(lbmpm_rk3d *ctx, void *hip_stream);
+/* owned planes [nz_local][ny][nx]; f = w rho at rest */
+int lbmpm_rk3d_set_density(lbmpm_rk3d *ctx, const double *rho_r, const double *rho_b);
+int lbmpm_rk3d_pack_halo(lbmpm_rk3d *ctx);
+int lbmpm_rk3d_unpack_halo(lbmpm_rk3d *ctx, int have_below, int have_above);
+/* with_diagnostics: also keep rhoR, rhoB, u of the streamed, boundary-corrected lattice */
+int lbmpm_rk3d_phase_field(lbmpm_rk3d *ctx, int with_diagnostics);
+int lbmpm_rk3d_collide(lbmpm_rk3d *ctx);
+int lbmpm_rk3d_step(lbmpm_rk3d *ctx, int64_t nsteps);
+int lbmpm_rk3d_step_timed(lbmpm_rk3d *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
+int lbmpm_rk3d_sync(lbmpm_rk3d *ctx);
+/* device pointer + size of a halo buffer (LBMPM_RK3D_BUF_*) for the caller's transport */
+int lbmpm_rk3d_buffer(lbmpm_rk3d *ctx, int which, void **device_ptr, int64_t *bytes);
+/* owned planes [nz_local][ny][nx] */
+int lbmpm_rk3d_get_field(lbmpm_rk3d *ctx, int field, double *out);
+int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *ctx);
+int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *ctx);
+const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *ctx);
+int64_t lbmpm_rk3d_device_bytes(const lbmpm_rk3d *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,14 @@ class SC2DConfig(C.Structure):
                 ("device", C.c_int32), ("variant", C.c_int32)]
 
 
+class RK3DConfig(C.Structure):
+    # mirrors struct lbmpm_rk3d_config (include/lbmpm.h)
+    _fields_ = [(n, C.c_int64) for n in ("nx", "ny", "nz_local", "nz_global", "z_offset")] + \
+               [(n, C.c_double) for n in ("ak_r", "ak_b", "beta", "tau_r", "tau_b", "solid_phi", "inlet_vz_r",
+                                          "inlet_vz_b", "outlet_rho_r", "outlet_rho_b")] + \
+               [("device", C.c_int32), ("variant", C.c_int32)]
+
+
 _lib = None
 
 # every symbol include/lbmpm.h declares (checked by tests/test_abi.py)
@@ -74,6 +82,23 @@ _SIGNATURES = {
     "lbmpm_sc2d_steps_done": (C.c_int64, [C.c_void_p]),
     "lbmpm_sc2d_dominant_kernel": (C.c_char_p, [C.c_void_p]),
     "lbmpm_sc2d_device_bytes": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk3d_create": (C.c_int, [C.POINTER(RK3DConfig), U8P, C.POINTER(C.c_void_p)]),
+    "lbmpm_rk3d_destroy": (None, [C.c_void_p]),
+    "lbmpm_rk3d_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lbmpm_rk3d_set_density": (C.c_int, [C.c_void_p, F64P, F64P]),
+    "lbmpm_rk3d_pack_halo": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3d_unpack_halo": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "lbmpm_rk3d_phase_field": (C.c_int, [C.c_void_p, C.c_int]),
+    "lbmpm_rk3d_collide": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3d_step": (C.c_int, [C.c_void_p, C.c_int64]),
+    "lbmpm_rk3d_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),
+    "lbmpm_rk3d_sync": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3d_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), I64P]),
+    "lbmpm_rk3d_get_field": (C.c_int, [C.c_void_p, C.c_int, F64P]),
+    "lbmpm_rk3d_num_fluid_nodes": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk3d_steps_done": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk3d_dominant_kernel": (C.c_char_p, [C.c_void_p]),
+    "lbmpm_rk3d_device_bytes": (C.c_int64, [C.c_void_p]),
 }
 
 

@@ -74,3 +74,42 @@ def initial_densities_rk(is_domain, image, num_buffering_layers, rho_r=1.0, rho_
     rR = np.where(fluid & red, rho_r, 0.0)
     rB = np.where(fluid & ~red, rho_b, 0.0)
     return rR, rB
+
+
+def porous_spheres(nx, ny, nz, porosity=0.65, rmin=6.0, rmax=20.0, seed=20260928, nbuf=10, walls=True):
+    """Synthetic 3-D pore space: union of uniformly placed spheres added until
+    the void fraction of the core drops to `porosity`; then the 3-D analogue of the reference's
+    image rules (RKD2Q9.py:407-414): solid side walls (x = 0, nx-1 and y = 0, ny-1) and `nbuf`
+    all-fluid buffer planes at the bottom and at the top.  Returns isDomain [nz, ny, nx] uint8."""
+    rng = np.random.default_rng(seed)
+    solid = np.zeros((nz, ny, nx), dtype=bool)
+    core = slice(nbuf, nz - nbuf)
+    target = (1.0 - porosity) * nx * ny * (nz - 2 * nbuf)
+    n = 0
+    count = 0
+    while count < target and n < 10 ** 7:
+        cx, cy, cz, r = rng.uniform(0, nx), rng.uniform(0, ny), rng.uniform(nbuf, nz - nbuf), rng.uniform(rmin, rmax)
+        x0, x1 = max(int(cx - r), 0), min(int(cx + r) + 2, nx)
+        y0, y1 = max(int(cy - r), 0), min(int(cy + r) + 2, ny)
+        z0, z1 = max(int(cz - r), nbuf), min(int(cz + r) + 2, nz - nbuf)
+        if z1 > z0:
+            zz, yy, xx = np.mgrid[z0:z1, y0:y1, x0:x1]
+            solid[z0:z1, y0:y1, x0:x1] |= (xx - cx) ** 2 + (yy - cy) ** 2 + (zz - cz) ** 2 <= r * r
+        n += 1
+        if n % 8 == 0:
+            count = int(solid[core].sum())
+    if walls:
+        solid[core, :, 0] = True; solid[core, :, -1] = True
+        solid[core, 0, :] = True; solid[core, -1, :] = True
+    solid[:nbuf] = False
+    solid[nz - nbuf:] = False
+    return (~solid).astype(np.uint8)
+
+
+def initial_densities_rk3d(is_domain, nbuf, rho_r=1.0, rho_b=1.0):
+    """3-D analogue of RKD2Q9.py:511-531: red below the top buffer planes, blue in them."""
+    nz = is_domain.shape[0]
+    zz = np.arange(nz)[:, None, None]
+    red = zz < nz - nbuf
+    fluid = is_domain == 1
+    return np.where(fluid & red, rho_r, 0.0), np.where(fluid & ~red, rho_b, 0.0)

@@ -1,0 +1,224 @@
+"""D3Q19 colour-gradient solver (perturbation operator) -- Python face of lbmpm_rk3d_*
+(include/lbmpm.h) with z-slab decomposition over torch.distributed (RCCL) or over virtual
+ranks inside one process.  All lattice arithmetic happens in liblbmpm_hip.so."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import F64P, U8P, RK3DConfig, check
+from .slab import partition_z, neighbour_exchange, local_exchange, DeviceBuffer
+
+FIELDS = dict(phi=0, rhoR=1, rhoB=2, vx=3, vy=4, vz=5)
+BUF = dict(f_send_up=0, f_send_down=1, f_recv_below=2, f_recv_above=3,
+           phi_send_up=4, phi_send_down=5, phi_recv_below=6, phi_recv_above=7)
+
+# names follow IniFiles/RKtwophasesetup3D.ini
+DEFAULT_PARAMS = dict(AkR=7.0e-3, AkB=7.0e-3, beta=1.0, tauR=1.0, tauB=1.0, SolidRhoR=0.7, SolidRhoB=0.0,
+                      velocityZR=0.0, velocityZB=-1.0e-4, densityRL=1.0e-8, densityBL=1.0)
+
+
+class RK3DSlab:
+    """One slab: planes [z0, z0+nzl) of a global [nz, ny, nx] lattice."""
+
+    def __init__(self, is_domain_global, z0, nzl, params=None, device=0):
+        L = _lib.lib()
+        p = dict(DEFAULT_PARAMS); p.update(params or {})
+        unknown = set(p) - set(DEFAULT_PARAMS)
+        if unknown:
+            raise KeyError("unknown RK3D parameters: %s" % sorted(unknown))
+        dom = np.ascontiguousarray(is_domain_global, dtype=np.uint8)
+        if dom.ndim != 3:
+            raise TypeError("is_domain must be a 3-D array [nz, ny, nx]")
+        self.nz, self.ny, self.nx = dom.shape
+        self.z0, self.nzl, self.device = int(z0), int(nzl), int(device)
+        halo = np.zeros((nzl + 2, self.ny, self.nx), dtype=np.uint8)
+        lo, hi = max(z0 - 1, 0), min(z0 + nzl + 1, self.nz)
+        halo[lo - (z0 - 1):hi - (z0 - 1)] = dom[lo:hi]
+        self.is_domain = np.ascontiguousarray(dom[z0:z0 + nzl])
+        cfg = RK3DConfig()
+        cfg.nx, cfg.ny, cfg.nz_local, cfg.nz_global, cfg.z_offset = self.nx, self.ny, nzl, self.nz, z0
+        cfg.ak_r, cfg.ak_b, cfg.beta = p["AkR"], p["AkB"], p["beta"]
+        cfg.tau_r, cfg.tau_b = p["tauR"], p["tauB"]
+        cfg.solid_phi = (p["SolidRhoR"] - p["SolidRhoB"]) / (p["SolidRhoR"] + p["SolidRhoB"])
+        cfg.inlet_vz_r, cfg.inlet_vz_b = p["velocityZR"], p["velocityZB"]
+        cfg.outlet_rho_r, cfg.outlet_rho_b = p["densityRL"], p["densityBL"]
+        cfg.device, cfg.variant = int(device), 0
+        self._h = C.c_void_p()
+        check(L.lbmpm_rk3d_create(C.byref(cfg), halo.ctypes.data_as(U8P), C.byref(self._h)), "lbmpm_rk3d_create")
+        self._L = L
+        self._tensors = {}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.lbmpm_rk3d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_density(self, rhoR, rhoB):
+        a = np.ascontiguousarray(rhoR, dtype=np.float64); b = np.ascontiguousarray(rhoB, dtype=np.float64)
+        if a.shape != (self.nzl, self.ny, self.nx) or b.shape != a.shape:
+            raise TypeError("density arrays must have shape %s" % ((self.nzl, self.ny, self.nx),))
+        check(self._L.lbmpm_rk3d_set_density(self._h, a.ctypes.data_as(F64P), b.ctypes.data_as(F64P)), "set_density")
+
+    def use_torch_stream(self, stream):
+        """Run this slab's kernels on a torch.cuda.Stream so that they are ordered with torch's
+        copies / RCCL operations issued under `with torch.cuda.stream(stream)`.  (Handle 0, the
+        legacy default stream, cannot be expressed through the C ABI: pass a real stream.)"""
+        if int(stream.cuda_stream) == 0:
+            raise ValueError("use a dedicated torch.cuda.Stream, not the default stream")
+        check(self._L.lbmpm_rk3d_set_stream(self._h, C.c_void_p(int(stream.cuda_stream))), "set_stream")
+
+    def buffer(self, name):
+        """torch view (zero copy) of a halo buffer"""
+        if name not in self._tensors:
+            ptr, n = C.c_void_p(), C.c_int64(0)
+            check(self._L.lbmpm_rk3d_buffer(self._h, BUF[name], C.byref(ptr), C.byref(n)), "lbmpm_rk3d_buffer")
+            self._tensors[name] = DeviceBuffer(ptr.value, n.value).tensor("cuda:%d" % self.device)
+        return self._tensors[name]
+
+    def pack(self):
+        check(self._L.lbmpm_rk3d_pack_halo(self._h), "pack_halo")
+
+    def unpack(self, have_below, have_above):
+        check(self._L.lbmpm_rk3d_unpack_halo(self._h, int(have_below), int(have_above)), "unpack_halo")
+
+    def phase_field(self, diagnostics=False):
+        check(self._L.lbmpm_rk3d_phase_field(self._h, 1 if diagnostics else 0), "phase_field")
+
+    def collide(self):
+        check(self._L.lbmpm_rk3d_collide(self._h), "collide")
+
+    def step_single(self, n):
+        check(self._L.lbmpm_rk3d_step(self._h, int(n)), "lbmpm_rk3d_step")
+
+    def step_timed(self, n):
+        a, b = C.c_double(0), C.c_double(0)
+        check(self._L.lbmpm_rk3d_step_timed(self._h, int(n), C.byref(a), C.byref(b)), "step_timed")
+        return a.value, b.value
+
+    def sync(self):
+        check(self._L.lbmpm_rk3d_sync(self._h), "sync")
+
+    def get(self, name):
+        out = np.empty((self.nzl, self.ny, self.nx), dtype=np.float64)
+        check(self._L.lbmpm_rk3d_get_field(self._h, FIELDS[name], out.ctypes.data_as(F64P)), "get_field(%s)" % name)
+        return out
+
+    @property
+    def num_fluid_nodes(self):
+        return int(self._L.lbmpm_rk3d_num_fluid_nodes(self._h))
+
+    @property
+    def steps_done(self):
+        return int(self._L.lbmpm_rk3d_steps_done(self._h))
+
+    @property
+    def dominant_kernel(self):
+        return self._L.lbmpm_rk3d_dominant_kernel(self._h).decode()
+
+
+class RK3DCluster:
+    """k slabs ('virtual ranks') in ONE process on one GPU, halos moved by device copies.
+    Exists to prove that the slab-decomposed time step equals the single-domain one."""
+
+    def __init__(self, is_domain_global, k, params=None, device=0):
+        nz = is_domain_global.shape[0]
+        self.parts = partition_z(nz, k)
+        import torch
+        self.slabs = [RK3DSlab(is_domain_global, z0, n, params, device) for z0, n in self.parts]
+        self.stream = torch.cuda.Stream(device)
+        self._torch = torch
+        for s in self.slabs:
+            s.use_torch_stream(self.stream)
+        self.k = k
+
+    def set_density(self, rhoR, rhoB):
+        for s, (z0, n) in zip(self.slabs, self.parts):
+            s.set_density(rhoR[z0:z0 + n], rhoB[z0:z0 + n])
+
+    def _exchange(self, kind):
+        S = self.slabs
+        local_exchange([s.buffer(kind + "_send_up") for s in S], [s.buffer(kind + "_send_down") for s in S],
+                       [s.buffer(kind + "_recv_below") for s in S], [s.buffer(kind + "_recv_above") for s in S])
+
+    def _halo_f(self):
+        for s in self.slabs:
+            s.pack()
+        self._exchange("f")
+        for r, s in enumerate(self.slabs):
+            s.unpack(r > 0, r + 1 < self.k)
+
+    def step(self, n):
+        with self._torch.cuda.stream(self.stream):
+            for _ in range(int(n)):
+                if self.slabs[0].steps_done > 0:
+                    self._halo_f()
+                for s in self.slabs:
+                    s.phase_field()
+                self._exchange("phi")
+                for s in self.slabs:
+                    s.collide()
+
+    def observe(self):
+        """rho, u, phi of the streamed + boundary-corrected lattice (what the next step starts from)"""
+        with self._torch.cuda.stream(self.stream):
+            if self.slabs[0].steps_done > 0:
+                self._halo_f()
+            for s in self.slabs:
+                s.phase_field(diagnostics=True)
+
+    def get(self, name):
+        return np.concatenate([s.get(name) for s in self.slabs], axis=0)
+
+    def close(self):
+        for s in self.slabs:
+            s.close()
+
+
+class RK3DDistributed:
+    """One slab per process/GPU; halos over torch.distributed P2P (RCCL over xGMI)."""
+
+    def __init__(self, is_domain_global, params=None, device=0, group=None):
+        import torch.distributed as dist
+        self.rank, self.world, self.group = dist.get_rank(group), dist.get_world_size(group), group
+        z0, n = partition_z(is_domain_global.shape[0], self.world)[self.rank]
+        self.z0, self.nzl = z0, n
+        import torch
+        self._torch = torch
+        self.slab = RK3DSlab(is_domain_global, z0, n, params, device)
+        self.stream = torch.cuda.Stream(device)
+        self.slab.use_torch_stream(self.stream)
+
+    def set_density(self, rhoR_global, rhoB_global):
+        self.slab.set_density(rhoR_global[self.z0:self.z0 + self.nzl], rhoB_global[self.z0:self.z0 + self.nzl])
+
+    def _exchange(self, kind):
+        s = self.slab
+        neighbour_exchange(s.buffer(kind + "_send_up"), s.buffer(kind + "_send_down"),
+                           s.buffer(kind + "_recv_below"), s.buffer(kind + "_recv_above"),
+                           self.rank, self.world, self.group)
+
+    def step(self, n):
+        s = self.slab
+        with self._torch.cuda.stream(self.stream):
+            for _ in range(int(n)):
+                if s.steps_done > 0 and self.world > 1:
+                    s.pack()
+                    self._exchange("f")
+                    s.unpack(self.rank > 0, self.rank + 1 < self.world)
+                s.phase_field()
+                if self.world > 1:
+                    self._exchange("phi")
+                s.collide()
+
+    def sync(self):
+        self.stream.synchronize()
+
+    def close(self):
+        self.slab.close()

@@ -1,0 +1,61 @@
+"""z-slab decomposition and neighbour halo exchange (host-side plumbing of the 3-D solver).
+
+Pure torch / Python: no lattice arithmetic here.  The same code path serves
+  * one process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI) and
+  * CPU tensors over gloo in the tests (tests/test_slab_cpu.py).
+"""
+import torch
+
+
+def partition_z(nz_global, world):
+    """Contiguous z-ranges, remainder planes to the lowest ranks.  The outermost ranks must
+    own at least the boundary plane pair (2 planes)."""
+    if world < 1 or nz_global < 2 * world:
+        raise ValueError("cannot cut %d planes into %d slabs of >= 2 planes" % (nz_global, world))
+    base, rem = divmod(nz_global, world)
+    out, z = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((z, n))
+        z += n
+    return out
+
+
+def neighbour_exchange(send_up, send_down, recv_from_below, recv_from_above, rank, world, group=None):
+    """Every rank sends `send_up` to rank+1 (which receives it in `recv_from_below`) and
+    `send_down` to rank-1 (received in `recv_from_above`).  No wrap-around: the global lattice is
+    not periodic in z.  Point-to-point only (ncclSend/ncclRecv pairs grouped in one batch), no
+    collective on the data path."""
+    import torch.distributed as dist
+    ops = []
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.isend, send_up, rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, recv_from_above, rank + 1, group))
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, send_down, rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, recv_from_below, rank - 1, group))
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
+def local_exchange(slabs_send_up, slabs_send_down, slabs_recv_below, slabs_recv_above):
+    """Same data movement between k 'virtual ranks' living in one process (lists indexed by
+    virtual rank): used to prove slab-decomposed == single-domain on one GPU."""
+    k = len(slabs_send_up)
+    for r in range(k):
+        if r + 1 < k:
+            slabs_recv_below[r + 1].copy_(slabs_send_up[r])
+            slabs_recv_above[r].copy_(slabs_send_down[r + 1])
+
+
+class DeviceBuffer:
+    """Zero-copy torch view of a raw device allocation owned by liblbmpm_hip.so."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes) // 8,), "typestr": "<f8",
+                                         "data": (int(ptr), False), "version": 2}
+
+    def tensor(self, device):
+        return torch.as_tensor(self, device=device)

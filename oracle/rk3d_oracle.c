@@ -1,0 +1,212 @@
+/*
+ * oracle/rk3d_oracle.c -- CPU statement of the D3Q19 colour-gradient model (perturbation
+ * operator) that the reference only ships an ini for (IniFiles/RKtwophasesetup3D.ini; the
+ * module RKColorGradientD3Q19 imported by main.py:22 is absent from the tree).
+ *
+ * TEST INFRASTRUCTURE ONLY (rules in oracle/rk_oracle.c).
+ *
+ * PARITY UNPINNED: there is no reference code or golden vector for this path.  The model is
+ * the D3Q19 extension of the reference's 2-D kernels, operator by operator:
+ *   colour gradient   G = 3 sum_i w_i e_i phi(x+e_i), solid neighbours carry the constant
+ *                     phi_s = (SolidRhoR-SolidRhoB)/(SolidRhoR+SolidRhoB)
+ *                     (AcceleratedRKGPU2D.py:1199-1219)
+ *   BGK on f_R, f_B   tau = 1/2 + 1/((1+phi)/(2(tauR-1/2)) + (1-phi)/(2(tauB-1/2)))   (A:1144-1160)
+ *   perturbation      f += (AkR+AkB)/2 |G| (w_i (e_i.G)^2/|G|^2 - B_i)                 (A:1225-1239)
+ *                     with the D3Q19 B_i of Liu, Valocchi & Kang 2012: -1/3, 1/18, 1/36
+ *   recolouring       f_R = rhoR/rho f + beta rhoR rhoB/rho^2 w_i cos(theta_i)         (A:1241-1267)
+ *   streaming         push + in-place half-way bounce-back == pull (A:340-417)
+ *   inlet  (z=nz-2)   Zou-He velocity per colour (A:657-695 -> Hecht & Harting 2010 D3Q19),
+ *                     ghost plane nz-1 = copy with rho re-summed (A:607-650)
+ *   outlet (z=1)      Zou-He pressure per colour (A:1008-1039), ghost plane 0 = copy (A:1045-1081)
+ * Validated by physics/self-consistency tests only (tests/test_oracle_rk3d.py).
+ *
+ * Layout here: dense AoS f[c][z][y][x][19] for clarity; x,y periodic, no wrap in z.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int64_t i64;
+
+#define Q 19
+static const int CX[Q] = {0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 1, -1, 1, -1, 0, 0, 0, 0};
+static const int CY[Q] = {0, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 0, 0, 1, -1, 1, -1};
+static const int CZ[Q] = {0, 0, 0, 0, 0, 1, -1, 0, 0, 0, 0, 1, -1, -1, 1, 1, -1, -1, 1};
+static const int OPP[Q] = {0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15, 18, 17};
+static double WT(int i) { return i == 0 ? 1. / 3. : (i < 7 ? 1. / 18. : 1. / 36.); }
+static double BI(int i) { return i == 0 ? -1. / 3. : (i < 7 ? 1. / 18. : 1. / 36.); }
+
+#if defined(_OPENMP)
+#define PARFOR _Pragma("omp parallel for schedule(static)")
+#else
+#define PARFOR
+#endif
+
+typedef struct {
+    i64 nx, ny, nz;
+    const uint8_t *dom;          /* [nz][ny][nx] 1 = fluid */
+    double akR, akB, beta, tauR, tauB, solidPhi, vzR, vzB, rhoOutR, rhoOutB;
+    double *fR, *fB, *gR, *gB;   /* [nz*ny*nx][19] current / scratch */
+    double *rhoR, *rhoB, *phi, *vx, *vy, *vz, *Gx, *Gy, *Gz;
+} rk3d_sim;
+
+static i64 wrap(i64 v, i64 n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
+
+static void zouhe_inlet(double uz, double *f, double *rho_out)
+{   /* top plane, unknown e_z = -1: 6, 12, 13, 16, 17 */
+    double s0 = f[0] + f[1] + f[2] + f[3] + f[4] + f[7] + f[8] + f[9] + f[10];
+    double sp = f[5] + f[11] + f[14] + f[15] + f[18];
+    double rho = (s0 + 2. * sp) / (1. + uz);
+    double Nx = 0.5 * ((f[1] + f[7] + f[9]) - (f[2] + f[8] + f[10]));
+    double Ny = 0.5 * ((f[3] + f[7] + f[10]) - (f[4] + f[8] + f[9]));
+    f[6] = f[5] - 1. / 3. * rho * uz;
+    f[12] = f[11] - 1. / 6. * rho * uz + Nx;
+    f[13] = f[14] - 1. / 6. * rho * uz - Nx;
+    f[16] = f[15] - 1. / 6. * rho * uz + Ny;
+    f[17] = f[18] - 1. / 6. * rho * uz - Ny;
+    *rho_out = rho;
+}
+
+static void zouhe_outlet(double rho, double *f)
+{   /* bottom plane, unknown e_z = +1: 5, 11, 14, 15, 18 */
+    double s0 = f[0] + f[1] + f[2] + f[3] + f[4] + f[7] + f[8] + f[9] + f[10];
+    double sm = f[6] + f[12] + f[13] + f[16] + f[17];
+    double uz = 1. - 1. / rho * (s0 + 2. * sm);
+    double Nx = 0.5 * ((f[1] + f[7] + f[9]) - (f[2] + f[8] + f[10]));
+    double Ny = 0.5 * ((f[3] + f[7] + f[10]) - (f[4] + f[8] + f[9]));
+    f[5] = f[6] + 1. / 3. * rho * uz;
+    f[11] = f[12] + 1. / 6. * rho * uz - Nx;
+    f[14] = f[13] + 1. / 6. * rho * uz + Nx;
+    f[15] = f[16] + 1. / 6. * rho * uz - Ny;
+    f[18] = f[17] + 1. / 6. * rho * uz + Ny;
+}
+
+static double sum19(const double *f) { double r = 0.; for (int i = 0; i < Q; ++i) r += f[i]; return r; }
+
+/* boundary planes + macroscopic fields of the current (post-streaming) populations */
+static void rk3d_bc_and_macro(rk3d_sim *s)
+{
+    i64 nx = s->nx, ny = s->ny, nz = s->nz, pl = nx * ny;
+    PARFOR
+    for (i64 z = 0; z < nz; ++z)
+        for (i64 k = 0; k < pl; ++k) {
+            i64 n = z * pl + k;
+            if (!s->dom[n]) continue;
+            s->rhoR[n] = sum19(s->fR + Q * n);
+            s->rhoB[n] = sum19(s->fB + Q * n);
+        }
+    for (i64 k = 0; k < pl; ++k) {          /* inlet plane nz-2, ghost nz-1 */
+        i64 n = (nz - 2) * pl + k, g = (nz - 1) * pl + k;
+        if (s->dom[n]) {
+            zouhe_inlet(s->vzR, s->fR + Q * n, &s->rhoR[n]);
+            zouhe_inlet(s->vzB, s->fB + Q * n, &s->rhoB[n]);
+        }
+        if (s->dom[g]) {
+            memcpy(s->fR + Q * g, s->fR + Q * n, sizeof(double) * Q);
+            memcpy(s->fB + Q * g, s->fB + Q * n, sizeof(double) * Q);
+            s->rhoR[g] = sum19(s->fR + Q * g);
+            s->rhoB[g] = sum19(s->fB + Q * g);
+        }
+    }
+    for (i64 k = 0; k < pl; ++k) {          /* outlet plane 1, ghost 0 */
+        i64 n = pl + k, g = k;
+        if (s->dom[n]) {
+            zouhe_outlet(s->rhoOutR, s->fR + Q * n); s->rhoR[n] = s->rhoOutR;
+            zouhe_outlet(s->rhoOutB, s->fB + Q * n); s->rhoB[n] = s->rhoOutB;
+        }
+        if (s->dom[g]) {
+            memcpy(s->fR + Q * g, s->fR + Q * n, sizeof(double) * Q);
+            memcpy(s->fB + Q * g, s->fB + Q * n, sizeof(double) * Q);
+            s->rhoR[g] = s->rhoR[n]; s->rhoB[g] = s->rhoB[n];
+        }
+    }
+    PARFOR
+    for (i64 n = 0; n < nz * pl; ++n) {
+        if (!s->dom[n]) continue;
+        const double *r = s->fR + Q * n, *b = s->fB + Q * n;
+        double mx = 0., my = 0., mz = 0.;
+        for (int i = 0; i < Q; ++i) { double t = r[i] + b[i]; mx += CX[i] * t; my += CY[i] * t; mz += CZ[i] * t; }
+        double rho = s->rhoR[n] + s->rhoB[n];
+        s->vx[n] = mx / rho; s->vy[n] = my / rho; s->vz[n] = mz / rho;
+        s->phi[n] = (s->rhoR[n] - s->rhoB[n]) / (s->rhoR[n] + s->rhoB[n]);
+    }
+}
+
+static void rk3d_collide_stream(rk3d_sim *s)
+{
+    i64 nx = s->nx, ny = s->ny, nz = s->nz, pl = nx * ny;
+    PARFOR
+    for (i64 z = 0; z < nz; ++z)
+        for (i64 y = 0; y < ny; ++y)
+            for (i64 x = 0; x < nx; ++x) {
+                i64 n = z * pl + y * nx + x;
+                if (!s->dom[n]) continue;
+                i64 nb[Q];
+                double gx = 0., gy = 0., gz = 0.;
+                for (int i = 1; i < Q; ++i) {
+                    i64 zz = z + CZ[i];
+                    nb[i] = -1;
+                    double ph = s->solidPhi;
+                    if (zz >= 0 && zz < nz) {
+                        i64 q = zz * pl + wrap(y + CY[i], ny) * nx + wrap(x + CX[i], nx);
+                        if (s->dom[q]) { nb[i] = q; ph = s->phi[q]; }
+                    }
+                    gx += 3. * WT(i) * CX[i] * ph; gy += 3. * WT(i) * CY[i] * ph; gz += 3. * WT(i) * CZ[i] * ph;
+                }
+                s->Gx[n] = gx; s->Gy[n] = gy; s->Gz[n] = gz;
+                double g2 = gx * gx + gy * gy + gz * gz, gn = sqrt(g2);
+                double rR = s->rhoR[n], rB = s->rhoB[n], rho = rR + rB, phi = s->phi[n];
+                double tau = 0.5 + 1. / ((1. + phi) / (2. * (s->tauR - 0.5)) + (1. - phi) / (2. * (s->tauB - 0.5)));
+                double ux = s->vx[n], uy = s->vy[n], uz = s->vz[n], usq = ux * ux + uy * uy + uz * uz;
+                double *r = s->fR + Q * n, *b = s->fB + Q * n;
+                for (int i = 0; i < Q; ++i) {
+                    double eu = CX[i] * ux + CY[i] * uy + CZ[i] * uz;
+                    double feq = rho * WT(i) * (1. + 3. * eu + 4.5 * eu * eu - 1.5 * usq);
+                    double ft = r[i] + b[i];
+                    ft = ft - (ft - feq) / tau;
+                    double eg = CX[i] * gx + CY[i] * gy + CZ[i] * gz;
+                    if (g2 != 0.) ft += (s->akR + s->akB) * 0.5 * gn * (WT(i) * (eg * eg) / g2 - BI(i));
+                    double en = sqrt((double)(CX[i] * CX[i] + CY[i] * CY[i] + CZ[i] * CZ[i]));
+                    double c = (en == 0. || gn == 0.) ? 0. : eg / (en * gn);
+                    double a = (s->beta * rR * rB / (rho * rho)) * WT(i) * c;
+                    double pr = rR / rho * ft + a, pb = rB / rho * ft - a;
+                    /* push with half-way bounce-back */
+                    if (i == 0) { s->gR[Q * n] = pr; s->gB[Q * n] = pb; }
+                    else if (nb[i] >= 0) { s->gR[Q * nb[i] + i] = pr; s->gB[Q * nb[i] + i] = pb; }
+                    else { s->gR[Q * n + OPP[i]] = pr; s->gB[Q * n + OPP[i]] = pb; }
+                }
+            }
+    double *t = s->fR; s->fR = s->gR; s->gR = t;
+    t = s->fB; s->fB = s->gB; s->gB = t;
+}
+
+void rk3d_run(rk3d_sim *s, i64 nsteps)
+{
+    for (i64 k = 0; k < nsteps; ++k) { rk3d_bc_and_macro(s); rk3d_collide_stream(s); }
+}
+
+/* densities / velocity / phi of the current state without touching the populations */
+void rk3d_observe(rk3d_sim *s)
+{
+    i64 N = s->nx * s->ny * s->nz;
+    PARFOR
+    for (i64 n = 0; n < N; ++n) {
+        if (!s->dom[n]) continue;
+        s->rhoR[n] = sum19(s->fR + Q * n);
+        s->rhoB[n] = sum19(s->fB + Q * n);
+    }
+}
+
+void rk3d_init(rk3d_sim *s, const double *rhoR0, const double *rhoB0)
+{
+    i64 N = s->nx * s->ny * s->nz;
+    for (i64 n = 0; n < N; ++n)
+        for (int i = 0; i < Q; ++i) {
+            s->fR[Q * n + i] = s->dom[n] ? WT(i) * rhoR0[n] : 0.;
+            s->fB[Q * n + i] = s->dom[n] ? WT(i) * rhoB0[n] : 0.;
+            s->gR[Q * n + i] = 0.; s->gB[Q * n + i] = 0.;
+        }
+}
+
+void rk3d_bc_and_macro_public(rk3d_sim *s) { rk3d_bc_and_macro(s); }

@@ -1,0 +1,83 @@
+"""CPU tests of the z-slab plumbing (openlbmpm_amd/slab.py): partitioning and the neighbour
+exchange over torch.distributed with the gloo backend, world_size 2 and 3 (the N>1 path of the
+3-D solver uses exactly this code with backend nccl = RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from openlbmpm_amd.slab import partition_z, neighbour_exchange, local_exchange
+
+
+def test_partition_covers_and_orders():
+    for nz, world in ((96, 1), (96, 8), (97, 8), (512, 8), (17, 4)):
+        parts = partition_z(nz, world)
+        assert parts[0][0] == 0 and sum(n for _, n in parts) == nz
+        for (z0, n), (z1, _) in zip(parts, parts[1:]):
+            assert z0 + n == z1
+        assert min(n for _, n in parts) >= 2 and max(n for _, n in parts) - min(n for _, n in parts) <= 1
+    with pytest.raises(ValueError):
+        partition_z(7, 4)
+
+
+def test_local_exchange_matches_definition():
+    k, m = 4, 10
+    up = [torch.full((m,), 10.0 + r) for r in range(k)]
+    dn = [torch.full((m,), 20.0 + r) for r in range(k)]
+    below = [torch.zeros(m) for _ in range(k)]
+    above = [torch.zeros(m) for _ in range(k)]
+    local_exchange(up, dn, below, above)
+    for r in range(k):
+        assert float(below[r][0]) == (10.0 + r - 1 if r > 0 else 0.0)
+        assert float(above[r][0]) == (20.0 + r + 1 if r + 1 < k else 0.0)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = 64
+        # every rank owns a 1-D "lattice" of m*world cells; a step = each cell takes the mean of its
+        # two z-neighbours; the slab version needs exactly one halo cell from each side.
+        rng = np.random.default_rng(1234)
+        full = rng.standard_normal(m * world)
+        (z0, n) = partition_z(m * world, world)[rank]
+        mine = torch.tensor(full[z0:z0 + n])
+        below, above = torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
+        for _ in range(3):
+            neighbour_exchange(mine[-1:].clone(), mine[:1].clone(), below, above, rank, world)
+            ext = torch.cat([below if rank > 0 else mine[:1], mine, above if rank + 1 < world else mine[-1:]])
+            mine = 0.5 * (ext[:-2] + ext[2:])
+        ref = full.copy()
+        for _ in range(3):
+            ext = np.concatenate([ref[:1], ref, ref[-1:]])
+            ref = 0.5 * (ext[:-2] + ext[2:])
+        ok = np.array_equal(mine.numpy(), ref[z0:z0 + n])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_neighbour_exchange_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]
