@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: MLUPS of the fused LBM time step on MI355X.
+"""bench.py -- headline benchmark: MLUPS of the LBM time step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2] [--size NX NY]
+    python bench.py --gpus N --steps K --warmup W [--workload c5|c2|c3] [--size ...]
 
-A "step" is one full lattice time step (stream + BCs + colour gradient + CSF force + MRT
-collision + recolouring) over the whole synthetic domain.  At N=1 the workload is
-BASELINE.json configs[1]: CSF colour-gradient D2Q9 MRT, 1024 x 1024 capillary
-(SimpleGeometry walls, parameters of IniFiles/RKtwophasesetup2D.ini).  2-D configs do not
-shard profitably ("replicas only"), so for N>1 each rank runs an
-independent replica of the same domain (weak scaling) and `value` is the aggregate.
+A "step" is one full lattice time step (stream + boundary planes + colour gradient / forces +
+collision + recolouring) over the whole synthetic domain.  MLUPS counts FLUID-node updates.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel, HBM bound, HIP-event timed on the solver's own stream) and `cpu_baseline` (the C
-oracle = a port of the reference algorithm, timed on the host cores of this box on a
-bounded sample; baseline only, N=1 only).
+Workloads (BASELINE.json configs):
+  c5 (default)  D3Q19 colour gradient, 512^3 synthetic porous medium -- the configuration the
+                metric "MLUPS at 1/2/4/8 GPUs; % of HBM roofline" is quoted on.  It fits one GPU
+                (82 GB) and is z-slab decomposed over N GPUs with RCCL point-to-point halo
+                exchange (strong scaling: the global 512^3 is fixed as N grows).
+  c2            CSF colour-gradient D2Q9 MRT, 1024^2 capillary (configs[1]); N>1 = replicas.
+  c3            explicit-forcing Shan-Chen D2Q9 MRT, 2048^2 porous (configs[2]); N>1 = replicas.
+At N=1 the c2 and c3 figures are measured too and reported under "secondary" in the same line.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HBM bound, HIP-event timed on the
+stream the kernel runs on) and, at N=1, `cpu_baseline` (the C oracle -- a port of the reference
+algorithm -- on this box's host cores, bounded sample; baseline only).
 """
 import argparse
 import json
@@ -27,118 +31,252 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-B_ALG = {"c2": 288.0}        # algorithmic bytes per lattice update
+B_ALG = {"c2": 288.0, "c3": 288.0, "c5": 608.0}   # algorithmic bytes / lattice update
+SEED = 20260928
 
 
-def build_c2(nx, ny, device, variant=0):
+# ----------------------------------------------------------------------------- workloads
+def build_c2(nx, ny, device):
     from openlbmpm_amd.rk2d import RK2DSolver
     from openlbmpm_amd.geometry import simple_geometry, initial_densities_rk
     dom = simple_geometry(nx, ny)
     rR, rB = initial_densities_rk(dom, False, 10, mode="intrusion")
-    s = RK2DSolver(dom, dict(relax="MRT"), device=device, variant=variant)
+    s = RK2DSolver(dom, dict(relax="MRT"), device=device)
     s.set_macro(rR, rB)
-    return s, dom, rR, rB
+    return s, float((rR + rB).sum()), lambda: float((s.get("rhoR") + s.get("rhoB")).sum())
 
 
-def cpu_baseline_c2(nx, ny, target_seconds=12.0):
-    """Time the oracle (C restatement of the reference algorithm, OpenMP over nodes) on a
-    bounded sample of the same workload: same domain and parameters, a few steps."""
+def build_c3(nx, ny, device):
+    from openlbmpm_amd.sc2d import SC2DSolver
+    from openlbmpm_amd.geometry import porous_disks, image_domain
+    img = porous_disks(nx, ny - 40, porosity=0.65, rmin=6.0, rmax=20.0, seed=SEED)
+    dom = image_domain(img, 20, 0.5)
+    ny2 = dom.shape[0]
+    ii = np.arange(ny2)[:, None] + np.zeros(dom.shape, dtype=np.int64)
+    lower = ii < ny2 - 20
+    fluid = dom == 1
+    r0 = np.where(fluid & lower, 1.0, 0.0) + np.where(fluid & ~lower, 0.02, 0.0)
+    r1 = np.where(fluid & lower, 0.02, 0.0) + np.where(fluid & ~lower, 1.0, 0.0)
+    s = SC2DSolver(dom, dict(inter="EFS", relax="MRT", outlet="Dirichlet"), device=device)
+    s.set_density(r0, r1)
+    return s, float((r0 + r1).sum()), None
+
+
+def c5_domain(n):
+    from openlbmpm_amd.geometry import porous_spheres
+    nx, ny, nz = n
+    return porous_spheres(nx, ny, nz, porosity=0.65, rmin=6.0, rmax=20.0, seed=SEED, nbuf=10)
+
+
+def c5_densities(dom_slab, z0, nz_global, nbuf=10):
+    zz = (np.arange(dom_slab.shape[0]) + z0)[:, None, None]
+    fluid = dom_slab == 1
+    red = zz < nz_global - nbuf
+    return np.where(fluid & red, 1.0, 0.0), np.where(fluid & ~red, 1.0, 0.0)
+
+
+def time_solver_2d(solver, steps, warmup):
+    solver.step(warmup)
+    solver.sync()
+    t0 = time.perf_counter()
+    ms_total, ms_dom = solver.step_timed(steps)
+    solver.sync()
+    return time.perf_counter() - t0, ms_total, ms_dom
+
+
+# ----------------------------------------------------------------------------- CPU baselines
+def cpu_baseline_c2(nx, ny, target_seconds=10.0):
     from oracle.rk import RKOracle
     from openlbmpm_amd.geometry import simple_geometry, initial_densities_rk
     dom = simple_geometry(nx, ny)
     rR, rB = initial_densities_rk(dom, False, 10, mode="intrusion")
     o = RKOracle(dom, dict(relax="MRT"), rR, rB)
-    o.run(1)                                   # touch memory / warm up
+    o.run(1)
     t0 = time.perf_counter(); o.run(2); dt = (time.perf_counter() - t0) / 2
     n = max(2, min(200, int(target_seconds / max(dt, 1e-6))))
     t0 = time.perf_counter(); o.run(n); el = time.perf_counter() - t0
-    mlups = o.N * n / el / 1e6
-    return dict(value=round(mlups, 3), unit="MLUPS", cores=o.threads(), kind="port",
-                sample="%dx%d capillary, %d steps of the C oracle (oracle/rk_oracle.c, OpenMP), %.1f s"
-                       % (nx, ny, n, el))
+    return dict(value=round(o.N * n / el / 1e6, 3), unit="MLUPS", cores=o.threads(), kind="port",
+                sample="c2 %dx%d capillary, %d steps of oracle/rk_oracle.c (OpenMP), %.1f s" % (nx, ny, n, el))
 
 
+def cpu_baseline_c5(edge=128, target_seconds=12.0):
+    from oracle.rk3d import RK3DOracle
+    from oracle import lib
+    from openlbmpm_amd.geometry import porous_spheres
+    dom = porous_spheres(edge, edge, edge, porosity=0.65, rmin=6.0, rmax=20.0, seed=SEED, nbuf=10)
+    rR, rB = c5_densities(dom, 0, edge)
+    o = RK3DOracle(dom, rR, rB)
+    nfl = int(dom.sum())
+    o.run(1)
+    t0 = time.perf_counter(); o.run(1); dt = time.perf_counter() - t0
+    n = max(1, min(100, int(target_seconds / max(dt, 1e-6))))
+    t0 = time.perf_counter(); o.run(n); el = time.perf_counter() - t0
+    return dict(value=round(nfl * n / el / 1e6, 3), unit="MLUPS", cores=int(lib().rk_oracle_threads()), kind="port",
+                sample="c5 model on a %d^3 porous sample (same generator/parameters), %d steps of "
+                       "oracle/rk3d_oracle.c (OpenMP), %.1f s" % (edge, n, el))
+
+
+# ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c2")
-    ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("NX", "NY"))
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c5", choices=["c5", "c2", "c3"])
+    ap.add_argument("--size", type=int, nargs="+", default=None, help="c5: NX NY NZ; c2/c3: NX NY")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="0 fused (default), 1 split-3 schedule")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if world > 1 and args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library is the only compute path)"
+    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library is the only compute path)"
-    torch.cuda.set_device(local_rank)
-
-    nx, ny = args.size if args.size else (1024, 1024)
-    if args.workload != "c2":
-        raise SystemExit("unknown workload %r" % args.workload)
-    solver, dom, rR0, rB0 = build_c2(nx, ny, local_rank, args.variant)
-    nfluid = solver.num_fluid_nodes
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    solver.step(args.warmup)
-    solver.sync()
-    barrier()
-    t0 = time.perf_counter()
-    ms_total, ms_dom = solver.step_timed(args.steps)     # HIP events on the solver's stream
-    solver.sync()
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    # sanity: the state must still be finite after the timed steps
-    rho = solver.get("rhoR") + solver.get("rhoB")
-    assert np.isfinite(rho).all(), "non-finite density after the timed run"
-    m0 = float((rR0 + rB0).sum())
-    assert abs(float(rho.sum()) - m0) / m0 < 1e-2, "mass drifted: the timed run did not do real work"
-
+    wl = args.workload
+    out = None
+    if wl == "c5":
+        from openlbmpm_amd.rk3d import RK3DDistributed, RK3DSlab
+        from openlbmpm_amd.slab import partition_z
+        size = tuple(args.size) if args.size else (512, 512, 512)
+        steps = args.steps if args.steps is not None else 100
+        warmup = args.warmup if args.warmup is not None else 10
+        dom = c5_domain(size)
+        nz = size[2]
+        nfluid_global = int(dom.sum())
+        z0, nzl = partition_z(nz, world)[rank]
+        rR, rB = c5_densities(dom[z0:z0 + nzl], z0, nz)
+        m0_local = float((rR + rB).sum())
+        if world == 1:
+            slab = RK3DSlab(dom, 0, nz, device=local_rank)
+            slab.set_density(rR, rB)
+            del rR, rB
+            slab.step_single(warmup)
+            slab.sync(); barrier()
+            t0 = time.perf_counter()
+            ms_total, ms_dom = slab.step_timed(steps)
+            slab.sync(); barrier()
+            wall = time.perf_counter() - t0
+            slab.phase_field(diagnostics=True)
+            rho = slab.get("rhoR") + slab.get("rhoB")
+            nfl_local, dom_kernel = slab.num_fluid_nodes, slab.dominant_kernel
+            slab.close()
+        else:
+            d = RK3DDistributed(dom, device=local_rank)
+            d.slab.set_density(rR, rB)
+            del rR, rB
+            d.step(warmup)
+            d.sync(); barrier()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            t0 = time.perf_counter()
+            d.step(steps, events=ev)
+            d.sync(); barrier()
+            wall = time.perf_counter() - t0
+            ms_dom = sum(a.elapsed_time(b) for a, b in ev)
+            ms_total = wall * 1e3
+            d.observe()
+            rho = d.slab.get("rhoR") + d.slab.get("rhoB")
+            nfl_local, dom_kernel = d.slab.num_fluid_nodes, d.slab.dominant_kernel
+            d.close()
+        assert np.isfinite(rho).all(), "non-finite density after the timed run"
+        assert abs(float(rho.sum()) - m0_local) / max(m0_local, 1.0) < 2e-2, "mass drifted: no real work done?"
+        if dist is not None:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        if rank == 0:
+            per_launch_ms = ms_dom / steps
+            achieved = B_ALG["c5"] * nfl_local / (per_launch_ms * 1e-3) / 1e9
+            out = {
+                "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid_global * steps / wall / 1e6, 2),
+                "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(wall * 1e3 / steps, 5), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "c5: D3Q19 colour gradient (perturbation operator, SRT; RKtwophasesetup3D.ini "
+                                       "parameters), %dx%dx%d synthetic porous medium (spheres r 6-20, porosity 0.65, "
+                                       "10 buffer planes, side walls), seed %d" % (size + (SEED,)),
+                           "fluid_nodes": nfluid_global, "lattice_nodes": int(np.prod(size)),
+                           "parallelism": "z-slabs x%d, RCCL p2p halo (5 populations x 2 colours + phi per face)" % world
+                                          if world > 1 else "1 gpu",
+                           "kernel_schedule": "phase_field + collide (split-2)",
+                           "parity": "unpinned (no 3-D code in the reference); checked against oracle/rk3d_oracle.c"},
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom_kernel,
+                             "avg_launch_ms": round(per_launch_ms, 5),
+                             "algorithmic_bytes_per_launch": B_ALG["c5"] * nfl_local},
+            }
+            if world == 1 and not args.no_secondary:
+                sec = []
+                for name, build, size2 in (("c2", build_c2, (1024, 1024)), ("c3", build_c3, (2048, 2048))):
+                    s, _, _ = build(size2[0], size2[1], local_rank)
+                    k = 1000 if name == "c2" else 300
+                    w, mt, md = time_solver_2d(s, k, k // 10)
+                    nf = s.num_fluid_nodes
+                    sec.append({"workload": name, "value": round(nf * k / w / 1e6, 2), "unit": "MLUPS",
+                                "ms_per_step": round(w * 1e3 / k, 5), "fluid_nodes": nf, "kernel": s.dominant_kernel,
+                                "roofline_frac": round(B_ALG[name] * nf / (md / k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                    s.close()
+                out["secondary"] = sec
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_c5()
+    else:
+        size = tuple(args.size) if args.size else ((1024, 1024) if wl == "c2" else (2048, 2048))
+        steps = args.steps if args.steps is not None else (2000 if wl == "c2" else 500)
+        warmup = args.warmup if args.warmup is not None else steps // 10
+        solver, m0, mass = (build_c2 if wl == "c2" else build_c3)(size[0], size[1], local_rank)
+        nfluid = solver.num_fluid_nodes
+        solver.step(warmup)
+        solver.sync(); barrier()
+        t0 = time.perf_counter()
+        ms_total, ms_dom = solver.step_timed(steps)
+        solver.sync(); barrier()
+        wall = time.perf_counter() - t0
+        if mass is not None:
+            m1 = mass()
+            assert np.isfinite(m1) and abs(m1 - m0) / m0 < 1e-2, "mass drifted: the timed run did not do real work"
+        if dist is not None:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        if rank == 0:
+            per_launch_ms = ms_dom / steps
+            achieved = B_ALG[wl] * nfluid / (per_launch_ms * 1e-3) / 1e9
+            desc = {"c2": "c2: CSF colour-gradient D2Q9 MRT, %dx%d capillary (SimpleGeometry walls, "
+                          "RKtwophasesetup2D.ini parameters, red intruding from the top quarter)",
+                    "c3": "c3: explicit-forcing Shan-Chen D2Q9 MRT (efs2D.ini parameters), %dx%d synthetic "
+                          "porous image (discs r 6-20, porosity 0.65)"}[wl] % size
+            out = {
+                "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid * steps * world / wall / 1e6, 2),
+                "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(wall * 1e3 / steps, 6), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": desc, "fluid_nodes": nfluid, "lattice_nodes": size[0] * size[1],
+                           "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
+                           "kernel_schedule": "fused", "device_ms_per_step_hip_events": round(ms_total / steps, 6)},
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                             "kernel": solver.dominant_kernel, "avg_launch_ms": round(per_launch_ms, 6),
+                             "algorithmic_bytes_per_launch": B_ALG[wl] * nfluid},
+            }
+            if world == 1 and not args.no_cpu_baseline and wl == "c2":
+                out["cpu_baseline"] = cpu_baseline_c2(*size)
+        solver.close()
     if rank == 0:
-        mlups = nfluid * args.steps * world / wall / 1e6
-        dom_ms_per_launch = ms_dom / args.steps
-        achieved = B_ALG[args.workload] * nfluid / (dom_ms_per_launch * 1e-3) / 1e9
-        out = {
-            "metric": "MLUPS (million lattice updates/s)", "value": round(mlups, 2), "unit": "MLUPS",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall * 1e3 / args.steps, 6), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "c2: CSF colour-gradient D2Q9 MRT, %dx%d capillary "
-                                   "(SimpleGeometry walls, RKtwophasesetup2D.ini parameters, "
-                                   "red intruding from the top quarter)" % (nx, ny),
-                       "fluid_nodes": nfluid, "lattice_nodes": nx * ny,
-                       "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
-                       "kernel_schedule": "fused" if args.variant == 0 else "split-3",
-                       "device_ms_per_step_hip_events": round(ms_total / args.steps, 6)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": solver.dominant_kernel,
-                         "avg_launch_ms": round(dom_ms_per_launch, 6),
-                         "algorithmic_bytes_per_launch": B_ALG[args.workload] * nfluid},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_c2(nx, ny)
         print(json.dumps(out), flush=True)
-    solver.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -239,6 +239,22 @@ __global__ void rk3d_unpack(RK3Dev p, double *f, const double *recv_from_below, 
         }
 }
 
+// f = w rho at rest on the owned planes (3-D analogue of RKD2Q9.py:577-601); rho arrays are dense
+// [nzl][ny][nx] on the device
+__global__ void rk3d_init_rest(RK3Dev p, const double *rho_r, const double *rho_b, double *f)
+{
+    const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
+    const bool fluid = p.flags[idx] & 1;
+    const size_t s = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
+    const double a = fluid ? rho_r[s] : 0., b = fluid ? rho_b[s] : 0.;
+    for (int i = 0; i < Q; ++i) {
+        f[(size_t)i * p.vol + idx] = wq(i) * a;
+        f[((size_t)Q + i) * p.vol + idx] = wq(i) * b;
+    }
+}
+
 __global__ void rk3d_setup_solidnbr(RK3Dev p, uint32_t *solidnbr)
 {
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
@@ -394,21 +410,16 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
 {
     LBMPM_REQUIRE(c && rho_r && rho_b, "lbmpm_rk3d_set_density: null argument");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
-    std::vector<double> h(2 * Q * c->vol, 0.0);
-    const size_t hp = (size_t)c->nx * c->ny;
-    for (int z = 0; z < c->nzl; ++z)
-        for (int y = 0; y < c->ny; ++y)
-            for (int x = 0; x < c->nx; ++x) {
-                const size_t s = (size_t)z * hp + (size_t)y * c->nx + x;
-                if (c->h_domain[s] != 1) continue;
-                const size_t d = (size_t)(z + 1) * c->plane2 + (size_t)y * c->pitch + x;
-                for (int i = 0; i < Q; ++i) {
-                    const double w = i == 0 ? 1. / 3. : (i < 7 ? 1. / 18. : 1. / 36.);
-                    h[(size_t)i * c->vol + d] = w * rho_r[s];
-                    h[(size_t)(Q + i) * c->vol + d] = w * rho_b[s];
-                }
-            }
-    LBMPM_HIP_TRY(hipMemcpyAsync(c->fA, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // stage the two density fields in the (idle) second population buffer, expand on the device
+    const size_t n = (size_t)c->nx * c->ny * c->nzl;
+    double *stage = c->fB;
+    LBMPM_HIP_TRY(hipMemcpyAsync(stage, rho_r, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    LBMPM_HIP_TRY(hipMemcpyAsync(stage + n, rho_b, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    LBMPM_HIP_TRY(hipMemsetAsync(c->fA, 0, 2 * Q * c->vol * sizeof(double), c->stream));
+    RK3Dev p = make_dev(c);
+    rk3d_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
+    LBMPM_HIP_TRY(hipGetLastError());
+    LBMPM_HIP_TRY(hipMemsetAsync(c->fB, 0, 2 * Q * c->vol * sizeof(double), c->stream));
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     c->streamed = false;
     c->steps = 0;

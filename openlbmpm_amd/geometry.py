@@ -93,11 +93,12 @@ def porous_spheres(nx, ny, nz, porosity=0.65, rmin=6.0, rmax=20.0, seed=20260928
         y0, y1 = max(int(cy - r), 0), min(int(cy + r) + 2, ny)
         z0, z1 = max(int(cz - r), nbuf), min(int(cz + r) + 2, nz - nbuf)
         if z1 > z0:
-            zz, yy, xx = np.mgrid[z0:z1, y0:y1, x0:x1]
-            solid[z0:z1, y0:y1, x0:x1] |= (xx - cx) ** 2 + (yy - cy) ** 2 + (zz - cz) ** 2 <= r * r
+            zz, yy, xx = np.ogrid[z0:z1, y0:y1, x0:x1]
+            ball = (xx - cx) ** 2 + (yy - cy) ** 2 + (zz - cz) ** 2 <= r * r
+            sub = solid[z0:z1, y0:y1, x0:x1]
+            count += int(np.count_nonzero(ball & ~sub))
+            sub |= ball
         n += 1
-        if n % 8 == 0:
-            count = int(solid[core].sum())
     if walls:
         solid[core, :, 0] = True; solid[core, :, -1] = True
         solid[core, 0, :] = True; solid[core, -1, :] = True

@@ -204,18 +204,34 @@ class RK3DDistributed:
                            s.buffer(kind + "_recv_below"), s.buffer(kind + "_recv_above"),
                            self.rank, self.world, self.group)
 
-    def step(self, n):
+    def _halo_f(self):
+        s = self.slab
+        if s.steps_done > 0 and self.world > 1:
+            s.pack()
+            self._exchange("f")
+            s.unpack(self.rank > 0, self.rank + 1 < self.world)
+
+    def step(self, n, events=None):
+        """events: optional list of n (start, stop) torch.cuda.Event pairs recorded around the
+        dominant kernel on the stream it runs on."""
         s = self.slab
         with self._torch.cuda.stream(self.stream):
-            for _ in range(int(n)):
-                if s.steps_done > 0 and self.world > 1:
-                    s.pack()
-                    self._exchange("f")
-                    s.unpack(self.rank > 0, self.rank + 1 < self.world)
+            for k in range(int(n)):
+                self._halo_f()
                 s.phase_field()
                 if self.world > 1:
                     self._exchange("phi")
+                if events is not None:
+                    events[k][0].record(self.stream)
                 s.collide()
+                if events is not None:
+                    events[k][1].record(self.stream)
+
+    def observe(self):
+        with self._torch.cuda.stream(self.stream):
+            self._halo_f()
+            self.slab.phase_field(diagnostics=True)
+        self.stream.synchronize()
 
     def sync(self):
         self.stream.synchronize()

@@ -1,0 +1,44 @@
+"""Closed forms used by the HIP kernels instead of the reference's dense 9x9 loops, checked
+against the matrices the reference builds (RKD2Q9.py:308-340, SimpleD2Q9.py:107-124)."""
+import numpy as np
+
+from oracle.rk import mrt_matrices
+from oracle.sc import transformation_matrix
+
+EX = np.array([0, 1, 0, -1, 0, 1, -1, -1, 1.]); EY = np.array([0, 0, 1, 0, -1, 1, 1, -1, -1.])
+W = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)
+
+
+def test_both_drivers_use_the_same_basis_with_orthogonal_rows():
+    M, Minv, _ = mrt_matrices()
+    assert np.array_equal(M, transformation_matrix())
+    n2 = (M * M).sum(axis=1)
+    assert np.array_equal(n2, [9, 36, 36, 6, 12, 6, 12, 4, 4])
+    assert np.allclose(M @ M.T, np.diag(n2))
+    assert np.max(np.abs(Minv - M.T / n2)) < 1e-15
+
+
+def test_equilibrium_and_guo_source_moments():
+    M, _, _ = mrt_matrices()
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        rho, ux, uy, Fx, Fy = rng.uniform(0.5, 2), *rng.uniform(-0.1, 0.1, 2), *rng.uniform(-0.01, 0.01, 2)
+        eu = EX * ux + EY * uy
+        feq = rho * W * (1 + 3 * eu + 4.5 * eu ** 2 - 1.5 * (ux * ux + uy * uy))
+        usq = ux * ux + uy * uy
+        meq = rho * np.array([1, -2 + 3 * usq, 1 - 3 * usq, ux, -ux, uy, -uy, ux * ux - uy * uy, ux * uy])
+        assert np.max(np.abs(M @ feq - meq)) < 1e-14
+        src = W * (3 * EX * Fx + 3 * EY * Fy + 9 * (EX * EX - 1 / 3) * ux * Fx + 9 * EX * EY * uy * Fx +
+                   9 * EY * EX * ux * Fy + 9 * (EY * EY - 1 / 3) * uy * Fy)
+        uF = ux * Fx + uy * Fy
+        ms = np.array([0, 6 * uF, -6 * uF, Fx, -Fx, Fy, -Fy, 2 * (ux * Fx - uy * Fy), ux * Fy + uy * Fx])
+        assert np.max(np.abs(M @ src - ms)) < 1e-15
+
+
+def test_recolouring_cosine_identity():
+    """cos(phi_i)|e_i| = (e_i . G)/|G| for every D2Q9 direction (used by the HIP recolouring)."""
+    g = np.array([0.3, -0.7])
+    gn = np.hypot(*g)
+    for ex, ey in zip(EX[1:], EY[1:]):
+        en = np.hypot(ex, ey)
+        assert abs((ex * g[0] + ey * g[1]) / (en * gn) * en - (ex * g[0] + ey * g[1]) / gn) < 1e-15
