@@ -35,6 +35,19 @@ B_ALG = {"c2": 288.0, "c3": 288.0, "c5": 608.0}   # algorithmic bytes / lattice 
 SEED = 20260928
 
 
+def pmc_traffic(kernel, workload_tag):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json), or None when no profile matches this exact workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            rec = json.load(fh)["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
+    if not rec or rec.get("workload") != workload_tag:
+        return None
+    return rec["traffic_bytes_per_launch"]
+
+
 # ----------------------------------------------------------------------------- workloads
 def build_c2(nx, ny, device):
     from openlbmpm_amd.rk2d import RK2DSolver
@@ -215,7 +228,9 @@ def main():
                            "kernel_schedule": "phase_field + collide (split-2)",
                            "parity": "unpinned (no 3-D code in the reference); checked against oracle/rk3d_oracle.c"},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom_kernel,
+                             "frac": round(achieved / HBM_PEAK_GBS, 4),
+                             "traffic": pmc_traffic(dom_kernel, "c5 %dx%dx%d" % size) if world == 1 else None,
+                             "kernel": dom_kernel,
                              "avg_launch_ms": round(per_launch_ms, 5),
                              "algorithmic_bytes_per_launch": B_ALG["c5"] * nfl_local},
             }
@@ -268,7 +283,8 @@ def main():
                            "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
                            "kernel_schedule": "fused", "device_ms_per_step_hip_events": round(ms_total / steps, 6)},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                             "frac": round(achieved / HBM_PEAK_GBS, 4),
+                             "traffic": pmc_traffic(solver.dominant_kernel, "%s %dx%d" % ((wl,) + size)),
                              "kernel": solver.dominant_kernel, "avg_launch_ms": round(per_launch_ms, 6),
                              "algorithmic_bytes_per_launch": B_ALG[wl] * nfluid},
             }
