@@ -148,12 +148,17 @@ def main():
     if world > 1 and args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library is the only compute path)"
+    local_rank = local_rank % torch.cuda.device_count()    # (lets a 1-GPU box rehearse the N>1 code path)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("LBMPM_DIST_BACKEND", "nccl")     # "gloo": 1-GPU rehearsal of the N>1 path
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if dist is not None:
@@ -208,7 +213,7 @@ def main():
         assert np.isfinite(rho).all(), "non-finite density after the timed run"
         assert abs(float(rho.sum()) - m0_local) / max(m0_local, 1.0) < 2e-2, "mass drifted: no real work done?"
         if dist is not None:
-            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         if rank == 0:
@@ -264,7 +269,7 @@ def main():
             m1 = mass()
             assert np.isfinite(m1) and abs(m1 - m0) / m0 < 1e-2, "mass drifted: the timed run did not do real work"
         if dist is not None:
-            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         if rank == 0:

@@ -27,6 +27,17 @@ def neighbour_exchange(send_up, send_down, recv_from_below, recv_from_above, ran
     not periodic in z.  Point-to-point only (ncclSend/ncclRecv pairs grouped in one batch), no
     collective on the data path."""
     import torch.distributed as dist
+    if send_up.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal transport (several ranks sharing ONE GPU, where RCCL refuses duplicate
+        # devices): stage through host memory; same neighbours, same buffers, same order
+        torch.cuda.current_stream(send_up.device).synchronize()
+        h = [t.cpu() for t in (send_up, send_down, recv_from_below, recv_from_above)]
+        neighbour_exchange(h[0], h[1], h[2], h[3], rank, world, group)
+        if rank > 0:
+            recv_from_below.copy_(h[2])
+        if rank + 1 < world:
+            recv_from_above.copy_(h[3])
+        return
     ops = []
     if rank + 1 < world:
         ops.append(dist.P2POp(dist.isend, send_up, rank + 1, group))

@@ -63,3 +63,42 @@ def test_single_slab_convenience_equals_phases():
     c.step(7); c.observe()
     assert np.array_equal(s.get("phi"), c.get("phi")) and np.array_equal(s.get("vz"), c.get("vz"))
     s.close(); c.close()
+
+
+def test_two_process_slab_run_equals_single_process(tmp_path):
+    """The N>1 orchestration of bench.py / RK3DDistributed with two OS processes sharing this one
+    GPU (gloo transport staged through the host, because RCCL refuses duplicate devices): the
+    gathered result must equal the single-process run bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from test_rk3d_gpu import _case
+from openlbmpm_amd.rk3d import RK3DDistributed
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+dom, rR, rB = _case(nx=33, ny=18, nz=41, seed=9)
+d = RK3DDistributed(dom, device=0)
+d.set_density(rR, rB)
+d.step(15); d.observe()
+np.save(os.path.join(%r, "phi_%%d.npy" %% dist.get_rank()), d.slab.get("phi"))
+np.save(os.path.join(%r, "vz_%%d.npy" %% dist.get_rank()), d.slab.get("vz"))
+d.close(); dist.destroy_process_group()
+''' % (root, root, str(tmp_path), str(tmp_path)))
+    env = dict(os.environ)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)], env=env, timeout=300)
+    from openlbmpm_amd.rk3d import RK3DCluster
+    dom, rR, rB = _case(nx=33, ny=18, nz=41, seed=9)
+    c = RK3DCluster(dom, 1)
+    c.set_density(rR, rB)
+    c.step(15); c.observe()
+    for f in ("phi", "vz"):
+        got = np.concatenate([np.load(tmp_path / ("%s_%d.npy" % (f, r))) for r in range(2)], axis=0)
+        assert np.array_equal(got, c.get(f)), f
+    c.close()
