@@ -195,7 +195,10 @@ typedef enum lbmpm_sc2d_field {
     LBMPM_SC_RHO0 = 2, LBMPM_SC_RHO1 = 3,    /* [ny][nx]     deviceFluidRho[k]             */
     LBMPM_SC_VX = 4, LBMPM_SC_VY = 5,        /* devicePhysicalVX/VY                        */
     LBMPM_SC_FX0 = 6, LBMPM_SC_FX1 = 7, LBMPM_SC_FY0 = 8, LBMPM_SC_FY1 = 9, /* deviceForceX/Y[k] */
-    LBMPM_SC_UEQX = 10, LBMPM_SC_UEQY = 11   /* EFS: deviceEquilibriumVX/VY                */
+    LBMPM_SC_UEQX = 10, LBMPM_SC_UEQY = 11,  /* EFS: deviceEquilibriumVX/VY                */
+    /* original Shan-Chen only: what the driver records mid-iteration, after the inlet kernels of
+     * the NEXT iteration (ShanChenD2Q9.py:1523-1572) */
+    LBMPM_SC_REC_PDF0 = 20, LBMPM_SC_REC_PDF1 = 21, LBMPM_SC_REC_RHO0 = 22, LBMPM_SC_REC_RHO1 = 23
 } lbmpm_sc2d_field;
 
 int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is_domain, lbmpm_sc2d **out);

@@ -1,0 +1,141 @@
+"""Reader for the reference's ini files (IniFiles/*.ini), same grammar and key names.
+
+String values keep their single quotes in the files (`Type = 'MRT'`; the reference compares
+against "'MRT'", RKD2Q9.py:36); option names are case-insensitive (configparser).  Known skews of
+the shipped files are accepted both ways: `SurfaceTension` vs
+`SurfaceTensionValue`; missing `[BodyForce] isBodyForce`.  Errors raise ConfigError (the
+reference prints and sys.exit()s).
+"""
+import configparser
+import os
+
+
+class ConfigError(ValueError):
+    pass
+
+
+def _unquote(v):
+    v = v.strip()
+    if len(v) >= 2 and v[0] == "'" and v[-1] == "'":
+        return v[1:-1]
+    return v
+
+
+class Ini:
+    def __init__(self, path):
+        if not os.path.isfile(path):
+            raise ConfigError("ini file not found: %s" % path)
+        self.path = path
+        self.cp = configparser.ConfigParser()
+        self.cp.read(path)
+
+    def raw(self, section, *keys, default=None):
+        if section not in self.cp:
+            if default is not None:
+                return default
+            raise ConfigError("%s: missing section [%s]" % (self.path, section))
+        for k in keys:
+            if k in self.cp[section]:
+                return self.cp[section][k]
+        if default is not None:
+            return default
+        raise ConfigError("%s: missing key %s in [%s]" % (self.path, "/".join(keys), section))
+
+    def str(self, section, *keys, default=None):
+        return _unquote(self.raw(section, *keys, default=default))
+
+    def _num(self, conv, section, keys, default):
+        v = self.raw(section, *keys, default=None if default is None else repr(default))
+        try:
+            return conv(_unquote(v).split(";")[0])
+        except ValueError:
+            raise ConfigError("%s: [%s] %s = %r is not a %s" % (self.path, section, keys[0], v, conv.__name__))
+
+    def float(self, section, *keys, default=None):
+        return self._num(float, section, keys, default)
+
+    def int(self, section, *keys, default=None):
+        return self._num(int, section, keys, default)
+
+    def floats(self, section, key, count=None):
+        v = [p for p in self.raw(section, key).split(",")]
+        try:
+            out = [float(p) for p in v]
+        except ValueError:
+            raise ConfigError("%s: [%s] %s must be a comma list of numbers" % (self.path, section, key))
+        if count is not None and len(out) != count:
+            raise ConfigError("%s: [%s] %s needs %d values" % (self.path, section, key, count))
+        return out
+
+
+def read_rk2d(ini_dir):
+    """RKtwophasesetup2D.ini -> dict (keys consumed by RKD2Q9.py:26-297)."""
+    c = Ini(os.path.join(ini_dir, "RKtwophasesetup2D.ini"))
+    p = {}
+    p["image"] = c.str("ImageSetup", "Existance") == "yes"
+    if not p["image"]:
+        p["nx"] = c.int("DomainSize", "xDomain"); p["ny"] = c.int("DomainSize", "yDomain")
+    p["nbuf"] = c.int("DomainSize", "numBufferingLayers")
+    p["ratio"] = c.float("DomainSize", "ratioTopToBottom")
+    p["tension_type"] = c.str("SurfaceTension", "SurfaceTensionType")
+    if p["tension_type"] not in ("CSF", "Perturbation"):
+        raise ConfigError("SurfaceTensionType must be 'CSF' or 'Perturbation'")
+    if p["tension_type"] == "Perturbation":
+        raise ConfigError("the 'Perturbation' driver path is dead in the reference (RKD2Q9.py:1099 passes 10 "
+                          "arguments to a 12-argument kernel); only 'CSF' is supported")
+    p["sigma"] = c.float("SurfaceTension", "SurfaceTensionValue", "SurfaceTension")
+    p["theta"] = c.float("SurfaceTension", "ContactAngle")
+    p["wetting"] = c.int("SurfaceTension", "WettingType")
+    p["beta"] = c.float("RKParameters", "BetaThickness")
+    p["delta"] = c.float("RKParameters", "DeltaValue")
+    p["tauR"] = c.float("FluidParameters", "TauR"); p["tauB"] = c.float("FluidParameters", "TauB")
+    p["rho0R"] = c.float("FluidParameters", "InitialRhoR"); p["rho0B"] = c.float("FluidParameters", "InitialRhoB")
+    p["tautype"] = c.int("FluidParameters", "TauType")
+    if c.str("BodyForce", "isBodyForce", default="'no'") == "yes":
+        raise ConfigError("body force is read but never used by the reference's CSF loop; not supported")
+    p["steps"] = c.int("TimeSetup", "TimeSteps"); p["interval"] = c.int("TimeSetup", "TimeInterval")
+    p["relax"] = c.str("RelaxationType", "Type")
+    p["inlet"] = c.str("BoundaryCondition", "BoundaryTypeInlet")
+    p["outlet"] = c.str("BoundaryCondition", "BoundaryTypeOutlet")
+    p["vyR"] = c.float("BoundaryCondition", "VelocityYR", default=0.0)
+    p["vyB"] = c.float("BoundaryCondition", "VelocityYB", default=0.0)
+    p["rhoBH"] = c.float("BoundaryCondition", "densityBH", default=1.0)
+    p["rhoRH"] = c.float("BoundaryCondition", "densityRH", default=1.0)
+    p["rhoBL"] = c.float("BoundaryCondition", "densityBL", default=1.0)
+    p["rhoRL"] = c.float("BoundaryCondition", "densityRL", default=1.0)
+    p["cycle"] = c.str("CyclesSetup", "IsCycle", default="'no'") == "yes"
+    p["last_step"] = c.int("CyclesSetup", "LastStep", default=0)
+    return p
+
+
+def read_sc2d(ini_dir):
+    """twophasesetup.ini + efs2D.ini | shanchen2D.ini -> dict (ShanChenD2Q9.py:42-157, :172-499)."""
+    c = Ini(os.path.join(ini_dir, "twophasesetup.ini"))
+    p = {}
+    p["image"] = c.str("PictureSetup", "Exist") == "yes"
+    if not p["image"]:
+        p["nx"] = c.int("SeparationBorder", "xGrid"); p["ny"] = c.int("SeparationBorder", "yGrid")
+    if c.int("FluidsTypes", "NumberOfFluids") != 2:
+        raise ConfigError("NumberOfFluids must be 2 (the reference's outlet kernel is hard-wired to two fluids)")
+    p["inter"] = c.str("InterType", "InteractionType")
+    if p["inter"] not in ("ShanChen", "EFS"):
+        raise ConfigError("InteractionType must be 'ShanChen' or 'EFS'")
+    p["relax"] = c.str("RelaxationType", "Type")
+    if c.str("DuplicateDomain", "Option", default="'no'") == "yes":
+        raise ConfigError("DuplicateDomain prompts interactively in the reference; not supported")
+    m = Ini(os.path.join(ini_dir, "efs2D.ini" if p["inter"] == "EFS" else "shanchen2D.ini"))
+    sec = "EFSParameters" if p["inter"] == "EFS" else "ShanChenParameters"
+    p["rho0"], p["rho1"] = m.floats("FluidProperties", "InitialDensities", 2)
+    p["bg0"], p["bg1"] = m.floats("FluidProperties", "BackgroundDensities", 2)
+    p["tau0"], p["tau1"] = m.floats("FluidProperties", "FluidsTau", 2)
+    p["G"] = m.floats(sec, "InteractionFluid", 1)[0]
+    p["Gs0"], p["Gs1"] = m.floats(sec, "InteractionSolid", 2)
+    if m.str("BoundaryDefinition", "BoundaryTypeInlet") != "Neumann" or m.str("BoundaryDefinition", "BoundaryMethod") != "ZouHe":
+        raise ConfigError("only BoundaryTypeInlet 'Neumann' with BoundaryMethod 'ZouHe' runs in the reference "
+                          "(the Dirichlet inlet references undefined attributes, ShanChenD2Q9.py:1497)")
+    p["outlet"] = m.str("BoundaryDefinition", "BoundaryTypeOutlet")
+    p["vy0"], p["vy1"] = m.floats("VelocityBoundary", "velocityY", 2)
+    if p["inter"] == "EFS" and m.int("ForceScheme", "ExplicitScheme") != 4:
+        raise ConfigError("ExplicitScheme 8/10 (higher isotropy) is not built yet")
+    p["steps"] = m.int("Time", "numberTimeStep")
+    return p

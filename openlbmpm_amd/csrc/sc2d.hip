@@ -341,6 +341,7 @@ __global__ __launch_bounds__(THREADS) void sc2d_fused(SCDev p, int tiles_x)
 
 // SC end-of-iteration view (D:1624-1629): streamed populations + outlet copies, rho, u with the
 // force of that iteration.
+template <bool INLET>
 __global__ __launch_bounds__(256) void sc2d_observe(SCDev p, double *out)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void sc2d_observe(SCDev p, double *out)
     const size_t idx = (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
     double f0[9], f1[9], r0, r1;
-    node_state<false>(p, x, y, f0, f1, r0, r1);
+    node_state<INLET>(p, x, y, f0, f1, r0, r1);
 #pragma unroll
     for (int j = 0; j < 9; ++j) { out[j * p.plane + idx] = f0[j]; out[(9 + j) * p.plane + idx] = f1[j]; }
     out[D_RHO * p.plane + idx] = r0; out[(D_RHO + 1) * p.plane + idx] = r1;
@@ -736,7 +737,13 @@ extern "C" int lbmpm_sc2d_enable_diagnostics(lbmpm_sc2d *c, int on)
 extern "C" int lbmpm_sc2d_get_field(lbmpm_sc2d *c, int field, double *out)
 {
     LBMPM_REQUIRE(c && out, "lbmpm_sc2d_get_field: null argument");
-    LBMPM_REQUIRE(field >= LBMPM_SC_PDF0 && field <= LBMPM_SC_UEQY, "unknown field id %d", field);
+    const bool rec = field >= LBMPM_SC_REC_PDF0 && field <= LBMPM_SC_REC_RHO1;
+    LBMPM_REQUIRE((field >= LBMPM_SC_PDF0 && field <= LBMPM_SC_UEQY) || rec, "unknown field id %d", field);
+    if (rec) {
+        LBMPM_REQUIRE(c->cfg.model == LBMPM_SC_MODEL_SHANCHEN, "LBMPM_SC_REC_* describe the original Shan-Chen loop "
+                      "(records are taken mid-iteration there); the EFS loop records the end-of-iteration fields");
+        field -= LBMPM_SC_REC_PDF0;
+    }
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     if (!c->keep_force) {
@@ -752,7 +759,8 @@ extern "C" int lbmpm_sc2d_get_field(lbmpm_sc2d *c, int field, double *out)
         if (!c->obs) { const int rc = dev_alloc(c, &c->obs, D_PLANES * c->plane); if (rc) return rc; }
         SCDev p = make_dev(c);
         const dim3 b(64, 4), g((c->nx + 63) / 64, (c->ny + 3) / 4);
-        sc2d_observe<<<g, b, 0, c->stream>>>(p, c->obs);
+        if (rec) sc2d_observe<true><<<g, b, 0, c->stream>>>(p, c->obs);
+        else sc2d_observe<false><<<g, b, 0, c->stream>>>(p, c->obs);
         LBMPM_HIP_TRY(hipGetLastError());
         LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
         src = c->obs;

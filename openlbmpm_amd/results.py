@@ -1,0 +1,79 @@
+"""Result files with the reference's HDF5 group / dataset names
+(RKD2Q9.py:348-357, :938-957; ShanChenD2Q9.py:503-511, :940-955).
+
+Backend: PyTables or h5py when importable (same file layout as the reference's `tables` calls);
+otherwise a `.npz` whose keys are the HDF5 paths (`/FluidMacro/FluidDensityRin0`, ...), so that
+post-processing only has to swap the loader.
+"""
+import os
+
+import numpy as np
+
+
+def _backend():
+    try:
+        import tables  # noqa: F401
+        return "tables"
+    except ImportError:
+        pass
+    try:
+        import h5py  # noqa: F401
+        return "h5py"
+    except ImportError:
+        return "npz"
+
+
+class ResultFile:
+    def __init__(self, directory, name, groups):
+        os.makedirs(directory, exist_ok=True)
+        self.backend = _backend()
+        self.groups = list(groups)
+        self.path = os.path.join(directory, name + (".h5" if self.backend != "npz" else ".npz"))
+        self._npz = {}
+        if self.backend == "tables":
+            import tables as tb
+            f = tb.open_file(self.path, "w")
+            for g, title in self.groups:
+                f.create_group(f.root, g, title)
+            f.close()
+        elif self.backend == "h5py":
+            import h5py
+            with h5py.File(self.path, "w") as f:
+                for g, _ in self.groups:
+                    f.create_group(g)
+
+    def write(self, group, name, array):
+        array = np.asarray(array)
+        if self.backend == "tables":
+            import tables as tb
+            f = tb.open_file(self.path, "a")
+            f.create_array("/" + group, name, array)
+            f.close()
+        elif self.backend == "h5py":
+            import h5py
+            with h5py.File(self.path, "a") as f:
+                f["/%s/%s" % (group, name)] = array
+        else:
+            self._npz["/%s/%s" % (group, name)] = np.array(array, copy=True)
+            np.savez_compressed(self.path, **self._npz)
+
+
+def load_results(path):
+    """dict path -> array for either backend"""
+    if path.endswith(".npz"):
+        d = np.load(path)
+        return {k: d[k] for k in d.files}
+    try:
+        import h5py
+        out = {}
+        with h5py.File(path, "r") as f:
+            f.visititems(lambda n, o: out.__setitem__("/" + n, o[()]) if hasattr(o, "shape") else None)
+        return out
+    except ImportError:
+        import tables as tb
+        out = {}
+        f = tb.open_file(path, "r")
+        for node in f.walk_nodes("/", "Array"):
+            out[node._v_pathname] = node.read()
+        f.close()
+        return out

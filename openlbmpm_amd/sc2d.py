@@ -11,7 +11,8 @@ import numpy as np
 from . import _lib
 from ._lib import F64P, U8P, SC2DConfig, check
 
-FIELDS = dict(f0=0, f1=1, rho0=2, rho1=3, vx=4, vy=5, Fx0=6, Fx1=7, Fy0=8, Fy1=9, ueqx=10, ueqy=11)
+FIELDS = dict(f0=0, f1=1, rho0=2, rho1=3, vx=4, vy=5, Fx0=6, Fx1=7, Fy0=8, Fy1=9, ueqx=10, ueqy=11,
+              rec_f0=20, rec_f1=21, rec_rho0=22, rec_rho1=23)
 
 # parameter names follow the reference ini files (twophasesetup.ini, efs2D.ini / shanchen2D.ini)
 DEFAULT_PARAMS = dict(inter="EFS", relax="SRT", tau0=1.0, tau1=1.0, G=0.20, Gs0=-0.14, Gs1=0.14,
@@ -97,7 +98,7 @@ class SC2DSolver:
         check(self._L.lbmpm_sc2d_sync(self._h), "sync")
 
     def get(self, name):
-        shape = (self.ny, self.nx, 9) if name in ("f0", "f1") else (self.ny, self.nx)
+        shape = (self.ny, self.nx, 9) if name in ("f0", "f1", "rec_f0", "rec_f1") else (self.ny, self.nx)
         out = np.empty(shape, dtype=np.float64)
         check(self._L.lbmpm_sc2d_get_field(self._h, FIELDS[name], out.ctypes.data_as(F64P)), "get_field(%s)" % name)
         return out

@@ -1,0 +1,148 @@
+"""Own ini fixtures in the reference's grammar (quoted strings, comments, key spellings of the
+shipped files incl. their skews) for the config / driver tests."""
+
+RK_INI = """[ImageSetup]
+Existance = 'no'
+
+[DomainSize]
+xDomain = {nx}
+yDomain = {ny}
+numBufferingLayers = 10
+ratioTopToBottom = 0.5
+
+[SurfaceTension]
+SurfaceTensionType = 'CSF'
+;;'CSF'-> continuum surface force
+SurfaceTension = 0.1
+ContactAngle = 60
+WettingType = 2
+;;1 - Y. Xu et al 2017
+
+[RKParameters]
+AlphaR = 0.44444444
+AlphaB = 0.44444444
+BetaThickness = 0.7
+AkR = 1.4e-1
+AkB = 1.4e-1
+DeltaValue = 0.98
+
+[FluidParameters]
+TauR = 1.0
+TauB = 1.0
+InitialRhoR = 1.0
+InitialRhoB = 1.0
+TauType = 2
+
+[BodyForce]
+bodyForceX = 0.0
+bodyForceY = 0.0
+
+[SolidBoundarySetup]
+SolidColorDiff = 0.5
+
+[BoundaryCondition]
+BoundaryTypeInlet = 'Neumann'
+NeumannType = 'ZouHe'
+velocityYR = -1.0e-4
+densityBH = 5e-8
+densityRH = 1.00536
+velocityYB = 0.0
+BoundaryTypeOutlet = 'Dirichlet'
+densityBL = 1.0
+densityRL = 5e-8
+
+[GradientType]
+Type = 'Isotropic'
+
+[TimeSetup]
+TimeSteps = {steps}
+TimeInterval = {interval}
+
+[Parallelism]
+Parallel = 'yes'
+xDimension = 128
+ThreadsNum = 32
+
+[RelaxationType]
+Type = '{relax}'
+;;MRT
+
+[CyclesSetup]
+IsCycle = 'no'
+LastStep = 100
+"""
+
+TWOPHASE_INI = """[PictureSetup]
+Exist = 'no'
+[SeparationBorder]
+xGrid = {nx}
+yGrid = {ny}
+[FluidsTypes]
+NumberOfFluids = 2
+[InterType]
+InteractionType = '{inter}'
+;;ShanChen: original Shan-Chen Model
+[Parallelism]
+Parallel = 'yes'
+xDimension = 256
+ThreadsNum = 32
+[RelaxationType]
+Type = '{relax}'
+[DuplicateDomain]
+Option = 'no'
+[DICycles]
+Option = 'no'
+LastStep =  1105
+"""
+
+MODEL_INI = """[FluidProperties]
+InitialDensities = 1.0,1.0
+BackgroundDensities = {bg},{bg}
+FluidsTau = 1.,1.
+
+[{section}]
+interactionFluid = {G}
+interactionSolid = {Gs0},{Gs1}
+potentialType = 'Simple'
+
+[BoundaryDefinition]
+BoundaryTypeInlet = 'Neumann'
+BoundaryMethod = 'ZouHe'
+BoundaryTypeOutlet = '{outlet}'
+
+[VelocityBoundary]
+velocityX = 0.0,0.0
+velocityY = 0.0,{vy1}
+
+[PressureBoundary]
+PressureInlet = 0.0, 0.0
+PressureOutlet = 1.0, 0.0
+
+[ForceScheme]
+ExplicitScheme = 4
+
+[BodyForce]
+Option = 'no'
+forceXG = 0.0
+forceYG = 0.0
+
+[Time]
+numberTimeStep = {steps}
+"""
+
+
+def write_rk(d, nx=20, ny=48, steps=60, interval=25, relax="MRT"):
+    import os
+    with open(os.path.join(d, "RKtwophasesetup2D.ini"), "w") as fh:
+        fh.write(RK_INI.format(nx=nx, ny=ny, steps=steps, interval=interval, relax=relax))
+
+
+def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirichlet"):
+    import os
+    with open(os.path.join(d, "twophasesetup.ini"), "w") as fh:
+        fh.write(TWOPHASE_INI.format(nx=nx, ny=ny, inter=inter, relax=relax))
+    efs = inter == "EFS"
+    with open(os.path.join(d, "efs2D.ini" if efs else "shanchen2D.ini"), "w") as fh:
+        fh.write(MODEL_INI.format(section="EFSParameters" if efs else "ShanChenParameters", bg=0.02 if efs else 0.06,
+                                  G=0.20 if efs else 3.8, Gs0=-0.14 if efs else -0.40, Gs1=0.14 if efs else 0.40,
+                                  outlet=outlet, vy1=-5.03e-4 if efs else -1.01e-3, steps=steps))

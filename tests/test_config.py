@@ -1,0 +1,39 @@
+"""CPU tests of the ini reader (reference grammar: quoted strings, case-insensitive keys, the key
+skews of the shipped files) and of the drivers' argument checking."""
+import os
+
+import pytest
+
+from ini_fixtures import write_rk, write_sc
+from openlbmpm_amd import config
+
+
+def test_rk_ini(tmp_path):
+    write_rk(str(tmp_path), nx=20, ny=200, steps=500001, interval=2500)
+    p = config.read_rk2d(str(tmp_path))
+    assert (p["nx"], p["ny"], p["steps"], p["interval"]) == (20, 200, 500001, 2500)
+    assert p["relax"] == "MRT" and p["inlet"] == "Neumann" and p["outlet"] == "Dirichlet"
+    assert p["sigma"] == 0.1          # shipped spelling "SurfaceTension" accepted for "SurfaceTensionValue"
+    assert p["vyR"] == -1.0e-4 and p["rhoRL"] == 5e-8 and p["wetting"] == 2 and not p["image"]
+
+
+def test_rk_ini_errors(tmp_path):
+    with pytest.raises(config.ConfigError):
+        config.read_rk2d(str(tmp_path))                      # file missing
+    write_rk(str(tmp_path))
+    path = os.path.join(str(tmp_path), "RKtwophasesetup2D.ini")
+    text = open(path).read()
+    open(path, "w").write(text.replace("'CSF'", "'Perturbation'", 1))
+    with pytest.raises(config.ConfigError):
+        config.read_rk2d(str(tmp_path))
+    open(path, "w").write(text.replace("TauR = 1.0", "TauR = fast"))
+    with pytest.raises(config.ConfigError):
+        config.read_rk2d(str(tmp_path))
+
+
+@pytest.mark.parametrize("inter", ["EFS", "ShanChen"])
+def test_sc_ini(tmp_path, inter):
+    write_sc(str(tmp_path), inter=inter, steps=300)
+    p = config.read_sc2d(str(tmp_path))
+    assert p["inter"] == inter and p["steps"] == 300 and (p["tau0"], p["tau1"]) == (1.0, 1.0)
+    assert p["G"] == (0.20 if inter == "EFS" else 3.8)
