@@ -13,7 +13,8 @@ Workloads (BASELINE.json configs):
                 exchange (strong scaling: the global 512^3 is fixed as N grows).
   c2            CSF colour-gradient D2Q9 MRT, 1024^2 capillary (configs[1]); N>1 = replicas.
   c3            explicit-forcing Shan-Chen D2Q9 MRT, 2048^2 porous (configs[2]); N>1 = replicas.
-At N=1 the c2 and c3 figures are measured too and reported under "secondary" in the same line.
+  c4            CSF colour gradient + D2Q5 tracer, 2048^2 porous (configs[3]); N>1 = replicas.
+At N=1 the c2, c3 and c4 figures are measured too and reported under "secondary" in the same line.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HBM bound, HIP-event timed on the
 stream the kernel runs on) and, at N=1, `cpu_baseline` (the C oracle -- a port of the reference
@@ -31,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-B_ALG = {"c2": 288.0, "c3": 288.0, "c5": 608.0}   # algorithmic bytes / lattice update
+B_ALG = {"c2": 288.0, "c3": 288.0, "c4": 368.0, "c5": 608.0}   # algorithmic bytes / lattice update
 SEED = 20260928
 
 
@@ -73,6 +74,20 @@ def build_c3(nx, ny, device):
     s = SC2DSolver(dom, dict(inter="EFS", relax="MRT", outlet="Dirichlet"), device=device)
     s.set_density(r0, r1)
     return s, float((r0 + r1).sum()), None
+
+
+def build_c4(nx, ny, device):
+    """CSF colour gradient D2Q9 MRT + one D2Q5-MRT tracer (D = 1/6, beta = 1), porous image"""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.geometry import porous_disks, image_domain, initial_densities_rk
+    img = porous_disks(nx, ny - 20, porosity=0.65, rmin=6.0, rmax=20.0, seed=SEED)
+    dom = image_domain(img, 10, 0.5)
+    rR, rB = initial_densities_rk(dom, True, 10)
+    s = RK2DSolver(dom, dict(relax="MRT"), device=device)
+    s.set_macro(rR, rB)
+    s.configure_tracers(diffX=(1. / 6.,), diffY=(1. / 6.,), beta=(1.0,), inlet_conc=(1.0,))
+    s.set_tracer(0, np.where(rB > 0, 0.0, 0.0))
+    return s, float((rR + rB).sum()), lambda: float((s.get("rhoR") + s.get("rhoB")).sum())
 
 
 def c5_domain(n):
@@ -135,7 +150,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c5", choices=["c5", "c2", "c3"])
+    ap.add_argument("--workload", default="c5", choices=["c5", "c2", "c3", "c4"])
     ap.add_argument("--size", type=int, nargs="+", default=None, help="c5: NX NY NZ; c2/c3: NX NY")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -241,7 +256,8 @@ def main():
             }
             if world == 1 and not args.no_secondary:
                 sec = []
-                for name, build, size2 in (("c2", build_c2, (1024, 1024)), ("c3", build_c3, (2048, 2048))):
+                for name, build, size2 in (("c2", build_c2, (1024, 1024)), ("c3", build_c3, (2048, 2048)),
+                                           ("c4", build_c4, (2048, 2048))):
                     s, _, _ = build(size2[0], size2[1], local_rank)
                     k = 1000 if name == "c2" else 300
                     w, mt, md = time_solver_2d(s, k, k // 10)
@@ -257,7 +273,7 @@ def main():
         size = tuple(args.size) if args.size else ((1024, 1024) if wl == "c2" else (2048, 2048))
         steps = args.steps if args.steps is not None else (2000 if wl == "c2" else 500)
         warmup = args.warmup if args.warmup is not None else steps // 10
-        solver, m0, mass = (build_c2 if wl == "c2" else build_c3)(size[0], size[1], local_rank)
+        solver, m0, mass = {"c2": build_c2, "c3": build_c3, "c4": build_c4}[wl](size[0], size[1], local_rank)
         nfluid = solver.num_fluid_nodes
         solver.step(warmup)
         solver.sync(); barrier()
@@ -278,7 +294,9 @@ def main():
             desc = {"c2": "c2: CSF colour-gradient D2Q9 MRT, %dx%d capillary (SimpleGeometry walls, "
                           "RKtwophasesetup2D.ini parameters, red intruding from the top quarter)",
                     "c3": "c3: explicit-forcing Shan-Chen D2Q9 MRT (efs2D.ini parameters), %dx%d synthetic "
-                          "porous image (discs r 6-20, porosity 0.65)"}[wl] % size
+                          "porous image (discs r 6-20, porosity 0.65)",
+                    "c4": "c4: CSF colour-gradient D2Q9 MRT + one D2Q5-MRT tracer, %dx%d synthetic porous "
+                          "image (discs r 6-20, porosity 0.65)"}[wl] % size
             out = {
                 "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid * steps * world / wall / 1e6, 2),
                 "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,

@@ -144,6 +144,33 @@ int lbmpm_rk2d_set_stream(lbmpm_rk2d *ctx, void *hip_stream);
 /* Copy a field to a dense host array (synchronises).  out must hold ny*nx (or ny*nx*9)
  * doubles.  Solid nodes read 0. */
 int lbmpm_rk2d_get_field(lbmpm_rk2d *ctx, int field, double *out);
+/* --- D2Q5 tracer transport coupled to the colour-gradient flow (BASELINE config 4).
+ * Replaces the D2Q5-MRT tracer sub-step of Transport2DRK.runTransport2DMPMCRKNew
+ * (RKCG2D/Transport2DRK.py:1341-1418), i.e. RKCG2D/AccelerateTransport2DRK.py:
+ *   calValueTransportDomain :957, calCollisionTransportLinearEqlMRTGPU :535,
+ *   calTransportWithInterfaceD2Q5 :976, calFreeConcBoundary3 :461, calStreamingTransportGPU :139,
+ *   calStreamingTransport2GPU :184, calInamuroConstConcBoundary :682, calConcentrationGPU :78,
+ *   fillNeighboringNodesTransport :51 (implicit in the mask)
+ * and the host matrices of Transport2DRK.py:313-347.  Fused into the flow kernel (+80 B per node
+ * and tracer).  Keys follow the (non-shipped) transportsetup.ini read at Transport2DRK.py:35-311. */
+typedef struct lbmpm_tracer_config {
+    int32_t num_tracers;            /* [TransportParameters] NumberTracers, 1..4          */
+    double diffusion_x[4];          /* [TransportMRT] DiffusionX                          */
+    double diffusion_y[4];          /* [TransportMRT] DiffusionY                          */
+    double diffusion_xy, diffusion_yx; /* [TransportMRT] DiffusionXY, DiffusionYX         */
+    double beta_interface[4];       /* [TransportParameters] BetaInterface                */
+    double criteria_rho;            /* criteriaFluidRho: tracer lives where rhoR <= this  */
+    double inlet_concentration[4];  /* [BoundaryCondition] ConcentrationInlet             */
+    int32_t dirichlet_inlet;        /* InletType 'Dirichlet' (Inamuro) on ghost row ny-1  */
+    int32_t free_outlet;            /* OutletType 'Freeflow' on row 0                     */
+} lbmpm_tracer_config;
+
+int lbmpm_rk2d_tracer_configure(lbmpm_rk2d *ctx, const lbmpm_tracer_config *cfg);
+/* dense [ny][nx] concentration; g = C w (Transport2DRK.py:399-470); before the first step */
+int lbmpm_rk2d_tracer_set_concentration(lbmpm_rk2d *ctx, int tracer, const double *conc);
+/* deviceTracerConc[tracer] after the last completed step, dense [ny][nx] */
+int lbmpm_rk2d_tracer_get_concentration(lbmpm_rk2d *ctx, int tracer, double *out);
+
 int64_t lbmpm_rk2d_num_fluid_nodes(const lbmpm_rk2d *ctx);
 int64_t lbmpm_rk2d_steps_done(const lbmpm_rk2d *ctx);
 /* Name of the dominant kernel as it appears in rocprofv3 --kernel-trace output. */

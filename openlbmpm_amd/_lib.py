@@ -32,6 +32,14 @@ class RK2DConfig(C.Structure):
                 ("device", C.c_int32), ("variant", C.c_int32)]
 
 
+class TracerConfig(C.Structure):
+    # mirrors struct lbmpm_tracer_config (include/lbmpm.h)
+    _fields_ = [("num_tracers", C.c_int32), ("diffusion_x", C.c_double * 4), ("diffusion_y", C.c_double * 4),
+                ("diffusion_xy", C.c_double), ("diffusion_yx", C.c_double), ("beta_interface", C.c_double * 4),
+                ("criteria_rho", C.c_double), ("inlet_concentration", C.c_double * 4),
+                ("dirichlet_inlet", C.c_int32), ("free_outlet", C.c_int32)]
+
+
 class SC2DConfig(C.Structure):
     # mirrors struct lbmpm_sc2d_config (include/lbmpm.h)
     _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("model", C.c_int32), ("relaxation", C.c_int32),
@@ -69,6 +77,9 @@ _SIGNATURES = {
     "lbmpm_rk2d_steps_done": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk2d_dominant_kernel": (C.c_char_p, [C.c_void_p]),
     "lbmpm_rk2d_device_bytes": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk2d_tracer_configure": (C.c_int, [C.c_void_p, C.POINTER(TracerConfig)]),
+    "lbmpm_rk2d_tracer_set_concentration": (C.c_int, [C.c_void_p, C.c_int, F64P]),
+    "lbmpm_rk2d_tracer_get_concentration": (C.c_int, [C.c_void_p, C.c_int, F64P]),
     "lbmpm_sc2d_create": (C.c_int, [C.POINTER(SC2DConfig), U8P, C.POINTER(C.c_void_p)]),
     "lbmpm_sc2d_destroy": (None, [C.c_void_p]),
     "lbmpm_sc2d_set_pdf": (C.c_int, [C.c_void_p, F64P, F64P]),

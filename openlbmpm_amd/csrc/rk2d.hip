@@ -40,6 +40,12 @@ struct RKDev {
     double sigma, cosT, sinT, beta, delta, tauR, tauB, vyIn, pInB, pInR, pOut;
     int wetting, tautype, inlet, outlet;
     int first;         // 1: fin holds the initial (already post-streaming) state
+    // D2Q5 tracer transport (AccelerateTransport2DRK.py), fused into phase D
+    int ntr, trFree, trDirichlet;
+    const double *gin;   // [ntr][5][plane]
+    double *gout;
+    double trCrit;
+    double trM[25], trA[4][25], trBeta[4], trCb[4];
 };
 
 // ---------------------------------------------------------------- boundary rows
@@ -413,7 +419,76 @@ struct FusedShape {
     static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;
 };
 
-template <bool MRT, typename SH>
+// Tracer sub-step of the coupled loop (Transport2DRK.py:1341-1418) for node (x,y), given the
+// flow's rhoR, physical velocity and wetting-corrected colour gradient of this step:
+//   pull-stream g (calStreamingTransportGPU/2GPU T:139-194, D2Q5 order 0,E,W,N,S; free outlet
+//   T:461-478 = "row 0 reads as row 1"), Inamuro inlet on the ghost row (T:682-698),
+//   C = sum g (T:78-90), indicator (T:957-970), MRT collision g += A (M g - M g_eq) (T:535-590),
+//   interface term (T:976-1013); store post-collision g.
+__device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, unsigned sn, double rhoR, double vx,
+                                               double vy, double gx, double gy)
+{
+    constexpr double W5[5] = {1. / 3., 1. / 6., 1. / 6., 1. / 6., 1. / 6.};
+    constexpr int VX5[5] = {0, 1, -1, 0, 0}, VY5[5] = {0, 0, 0, 1, -1}, OPP5[5] = {0, 2, 1, 4, 3};
+    constexpr int SRCBIT[5] = {0, 2, 0, 3, 1};    // D2Q9 solid bit of the node a D2Q5 population comes from
+    const bool first = p.first != 0;
+    const int yo = (p.trFree && y == 0 && !first) ? 1 : y;          // own-node reads
+    const size_t own = (size_t)yo * p.pitch + x, idx = (size_t)y * p.pitch + x;
+    const double gn = sqrt(gx * gx + gy * gy);
+    double ux = 0., uy = 0., un = 0.;
+    if (gn > 1.0e-8) { ux = -gx / gn; uy = -gy / gn; un = sqrt(ux * ux + uy * uy); }
+    const double ind = (rhoR > p.trCrit) ? -(1. - 1.) : -(1. - 0.);
+    for (int t = 0; t < p.ntr; ++t) {
+        const double *gi = p.gin + (size_t)t * 5 * p.plane;
+        double g[5];
+        g[0] = gi[own];
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+            if (first) { g[j] = gi[j * p.plane + idx]; continue; }
+            if ((sn >> SRCBIT[j]) & 1u) { g[j] = gi[OPP5[j] * p.plane + own]; continue; }     // bounce-back
+            int ys = lbmpm_dev::wrapi(y - VY5[j], p.ny);
+            if (p.trFree && ys == 0) ys = 1;
+            g[j] = gi[j * p.plane + (size_t)ys * p.pitch + lbmpm_dev::wrapi(x - VX5[j], p.nx)];
+        }
+        if (!first && p.trDirichlet && y == p.ny - 1) {
+            const double sm = g[0] + g[1] + g[2] + g[3];
+            const double u = (p.trCb[t] - sm) / W5[4];
+            g[4] = W5[4] * u;
+        }
+        double C = 0.;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) C += g[j];
+        double diff[5], d[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            double ve = 0., vp = 0.;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const double eq = C * W5[k] * (1. + 3. * ((double)VX5[k] * vx + (double)VY5[k] * vy));
+                ve += p.trM[5 * j + k] * eq;
+                vp += g[k] * p.trM[5 * j + k];
+            }
+            diff[j] = vp - ve;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            double v = 0.;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v += p.trA[t][5 * j + k] * diff[k];
+            d[j] = v;
+        }
+        double *go = p.gout + (size_t)t * 5 * p.plane;
+        go[idx] = g[0] + d[0];
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+            double c = 0.;
+            if (un > 1.0e-8) c = ((double)VX5[j] * ux + (double)VY5[j] * uy) / (1. * un);
+            go[j * p.plane + idx] = (g[j] + d[j]) + p.trBeta[t] * ind * (W5[j] * C) * c;
+        }
+    }
+}
+
+template <bool MRT, bool TRACER, typename SH>
 __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
 {
     constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
@@ -582,6 +657,7 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
             p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K;
             p.phi[idx] = phi; p.G[idx] = gx[m]; p.G[p.plane + idx] = gy[m];
         }
+        if (TRACER) tracer_substep(p, x, y, sn[m], rR[m], vx, vy, gx[m], gy[m]);
         collide<MRT>(p, f, rR[m], rB[m], phi, vx, vy, Fx, Fy);
         double fR[9], fB[9];
         recolor(p.beta, f, rR[m], rB[m], gx[m], gy[m], fR, fB);
@@ -613,6 +689,40 @@ __global__ __launch_bounds__(BX *BY) void rk2d_observe(RKDev p, double *out /*[2
     const double rs = rB + rR;
     out[20 * p.plane + idx] = (fT[1] - fT[3] + fT[5] - fT[6] - fT[7] + fT[8] + 0.5 * p.F[idx]) / rs;
     out[21 * p.plane + idx] = (fT[2] - fT[4] + fT[5] + fT[6] - fT[7] - fT[8] + 0.5 * p.F[p.plane + idx]) / rs;
+}
+
+// Tracer concentration as the reference's deviceTracerConc holds it after the last completed step
+// (streamed + inlet-corrected populations, calConcentrationGPU T:78-90)
+__global__ __launch_bounds__(BX *BY) void rk2d_observe_tracer(RKDev p, int t, double *out)
+{
+    constexpr double W5[5] = {1. / 3., 1. / 6., 1. / 6., 1. / 6., 1. / 6.};
+    constexpr int VX5[5] = {0, 1, -1, 0, 0}, VY5[5] = {0, 0, 0, 1, -1}, OPP5[5] = {0, 2, 1, 4, 3};
+    constexpr int SRCBIT[5] = {0, 2, 0, 3, 1};
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    const bool first = p.first != 0;
+    const unsigned sn = p.solidnbr[idx];
+    const int yo = (p.trFree && y == 0 && !first) ? 1 : y;
+    const size_t own = (size_t)yo * p.pitch + x;
+    const double *gi = p.gin + (size_t)t * 5 * p.plane;
+    double g[5];
+    g[0] = gi[own];
+    for (int j = 1; j < 5; ++j) {
+        if (first) { g[j] = gi[j * p.plane + idx]; continue; }
+        if ((sn >> SRCBIT[j]) & 1u) { g[j] = gi[OPP5[j] * p.plane + own]; continue; }
+        int ys = wrapi(y - VY5[j], p.ny);
+        if (p.trFree && ys == 0) ys = 1;
+        g[j] = gi[j * p.plane + (size_t)ys * p.pitch + wrapi(x - VX5[j], p.nx)];
+    }
+    if (!first && p.trDirichlet && y == p.ny - 1) {
+        const double sm = g[0] + g[1] + g[2] + g[3];
+        g[4] = W5[4] * ((p.trCb[t] - sm) / W5[4]);
+    }
+    double C = 0.;
+    for (int j = 0; j < 5; ++j) C += g[j];
+    out[idx] = C;
 }
 
 // ---------------------------------------------------------------- set-up kernels
@@ -659,6 +769,9 @@ struct lbmpm_rk2d {
     double *fA = nullptr, *fB = nullptr;   // ping-pong [2][9][plane]; fA holds the current state
     double *F = nullptr, *ns = nullptr, *phi = nullptr, *G = nullptr, *diag = nullptr, *obs = nullptr;
     std::vector<uint8_t> h_domain;
+    int ntr = 0, trFree = 0, trDirichlet = 0;
+    double *gA = nullptr, *gB = nullptr;
+    double trCrit = 0.5, trM[25] = {0}, trA[4][25] = {{0}}, trBeta[4] = {0}, trCb[4] = {0};
     int shape = 0;            // fused tile shape (LBMPM_RK2D_SHAPE, tuning only)
     bool streamed = false;    // false: fA holds the initial (already "post-streaming") state
     bool diag_valid = false;
@@ -683,6 +796,10 @@ RKDev make_dev(const lbmpm_rk2d *c)
     p.wetting = c->cfg.wetting_type; p.tautype = c->cfg.tau_type;
     p.inlet = c->cfg.inlet_type; p.outlet = c->cfg.outlet_type;
     p.first = c->streamed ? 0 : 1;
+    p.ntr = c->ntr; p.trFree = c->trFree; p.trDirichlet = c->trDirichlet; p.gin = c->gA; p.gout = c->gB;
+    p.trCrit = c->trCrit;
+    memcpy(p.trM, c->trM, sizeof(p.trM)); memcpy(p.trA, c->trA, sizeof(p.trA));
+    memcpy(p.trBeta, c->trBeta, sizeof(p.trBeta)); memcpy(p.trCb, c->trCb, sizeof(p.trCb));
     return p;
 }
 
@@ -693,8 +810,8 @@ void launch_fused_shape(lbmpm_rk2d *c, const RKDev &p)
 {
     const int tiles_x = (c->nx + SH::TW - 1) / SH::TW, tiles_y = (c->ny + SH::TH - 1) / SH::TH;
     const dim3 g(tiles_x * tiles_y), b(SH::THREADS);
-    if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2d_fused<true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
-    else rk2d_fused<false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+    if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2d_fused<true, false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+    else rk2d_fused<false, false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
 }
 
 int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
@@ -706,6 +823,13 @@ int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
     if (c->cfg.variant == 0) {
         const bool ev = timed && c->pool.take(&e0, &e1);
         if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+        if (c->ntr > 0) {
+            using SH = FusedShape<8, 1>;
+            const int tiles_x = (c->nx + SH::TW - 1) / SH::TW, tiles_y = (c->ny + SH::TH - 1) / SH::TH;
+            const dim3 g(tiles_x * tiles_y), b(SH::THREADS);
+            if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2d_fused<true, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+            else rk2d_fused<false, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+        } else
         switch (c->shape) {
             // tile-shape sweep on MI355X (1024^2): 64x8 / 1 node per thread is the
             // default; the others stay selectable for tuning (LBMPM_RK2D_SHAPE)
@@ -726,6 +850,7 @@ int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
     }
     LBMPM_HIP_TRY(hipGetLastError());
     std::swap(c->fA, c->fB);
+    if (c->ntr > 0) std::swap(c->gA, c->gB);
     c->streamed = true;
     c->diag_valid = diag;
     c->steps += 1;
@@ -831,7 +956,7 @@ extern "C" void lbmpm_rk2d_destroy(lbmpm_rk2d *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *ptr : {(void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->F,
-                      (void *)c->ns, (void *)c->phi, (void *)c->G, (void *)c->diag, (void *)c->obs})
+                      (void *)c->ns, (void *)c->phi, (void *)c->G, (void *)c->diag, (void *)c->obs, (void *)c->gA, (void *)c->gB})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1019,6 +1144,96 @@ extern "C" int lbmpm_rk2d_get_field(lbmpm_rk2d *c, int field, double *out)
     }
     set_error("lbmpm_rk2d_get_field: unknown field id %d", field);
     return LBMPM_ERR_INVALID;
+}
+
+namespace {
+bool invert5(const double in[25], double out[25])
+{   // Gauss-Jordan with partial pivoting
+    double a[5][10];
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j) { a[i][j] = in[5 * i + j]; a[i][5 + j] = (i == j) ? 1. : 0.; }
+    for (int c = 0; c < 5; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 5; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (fabs(a[piv][c]) < 1e-300) return false;
+        if (piv != c) for (int j = 0; j < 10; ++j) std::swap(a[piv][j], a[c][j]);
+        const double d = a[c][c];
+        for (int j = 0; j < 10; ++j) a[c][j] /= d;
+        for (int r = 0; r < 5; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            if (f != 0.) for (int j = 0; j < 10; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) out[5 * i + j] = a[i][5 + j];
+    return true;
+}
+}  // namespace
+
+extern "C" int lbmpm_rk2d_tracer_configure(lbmpm_rk2d *c, const lbmpm_tracer_config *t)
+{
+    LBMPM_REQUIRE(c && t, "lbmpm_rk2d_tracer_configure: null argument");
+    LBMPM_REQUIRE(t->num_tracers >= 1 && t->num_tracers <= 4, "NumberTracers must be 1..4 (got %d)", t->num_tracers);
+    LBMPM_REQUIRE(c->cfg.variant == 0, "tracer transport is fused into the default (fused) schedule only");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    // D2Q5 moment matrix and collision matrix -M^-1 S^-1 (Transport2DRK.py:316-347)
+    const double M[25] = {1, 1, 1, 1, 1,   0, 1, -1, 0, 0,   0, 0, 0, 1, -1,   4, -1, -1, -1, -1,   0, 1, 1, -1, -1};
+    double Minv[25];
+    if (!invert5(M, Minv)) { set_error("singular D2Q5 matrix"); return LBMPM_ERR_INVALID; }
+    memcpy(c->trM, M, sizeof(M));
+    for (int k = 0; k < t->num_tracers; ++k) {
+        double S[25] = {0}, Sinv[25];
+        S[0] = 1.; S[18] = 1.; S[24] = 1.;
+        S[6] = 0.5 + 3. * t->diffusion_x[k]; S[12] = 0.5 + 3. * t->diffusion_y[k];
+        S[7] = 3. * t->diffusion_xy; S[11] = 3. * t->diffusion_yx;
+        if (!invert5(S, Sinv)) { set_error("singular tracer relaxation matrix"); return LBMPM_ERR_INVALID; }
+        for (int i = 0; i < 5; ++i)
+            for (int j = 0; j < 5; ++j) {
+                double v = 0.;
+                for (int m = 0; m < 5; ++m) v += Minv[5 * i + m] * Sinv[5 * m + j];
+                c->trA[k][5 * i + j] = -v;
+            }
+        c->trBeta[k] = t->beta_interface[k];
+        c->trCb[k] = t->inlet_concentration[k];
+    }
+    c->trCrit = t->criteria_rho; c->trFree = t->free_outlet ? 1 : 0; c->trDirichlet = t->dirichlet_inlet ? 1 : 0;
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->gA) { (void)hipFree(c->gA); (void)hipFree(c->gB); c->gA = c->gB = nullptr; c->bytes -= (int64_t)(2 * c->ntr * 5 * c->plane * sizeof(double)); }
+    c->ntr = t->num_tracers;
+    int rc = dev_alloc(c, &c->gA, (size_t)c->ntr * 5 * c->plane);
+    if (rc == LBMPM_OK) rc = dev_alloc(c, &c->gB, (size_t)c->ntr * 5 * c->plane);
+    return rc;
+}
+
+extern "C" int lbmpm_rk2d_tracer_set_concentration(lbmpm_rk2d *c, int tracer, const double *conc)
+{
+    LBMPM_REQUIRE(c && conc, "lbmpm_rk2d_tracer_set_concentration: null argument");
+    LBMPM_REQUIRE(tracer >= 0 && tracer < c->ntr, "tracer index %d out of range (configured: %d)", tracer, c->ntr);
+    LBMPM_REQUIRE(!c->streamed, "set the tracer concentration before the first time step (after lbmpm_rk2d_set_pdf/_set_macro)");
+    static const double W5[5] = {1. / 3., 1. / 6., 1. / 6., 1. / 6., 1. / 6.};
+    std::vector<double> h(5 * c->plane, 0.0);
+    for (int y = 0; y < c->ny; ++y)
+        for (int x = 0; x < c->nx; ++x) {
+            const size_t k = (size_t)y * c->nx + x;
+            if (c->h_domain[k] != 1) continue;
+            for (int j = 0; j < 5; ++j) h[j * c->plane + (size_t)y * c->pitch + x] = conc[k] * W5[j];   // g = C w
+        }
+    LBMPM_HIP_TRY(hipMemcpyAsync(c->gA + (size_t)tracer * 5 * c->plane, h.data(), h.size() * sizeof(double),
+                                 hipMemcpyHostToDevice, c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk2d_tracer_get_concentration(lbmpm_rk2d *c, int tracer, double *out)
+{
+    LBMPM_REQUIRE(c && out, "lbmpm_rk2d_tracer_get_concentration: null argument");
+    LBMPM_REQUIRE(tracer >= 0 && tracer < c->ntr, "tracer index %d out of range (configured: %d)", tracer, c->ntr);
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->obs) { const int rc = dev_alloc(c, &c->obs, 22 * c->plane); if (rc) return rc; }
+    RKDev p = make_dev(c);
+    rk2d_observe_tracer<<<grid_of(c), dim3(BX, BY), 0, c->stream>>>(p, tracer, c->obs);
+    LBMPM_HIP_TRY(hipGetLastError());
+    return copy_plane(c, c->obs, out, 1);
 }
 
 extern "C" int64_t lbmpm_rk2d_num_fluid_nodes(const lbmpm_rk2d *c) { return c ? c->nfluid : 0; }

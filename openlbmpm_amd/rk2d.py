@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import F64P, U8P, RK2DConfig, check
+from ._lib import F64P, U8P, RK2DConfig, TracerConfig, check
 
 FIELDS = dict(fR=0, fB=1, rhoR=2, rhoB=3, vx=4, vy=5, phi=6, Gx=7, Gy=8, Fx=9, Fy=10, K=11,
               rec_fR=20, rec_fB=21, rec_rhoR=22, rec_rhoB=23, rec_vx=24, rec_vy=25)
@@ -98,6 +98,35 @@ class RK2DSolver:
 
     def set_stream(self, hip_stream_handle):
         check(self._L.lbmpm_rk2d_set_stream(self._h, C.c_void_p(hip_stream_handle)), "set_stream")
+
+    # -- tracer transport (BASELINE config 4)
+    def configure_tracers(self, diffX=(1. / 6.,), diffY=(1. / 6.,), dXY=0.0, dYX=0.0, beta=(1.0,), crit=0.5,
+                          inlet_conc=(1.0,), free_outlet=True, dirichlet_inlet=True):
+        """D2Q5-MRT tracers advected by the flow (keys of the reference's transportsetup.ini,
+        Transport2DRK.py:35-311)."""
+        n = len(diffX)
+        if not (len(diffY) == len(beta) == len(inlet_conc) == n):
+            raise ValueError("per-tracer lists must have the same length")
+        t = TracerConfig()
+        t.num_tracers = n
+        for k in range(n):
+            t.diffusion_x[k], t.diffusion_y[k] = diffX[k], diffY[k]
+            t.beta_interface[k], t.inlet_concentration[k] = beta[k], inlet_conc[k]
+        t.diffusion_xy, t.diffusion_yx, t.criteria_rho = dXY, dYX, crit
+        t.dirichlet_inlet, t.free_outlet = int(dirichlet_inlet), int(free_outlet)
+        check(self._L.lbmpm_rk2d_tracer_configure(self._h, C.byref(t)), "lbmpm_rk2d_tracer_configure")
+        self.num_tracers = n
+
+    def set_tracer(self, k, conc):
+        a = _f64(conc)
+        if a.shape != (self.ny, self.nx):
+            raise TypeError("concentration must have shape %s" % ((self.ny, self.nx),))
+        check(self._L.lbmpm_rk2d_tracer_set_concentration(self._h, int(k), a.ctypes.data_as(F64P)), "tracer_set")
+
+    def get_tracer(self, k, compact=False):
+        out = np.empty((self.ny, self.nx), dtype=np.float64)
+        check(self._L.lbmpm_rk2d_tracer_get_concentration(self._h, int(k), out.ctypes.data_as(F64P)), "tracer_get")
+        return out.reshape(-1)[self.is_domain.reshape(-1) == 1] if compact else out
 
     # -- time stepping
     def step(self, nsteps=1):

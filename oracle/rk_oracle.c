@@ -699,7 +699,8 @@ typedef struct {
 } rk_sim;
 
 /* One pass of the while-loop body of runRKColorGradient2DCSF, D:1295-1490 */
-void rk_csf_step(rk_sim *s)
+/* first half: boundary kernels ... wetting-corrected colour gradient (D:1299-1424) */
+void rk_csf_step_a(rk_sim *s)
 {
     i64 N = s->N;
     if (s->inletType == 0) {
@@ -728,6 +729,12 @@ void rk_csf_step(rk_sim *s)
         if (s->wettingType == 1) rk_wetting1(s->Wf, s->cosT, s->sinT, s->fluidWet, s->nsx, s->nsy, s->Gx, s->Gy);
         else if (s->wettingType == 2) rk_wetting2(s->Wf, s->cosT, s->sinT, s->fluidWet, s->nsx, s->nsy, s->Gx, s->Gy);
     }
+}
+
+/* second half: CSF force ... streaming and densities (D:1425-1490) */
+void rk_csf_step_b(rk_sim *s)
+{
+    i64 N = s->N;
     rk_force(N, s->wettingType, s->sigma, s->nbr, s->Gx, s->Gy, s->Fx, s->Fy, s->K);
     if (!s->mrt) {
         rk_collide_srt(N, s->tauType, s->tauR, s->tauB, s->delta, s->vx, s->vy, s->rhoR, s->rhoB, s->phi, s->fT);
@@ -744,6 +751,8 @@ void rk_csf_step(rk_sim *s)
     rk_total_pdf(N, s->fR, s->fB, s->fT);
     rk_macro_density(N, s->fR, s->fB, s->rhoR, s->rhoB);
 }
+
+void rk_csf_step(rk_sim *s) { rk_csf_step_a(s); rk_csf_step_b(s); }
 
 void rk_csf_run(rk_sim *s, i64 nsteps)
 {
