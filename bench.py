@@ -86,7 +86,7 @@ def build_c4(nx, ny, device):
     s = RK2DSolver(dom, dict(relax="MRT"), device=device)
     s.set_macro(rR, rB)
     s.configure_tracers(diffX=(1. / 6.,), diffY=(1. / 6.,), beta=(1.0,), inlet_conc=(1.0,))
-    s.set_tracer(0, np.where(rB > 0, 0.0, 0.0))
+    s.set_tracer(0, np.where(rB > 0, 0.5, 0.0))
     return s, float((rR + rB).sum()), lambda: float((s.get("rhoR") + s.get("rhoB")).sum())
 
 

@@ -1,0 +1,128 @@
+"""Runtime of the drop-in path: device arrays + kernel objects that look like Numba's
+(`kernel[grid, block](*args)`) and forward to the kernel-level C ABI (include/lbmpm_kernels.h).
+
+With `openlbmpm_amd/dropin` FIRST on PYTHONPATH, `from numba import cuda`,
+`import AcceleratedRKGPU2D as RKGPU2D`, `from OptimizedD2Q9GPU import *` ... resolve to this
+package, so a reference-style driver loop runs on MI355X with its launch statements unchanged.
+The launch configuration is accepted and ignored (the HIP kernels size their own grids); the explicit
+Numba signatures become the checks below (argument count, dtype, C-contiguity -> TypeError).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.dirname(_PKG) not in sys.path:
+    sys.path.insert(0, os.path.dirname(_PKG))
+from openlbmpm_amd import _lib                     # noqa: E402
+from openlbmpm_amd._kernel_specs import KERNELS    # noqa: E402
+
+_ready = False
+
+
+def _L():
+    global _ready
+    L = _lib.lib()
+    if not _ready:
+        for (mod, name), (sym, kinds) in KERNELS.items():
+            fn = getattr(L, sym)
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p] + list(kinds)
+        L.lbmpm_device_malloc.restype = C.c_int
+        L.lbmpm_device_malloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
+        L.lbmpm_device_free.argtypes = [C.c_void_p]
+        L.lbmpm_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.lbmpm_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        _ready = True
+    return L
+
+
+class DeviceNDArray:
+    """Device buffer with the slice of numba.cuda.DeviceNDArray the reference drivers use."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        p = C.c_void_p()
+        _lib.check(_L().lbmpm_device_malloc(self.nbytes, C.byref(p)), "lbmpm_device_malloc")
+        self.ptr = p.value
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def copy_to_host(self, ary=None, stream=0):
+        out = np.empty(self.shape, dtype=self.dtype) if ary is None else ary
+        if out.nbytes != self.nbytes or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("host array does not match the device array")
+        _lib.check(_L().lbmpm_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes), "copy_to_host")
+        return out
+
+    def copy_to_device(self, ary, stream=0):
+        a = np.ascontiguousarray(ary, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        _lib.check(_L().lbmpm_memcpy_h2d(self.ptr, a.ctypes.data_as(C.c_void_p), self.nbytes), "copy_to_device")
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                _L().lbmpm_device_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def to_device(ary, stream=0, copy=True, to=None):
+    a = np.ascontiguousarray(ary)
+    d = DeviceNDArray(a.shape, a.dtype)
+    d.copy_to_device(a)
+    return d
+
+
+def device_array_like(ary, stream=0):
+    return DeviceNDArray(ary.shape, ary.dtype)      # uninitialised, like Numba's
+
+
+def device_array(shape, dtype=np.float64, strides=None, order="C", stream=0):
+    return DeviceNDArray(shape, dtype)
+
+
+class Kernel:
+    def __init__(self, module, name):
+        self.module, self.name = module, name
+        self.sym, self.kinds = KERNELS[(module, name)]
+        self.__name__ = name
+
+    def __getitem__(self, launch_config):            # kernel[grid, block] / kernel[grid, block, stream]
+        return self
+
+    def __call__(self, *args):
+        if len(args) != len(self.kinds):
+            raise TypeError("%s() takes %d arguments (%d given)" % (self.name, len(self.kinds), len(args)))
+        conv = []
+        for i, (a, k) in enumerate(zip(args, self.kinds)):
+            if k is C.c_void_p:
+                if not isinstance(a, DeviceNDArray):
+                    raise TypeError("%s(): argument %d must be a device array (use cuda.to_device)" % (self.name, i))
+                if a.dtype not in (np.dtype(np.float64), np.dtype(np.int64)):
+                    raise TypeError("%s(): argument %d has dtype %s; float64/int64 expected" % (self.name, i, a.dtype))
+                conv.append(C.c_void_p(a.ptr))
+            elif k is C.c_int64:
+                if isinstance(a, (float, np.floating)) and float(a) != int(a):
+                    raise TypeError("%s(): argument %d must be an integer" % (self.name, i))
+                conv.append(C.c_int64(int(a)))
+            else:
+                conv.append(C.c_double(float(a)))
+        _lib.check(getattr(_L(), self.sym)(None, *conv), self.name)
+
+
+def export(module, namespace):
+    """populate a module namespace with the kernel objects of one reference module"""
+    for (mod, name) in KERNELS:
+        if mod == module:
+            namespace[name] = Kernel(mod, name)

@@ -30,6 +30,19 @@ def test_library_exports_every_declared_symbol():
     assert L.lbmpm_version().startswith(b"liblbmpm_hip")
 
 
+def test_kernel_level_symbols_exported():
+    from openlbmpm_amd import _lib
+    from openlbmpm_amd._kernel_specs import KERNELS
+    L = _lib.lib()
+    text = open(os.path.join(ROOT, "include", "lbmpm_kernels.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(lbmpm_[a-zA-Z0-9_]+)\s*\(", text)))
+    assert len(names) >= 65
+    for n in names:
+        assert hasattr(L, n), "liblbmpm_hip.so does not export %s" % n
+    assert {sym for sym, _ in KERNELS.values()} <= set(names)
+
+
 def test_config_struct_layout_matches_c():
     """Compile a tiny C program against include/lbmpm.h and compare sizeof/offsetof."""
     from openlbmpm_amd import _lib

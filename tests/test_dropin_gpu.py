@@ -1,0 +1,270 @@
+"""GPU tests of the kernel-level drop-in path (include/lbmpm_kernels.h through the numba.cuda-shaped
+shim in openlbmpm_amd/dropin).  The loops below are the reference drivers' own launch statements
+(RKD2Q9.py:1295-1490, ShanChenD2Q9.py:1714-2087 / :1492-1629) with the kernel objects resolved to the
+pre-built HIP kernels; results are compared with the golden vectors the real reference produced."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_params, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    sys.path.insert(0, os.path.join(ROOT, "openlbmpm_amd", "dropin"))
+    for m in ("numba", "numba.cuda"):
+        sys.modules.pop(m, None)
+    from numba import cuda
+    import AcceleratedRKGPU2D as RKGPU2D
+    import OptimizedD2Q9GPU as OPT
+    import ExplicitD2Q9GPU as EXP
+    import AccelerateTransport2DRK as TR
+    yield cuda, RKGPU2D, OPT, EXP, TR
+    sys.path.remove(os.path.join(ROOT, "openlbmpm_amd", "dropin"))
+    for m in ("numba", "numba.cuda"):
+        sys.modules.pop(m, None)
+
+
+def test_colour_gradient_loop_with_reference_launch_statements(dropin):
+    cuda, RKGPU2D, _, _, _ = dropin
+    from oracle.rk import RKOracle, simple_geometry, mrt_matrices
+    d = np.load(os.path.join(GOLDEN, "rk_csf_mrt_capillary.npz"))
+    par = load_params(d)
+    xDomain, yDomain = par["nx"], par["ny"]
+    o = RKOracle(simple_geometry(xDomain, yDomain), par)       # host set-up only (tables, initial fields)
+    assert cuda.is_available()
+    totalNodes = o.N
+    xDimension, threadNum = 128, 32
+    grid1D = (int(xDimension / threadNum), math.ceil(totalNodes / xDimension)); threadPerBlock1D = (threadNum, 1)
+    # neighbour tables by the drop-in kernels themselves (RKD2Q9.py:709-716)
+    deviceFluidNodes = cuda.to_device(o.fluidNodes); deviceIdx = cuda.to_device(o.newIndex)
+    deviceNeighboringNodes = cuda.to_device(np.zeros(8 * totalNodes, dtype=np.int64))
+    RKGPU2D.fillNeighboringNodes[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension, deviceFluidNodes,
+                                                          deviceIdx, deviceNeighboringNodes)
+    assert np.array_equal(deviceNeighboringNodes.copy_to_host(), d["neighboringNodes"])
+    deviceWet = cuda.to_device(o.wettingSolidNodes)
+    deviceNeighboringWettingSolid = cuda.to_device(np.zeros(8 * o.W, dtype=np.int64))
+    RKGPU2D.fillNeighboringWettingNodes[grid1D, threadPerBlock1D](o.W, xDomain, yDomain, xDimension, deviceWet, deviceIdx,
+                                                                 deviceNeighboringWettingSolid)
+    assert np.array_equal(deviceNeighboringWettingSolid.copy_to_host(), d["neighboringWettingSolidNodes"])
+    # device arrays as in RKD2Q9.py:1243-1287
+    deviceFluidRhoR = cuda.to_device(o.rhoR); deviceFluidRhoB = cuda.to_device(o.rhoB)
+    deviceFluidPDFR = cuda.to_device(o.fR); deviceFluidPDFB = cuda.to_device(o.fB)
+    deviceFluidPDFRNew = cuda.to_device(np.zeros_like(o.fR)); deviceFluidPDFBNew = cuda.to_device(np.zeros_like(o.fB))
+    devicePhysicalVX = cuda.to_device(np.zeros(totalNodes)); devicePhysicalVY = cuda.to_device(np.zeros(totalNodes))
+    deviceColorValue = cuda.to_device(np.zeros(totalNodes))
+    deviceFluidPDFTotal = cuda.to_device(o.fR + o.fB)
+    deviceForceX = cuda.to_device(np.zeros(totalNodes)); deviceForceY = cuda.to_device(np.zeros(totalNodes))
+    deviceGradientX = cuda.to_device(np.zeros(totalNodes)); deviceGradientY = cuda.to_device(np.zeros(totalNodes))
+    deviceSolidColor = cuda.to_device(np.zeros(o.W)); deviceKValue = cuda.to_device(o.rhoB)
+    deviceFluidNodesWithSolid = cuda.to_device(o.fluidWet)
+    deviceUnitNsx = cuda.to_device(o.nsx); deviceUnitNsy = cuda.to_device(o.nsy)
+    w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+    deviceWeightsCoeff = cuda.to_device(w)
+    deviceUnitEX = cuda.to_device(np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.]))
+    deviceUnitEY = cuda.to_device(np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.]))
+    M, Minv, S = mrt_matrices()
+    deviceTransformationM = cuda.to_device(M); deviceTransformationIM = cuda.to_device(Minv); deviceCollisionM = cuda.to_device(S)
+    th = par["theta"] / 180. * np.pi
+    cosTheta, sinTheta = float(np.cos(th)), float(np.sin(th))
+    specificVY = par["vyB"] + par["vyR"]; totalPressure = par["rhoBL"] + par["rhoRL"]
+    numColorSolid, numWettingFluid = o.W, o.Wf
+
+    snaps = [int(k) for k in d["snaps"] if int(k) <= 50]
+    for iStep in range(1, max(snaps) + 1):
+        RKGPU2D.constantTotalVelocityInlet[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension, specificVY,
+                deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR,
+                deviceFluidPDFB, deviceFluidPDFTotal, devicePhysicalVY)
+        RKGPU2D.ghostPointsConstantVelocityRK[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension,
+                deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR,
+                deviceFluidPDFB, deviceForceX, deviceForceY)
+        RKGPU2D.calConstPressureLowerGPUTotal[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, totalPressure,
+                deviceFluidNodes, deviceFluidPDFTotal, devicePhysicalVY, deviceFluidRhoR, deviceFluidRhoB,
+                deviceFluidPDFR, deviceFluidPDFB)
+        RKGPU2D.ghostPointsConstPressureLowerRK[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
+                deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR, deviceFluidPDFB)
+        RKGPU2D.calTotalFluidPDF[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFR, deviceFluidPDFB,
+                deviceFluidPDFTotal)
+        RKGPU2D.calPhysicalVelocityRKGPU2DNew1[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFTotal,
+                deviceFluidRhoR, deviceFluidRhoB, devicePhysicalVX, devicePhysicalVY, deviceForceX, deviceForceY)
+        RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidRhoR, deviceFluidRhoB,
+                deviceColorValue)
+        RKGPU2D.calColorValueOnSolid[grid1D, threadPerBlock1D](numColorSolid, xDimension, deviceNeighboringWettingSolid,
+                deviceWeightsCoeff, deviceColorValue, deviceSolidColor)
+        RKGPU2D.calRKInitialGradient[grid1D, threadPerBlock1D](totalNodes, xDimension, numColorSolid, deviceFluidNodes,
+                deviceNeighboringNodes, deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, deviceColorValue, deviceSolidColor,
+                deviceGradientX, deviceGradientY)
+        RKGPU2D.updateColorGradientOnWettingNew[grid1D, threadPerBlock1D](numWettingFluid, xDimension, cosTheta, sinTheta,
+                deviceFluidNodesWithSolid, deviceUnitNsx, deviceUnitNsy, deviceGradientX, deviceGradientY)
+        RKGPU2D.calForceTermInColorGradientNew2D[grid1D, threadPerBlock1D](totalNodes, xDimension, par["sigma"],
+                deviceNeighboringNodes, deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, deviceGradientX, deviceGradientY,
+                deviceForceX, deviceForceY, deviceKValue)
+        RKGPU2D.calRKCollision1TotalGPU2DMRTM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
+                par["tauB"], par["delta"], deviceUnitEX, deviceUnitEY, deviceWeightsCoeff, devicePhysicalVX, devicePhysicalVY,
+                deviceFluidRhoR, deviceFluidRhoB, deviceColorValue, deviceFluidPDFTotal, deviceTransformationM,
+                deviceTransformationIM, deviceCollisionM)
+        RKGPU2D.calPerturbationFromForce2DMRT[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
+                par["tauB"], par["delta"], deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, devicePhysicalVX, devicePhysicalVY,
+                deviceForceX, deviceForceY, deviceColorValue, deviceFluidPDFTotal, deviceTransformationM,
+                deviceTransformationIM, deviceCollisionM, deviceFluidRhoR, deviceFluidRhoB)
+        RKGPU2D.calRecoloringProcessM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["beta"], deviceWeightsCoeff,
+                deviceFluidRhoR, deviceFluidRhoB, deviceUnitEX, deviceUnitEY, deviceGradientX, deviceGradientY,
+                deviceFluidPDFR, deviceFluidPDFB, deviceFluidPDFTotal)
+        RKGPU2D.calStreaming1GPU[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidNodes, deviceNeighboringNodes,
+                deviceFluidPDFR, deviceFluidPDFRNew)
+        RKGPU2D.calStreaming1GPU[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidNodes, deviceNeighboringNodes,
+                deviceFluidPDFB, deviceFluidPDFBNew)
+        RKGPU2D.calStreaming2GPU[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFRNew, deviceFluidPDFR)
+        RKGPU2D.calStreaming2GPU[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFBNew, deviceFluidPDFB)
+        RKGPU2D.calTotalFluidPDF[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFR, deviceFluidPDFB,
+                deviceFluidPDFTotal)
+        RKGPU2D.calMacroDensityRKGPU2D[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFR, deviceFluidPDFB,
+                deviceFluidRhoR, deviceFluidRhoB)
+        if iStep in snaps:
+            got = dict(fR=deviceFluidPDFR, fB=deviceFluidPDFB, rhoR=deviceFluidRhoR, rhoB=deviceFluidRhoB,
+                       vx=devicePhysicalVX, vy=devicePhysicalVY, phi=deviceColorValue, Gx=deviceGradientX,
+                       Gy=deviceGradientY, Fx=deviceForceX, Fy=deviceForceY, K=deviceKValue)
+            for name, arr in got.items():
+                e = rel_err(arr.copy_to_host(), d["s%d_%s" % (iStep, name)])
+                assert e < 1e-11, "step %d %s rel err %.3e" % (iStep, name, e)
+    with pytest.raises(TypeError):       # wrong argument count, like Numba's explicit signatures
+        RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidRhoR, deviceFluidRhoB)
+    with pytest.raises(TypeError):       # host array where a device array is expected
+        RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](totalNodes, xDimension, o.rhoR, deviceFluidRhoB, deviceColorValue)
+
+
+@pytest.mark.parametrize("scenario", ["efs_srt_dirichlet", "efs_mrt_dirichlet", "efs_srt_convective"])
+def test_explicit_forcing_loop_with_reference_launch_statements(dropin, scenario):
+    cuda, _, OPT, EXP, _ = dropin
+    from oracle.sc import SCOracle, simple_geometry, collision_matrices
+    g = np.load(os.path.join(GOLDEN, "sc_%s.npz" % scenario))
+    par = load_params(g)
+    nx, ny = par["nx"], par["ny"]
+    keys = ("inter", "relax", "rho0", "rho1", "bg0", "bg1", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "vy0", "vy1")
+    o = SCOracle.__new__(SCOracle)          # host set-up only: tables + initial densities
+    from oracle.sc import initial_densities
+    from oracle import lib as olib
+    dom = simple_geometry(nx, ny)
+    fluidNodes = np.flatnonzero(dom.reshape(-1) == 1).astype(np.int64)
+    N = fluidNodes.size
+    newIndex = -np.ones(nx * ny, dtype=np.int64); newIndex[fluidNodes] = np.arange(N)
+    typesFluids = 2
+    rho0 = initial_densities(dom, False, par).reshape(2, -1)[:, fluidNodes]
+    w9 = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+    optFluidPDF = np.ascontiguousarray(w9[None, None, :] * rho0[:, :, None])
+    xDimension, threadNum = 256, 32
+    grid1D = (int(xDimension / threadNum), math.ceil(N / xDimension)); tpb = (threadNum, 1)
+    dFluidIndices = cuda.to_device(fluidNodes); dIdx = cuda.to_device(newIndex)
+    dNbr = cuda.to_device(np.zeros(8 * N, dtype=np.int64))
+    OPT.fillNeighboringNodes[grid1D, tpb](N, nx, ny, xDimension, dFluidIndices, dIdx, dNbr)
+    assert np.array_equal(dNbr.copy_to_host(), g["neighboringNodes"])
+    dPDF = cuda.to_device(optFluidPDF); dPDFold = cuda.to_device(optFluidPDF); dPDFNew = cuda.to_device(optFluidPDF)
+    dRho = cuda.to_device(np.ascontiguousarray(rho0)); dPot = cuda.to_device(np.zeros((2, N)))
+    dEqVX = cuda.to_device(np.zeros(N)); dEqVY = cuda.to_device(np.zeros(N))
+    dFx = cuda.to_device(np.zeros((2, N))); dFy = cuda.to_device(np.zeros((2, N)))
+    dFeq = cuda.to_device(optFluidPDF); dFF = cuda.to_device(np.zeros_like(optFluidPDF))
+    dVX = cuda.to_device(np.zeros(N)); dVY = cuda.to_device(np.zeros(N))
+    tau = np.array([par["tau0"], par["tau1"]])
+    dTau = cuda.to_device(tau)
+    dG = cuda.to_device(np.array([[0., par["G"]], [par["G"], 0.]])); dGs = cuda.to_device(np.array([par["Gs0"], par["Gs1"]]))
+    dEX = cuda.to_device(np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.])); dEY = cuda.to_device(np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.]))
+    dWI = cuda.to_device(np.array([1. / 3.] * 4 + [1. / 12.] * 4)); dW = cuda.to_device(w9)
+    dVelY = cuda.to_device(np.array([par["vy0"], par["vy1"]]))
+    mrt = par["relax"] == "MRT"
+    if mrt:
+        dLam = cuda.to_device(collision_matrices(tau)); dConserveS = cuda.to_device(np.ones(2))
+        dFFM = cuda.to_device(np.zeros_like(optFluidPDF)); dPDFM = cuda.to_device(optFluidPDF)
+
+    def chain():
+        OPT.calFluidPotentialGPUEql[grid1D, tpb](N, typesFluids, xDimension, dRho, dPot)
+        EXP.calExplicit4thOrderScheme[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbr, dWI, dG, dGs, dPot, dFx, dFy)
+        if mrt:
+            EXP.transformEquilibriumVelocity[grid1D, tpb](N, typesFluids, xDimension, dEX, dEY, dRho, dFx, dFy, dPDF,
+                                                          dConserveS, dEqVX, dEqVY)
+        else:
+            EXP.calEquilibriumVEFGPU[grid1D, tpb](N, typesFluids, xDimension, dTau, dEX, dEY, dRho, dFx, dFy, dPDF, dEqVX, dEqVY)
+        EXP.calEquilibriumFuncEFGPU[grid1D, tpb](N, typesFluids, xDimension, dW, dEX, dEY, dRho, dEqVX, dEqVY, dFeq)
+        EXP.calForceDistrGPU[grid1D, tpb](N, typesFluids, xDimension, dEX, dEY, dEqVX, dEqVY, dRho, dFx, dFy, dFeq, dFF)
+
+    def inlet():
+        OPT.constantVelocityZouHeBoundaryHigher[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dVelY, dFluidIndices, dRho, dPDF)
+        OPT.ghostPointsConstantVelocityInlet[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+
+    def outlet_dirichlet():
+        OPT.constantPressureZouHeBoundaryLower[grid1D, tpb](N, typesFluids, nx, xDimension, 1.002, dFluidIndices, dRho, dPDF)
+        OPT.ghostPointsConstantPressureOutlet[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+
+    # pre-loop, ShanChenD2Q9.py:1714-1849
+    chain()
+    EXP.transformPDFGPU[grid1D, tpb](N, typesFluids, xDimension, dPDF, dFF)
+    inlet()
+    if par["outlet"] == "Dirichlet":
+        outlet_dirichlet()
+    snaps = [int(k) for k in g["snaps"] if int(k) <= 10]
+    for i in range(max(snaps) + 1):          # ShanChenD2Q9.py:1852-2087
+        OPT.savePDFLastStep[grid1D, tpb](N, typesFluids, xDimension, dPDF, dPDFold)
+        if mrt:
+            EXP.transfromForceTerm[grid1D, tpb](N, typesFluids, xDimension, dFF, dLam, dFFM)
+            EXP.transformPDFandEquil[grid1D, tpb](N, typesFluids, xDimension, dPDF, dFeq, dLam, dPDFM)
+            EXP.calAfterCollisionMRT[grid1D, tpb](N, typesFluids, xDimension, dPDF, dFF, dFeq, dPDFM, dFFM)
+        else:
+            EXP.calCollisionEXGPU[grid1D, tpb](N, typesFluids, xDimension, dTau, dPDF, dFeq, dFF)
+        OPT.calStreaming1GPU[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbr, dPDF, dPDFNew)
+        OPT.calStreaming2GPU[grid1D, tpb](N, typesFluids, xDimension, dPDFNew, dPDF)
+        OPT.calFluidRhoGPU[grid1D, tpb](N, typesFluids, xDimension, dRho, dPDF)
+        OPT.calPhysicalVelocity[grid1D, tpb](N, typesFluids, xDimension, dPDF, dRho, dFx, dFy, dVX, dVY)
+        if par["outlet"] == "Convective":
+            OPT.convectiveOutletEachGPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dPDFold, dRho, dVY)
+            OPT.convectiveOutletEach2GPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dPDFold, dRho, dVY)
+            OPT.convectiveOutletEach3GPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dPDFold, dRho, dVY)
+        else:
+            outlet_dirichlet()
+        inlet()
+        OPT.calFluidRhoGPU[grid1D, tpb](N, typesFluids, xDimension, dRho, dPDF)
+        OPT.calPhysicalVelocity[grid1D, tpb](N, typesFluids, xDimension, dPDF, dRho, dFx, dFy, dVX, dVY)
+        chain()
+        if i in snaps:
+            for name, arr in dict(f=dPDF, rho=dRho, Fx=dFx, Fy=dFy, vx=dVX, vy=dVY, ueqx=dEqVX, ueqy=dEqVY, feq=dFeq,
+                                  fforce=dFF).items():
+                e = rel_err(arr.copy_to_host(), g["s%d_%s" % (i, name)])
+                assert e < 1e-11, "%s pass %d %s rel err %.3e" % (scenario, i, name, e)
+
+
+def test_tracer_kernels_against_reference_vectors(dropin):
+    cuda, _, _, _, TR = dropin
+    d = np.load(os.path.join(GOLDEN, "tr_kernels.npz"))
+    N = int(d["fluidNodes"].size); ny, nx = d["isDomain"].shape; nT = 2
+    cfg = ((4, math.ceil(N / 128)), (32, 1)); xDim = 128
+    dev = lambda a: cuda.to_device(np.ascontiguousarray(a))
+    newidx = -np.ones((ny, nx), dtype=np.int64); newidx.reshape(-1)[d["fluidNodes"]] = np.arange(N)
+    dFl = dev(d["fluidNodes"]); dNbr = dev(np.zeros(4 * N, dtype=np.int64))
+    TR.fillNeighboringNodesTransport[cfg](N, nx, ny, xDim, dFl, dev(newidx), dNbr)
+    assert np.array_equal(dNbr.copy_to_host(), d["nbr"])
+    dC = dev(np.zeros((nT, N))); dG = dev(d["conc_in_g"])
+    TR.calConcentrationGPU[cfg](N, nT, xDim, 5, dC, dG)
+    assert rel_err(dC.copy_to_host(), d["conc_out"]) < 1e-13
+    uvx = dev(np.array([0., 1., -1, 0., 0.])); uvy = dev(np.array([0., 0., 0., 1., -1.]))
+    w = dev(d["w"])
+    TR.calCollisionTransportLinearEqlMRTGPU[cfg](N, xDim, nT, uvx, uvy, dev(d["col_vx"]), dev(d["col_vy"]), dC, dG, dev(d["M"]),
+                                                 dev(d["A"]), w)
+    assert rel_err(dG.copy_to_host(), d["col_out_g"]) < 1e-13
+    dInd = dev(np.zeros(N))
+    TR.calValueTransportDomain[cfg](N, xDim, 0.5, dInd, dev(d["ind_rhoR"]))
+    assert np.array_equal(dInd.copy_to_host(), d["ind_out"])
+    ex9 = dev(np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.])); ey9 = dev(np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.]))
+    TR.calTransportWithInterfaceD2Q5[cfg](N, xDim, nT, dev(d["itf_beta"]), dInd, ex9, ey9, dev(d["itf_Gx"]), dev(d["itf_Gy"]), w, dC, dG)
+    assert rel_err(dG.copy_to_host(), d["itf_out_g"]) < 1e-13
+    TR.calFreeConcBoundary3[cfg](N, nT, nx, xDim, dFl, dNbr, dC, dG)
+    assert np.array_equal(dG.copy_to_host(), d["free_out_g"])
+    dGN = dev(np.zeros((nT, N, 5)))
+    TR.calStreamingTransportGPU[cfg](N, xDim, nT, dNbr, dG, dGN)
+    TR.calStreamingTransport2GPU[cfg](N, nT, xDim, dGN, dG)
+    assert np.array_equal(dG.copy_to_host(), d["str_out_g"])
+    TR.calInamuroConstConcBoundary[cfg](N, xDim, nT, ny, nx, dFl, dNbr, dev(d["ina_cb"]), w, dG)
+    assert rel_err(dG.copy_to_host(), d["ina_out_g"]) < 1e-13

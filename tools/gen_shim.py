@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""One-off generator of the kernel-level (drop-in) boundary from ONE spec table:
+  include/lbmpm_kernels.h                         C declarations, one per reference kernel
+  openlbmpm_amd/csrc/sparse_entry_gen.h           extern "C" definitions forwarding to the launchers
+  openlbmpm_amd/_kernel_specs.py                  ctypes signatures for the Python shim
+Argument lists are the reference kernels' own (module, name, citation), minus the launch
+configuration.  kinds: i = int64, d = float64, I = int64*, D = float64*."""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A = "RKCG2D/AcceleratedRKGPU2D.py"; O = "ShanChen2D/OptimizedD2Q9GPU.py"; E = "ShanChen2D/ExplicitD2Q9GPU.py"
+T = "RKCG2D/AccelerateTransport2DRK.py"
+
+# (module tag, reference kernel, file:line, "name:kind ...", launcher call)
+SPEC = [
+ ("rk", "fillNeighboringNodes", A + ":15", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
+  "launch_rk_fill_neighbors(st, totalNodes, nx, ny, fluidNodes, domainNewIndex, neighboringNodes)"),
+ ("rk", "fillNeighboringWettingNodes", A + ":58", "totalWettingNodes:i nx:i ny:i xDim:i wettingNodes:I domainNewIndex:I neighboringWettingNodes:I",
+  "launch_rk_fill_neighbors(st, totalWettingNodes, nx, ny, wettingNodes, domainNewIndex, neighboringWettingNodes)"),
+ ("rk", "calMacroDensityRKGPU2D", A + ":103", "totalNodes:i xDim:i fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_macro_density(st, totalNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB)"),
+ ("rk", "calStreaming1GPU", A + ":340", "totalNum:i xDim:i fluidNodes:I neighboringNodes:I fluidPDF:D fluidPDFNew:D",
+  "launch_rk_stream1(st, totalNum, neighboringNodes, fluidPDF, fluidPDFNew)"),
+ ("rk", "calStreaming2GPU", A + ":409", "totalNum:i xDim:i fluidPDFNew:D fluidPDF:D",
+  "launch_rk_stream2(st, totalNum, fluidPDFNew, fluidPDF)"),
+ ("rk", "ghostPointsConstantVelocityRK", A + ":607", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D forceX:D forceY:D",
+  "launch_rk_ghost_inlet_velocity(st, totalNodes, nx, ny, fluidNodes, neighboringNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rk", "convectiveOutletGPU", A + ":700", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_outlet_convective_row(st, totalNodes, nx, 2, fluidNodes, neighboringNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB)"),
+ ("rk", "convectiveOutletGhost2GPU", A + ":731", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_outlet_convective_row(st, totalNodes, nx, 1, fluidNodes, neighboringNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB)"),
+ ("rk", "convectiveOutletGhost3GPU", A + ":762", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_outlet_convective_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB)"),
+ ("rk", "calConstPressureInletGPU", A + ":925", "totalNodes:i nx:i ny:i xDim:i constPHB:d constPHR:d fluidNodes:I fluidRhoB:D fluidRhoR:D fluidPDFB:D fluidPDFR:D",
+  "launch_rk_inlet_pressure(st, totalNodes, nx, ny, constPHB, constPHR, fluidNodes, fluidRhoB, fluidRhoR, fluidPDFB, fluidPDFR)"),
+ ("rk", "ghostPointsConstPressureInletRK", A + ":968", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_ghost_inlet_pressure(st, totalNodes, nx, ny, fluidNodes, neighboringNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rk", "ghostPointsConstPressureLowerRK", A + ":1045", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_ghost_outlet_pressure(st, totalNodes, nx, neighboringNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rk", "calPhaseFieldPhi", A + ":1348", "totalNodes:i xDim:i fluidRhoR:D fluidRhoB:D phiValue:D",
+  "launch_rk_phase_field(st, totalNodes, fluidRhoR, fluidRhoB, phiValue)"),
+ ("rk", "calTotalFluidPDF", A + ":1414", "totalNodes:i xDim:i fluidPDFR:D fluidPDFB:D fluidPDFTotal:D",
+  "launch_rk_total_pdf(st, totalNodes, fluidPDFR, fluidPDFB, fluidPDFTotal)"),
+ ("rk", "calColorValueOnSolid", A + ":1560", "totalSolidWetting:i xDim:i neighboringWettingSolid:I weightsCoeff:D colorValueFluid:D colorValueSolid:D",
+  "launch_rk_color_on_solid(st, totalSolidWetting, neighboringWettingSolid, colorValueFluid, colorValueSolid)"),
+ ("rk", "calRKInitialGradient", A + ":1584", "totalNodes:i xDim:i numColorSolid:i fluidNodes:I neighboringNodes:I weightsCoeff:D unitEX:D unitEY:D colorValueFluid:D colorValueSolid:D gradientX:D gradientY:D",
+  "launch_rk_gradient(st, totalNodes, neighboringNodes, colorValueFluid, colorValueSolid, gradientX, gradientY)"),
+ ("rk", "updateColorGradientOnWetting", A + ":1639", "totalFluidWettingNodes:i xDim:i cosTheta:d sinTheta:d fluidNodesWetting:I unitVectorNsx:D unitVectorNsy:D gradientX:D gradientY:D",
+  "launch_rk_wetting1(st, totalFluidWettingNodes, cosTheta, sinTheta, fluidNodesWetting, unitVectorNsx, unitVectorNsy, gradientX, gradientY)"),
+ ("rk", "updateColorGradientOnWettingNew", A + ":2430", "totalFluidWettingNodes:i xDim:i cosTheta:d sinTheta:d fluidNodesWetting:I unitVectorNsx:D unitVectorNsy:D gradientX:D gradientY:D",
+  "launch_rk_wetting2(st, totalFluidWettingNodes, cosTheta, sinTheta, fluidNodesWetting, unitVectorNsx, unitVectorNsy, gradientX, gradientY)"),
+ ("rk", "calForceTermInColorGradient2D", A + ":1686", "totalNodes:i xDim:i surfaceTension:d neighboringNodes:I weightsCoeff:D unitEX:D unitEY:D gradientX:D gradientY:D forceX:D forceY:D KValue:D",
+  "launch_rk_force(st, totalNodes, 1, surfaceTension, neighboringNodes, gradientX, gradientY, forceX, forceY, KValue)"),
+ ("rk", "calForceTermInColorGradientNew2D", A + ":2499", "totalNodes:i xDim:i surfaceTension:d neighboringNodes:I weightsCoeff:D unitEX:D unitEY:D gradientX:D gradientY:D forceX:D forceY:D KValue:D",
+  "launch_rk_force(st, totalNodes, 2, surfaceTension, neighboringNodes, gradientX, gradientY, forceX, forceY, KValue)"),
+ ("rk", "calPerturbationFromForce2D", A + ":1743", "totalNodes:i xDim:i optionF:i tauR:d tauB:d deltaValue:d weightsCoeff:D unitEX:D unitEY:D physicalVX:D physicalVY:D forceX:D forceY:D colorValue:D fluidTotalPDF:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_force_srt(st, totalNodes, (int)optionF, tauR, tauB, deltaValue, physicalVX, physicalVY, forceX, forceY, colorValue, fluidTotalPDF, fluidRhoR, fluidRhoB)"),
+ ("rk", "calRKCollision1TotalGPU2DSRTM", A + ":1804", "totalNodes:i xDim:i optionF:i tauR:d tauB:d deltaValue:d unitEX:D unitEY:D weightsCoeff:D physicalVX:D physicalVY:D fluidRhoR:D fluidRhoB:D ColorValue:D fluidPDFTotal:D",
+  "launch_rk_collide_srt(st, totalNodes, (int)optionF, tauR, tauB, deltaValue, physicalVX, physicalVY, fluidRhoR, fluidRhoB, ColorValue, fluidPDFTotal)"),
+ ("rk", "calRecoloringProcessM", A + ":1857", "totalNodes:i xDim:i betaValue:d weightsCoeff:D fluidRhoR:D fluidRhoB:D unitEX:D unitEY:D gradientX:D gradientY:D fluidPDFR:D fluidPDFB:D fluidPDFTotal:D",
+  "launch_rk_recolor(st, totalNodes, betaValue, fluidRhoR, fluidRhoB, gradientX, gradientY, fluidPDFR, fluidPDFB, fluidPDFTotal)"),
+ ("rk", "calRKCollision1TotalGPU2DMRTM", A + ":1938", "totalNodes:i xDim:i optionF:i tauR:d tauB:d deltaValue:d unitEX:D unitEY:D weightsCoeff:D physicalVX:D physicalVY:D fluidRhoR:D fluidRhoB:D ColorValue:D fluidPDFTotal:D transformationM:D inverseTM:D collisionS:D",
+  "launch_rk_collide_mrt(st, totalNodes, (int)optionF, tauR, tauB, deltaValue, physicalVX, physicalVY, fluidRhoR, fluidRhoB, ColorValue, fluidPDFTotal, transformationM, inverseTM, collisionS)"),
+ ("rk", "calPerturbationFromForce2DMRT", A + ":2027", "totalNodes:i xDim:i optionF:i tauR:d tauB:d deltaValue:d weightsCoeff:D unitEX:D unitEY:D physicalVX:D physicalVY:D forceX:D forceY:D colorValue:D fluidTotalPDF:D transformationM:D inverseTM:D collisionS:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_force_mrt(st, totalNodes, (int)optionF, tauR, tauB, deltaValue, physicalVX, physicalVY, forceX, forceY, colorValue, fluidTotalPDF, transformationM, inverseTM, collisionS, fluidRhoR, fluidRhoB)"),
+ ("rk", "constantTotalVelocityInlet", A + ":2348", "totalNodes:i nx:i ny:i xDim:i specificVY:d fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D fluidPDFTotal:D physicalVY:D",
+  "launch_rk_inlet_velocity_total(st, totalNodes, nx, ny, specificVY, fluidNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB, fluidPDFTotal, physicalVY)"),
+ ("rk", "calConstPressureLowerGPUTotal", A + ":2560", "totalNodes:i nx:i xDim:i constPL:d fluidNodes:I fluidPDFTotal:D physicalVY:D fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_outlet_pressure_total(st, totalNodes, nx, constPL, fluidNodes, fluidPDFTotal, physicalVY, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rk", "calPhysicalVelocityRKGPU2DNew1", A + ":2634", "totalNodes:i xDim:i fluidPDFTotal:D fluidRhoR:D fluidRhoB:D physicalVX:D physicalVY:D forceX:D forceY:D",
+  "launch_rk_velocity(st, totalNodes, fluidPDFTotal, fluidRhoR, fluidRhoB, physicalVX, physicalVY, forceX, forceY)"),
+ # ---------------- Shan-Chen / EFS (two fluids)
+ ("sc", "fillNeighboringNodes", O + ":22", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
+  "launch_rk_fill_neighbors(st, totalNodes, nx, ny, fluidNodes, domainNewIndex, neighboringNodes)"),
+ ("sc", "savePDFLastStep", O + ":70", "totalNodes:i numFluids:i xDim:i fluidPDF:D fluidPDFOld:D",
+  "sc_check_nf(numFluids); hipMemcpyAsync(fluidPDFOld, fluidPDF, sizeof(double) * 2 * 9 * (size_t)totalNodes, hipMemcpyDeviceToDevice, st)"),
+ ("sc", "calFluidRhoGPU", O + ":84", "totalNodes:i numFluids:i xDim:i fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_rho(st, totalNodes, fluidRho, fluidPDF)"),
+ ("sc", "calFluidPotentialGPUEql", O + ":99", "totalNodes:i numFluids:i xDim:i fluidRho:D fluidPotential:D",
+  "sc_check_nf(numFluids); hipMemcpyAsync(fluidPotential, fluidRho, sizeof(double) * 2 * (size_t)totalNodes, hipMemcpyDeviceToDevice, st)"),
+ ("sc", "calPhysicalVelocity", O + ":156", "totalNodes:i numFluids:i xDim:i fluidPDF:D fluidRho:D forceX:D forceY:D velocityPX:D velocityPY:D",
+  "sc_check_nf(numFluids); launch_sc_physical_velocity(st, totalNodes, fluidPDF, fluidRho, forceX, forceY, velocityPX, velocityPY)"),
+ ("sc", "calStreaming1GPU", O + ":452", "totalNum:i numFluids:i xDim:i fluidNodes:I neighboringNodes:I fluidPDF:D fluidPDFNew:D",
+  "sc_check_nf(numFluids); launch_sc_stream1(st, totalNum, neighboringNodes, fluidPDF, fluidPDFNew)"),
+ ("sc", "calStreaming2GPU", O + ":539", "totalNum:i numFluids:i xDim:i fluidPDFNew:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_stream2(st, totalNum, fluidPDFNew, fluidPDF)"),
+ ("sc", "constantPressureZouHeBoundaryLower", O + ":555", "totalNodes:i numFluids:i nx:i xDim:i densityL:d fluidNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_outlet_pressure(st, totalNodes, nx, fluidNodes, fluidRho, fluidPDF)"),
+ ("sc", "ghostPointsConstantVelocityInlet", O + ":710", "totalNodes:i numFluids:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_ghost_inlet(st, totalNodes, nx, ny, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
+ ("sc", "ghostPointsConstantPressureOutlet", O + ":743", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_ghost_outlet(st, totalNodes, nx, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
+ ("sc", "constantVelocityZouHeBoundaryHigher", O + ":839", "totalNodes:i numFluids:i nx:i ny:i xDim:i specificVY:D fluidNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_inlet_velocity(st, totalNodes, nx, ny, specificVY, fluidNodes, fluidRho, fluidPDF)"),
+ ("sc", "convectiveOutletGPU", O + ":960", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidRho:D",
+  "sc_check_nf(numFluids); launch_sc_outlet_copy_row(st, totalNodes, nx, 2, fluidNodes, neighboringNodes, fluidPDFNew, fluidRho)"),
+ ("sc", "convectiveOutletGhost2GPU", O + ":988", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidRho:D",
+  "sc_check_nf(numFluids); launch_sc_outlet_copy_row(st, totalNodes, nx, 1, fluidNodes, neighboringNodes, fluidPDFNew, fluidRho)"),
+ ("sc", "convectiveOutletGhost3GPU", O + ":1016", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidRho:D",
+  "sc_check_nf(numFluids); launch_sc_outlet_copy_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, fluidPDFNew, fluidRho)"),
+ ("sc", "convectiveOutletEachGPU", O + ":1044", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidPDFOld:D fluidRho:D physicalVY:D",
+  "sc_check_nf(numFluids); launch_sc_outlet_convective_row(st, totalNodes, nx, 2, fluidNodes, neighboringNodes, fluidPDFNew, fluidPDFOld, fluidRho, physicalVY)"),
+ ("sc", "convectiveOutletEach2GPU", O + ":1070", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidPDFOld:D fluidRho:D physicalVY:D",
+  "sc_check_nf(numFluids); launch_sc_outlet_convective_row(st, totalNodes, nx, 1, fluidNodes, neighboringNodes, fluidPDFNew, fluidPDFOld, fluidRho, physicalVY)"),
+ ("sc", "convectiveOutletEach3GPU", O + ":1098", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidPDFOld:D fluidRho:D physicalVY:D",
+  "sc_check_nf(numFluids); launch_sc_outlet_convective_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, fluidPDFNew, fluidPDFOld, fluidRho, physicalVY)"),
+ ("sc", "interactionCollisionProcess", O + ":1274", "totalNodes:i numFluids:i xDim:i weightInter:D tau:D interCoeff:D interSolid:D weightsCoeff:D fluidRho:D fluidPotential:D fluidPDF:D fluidPDFNew:D fluidNodes:I neighboringNodes:I forceX:D forceY:D",
+  "sc_check_nf(numFluids); launch_sc_interaction_collision(st, totalNodes, tau, interCoeff, interSolid, fluidRho, fluidPotential, fluidPDF, neighboringNodes, forceX, forceY)"),
+ ("sc", "calExplicit4thOrderScheme", E + ":51", "totalNodes:i numFluids:i xDim:i fluidNodes:I neighboringNodes:I weightInter:D interactionCoeff:D interactionSolid:D fluidPotential:D forceX:D forceY:D",
+  "sc_check_nf(numFluids); launch_sc_efs_force4(st, totalNodes, neighboringNodes, interactionCoeff, interactionSolid, fluidPotential, forceX, forceY)"),
+ ("sc", "calEquilibriumFuncEFGPU", E + ":227", "totalNum:i numFluids:i xDim:i weightCoeff:D EX:D EY:D fluidRho:D equilibriumVX:D equilibriumVY:D fEq:D",
+  "sc_check_nf(numFluids); launch_sc_efs_feq(st, totalNum, fluidRho, equilibriumVX, equilibriumVY, fEq)"),
+ ("sc", "calForceDistrGPU", E + ":255", "totalNodes:i numFluids:i xDim:i EX:D EY:D equilibriumVX:D equilibriumVY:D fluidRho:D forceX:D forceY:D fEq:D fForce:D",
+  "sc_check_nf(numFluids); launch_sc_efs_fforce(st, totalNodes, equilibriumVX, equilibriumVY, fluidRho, forceX, forceY, fEq, fForce)"),
+ ("sc", "transformPDFGPU", E + ":278", "totalNodes:i numFluids:i xDim:i fluidPDF:D fForce:D",
+  "sc_check_nf(numFluids); launch_sc_efs_transform(st, totalNodes, fluidPDF, fForce)"),
+ ("sc", "calCollisionEXGPU", E + ":294", "totalNodes:i numFluids:i xDim:i tau:D fluidPDF:D fEq:D fForce:D",
+  "sc_check_nf(numFluids); launch_sc_efs_collide_srt(st, totalNodes, tau, fluidPDF, fEq, fForce)"),
+ ("sc", "calEquilibriumVEFGPU", E + ":340", "totalNodes:i numFluids:i xDim:i tau:D EX:D EY:D fluidRho:D forceX:D forceY:D fluidPDF:D eqVX:D eqVY:D",
+  "sc_check_nf(numFluids); launch_sc_efs_ueq(st, totalNodes, tau, 1, fluidRho, forceX, forceY, fluidPDF, eqVX, eqVY)"),
+ ("sc", "transformEquilibriumVelocity", E + ":1426", "totalNodes:i numFluids:i xDim:i EX:D EY:D fluidRho:D forceX:D forceY:D fluidPDF:D conserveS:D eqVX:D eqVY:D",
+  "sc_check_nf(numFluids); launch_sc_efs_ueq(st, totalNodes, conserveS, 0, fluidRho, forceX, forceY, fluidPDF, eqVX, eqVY)"),
+ ("sc", "transformPDFandEquil", E + ":1379", "totalNodes:i numFluids:i xDim:i fluidPDF:D fEq:D collisionMatrix:D fluidPDFM:D",
+  "sc_check_nf(numFluids); launch_sc_mrt_transform_pdf_eq(st, totalNodes, fluidPDF, fEq, collisionMatrix, fluidPDFM)"),
+ ("sc", "transfromForceTerm", E + ":1404", "totalNodes:i numFluids:i xDim:i fForce:D collisionMatrix:D fForceM:D",
+  "sc_check_nf(numFluids); launch_sc_mrt_transform_force(st, totalNodes, fForce, collisionMatrix, fForceM)"),
+ ("sc", "calAfterCollisionMRT", E + ":1457", "totalNodes:i numFluids:i xDim:i fluidPDF:D fForce:D fEq:D fluidPDFM:D fForceM:D",
+  "sc_check_nf(numFluids); launch_sc_mrt_after_collision(st, totalNodes, fluidPDF, fForce, fEq, fluidPDFM, fForceM)"),
+ # ---------------- tracer transport
+ ("tr", "fillNeighboringNodesTransport", T + ":51", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
+  "launch_tr_fill_neighbors(st, totalNodes, nx, ny, fluidNodes, domainNewIndex, neighboringNodes)"),
+ ("tr", "calConcentrationGPU", T + ":78", "totalNodes:i numTracers:i xDim:i numSchemes:i tracerConc:D tracerPDF:D",
+  "tr_check_q5(numSchemes); launch_tr_concentration(st, totalNodes, (int)numTracers, tracerConc, tracerPDF)"),
+ ("tr", "calCollisionTransportLinearEqlMRTGPU", T + ":535", "totalNodes:i xDim:i numTracers:i unitVX:D unitVY:D velocityVX:D velocityVY:D tracerConc:D tracerPDF:D transportM:D inverseRelaxationMS:D weightsCoeff:D",
+  "launch_tr_collide_mrt(st, totalNodes, (int)numTracers, velocityVX, velocityVY, tracerConc, tracerPDF, transportM, inverseRelaxationMS)"),
+ ("tr", "calStreamingTransportGPU", T + ":139", "totalNodes:i xDim:i numTracers:i neighboringNodes:I tracerPDF:D tracerPDFNew:D",
+  "launch_tr_stream1(st, totalNodes, (int)numTracers, neighboringNodes, tracerPDF, tracerPDFNew)"),
+ ("tr", "calStreamingTransport2GPU", T + ":184", "totalNum:i numTracers:i xDim:i tracerPDFNew:D tracerPDF:D",
+  "launch_tr_stream2(st, totalNum, (int)numTracers, tracerPDFNew, tracerPDF)"),
+ ("tr", "calFreeConcBoundary3", T + ":461", "totalNodes:i numTracers:i nx:i xDim:i fluidNodes:I neighboringNodes:I tracerConc:D tracerPDF:D",
+  "launch_tr_free_outlet(st, totalNodes, (int)numTracers, nx, fluidNodes, neighboringNodes, tracerPDF)"),
+ ("tr", "calInamuroConstConcBoundary", T + ":682", "totalNodes:i xDim:i numTracers:i ny:i nx:i fluidNodes:I neighboringTRNodes:I concBoundary:D weightsCoeff:D tracerPDF:D",
+  "launch_tr_inlet_inamuro(st, totalNodes, (int)numTracers, ny, nx, fluidNodes, concBoundary, tracerPDF)"),
+ ("tr", "calValueTransportDomain", T + ":957", "totalNodes:i xDim:i critiriaValue:d valueTransportDomain:D fluidRhoR:D",
+  "launch_tr_indicator(st, totalNodes, critiriaValue, valueTransportDomain, fluidRhoR)"),
+ ("tr", "calTransportWithInterfaceD2Q5", T + ":976", "totalNodes:i xDim:i numTracers:i betaTracer:D valueTransportDomain:D unitEX:D unitEY:D gradientX:D gradientY:D weightsCoeff:D tracerConc:D tracerPDF:D",
+  "launch_tr_interface(st, totalNodes, (int)numTracers, betaTracer, valueTransportDomain, gradientX, gradientY, tracerConc, tracerPDF)"),
+]
+
+CT = {"i": "int64_t", "d": "double", "I": "int64_t *", "D": "double *"}
+PY = {"i": "C.c_int64", "d": "C.c_double", "I": "C.c_void_p", "D": "C.c_void_p"}
+
+
+def main():
+    hdr = ['''/*
+ * lbmpm_kernels.h -- kernel-level (drop-in) C ABI of liblbmpm_hip.so: one entry point per reference
+ * @cuda.jit kernel that a WORKING reference driver loop launches, on the reference's own sparse
+ * arrays (AoS f[N][9] / f[nF][N][9] float64, int64 neighbour tables), same argument order as the
+ * Numba signature minus the launch configuration `[grid, block]`.  GENERATED by tools/gen_shim.py.
+ *
+ * All pointers are DEVICE pointers (see lbmpm_device_malloc & co below); `stream` is a hipStream_t
+ * (NULL = the legacy default stream, which is what Numba's default-stream launches use).
+ * Arguments the reference passes but the arithmetic does not need (xDim, the lattice-constant
+ * arrays) are accepted and ignored.  Every call enqueues asynchronously and returns 0 or a
+ * negative lbmpm_status.  Shan-Chen entry points require numFluids == 2 (like the reference's
+ * outlet kernel); tracer entry points the D2Q5 scheme (numSchemes == 5).
+ */
+#ifndef LBMPM_KERNELS_H
+#define LBMPM_KERNELS_H
+#include "lbmpm.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* device-memory facade used by the numba.cuda-shaped Python shim (to_device / copy_to_host) */
+int lbmpm_device_malloc(int64_t bytes, void **out);
+int lbmpm_device_free(void *ptr);
+int lbmpm_memcpy_h2d(void *dst, const void *src, int64_t bytes);
+int lbmpm_memcpy_d2h(void *dst, const void *src, int64_t bytes);   /* synchronises, like copy_to_host */
+int lbmpm_device_synchronize(void);
+''']
+    ent = ["// GENERATED by tools/gen_shim.py -- extern \"C\" kernel-level entry points\n#pragma once\n"]
+    py = ['"""GENERATED by tools/gen_shim.py: ctypes signatures of the kernel-level entry points."""\nimport ctypes as C\n\nKERNELS = {']
+    for mod, name, cite, args, call in SPEC:
+        al = [a.split(":") for a in args.split()]
+        cargs = ", ".join("%s%s" % (CT[k] + ("" if CT[k].endswith("*") else " "), n) for n, k in al)
+        sym = "lbmpm_%s_%s" % (mod, name)
+        hdr.append("/* %s %s */\nint %s(void *stream, %s);" % (cite, name, sym, cargs))
+        ent.append("extern \"C\" int %s(void *stream, %s)\n{\n    hipStream_t st = static_cast<hipStream_t>(stream);\n"
+                   "    (void)st;%s\n    %s;\n    LBMPM_HIP_TRY(hipGetLastError());\n    return LBMPM_OK;\n}\n"
+                   % (sym, cargs, "".join(" (void)%s;" % n for n, k in al), call))
+        py.append("    (%r, %r): (%r, [%s])," % (mod, name, sym, ", ".join(PY[k] for n, k in al)))
+    hdr.append("\n#ifdef __cplusplus\n}\n#endif\n#endif /* LBMPM_KERNELS_H */\n")
+    py.append("}\n")
+    open(os.path.join(ROOT, "include", "lbmpm_kernels.h"), "w").write("\n".join(hdr))
+    open(os.path.join(ROOT, "openlbmpm_amd", "csrc", "sparse_entry_gen.h"), "w").write("\n".join(ent))
+    open(os.path.join(ROOT, "openlbmpm_amd", "_kernel_specs.py"), "w").write("\n".join(py))
+    print(len(SPEC), "entry points")
+
+
+if __name__ == "__main__":
+    main()
