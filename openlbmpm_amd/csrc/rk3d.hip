@@ -7,9 +7,9 @@
 // oracle/rk3d_oracle.c and DESIGN.md).  PARITY UNPINNED against the reference; pinned
 // against the independent CPU statement oracle/rk3d_oracle.c.
 //
-// Layout per rank: dense SoA f[c][q][zl][y][x], zl = 0..nzl+1 where zl = 1..nzl are the owned
-// planes and zl = 0 / nzl+1 are halo planes holding the neighbour rank's outermost plane
-// (only the five populations that cross the cut are ever filled / read).  x, y periodic;
+// Layout per rank: dense, plane-major SoA f[zl][colour][q][y][x], zl = 0..nzl+1 where zl = 1..nzl
+// are the owned planes and zl = 0 / nzl+1 are halo planes holding the neighbour rank's outermost
+// plane (only the five populations that cross the cut are ever filled / read).  x, y periodic;
 // z not (planes 0 and nz-1 of the global lattice are boundary ghost planes).
 // One time step = [f halo exchange] -> phase_field -> [phi halo exchange] -> collide.
 #include "lbmpm_common.h"
@@ -33,44 +33,87 @@ __device__ __forceinline__ constexpr double bq(int i) { return i == 0 ? -1. / 3.
 
 struct RK3Dev {
     int nx, ny, nzl, pitch;
+    unsigned plane_bytes;        // bytes of one [y][x] plane of doubles
     size_t plane2, vol;
     int z0, nzg;                 // global z of local plane zl is z0 + zl - 1
     const uint8_t *flags;        // [vol]
     const uint32_t *solidnbr;    // [vol], bit (i-1) <=> node + e_i is not fluid
-    const double *fin;
+    const double *fin;           // [nzl+2][2][Q][plane2]
     double *fout;
-    double *phi;                 // [vol]
+    double *phi;                 // [vol]; non-fluid cells hold solidPhi
     double *diag;                // [5][vol] rhoR, rhoB, vx, vy, vz or nullptr
     double ak, beta, tauR, tauB, solidPhi, vzR, vzB, rhoOutR, rhoOutB;
-    int first;
+    int first, fill;
 };
 
-__device__ __forceinline__ void pull3(const RK3Dev &p, int x, int y, int zl, double fR[Q], double fB[Q])
+// ---- addressing.  Populations are stored plane-major, f[zl][colour][q][y][x]: everything a node
+// touches in one step (38 populations x 3 planes) lies within 114 consecutive planes, so every
+// access is <uniform 64-bit base in SGPRs> + <32-bit byte offset in one VGPR>; the nine in-plane
+// offsets of a node's 3 x 3 neighbourhood are computed once.
+struct Cell { unsigned o[3][3]; };     // o[1 + dy][1 + dx] = byte offset of (y + dy, x + dx) inside a plane, periodic
+
+__device__ __forceinline__ Cell make_cell(const RK3Dev &p, int x, int y)
+{
+    Cell c;
+    const int xs[3] = {wrapi(x - 1, p.nx), x, wrapi(x + 1, p.nx)}, ys[3] = {wrapi(y - 1, p.ny), y, wrapi(y + 1, p.ny)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) c.o[a][b] = (unsigned)(ys[a] * p.pitch + xs[b]) * 8u;
+    return c;
+}
+
+// a per-iteration copy the optimiser cannot prove loop-invariant: keeps the 2 x 18 derived load
+// offsets from being hoisted out of the march loop into (and held in) ~70 registers
+__device__ __forceinline__ Cell fresh(const Cell &c)
+{
+    Cell r = c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) asm volatile("" : "+v"(r.o[a][b]));
+    return r;
+}
+
+__device__ __forceinline__ const char *plane_ptr(const double *f, const RK3Dev &p, int zl)
+{
+    return reinterpret_cast<const char *>(f) + (size_t)zl * (2 * Q) * p.plane_bytes;
+}
+__device__ __forceinline__ double ldg(const char *uniform_base, unsigned off) { return *reinterpret_cast<const double *>(uniform_base + off); }
+__device__ __forceinline__ void stg(char *uniform_base, unsigned off, double v) { *reinterpret_cast<double *>(uniform_base + off) = v; }
+
+// Pull streaming with half-way bounce-back folded into the address: where the upstream cell is
+// not fluid the lane reads the opposite population of its own cell instead (one load per
+// direction either way, no divergent second pass).  sn = solidnbr word of the node.
+template <bool FIRST>   // FIRST: the state given by set_density has not been streamed yet, "pull" in place
+__device__ __forceinline__ void pull3(const RK3Dev &p, const Cell &c, int zl, unsigned sn, double fR[Q], double fB[Q])
 {
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ, OPP[Q] = LBMPM_D3Q19_OPP;
-    const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
-    const double *fr = p.fin, *fb = p.fin + (size_t)Q * p.vol;
-    const bool first = p.first != 0;
-    const unsigned sn = first ? 0u : p.solidnbr[idx];
-    fR[0] = fr[idx];
-    fB[0] = fb[idx];
+    const unsigned pb = p.plane_bytes, own = c.o[1][1];
+    const char *red = plane_ptr(p.fin, p, zl - 1), *blue = red + (size_t)Q * pb;   // slots 0..113 = planes zl-1, zl, zl+1
+    fR[0] = ldg(red, (unsigned)(2 * Q) * pb + own);
+    fB[0] = ldg(blue, (unsigned)(2 * Q) * pb + own);
 #pragma unroll
     for (int i = 1; i < Q; ++i) {
-        const int xs = wrapi(x - CX[i], p.nx), ys = wrapi(y - CY[i], p.ny), zs = zl - CZ[i];
-        const size_t s = first ? idx : (size_t)zs * p.plane2 + (size_t)ys * p.pitch + xs;
-        fR[i] = fr[(size_t)i * p.vol + s];
-        fB[i] = fb[(size_t)i * p.vol + s];
+        const unsigned up = (unsigned)((1 - CZ[i]) * 2 * Q + i) * pb + c.o[1 - CY[i]][1 - CX[i]];
+        const unsigned back = (unsigned)(2 * Q + OPP[i]) * pb + own;
+        const unsigned s = FIRST ? (unsigned)(2 * Q + i) * pb + own : (((sn >> (OPP[i] - 1)) & 1u) ? back : up);
+        fR[i] = ldg(red, s);
+        fB[i] = ldg(blue, s);
     }
-    if (sn != 0) {
-#pragma unroll
-        for (int i = 1; i < Q; ++i) {
-            const int o = OPP[i];
-            if ((sn >> (o - 1)) & 1u) {
-                fR[i] = fr[(size_t)o * p.vol + idx];
-                fB[i] = fb[(size_t)o * p.vol + idx];
-            }
-        }
-    }
+}
+
+// solidnbr word (bit 31 = the cell itself is fluid) of the cell with in-plane byte offset own
+__device__ __forceinline__ unsigned load_meta(const RK3Dev &p, int zl, unsigned own)
+{
+    return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.solidnbr + (size_t)zl * p.plane2) + (own >> 1));
+}
+
+// plane the populations of plane zl are pulled around: the ghost planes copy their neighbour
+__device__ __forceinline__ int source_plane(const RK3Dev &p, int zl)
+{
+    const int zg = p.z0 + zl - 1;
+    return zg == p.nzg - 1 ? zl - 1 : (zg == 0 ? zl + 1 : zl);
 }
 
 __device__ __forceinline__ double sum19(const double f[Q])
@@ -113,16 +156,10 @@ __device__ __forceinline__ void zouhe_outlet(double rho, double f[Q])
     f[18] = f[17] + 1. / 6. * rho * uz + Ny;
 }
 
-// post-streaming, post-boundary state of node (x, y, zl)
-__device__ __forceinline__ void node_state3(const RK3Dev &p, int x, int y, int zl, double fR[Q], double fB[Q],
-                                            double &rR, double &rB)
+// boundary planes: Zou-He per colour on the pulled populations of plane zl (pulled around source_plane(zl))
+__device__ __forceinline__ void finish_state3(const RK3Dev &p, int zl, double fR[Q], double fB[Q], double &rR, double &rB)
 {
-    const int zg = p.z0 + zl - 1;
-    int zs = zl;
-    if (zg == p.nzg - 1) zs = zl - 1;       // ghost plane <- inlet plane
-    if (zg == 0) zs = zl + 1;               // ghost plane <- outlet plane
-    const int zsg = p.z0 + zs - 1;
-    pull3(p, x, y, zs, fR, fB);
+    const int zg = p.z0 + zl - 1, zsg = p.z0 + source_plane(p, zl) - 1;
     rR = sum19(fR);
     rB = sum19(fB);
     if (zsg == p.nzg - 2) {
@@ -136,17 +173,30 @@ __device__ __forceinline__ void node_state3(const RK3Dev &p, int x, int y, int z
     }
 }
 
+// post-streaming, post-boundary state of the node with in-plane neighbourhood c on plane zl
+__device__ __forceinline__ void node_state3(const RK3Dev &p, const Cell &c, int zl, double fR[Q], double fB[Q], double &rR,
+                                            double &rB)
+{
+    const int zs = source_plane(p, zl);
+    if (p.first) pull3<true>(p, c, zs, 0u, fR, fB);
+    else pull3<false>(p, c, zs, load_meta(p, zs, c.o[1][1]), fR, fB);
+    finish_state3(p, zl, fR, fB, rR, rB);
+}
+
 constexpr int BX3 = 64, BY3 = 4;
 
-// K1: phase field of the streamed, boundary-corrected lattice on the owned planes
-__global__ __launch_bounds__(BX3 *BY3) void rk3d_phase_field(RK3Dev p)
+// K1: phase field of the streamed, boundary-corrected lattice on the planes zl0 .. zl0+gridDim.z-1
+// (all owned planes for the split variant and for diagnostics; only the planes next to a
+// neighbour rank for the fused variant)
+__global__ __launch_bounds__(BX3 *BY3) void rk3d_phase_field(RK3Dev p, int zl0)
 {
-    const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
+    const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + zl0;
     if (x >= p.nx || y >= p.ny) return;
     const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
+    const Cell c = make_cell(p, x, y);
     double fR[Q], fB[Q], rR, rB;
-    node_state3(p, x, y, zl, fR, fB, rR, rB);
+    node_state3(p, c, zl, fR, fB, rR, rB);
     p.phi[idx] = (rR - rB) / (rR + rB);
     if (p.diag) {
         constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
@@ -162,32 +212,18 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3d_phase_field(RK3Dev p)
     }
 }
 
-// K2 (dominant): stream + boundaries again, colour gradient, BGK, perturbation, recolouring, store
-__global__ __launch_bounds__(BX3 *BY3) void rk3d_collide(RK3Dev p)
+// BGK + perturbation + recolouring of one node from the colour-blind populations ft = fR + fB,
+// the colour densities and the colour gradient; stores the post-collision populations of plane zl.
+// Lanes of non-fluid cells whose 128-byte line holds fluid store zeros: partially written
+// lines cost the memory system a read-modify-write (measured: +35 % kernel time at porosity 0.65).
+__device__ __forceinline__ void collide_store(const RK3Dev &p, int zl, unsigned own, bool fluid, const double ft_in[Q],
+                                              double rR, double rB, double gx, double gy, double gz)
 {
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
-    const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
-    if (x >= p.nx || y >= p.ny) return;
-    const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
-    if (!(p.flags[idx] & 1)) return;
-    double fR[Q], fB[Q], rR, rB;
-    node_state3(p, x, y, zl, fR, fB, rR, rB);
-    const unsigned sn = p.solidnbr[idx];
-    double gx = 0., gy = 0., gz = 0., mx = 0., my = 0., mz = 0.;
-#pragma unroll
-    for (int i = 1; i < Q; ++i) {
-        double ph = p.solidPhi;
-        if (!((sn >> (i - 1)) & 1u)) {
-            const size_t n = (size_t)(zl + CZ[i]) * p.plane2 + (size_t)wrapi(y + CY[i], p.ny) * p.pitch + wrapi(x + CX[i], p.nx);
-            ph = p.phi[n];
-        }
-        gx += 3. * wq(i) * (double)CX[i] * ph;
-        gy += 3. * wq(i) * (double)CY[i] * ph;
-        gz += 3. * wq(i) * (double)CZ[i] * ph;
-    }
+    double mx = 0., my = 0., mz = 0.;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
-        const double t = fR[i] + fB[i];
+        const double t = ft_in[i];
         mx += (double)CX[i] * t; my += (double)CY[i] * t; mz += (double)CZ[i] * t;
     }
     const double rho = rR + rB;
@@ -196,20 +232,183 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3d_collide(RK3Dev p)
     const double tau = 0.5 + 1. / ((1. + phi) / (2. * (p.tauR - 0.5)) + (1. - phi) / (2. * (p.tauB - 0.5)));
     const double g2 = gx * gx + gy * gy + gz * gz, gn = sqrt(g2);
     const double kR = rR / rho, kB = rB / rho, arc = p.beta * rR * rB / (rho * rho);
-    double *fr = p.fout, *fb = p.fout + (size_t)Q * p.vol;
+    char *red = const_cast<char *>(plane_ptr(p.fout, p, zl)), *blue = red + (size_t)Q * p.plane_bytes;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
         const double eu = (double)CX[i] * ux + (double)CY[i] * uy + (double)CZ[i] * uz;
         const double feq = rho * wq(i) * (1. + 3. * eu + 4.5 * eu * eu - 1.5 * usq);
-        double ft = fR[i] + fB[i];
+        double ft = ft_in[i];
         ft = ft - (ft - feq) / tau;
         const double eg = (double)CX[i] * gx + (double)CY[i] * gy + (double)CZ[i] * gz;
         if (g2 != 0.) ft += p.ak * gn * (wq(i) * (eg * eg) / g2 - bq(i));
         const double en = (i == 0) ? 0. : (i < 7 ? 1. : sqrt(2.));
         const double c = (en == 0. || gn == 0.) ? 0. : eg / (en * gn);
         const double a = arc * wq(i) * c;
-        fr[(size_t)i * p.vol + idx] = kR * ft + a;
-        fb[(size_t)i * p.vol + idx] = kB * ft - a;
+        stg(red + (size_t)i * p.plane_bytes, own, fluid ? kR * ft + a : 0.);
+        stg(blue + (size_t)i * p.plane_bytes, own, fluid ? kB * ft - a : 0.);
+        __builtin_amdgcn_sched_barrier(0);      // one direction's temporaries at a time: registers are the scarce resource here
+    }
+}
+
+// true when the 128-byte line (16 lanes) this lane stores into holds at least one fluid node
+__device__ __forceinline__ bool line_has_fluid(bool fluid, unsigned lane, int fill)
+{
+    if (!fill) return fluid;
+    const unsigned long long m = __ballot(fluid);
+    const unsigned g = (unsigned)fill;
+    return ((m >> (lane & (64u - g))) & ((g == 64u) ? ~0ull : ((1ull << g) - 1ull))) != 0;
+}
+
+// K2 of the split variant: stream + boundaries again, colour gradient from the global phase field,
+// collision, store
+__global__ __launch_bounds__(BX3 *BY3) void rk3d_collide(RK3Dev p)
+{
+    constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+    const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
+    const bool fluid = p.flags[idx] & 1;
+    if (!line_has_fluid(fluid, threadIdx.x, p.fill)) return;
+    const Cell c = make_cell(p, x, y);
+    double fR[Q], fB[Q], rR, rB;
+    node_state3(p, c, zl, fR, fB, rR, rB);
+    const char *ph0 = reinterpret_cast<const char *>(p.phi + (size_t)(zl - 1) * p.plane2);
+    double gx = 0., gy = 0., gz = 0.;
+#pragma unroll
+    for (int i = 1; i < Q; ++i) {
+        const double ph = ldg(ph0, (unsigned)(1 + CZ[i]) * p.plane_bytes + c.o[1 + CY[i]][1 + CX[i]]);   // non-fluid cells hold solidPhi
+        gx += 3. * wq(i) * (double)CX[i] * ph;
+        gy += 3. * wq(i) * (double)CY[i] * ph;
+        gz += 3. * wq(i) * (double)CZ[i] * ph;
+    }
+    double ft[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) ft[i] = fR[i] + fB[i];
+    collide_store(p, zl, c.o[1][1], fluid, ft, rR, rB, gx, gy, gz);
+}
+
+// Fused time step (default): one block owns a TX x TY column of nodes and marches along z.
+// At march step z every thread pulls the populations of its node of plane z+1 ONCE, reduces them to
+// what the collision needs (19 colour-blind sums + 2 densities), parks that in LDS and puts the
+// node's phase field into a four-plane LDS ring (the ring also covers the one-cell rim around the
+// tile, whose phase field the first waves recompute; those pulls mostly hit L2, the cells belong
+// to neighbouring tiles of the same XCD band); after one barrier the thread collides its node of
+// plane z from the parked state of the previous march step and the ring.  Per node and step the
+// HBM sees 38 population reads + 38 writes: the separate phase-field sweep and the global
+// phase-field round trip of the split variant are gone.  Registers are kept under 168 so that
+// three blocks (12 waves) share a CU and cover each other's load latency.
+template <int TX, int TY>
+struct March {
+    static constexpr int FX = TX + 2, FY = TY + 2, NT = TX * TY, NH = 2 * TX + 2 * FY, RING = 4;
+    static_assert(NT % 64 == 0 && (TX == 32 || TX == 64) && NH <= NT, "tile rows must fill 128-byte lines");
+};
+
+// lattice coordinate of tile-frame coordinate g (periodic), or -1 when nobody needs it
+__device__ __forceinline__ int ring_coord(int g, int n) { return g < -1 || g > n ? -1 : (g == -1 ? n - 1 : (g == n ? 0 : g)); }
+
+// meta word of plane zl: for ghost planes the word of the source plane decides the bounce-back
+// addresses, the fluid bit is the same (identical geometry by construction); 0 outside the owned planes
+__device__ __forceinline__ unsigned plane_meta(const RK3Dev &p, int zl, unsigned own)
+{
+    if (zl < 1 || zl > p.nzl) return 0u;
+    return load_meta(p, source_plane(p, zl), own);
+}
+
+// phase field of a cell of plane zl for the ring; leaves the pulled, boundary-corrected populations
+// and densities of a fluid node of an owned plane in fR/fB/rR/rB
+template <bool FIRST>
+__device__ __forceinline__ double ring_phi(const RK3Dev &p, const Cell &c, int zl, unsigned meta, double fR[Q], double fB[Q],
+                                           double &rR, double &rB)
+{
+    if (zl == 0 || zl == p.nzl + 1) return (p.phi + (size_t)zl * p.plane2)[c.o[1][1] >> 3];   // neighbour rank's plane (or outside: solidPhi)
+    if (!(meta >> 31)) return p.solidPhi;
+    pull3<FIRST>(p, c, source_plane(p, zl), meta, fR, fB);
+    finish_state3(p, zl, fR, fB, rR, rB);
+    return (rR - rB) / (rR + rB);
+}
+
+template <int TX, int TY, bool FIRST>
+__global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len)
+{
+    using M = March<TX, TY>;
+    constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+    __shared__ double sphi[M::RING][M::FY][M::FX];
+    __shared__ double park[Q + 2][M::NT];
+    // workgroup b runs on XCD b % 8: every XCD owns a band of tile rows, so rim re-reads hit its L2
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int tx = slot % tilesX, r = slot / tilesX, ty = xcd * rows_per_xcd + r % rows_per_xcd, chunk = r / rows_per_xcd;
+    if (ty >= tilesY) return;
+    const int tid = threadIdx.x, lx = tid % TX, ly = tid / TX;
+    const int x = tx * TX + lx, y = ty * TY + ly;
+    const bool own = x < p.nx && y < p.ny;
+    const int xo = ring_coord(x, p.nx), yo = ring_coord(y, p.ny);           // own cell (may be the wrapped rim of a cut tile)
+    const bool has_own = xo >= 0 && yo >= 0;
+    const Cell co = make_cell(p, has_own ? xo : 0, has_own ? yo : 0);
+    const unsigned own_off = co.o[1][1];
+    // rim cell of this thread: bottom row, top row, then the two columns (corners included)
+    int hlx = 0, hly = 0;
+    bool has_rim = false;
+    Cell ch = co;
+    if (tid < M::NH) {
+        if (tid < 2 * TX) { hlx = 1 + tid % TX; hly = tid < TX ? 0 : M::FY - 1; }
+        else { const int k = tid - 2 * TX; hlx = k < M::FY ? 0 : M::FX - 1; hly = k % M::FY; }
+        const int hx = ring_coord(tx * TX + hlx - 1, p.nx), hy = ring_coord(ty * TY + hly - 1, p.ny);
+        has_rim = hx >= 0 && hy >= 0;
+        if (has_rim) ch = make_cell(p, hx, hy);
+    }
+    const int za = 1 + chunk * chunk_len, zb = min(za + chunk_len - 1, p.nzl);
+    unsigned meta_o = has_own ? plane_meta(p, za - 1, own_off) : 0u;        // meta words one plane ahead of their use
+    unsigned meta_h = has_rim ? plane_meta(p, za - 1, ch.o[1][1]) : 0u;
+    bool fluid = false;
+#pragma unroll
+    for (int i = 0; i < Q + 2; ++i) park[i][tid] = 1.;
+
+    for (int z = za - 2; z <= zb; ++z) {
+        const unsigned mo = meta_o, mh = meta_h;
+        meta_o = has_own ? plane_meta(p, z + 2, own_off) : 0u;
+        meta_h = has_rim ? plane_meta(p, z + 2, ch.o[1][1]) : 0u;
+        // ---- plane z + 1, rim cells: phase field only
+        if (has_rim) {
+            double fR[Q], fB[Q], a, c;
+            sphi[(z + 1) & (M::RING - 1)][hly][hlx] = ring_phi<FIRST>(p, fresh(ch), z + 1, mh, fR, fB, a, c);
+        }
+        // ---- plane z + 1, own cell: pull once, phase field into the ring, reduced state into the park
+        //      (the park still holds plane z: swap)
+        double ft[Q], rR, rB;
+        {
+            double fR[Q], fB[Q], rRn = 1., rBn = 1.;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) { fR[i] = 0.; fB[i] = 0.; }
+            double ph = p.solidPhi;
+            if (has_own) {
+                ph = ring_phi<FIRST>(p, fresh(co), z + 1, mo, fR, fB, rRn, rBn);
+                sphi[(z + 1) & (M::RING - 1)][ly + 1][lx + 1] = ph;
+            }
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                ft[i] = park[i][tid];
+                park[i][tid] = fR[i] + fB[i];
+            }
+            rR = park[Q][tid]; rB = park[Q + 1][tid];
+            park[Q][tid] = rRn; park[Q + 1][tid] = rBn;
+        }
+        __syncthreads();
+        // ---- plane z: collide
+        if (z >= za) {
+            const bool isfl = fluid && own;
+            if (line_has_fluid(isfl, tid & 63, p.fill) && own) {
+                double gx = 0., gy = 0., gz = 0.;
+#pragma unroll
+                for (int i = 1; i < Q; ++i) {
+                    const double ph = sphi[(z + CZ[i]) & (M::RING - 1)][ly + 1 + CY[i]][lx + 1 + CX[i]];
+                    gx += 3. * wq(i) * (double)CX[i] * ph;
+                    gy += 3. * wq(i) * (double)CY[i] * ph;
+                    gz += 3. * wq(i) * (double)CZ[i] * ph;
+                }
+                collide_store(p, z, own_off, isfl, ft, rR, rB, gx, gy, gz);
+            }
+        }
+        fluid = (mo >> 31) && z + 1 >= 1 && z + 1 <= p.nzl;
     }
 }
 
@@ -219,10 +418,11 @@ __global__ void rk3d_pack(RK3Dev p, const double *f, double *send_up, double *se
     constexpr int UP[5] = {5, 11, 14, 15, 18}, DN[5] = {6, 12, 13, 16, 17};
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= p.plane2) return;
+    const double *top = f + (size_t)p.nzl * 2 * Q * p.plane2, *bot = f + (size_t)2 * Q * p.plane2;
     for (int c = 0; c < 2; ++c)
         for (int j = 0; j < 5; ++j) {
-            send_up[(size_t)(c * 5 + j) * p.plane2 + k] = f[((size_t)c * Q + UP[j]) * p.vol + (size_t)p.nzl * p.plane2 + k];
-            send_dn[(size_t)(c * 5 + j) * p.plane2 + k] = f[((size_t)c * Q + DN[j]) * p.vol + p.plane2 + k];
+            send_up[(size_t)(c * 5 + j) * p.plane2 + k] = top[(size_t)(c * Q + UP[j]) * p.plane2 + k];
+            send_dn[(size_t)(c * 5 + j) * p.plane2 + k] = bot[(size_t)(c * Q + DN[j]) * p.plane2 + k];
         }
 }
 
@@ -232,10 +432,11 @@ __global__ void rk3d_unpack(RK3Dev p, double *f, const double *recv_from_below, 
     constexpr int UP[5] = {5, 11, 14, 15, 18}, DN[5] = {6, 12, 13, 16, 17};
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= p.plane2) return;
+    double *lo = f, *hi = f + (size_t)(p.nzl + 1) * 2 * Q * p.plane2;
     for (int c = 0; c < 2; ++c)
         for (int j = 0; j < 5; ++j) {
-            if (have_below) f[((size_t)c * Q + UP[j]) * p.vol + k] = recv_from_below[(size_t)(c * 5 + j) * p.plane2 + k];
-            if (have_above) f[((size_t)c * Q + DN[j]) * p.vol + (size_t)(p.nzl + 1) * p.plane2 + k] = recv_from_above[(size_t)(c * 5 + j) * p.plane2 + k];
+            if (have_below) lo[(size_t)(c * Q + UP[j]) * p.plane2 + k] = recv_from_below[(size_t)(c * 5 + j) * p.plane2 + k];
+            if (have_above) hi[(size_t)(c * Q + DN[j]) * p.plane2 + k] = recv_from_above[(size_t)(c * 5 + j) * p.plane2 + k];
         }
 }
 
@@ -245,14 +446,22 @@ __global__ void rk3d_init_rest(RK3Dev p, const double *rho_r, const double *rho_
 {
     const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
     if (x >= p.nx || y >= p.ny) return;
-    const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
-    const bool fluid = p.flags[idx] & 1;
+    const size_t cell = (size_t)y * p.pitch + x;
+    const bool fluid = p.flags[(size_t)zl * p.plane2 + cell] & 1;
     const size_t s = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
     const double a = fluid ? rho_r[s] : 0., b = fluid ? rho_b[s] : 0.;
+    double *pl = f + (size_t)zl * 2 * Q * p.plane2;
     for (int i = 0; i < Q; ++i) {
-        f[(size_t)i * p.vol + idx] = wq(i) * a;
-        f[((size_t)Q + i) * p.vol + idx] = wq(i) * b;
+        pl[(size_t)i * p.plane2 + cell] = wq(i) * a;
+        pl[(size_t)(Q + i) * p.plane2 + cell] = wq(i) * b;
     }
+}
+
+// phi of every non-fluid cell (halo planes outside the lattice included) = the wetting value
+__global__ void rk3d_init_phi(RK3Dev p, double *phi)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < p.vol && !(p.flags[k] & 1)) phi[k] = p.solidPhi;
 }
 
 __global__ void rk3d_setup_solidnbr(RK3Dev p, uint32_t *solidnbr)
@@ -268,6 +477,7 @@ __global__ void rk3d_setup_solidnbr(RK3Dev p, uint32_t *solidnbr)
             fluid = p.flags[(size_t)zn * p.plane2 + (size_t)wrapi(y + CY[i], p.ny) * p.pitch + wrapi(x + CX[i], p.nx)] & 1;
         if (!fluid) b |= 1u << (i - 1);
     }
+    if (p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1) b |= 1u << 31;
     solidnbr[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] = b;
 }
 
@@ -287,6 +497,7 @@ struct lbmpm_rk3d {
     double *send_up = nullptr, *send_dn = nullptr, *recv_below = nullptr, *recv_above = nullptr;
     std::vector<uint8_t> h_domain;   // owned planes only, [nzl][ny][nx]
     bool streamed = false;
+    int variant = 0, tile = 0, chunk_len = 32, fill = 16;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL
     int64_t steps = 0, bytes = 0;
     lbmpm::EventPool pool;
 };
@@ -297,12 +508,14 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
 {
     RK3Dev p{};
     p.nx = c->nx; p.ny = c->ny; p.nzl = c->nzl; p.pitch = c->pitch; p.plane2 = c->plane2; p.vol = c->vol;
+    p.plane_bytes = (unsigned)(c->plane2 * sizeof(double));
     p.z0 = (int)c->cfg.z_offset; p.nzg = (int)c->cfg.nz_global;
     p.flags = c->flags; p.solidnbr = c->solidnbr; p.fin = c->fA; p.fout = c->fB; p.phi = c->phi; p.diag = nullptr;
     p.ak = (c->cfg.ak_r + c->cfg.ak_b) * 0.5; p.beta = c->cfg.beta; p.tauR = c->cfg.tau_r; p.tauB = c->cfg.tau_b;
     p.solidPhi = c->cfg.solid_phi; p.vzR = c->cfg.inlet_vz_r; p.vzB = c->cfg.inlet_vz_b;
     p.rhoOutR = c->cfg.outlet_rho_r; p.rhoOutB = c->cfg.outlet_rho_b;
     p.first = c->streamed ? 0 : 1;
+    p.fill = c->fill;
     return p;
 }
 
@@ -333,11 +546,21 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
                   (long long)cfg->z_offset, (long long)(cfg->z_offset + cfg->nz_local), (long long)cfg->nz_global);
     LBMPM_REQUIRE(cfg->tau_r > 0.5 && cfg->tau_b > 0.5, "TauR/TauB must exceed 0.5");
     LBMPM_REQUIRE((double)cfg->nx * cfg->ny * (cfg->nz_local + 2) < 2.0e9, "slab too large for 32-bit plane indices");
+    LBMPM_REQUIRE((double)(cfg->nx + 31) * cfg->ny * 8.0 * 6 * Q < 4.0e9, "xy plane too large: 114 planes must fit 32-bit byte offsets (about 4.3M cells per plane)");
+    int variant = cfg->variant, tile = 0, chunk_len = 32, fill = 16;
+    if (const char *e = getenv("LBMPM_RK3D_VARIANT")) variant = atoi(e);
+    if (const char *e = getenv("LBMPM_RK3D_TILE")) tile = atoi(e);
+    if (const char *e = getenv("LBMPM_RK3D_CHUNK")) chunk_len = atoi(e) > 0 ? atoi(e) : 32;
+    if (const char *e = getenv("LBMPM_RK3D_FILL")) fill = atoi(e);
+    LBMPM_REQUIRE(variant == 0 || variant == 1, "lbmpm_rk3d_create: variant must be 0 (fused) or 1 (split)");
+    LBMPM_REQUIRE(fill == 0 || fill == 4 || fill == 8 || fill == 16 || fill == 32 || fill == 64,
+                  "LBMPM_RK3D_FILL must be 0 or a power of two <= 64");
     LBMPM_HIP_TRY(hipSetDevice(cfg->device));
     lbmpm_rk3d *c = new (std::nothrow) lbmpm_rk3d();
     if (!c) { set_error("out of host memory"); return LBMPM_ERR_NOMEM; }
     c->cfg = *cfg;
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny; c->nzl = (int)cfg->nz_local;
+    c->variant = variant; c->tile = tile; c->chunk_len = chunk_len; c->fill = fill;
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
     c->vol = c->plane2 * (size_t)(c->nzl + 2);
@@ -373,6 +596,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (e != hipSuccess) { set_error("flags upload failed: %s", hipGetErrorString(e)); lbmpm_rk3d_destroy(c); return LBMPM_ERR_HIP; }
     RK3Dev p = make_dev(c);
     rk3d_setup_solidnbr<<<grid3(c, c->nzl + 2), dim3(BX3, BY3), 0, c->stream>>>(p, c->solidnbr);
+    rk3d_init_phi<<<dim3((unsigned)((c->vol + 255) / 256)), dim3(256), 0, c->stream>>>(p, c->phi);
     e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { set_error("set-up kernel failed: %s", hipGetErrorString(e)); lbmpm_rk3d_destroy(c); return LBMPM_ERR_HIP; }
@@ -454,16 +678,38 @@ extern "C" int lbmpm_rk3d_phase_field(lbmpm_rk3d *c, int with_diagnostics)
     if (with_diagnostics && !c->diag) { const int rc = dev_alloc(c, &c->diag, 5 * c->vol); if (rc) return rc; }
     RK3Dev p = make_dev(c);
     p.diag = with_diagnostics ? c->diag : nullptr;
-    rk3d_phase_field<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p);
+    if (c->variant == 1 || with_diagnostics) {
+        rk3d_phase_field<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, 1);
+    } else {
+        // fused variant: the marching kernel computes the phase field itself; only the planes a
+        // neighbour rank needs are produced here
+        if (c->cfg.z_offset > 0) rk3d_phase_field<<<grid3(c, 1), dim3(BX3, BY3), 0, c->stream>>>(p, 1);
+        if (c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global && (c->nzl > 1 || c->cfg.z_offset == 0))
+            rk3d_phase_field<<<grid3(c, 1), dim3(BX3, BY3), 0, c->stream>>>(p, c->nzl);
+    }
     LBMPM_HIP_TRY(hipGetLastError());
     return LBMPM_OK;
 }
+
+namespace {
+template <int TX, int TY>
+void launch_fused(lbmpm_rk3d *c, const RK3Dev &p)
+{
+    const int tilesX = (c->nx + TX - 1) / TX, tilesY = (c->ny + TY - 1) / TY, rpx = (tilesY + 7) / 8;
+    const int nchunks = (c->nzl + c->chunk_len - 1) / c->chunk_len;
+    const dim3 grid((unsigned)(8 * tilesX * rpx * nchunks)), block(TX * TY);
+    if (p.first) rk3d_fused<TX, TY, true><<<grid, block, 0, c->stream>>>(p, tilesX, tilesY, rpx, c->chunk_len);
+    else rk3d_fused<TX, TY, false><<<grid, block, 0, c->stream>>>(p, tilesX, tilesY, rpx, c->chunk_len);
+}
+}  // namespace
 
 extern "C" int lbmpm_rk3d_collide(lbmpm_rk3d *c)
 {
     LBMPM_REQUIRE(c, "null context");
     RK3Dev p = make_dev(c);
-    rk3d_collide<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p);
+    if (c->variant == 1) rk3d_collide<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p);
+    else if (c->tile == 1) launch_fused<32, 8>(c, p);
+    else launch_fused<64, 4>(c, p);
     LBMPM_HIP_TRY(hipGetLastError());
     std::swap(c->fA, c->fB);
     c->streamed = true;
@@ -581,4 +827,4 @@ extern "C" int lbmpm_rk3d_get_field(lbmpm_rk3d *c, int field, double *out)
 extern "C" int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *c) { return c ? c->nfluid : 0; }
 extern "C" int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *c) { return c ? c->steps : 0; }
 extern "C" int64_t lbmpm_rk3d_device_bytes(const lbmpm_rk3d *c) { return c ? c->bytes : 0; }
-extern "C" const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *c) { (void)c; return "rk3d_collide"; }
+extern "C" const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *c) { return (c && c->variant == 1) ? "rk3d_collide" : "rk3d_fused"; }

@@ -22,6 +22,16 @@ def run(dom, label, steps=20):
     s.close()
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-dom = np.ones((n, n, n), dtype=np.uint8)
-run(dom, "all fluid %d^3" % n)
-run(porous_spheres(n, n, n, seed=bench.SEED), "porous %d^3" % n)
+which = sys.argv[2] if len(sys.argv) > 2 else "both"
+envs = sys.argv[3:] or [""]          # e.g. LBMPM_RK3D_TILE=1,LBMPM_RK3D_CHUNK=32  (one run per argument)
+doms = []
+if which in ("both", "fluid"):
+    doms.append((np.ones((n, n, n), dtype=np.uint8), "all fluid %d^3" % n))
+if which in ("both", "porous"):
+    doms.append((porous_spheres(n, n, n, seed=bench.SEED), "porous %d^3" % n))
+for e in envs:
+    for kv in filter(None, e.split(",")):
+        k, v = kv.split("=")
+        os.environ[k] = v
+    for dom, label in doms:
+        run(dom, (label + " " + e).strip())
