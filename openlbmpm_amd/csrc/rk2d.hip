@@ -627,9 +627,14 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
     // ---- phase D: force, velocity, collision, recolouring, store
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
-        if (!act[m]) continue;
         const int x = tx0 + lx, y = ty0 + ly + m * TY;
+        // non-fluid lanes of a 128-byte line that holds fluid write zeros into their dead slots
+        if (!(lbmpm_dev::line_has_active(act[m], tid & 63) && x < p.nx && y < p.ny)) continue;
         const size_t idx = (size_t)y * p.pitch + x;
+        double fR[9], fB[9], Fx = 0., Fy = 0.;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { fR[i] = 0.; fB[i] = 0.; }
+        if (act[m]) {
         const int ri = (H + ly + m * TY) * RW + H + lx;
         const double ux = s_ux[ri], uy = s_uy[ri];
         double pyx = 0., pxy = 0., px = 0., py = 0.;
@@ -645,22 +650,22 @@ __global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
         }
         const double K = ux * uy * (pyx + pxy) - uy * uy * px - ux * ux * py;
         const double sgn = (p.wetting == 2) ? -0.5 : 0.5;
-        const double Fx = sgn * p.sigma * K * gx[m], Fy = sgn * p.sigma * K * gy[m];
+        Fx = sgn * p.sigma * K * gx[m]; Fy = sgn * p.sigma * K * gy[m];
         const double rs = rB[m] + rR[m];
         double *f = fT[m];
         const double vx = (f[1] - f[3] + f[5] - f[6] - f[7] + f[8] + 0.5 * Fpx[m]) / rs;
         const double vy = (f[2] - f[4] + f[5] + f[6] - f[7] - f[8] + 0.5 * Fpy[m]) / rs;
         const double phi = (rR[m] - rB[m]) / (rR[m] + rB[m]);
-        p.F[idx] = Fx;
-        p.F[p.plane + idx] = Fy;
         if (p.diag) {
             p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K;
             p.phi[idx] = phi; p.G[idx] = gx[m]; p.G[p.plane + idx] = gy[m];
         }
         if (TRACER) tracer_substep(p, x, y, sn[m], rR[m], vx, vy, gx[m], gy[m]);
         collide<MRT>(p, f, rR[m], rB[m], phi, vx, vy, Fx, Fy);
-        double fR[9], fB[9];
         recolor(p.beta, f, rR[m], rB[m], gx[m], gy[m], fR, fB);
+        }
+        p.F[idx] = Fx;
+        p.F[p.plane + idx] = Fy;
         double *fr = p.fout, *fb = p.fout + 9 * p.plane;
 #pragma unroll
         for (int i = 0; i < 9; ++i) { fr[i * p.plane + idx] = fR[i]; fb[i * p.plane + idx] = fB[i]; }

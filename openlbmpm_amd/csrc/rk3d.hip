@@ -42,7 +42,7 @@ struct RK3Dev {
     double *fout;
     double *phi;                 // [vol]; non-fluid cells hold solidPhi
     double *diag;                // [5][vol] rhoR, rhoB, vx, vy, vz or nullptr
-    double ak, beta, tauR, tauB, solidPhi, vzR, vzB, rhoOutR, rhoOutB;
+    double ak, beta, cR, cB, solidPhi, vzR, vzB, rhoOutR, rhoOutB;   // cX = 1 / (2 (tauX - 1/2))
     int first, fill;
 };
 
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3d_phase_field(RK3Dev p, int zl0)
 __device__ __forceinline__ void collide_store(const RK3Dev &p, int zl, unsigned own, bool fluid, const double ft_in[Q],
                                               double rR, double rB, double gx, double gy, double gz)
 {
+#pragma clang fp contract(fast)      // fused multiply-adds here (the 2-D kernels stay uncontracted for bit parity with the reference)
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
     double mx = 0., my = 0., mz = 0.;
 #pragma unroll
@@ -226,24 +227,26 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, int zl, unsigned 
         const double t = ft_in[i];
         mx += (double)CX[i] * t; my += (double)CY[i] * t; mz += (double)CZ[i] * t;
     }
-    const double rho = rR + rB;
-    const double ux = mx / rho, uy = my / rho, uz = mz / rho, usq = ux * ux + uy * uy + uz * uz;
-    const double phi = (rR - rB) / (rR + rB);
-    const double tau = 0.5 + 1. / ((1. + phi) / (2. * (p.tauR - 0.5)) + (1. - phi) / (2. * (p.tauB - 0.5)));
+    // five divisions per node instead of three per direction: reciprocals once, products after
+    // (differs from the division form of oracle/rk3d_oracle.c by rounding only; tests bound it)
+    const double rho = rR + rB, irho = 1. / rho;
+    const double ux = mx * irho, uy = my * irho, uz = mz * irho, usq = ux * ux + uy * uy + uz * uz;
+    const double phi = (rR - rB) * irho;
+    const double omega = 1. / (0.5 + 1. / ((1. + phi) * p.cR + (1. - phi) * p.cB));
     const double g2 = gx * gx + gy * gy + gz * gz, gn = sqrt(g2);
-    const double kR = rR / rho, kB = rB / rho, arc = p.beta * rR * rB / (rho * rho);
+    const double ig2 = g2 != 0. ? 1. / g2 : 0., ign = gn * ig2;
+    const double kR = rR * irho, kB = rB * irho, arc = p.beta * rR * rB * irho * irho, akgn = p.ak * gn;
     char *red = const_cast<char *>(plane_ptr(p.fout, p, zl)), *blue = red + (size_t)Q * p.plane_bytes;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
         const double eu = (double)CX[i] * ux + (double)CY[i] * uy + (double)CZ[i] * uz;
         const double feq = rho * wq(i) * (1. + 3. * eu + 4.5 * eu * eu - 1.5 * usq);
         double ft = ft_in[i];
-        ft = ft - (ft - feq) / tau;
+        ft = ft - (ft - feq) * omega;
         const double eg = (double)CX[i] * gx + (double)CY[i] * gy + (double)CZ[i] * gz;
-        if (g2 != 0.) ft += p.ak * gn * (wq(i) * (eg * eg) / g2 - bq(i));
-        const double en = (i == 0) ? 0. : (i < 7 ? 1. : sqrt(2.));
-        const double c = (en == 0. || gn == 0.) ? 0. : eg / (en * gn);
-        const double a = arc * wq(i) * c;
+        ft += akgn * (wq(i) * (eg * eg) * ig2 - bq(i));
+        const double ien = (i == 0) ? 0. : (i < 7 ? 1. : 0.70710678118654752440);
+        const double a = arc * wq(i) * (eg * ien * ign);
         stg(red + (size_t)i * p.plane_bytes, own, fluid ? kR * ft + a : 0.);
         stg(blue + (size_t)i * p.plane_bytes, own, fluid ? kB * ft - a : 0.);
         __builtin_amdgcn_sched_barrier(0);      // one direction's temporaries at a time: registers are the scarce resource here
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
     using M = March<TX, TY>;
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
     __shared__ double sphi[M::RING][M::FY][M::FX];
-    __shared__ double park[Q + 2][M::NT];
+    __shared__ double park[Q][M::NT];
     // workgroup b runs on XCD b % 8: every XCD owns a band of tile rows, so rim re-reads hit its L2
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
     const int tx = slot % tilesX, r = slot / tilesX, ty = xcd * rows_per_xcd + r % rows_per_xcd, chunk = r / rows_per_xcd;
@@ -360,8 +363,9 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
     unsigned meta_o = has_own ? plane_meta(p, za - 1, own_off) : 0u;        // meta words one plane ahead of their use
     unsigned meta_h = has_rim ? plane_meta(p, za - 1, ch.o[1][1]) : 0u;
     bool fluid = false;
+    double rR = 1., rB = 1.;                    // densities of the parked plane
 #pragma unroll
-    for (int i = 0; i < Q + 2; ++i) park[i][tid] = 1.;
+    for (int i = 0; i < Q; ++i) park[i][tid] = 1.;
 
     for (int z = za - 2; z <= zb; ++z) {
         const unsigned mo = meta_o, mh = meta_h;
@@ -374,7 +378,8 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
         }
         // ---- plane z + 1, own cell: pull once, phase field into the ring, reduced state into the park
         //      (the park still holds plane z: swap)
-        double ft[Q], rR, rB;
+        double ft[Q];
+        const double rRz = rR, rBz = rB;
         {
             double fR[Q], fB[Q], rRn = 1., rBn = 1.;
 #pragma unroll
@@ -389,8 +394,7 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
                 ft[i] = park[i][tid];
                 park[i][tid] = fR[i] + fB[i];
             }
-            rR = park[Q][tid]; rB = park[Q + 1][tid];
-            park[Q][tid] = rRn; park[Q + 1][tid] = rBn;
+            rR = rRn; rB = rBn;
         }
         __syncthreads();
         // ---- plane z: collide
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
                     gy += 3. * wq(i) * (double)CY[i] * ph;
                     gz += 3. * wq(i) * (double)CZ[i] * ph;
                 }
-                collide_store(p, z, own_off, isfl, ft, rR, rB, gx, gy, gz);
+                collide_store(p, z, own_off, isfl, ft, rRz, rBz, gx, gy, gz);
             }
         }
         fluid = (mo >> 31) && z + 1 >= 1 && z + 1 <= p.nzl;
@@ -511,7 +515,7 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     p.plane_bytes = (unsigned)(c->plane2 * sizeof(double));
     p.z0 = (int)c->cfg.z_offset; p.nzg = (int)c->cfg.nz_global;
     p.flags = c->flags; p.solidnbr = c->solidnbr; p.fin = c->fA; p.fout = c->fB; p.phi = c->phi; p.diag = nullptr;
-    p.ak = (c->cfg.ak_r + c->cfg.ak_b) * 0.5; p.beta = c->cfg.beta; p.tauR = c->cfg.tau_r; p.tauB = c->cfg.tau_b;
+    p.ak = (c->cfg.ak_r + c->cfg.ak_b) * 0.5; p.beta = c->cfg.beta; p.cR = 1. / (2. * (c->cfg.tau_r - 0.5)); p.cB = 1. / (2. * (c->cfg.tau_b - 0.5));
     p.solidPhi = c->cfg.solid_phi; p.vzR = c->cfg.inlet_vz_r; p.vzB = c->cfg.inlet_vz_b;
     p.rhoOutR = c->cfg.outlet_rho_r; p.rhoOutB = c->cfg.outlet_rho_b;
     p.first = c->streamed ? 0 : 1;
@@ -709,6 +713,8 @@ extern "C" int lbmpm_rk3d_collide(lbmpm_rk3d *c)
     RK3Dev p = make_dev(c);
     if (c->variant == 1) rk3d_collide<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p);
     else if (c->tile == 1) launch_fused<32, 8>(c, p);
+    else if (c->tile == 2) launch_fused<64, 6>(c, p);
+    else if (c->tile == 3) launch_fused<64, 8>(c, p);
     else launch_fused<64, 4>(c, p);
     LBMPM_HIP_TRY(hipGetLastError());
     std::swap(c->fA, c->fB);

@@ -297,8 +297,13 @@ __global__ __launch_bounds__(THREADS) void sc2d_fused(SCDev p, int tiles_x)
         s_psi1[ry * RW + rx] = b;
     }
     __syncthreads();
-    if (!act) return;
-
+    const bool line = lbmpm_dev::line_has_active(act, tid & 63) && inside;
+    if (!line) return;
+    if (!act) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { f0[j] = 0.; f1[j] = 0.; }
+    }
+    else {
     // phase D: force chain, collision, store
     double nb0[9], nb1[9];
 #pragma unroll
@@ -334,6 +339,8 @@ __global__ __launch_bounds__(THREADS) void sc2d_fused(SCDev p, int tiles_x)
     }
     chain_collide<MRT>(p, f0, f1, rho, Fx, Fy, ueqx, ueqy);
     if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
+    }
+    // non-fluid lanes of a line that holds fluid write zeros into their dead slots (full-line stores)
     double *o0 = p.fout, *o1 = p.fout + 9 * p.plane;
 #pragma unroll
     for (int j = 0; j < 9; ++j) { o0[j * p.plane + idx] = f0[j]; o1[j * p.plane + idx] = f1[j]; }
