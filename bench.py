@@ -252,6 +252,8 @@ def main():
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
                              "traffic": pmc_traffic(dom_kernel, "c5 %dx%dx%d" % size) if world == 1 else None,
                              "kernel": dom_kernel,
+                             "note": None if world == 1 else "N>1: the kernel runs as interior + boundary launches on two "
+                                     "streams under the halo exchange; avg_launch_ms brackets the whole step, exchange included",
                              "avg_launch_ms": round(per_launch_ms, 5),
                              "algorithmic_bytes_per_launch": B_ALG["c5"] * nfl_local},
             }

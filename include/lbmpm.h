@@ -257,7 +257,9 @@ int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
  *     pack_halo -> [caller moves F_SEND_* to the neighbours' F_RECV_*] -> unpack_halo
  *     -> phase_field -> [caller moves PHI_SEND_* to the neighbours' PHI_RECV_*] -> collide
  * (the first step after set_density needs no population exchange).  With a single slab
- * lbmpm_rk3d_step does all of it.
+ * lbmpm_rk3d_step does all of it.  variant 0 (default): collide is one fused z-marching kernel
+ * that computes the phase field itself, phase_field(ctx, 0) then only produces the planes the
+ * neighbours need; variant 1: phase_field and collide are two full sweeps.
  * ---------------------------------------------------------------------------------- */
 typedef struct lbmpm_rk3d_config {
     int64_t nx, ny, nz_local, nz_global, z_offset;
@@ -292,6 +294,13 @@ int lbmpm_rk3d_unpack_halo(lbmpm_rk3d *ctx, int have_below, int have_above);
 /* with_diagnostics: also keep rhoR, rhoB, u of the streamed, boundary-corrected lattice */
 int lbmpm_rk3d_phase_field(lbmpm_rk3d *ctx, int with_diagnostics);
 int lbmpm_rk3d_collide(lbmpm_rk3d *ctx);
+/* Overlap of the halo exchange with the bulk of the step: call collide_interior FIRST in a step
+ * (it collides the planes that do not depend on the neighbours on a second stream), then
+ * pack_halo .. unpack_halo .. phase_field .. [phi exchange] as above on the context's stream, then
+ * collide_boundary (the planes next to the slab faces; joins the two streams and ends the
+ * step).  collide_boundary without a preceding collide_interior equals lbmpm_rk3d_collide. */
+int lbmpm_rk3d_collide_interior(lbmpm_rk3d *ctx);
+int lbmpm_rk3d_collide_boundary(lbmpm_rk3d *ctx);
 int lbmpm_rk3d_step(lbmpm_rk3d *ctx, int64_t nsteps);
 int lbmpm_rk3d_step_timed(lbmpm_rk3d *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
 int lbmpm_rk3d_sync(lbmpm_rk3d *ctx);

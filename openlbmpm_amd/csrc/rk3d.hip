@@ -331,7 +331,7 @@ __device__ __forceinline__ double ring_phi(const RK3Dev &p, const Cell &c, int z
 }
 
 template <int TX, int TY, bool FIRST>
-__global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len)
+__global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last)
 {
     using M = March<TX, TY>;
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
         has_rim = hx >= 0 && hy >= 0;
         if (has_rim) ch = make_cell(p, hx, hy);
     }
-    const int za = 1 + chunk * chunk_len, zb = min(za + chunk_len - 1, p.nzl);
+    const int za = z_first + chunk * chunk_len, zb = min(za + chunk_len - 1, z_last);      // owned planes of this block
     unsigned meta_o = has_own ? plane_meta(p, za - 1, own_off) : 0u;        // meta words one plane ahead of their use
     unsigned meta_h = has_rim ? plane_meta(p, za - 1, ch.o[1][1]) : 0u;
     bool fluid = false;
@@ -501,7 +501,10 @@ struct lbmpm_rk3d {
     double *send_up = nullptr, *send_dn = nullptr, *recv_below = nullptr, *recv_above = nullptr;
     std::vector<uint8_t> h_domain;   // owned planes only, [nzl][ny][nx]
     bool streamed = false;
-    int variant = 0, tile = 0, chunk_len = 32, fill = 16;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL
+    int variant = 0, tile = 0, chunk_len = 32, fill = 16, boundary = 8;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL / _BOUNDARY
+    hipStream_t aux = nullptr;       // second stream for the interior planes (lbmpm_rk3d_collide_interior)
+    hipEvent_t ev_dep = nullptr, ev_done = nullptr;
+    bool interior_pending = false;
     int64_t steps = 0, bytes = 0;
     lbmpm::EventPool pool;
 };
@@ -565,6 +568,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     c->cfg = *cfg;
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny; c->nzl = (int)cfg->nz_local;
     c->variant = variant; c->tile = tile; c->chunk_len = chunk_len; c->fill = fill;
+    if (const char *e = getenv("LBMPM_RK3D_BOUNDARY")) c->boundary = atoi(e) >= 2 ? atoi(e) : 2;
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
     c->vol = c->plane2 * (size_t)(c->nzl + 2);
@@ -617,6 +621,7 @@ extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); (void)hipEventDestroy(c->ev_dep); (void)hipEventDestroy(c->ev_done); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -697,29 +702,83 @@ extern "C" int lbmpm_rk3d_phase_field(lbmpm_rk3d *c, int with_diagnostics)
 
 namespace {
 template <int TX, int TY>
-void launch_fused(lbmpm_rk3d *c, const RK3Dev &p)
+void launch_fused(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last)
 {
     const int tilesX = (c->nx + TX - 1) / TX, tilesY = (c->ny + TY - 1) / TY, rpx = (tilesY + 7) / 8;
-    const int nchunks = (c->nzl + c->chunk_len - 1) / c->chunk_len;
+    const int nchunks = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
     const dim3 grid((unsigned)(8 * tilesX * rpx * nchunks)), block(TX * TY);
-    if (p.first) rk3d_fused<TX, TY, true><<<grid, block, 0, c->stream>>>(p, tilesX, tilesY, rpx, c->chunk_len);
-    else rk3d_fused<TX, TY, false><<<grid, block, 0, c->stream>>>(p, tilesX, tilesY, rpx, c->chunk_len);
+    if (p.first) rk3d_fused<TX, TY, true><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+    else rk3d_fused<TX, TY, false><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+}
+
+// planes z_first..z_last of the time step on stream st
+void launch_step_range(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last)
+{
+    if (z_last < z_first) return;
+    if (c->tile == 1) launch_fused<64, 4>(c, p, st, z_first, z_last);        // 3 blocks/CU, 55 % rim
+    else if (c->tile == 2) launch_fused<32, 8>(c, p, st, z_first, z_last);
+    else launch_fused<64, 8>(c, p, st, z_first, z_last);                     // default: 1 block/CU, 29 % rim
+}
+
+void finish_step(lbmpm_rk3d *c)
+{
+    std::swap(c->fA, c->fB);
+    c->streamed = true;
+    c->steps += 1;
 }
 }  // namespace
 
 extern "C" int lbmpm_rk3d_collide(lbmpm_rk3d *c)
 {
     LBMPM_REQUIRE(c, "null context");
+    LBMPM_REQUIRE(!c->interior_pending, "lbmpm_rk3d_collide after lbmpm_rk3d_collide_interior: finish the step with lbmpm_rk3d_collide_boundary");
     RK3Dev p = make_dev(c);
     if (c->variant == 1) rk3d_collide<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p);
-    else if (c->tile == 1) launch_fused<32, 8>(c, p);
-    else if (c->tile == 2) launch_fused<64, 6>(c, p);
-    else if (c->tile == 3) launch_fused<64, 8>(c, p);
-    else launch_fused<64, 4>(c, p);
+    else launch_step_range(c, p, c->stream, 1, c->nzl);
     LBMPM_HIP_TRY(hipGetLastError());
-    std::swap(c->fA, c->fB);
-    c->streamed = true;
-    c->steps += 1;
+    finish_step(c);
+    return LBMPM_OK;
+}
+
+// Overlap of the halo exchange with the bulk of the step (fused variant): the planes at least
+// `boundary` planes away from both faces of the slab need neither the neighbours' populations nor
+// their phase field, so they are collided on a second stream while the caller packs, exchanges
+// and unpacks on the context's stream; lbmpm_rk3d_collide_boundary then does the planes next to
+// the faces and joins the two streams.
+extern "C" int lbmpm_rk3d_collide_interior(lbmpm_rk3d *c)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_REQUIRE(!c->interior_pending, "lbmpm_rk3d_collide_interior called twice in one step");
+    const int cb = c->boundary;
+    if (c->variant == 1 || c->nzl < 2 * cb + 1) return LBMPM_OK;       // nothing to overlap: collide_boundary does the whole slab
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->aux) {
+        LBMPM_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
+        LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    }
+    LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));                // everything issued so far (previous step) first
+    LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));
+    RK3Dev p = make_dev(c);
+    launch_step_range(c, p, c->aux, cb + 1, c->nzl - cb);
+    LBMPM_HIP_TRY(hipGetLastError());
+    LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));
+    c->interior_pending = true;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3d_collide_boundary(lbmpm_rk3d *c)
+{
+    LBMPM_REQUIRE(c, "null context");
+    if (!c->interior_pending) return lbmpm_rk3d_collide(c);
+    const int cb = c->boundary;
+    RK3Dev p = make_dev(c);
+    launch_step_range(c, p, c->stream, 1, cb);
+    launch_step_range(c, p, c->stream, c->nzl - cb + 1, c->nzl);
+    LBMPM_HIP_TRY(hipGetLastError());
+    LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    c->interior_pending = false;
+    finish_step(c);
     return LBMPM_OK;
 }
 

@@ -94,6 +94,13 @@ class RK3DSlab:
     def collide(self):
         check(self._L.lbmpm_rk3d_collide(self._h), "collide")
 
+    def collide_interior(self):
+        """start the planes that do not depend on the neighbours on the slab's second stream"""
+        check(self._L.lbmpm_rk3d_collide_interior(self._h), "collide_interior")
+
+    def collide_boundary(self):
+        check(self._L.lbmpm_rk3d_collide_boundary(self._h), "collide_boundary")
+
     def step_single(self, n):
         check(self._L.lbmpm_rk3d_step(self._h, int(n)), "lbmpm_rk3d_step")
 
@@ -157,13 +164,15 @@ class RK3DCluster:
     def step(self, n):
         with self._torch.cuda.stream(self.stream):
             for _ in range(int(n)):
+                for s in self.slabs:
+                    s.collide_interior()
                 if self.slabs[0].steps_done > 0:
                     self._halo_f()
                 for s in self.slabs:
                     s.phase_field()
                 self._exchange("phi")
                 for s in self.slabs:
-                    s.collide()
+                    s.collide_boundary()
 
     def observe(self):
         """rho, u, phi of the streamed + boundary-corrected lattice (what the next step starts from)"""
@@ -212,18 +221,21 @@ class RK3DDistributed:
             s.unpack(self.rank > 0, self.rank + 1 < self.world)
 
     def step(self, n, events=None):
-        """events: optional list of n (start, stop) torch.cuda.Event pairs recorded around the
-        dominant kernel on the stream it runs on."""
+        """events: optional list of n (start, stop) torch.cuda.Event pairs recorded around each step
+        on the slab's main stream (the interior part of the fused kernel runs on a second stream and
+        is joined before the stop event)."""
         s = self.slab
         with self._torch.cuda.stream(self.stream):
             for k in range(int(n)):
+                if events is not None:
+                    events[k][0].record(self.stream)
+                if self.world > 1:
+                    s.collide_interior()       # bulk of the slab on its second stream, under the exchange
                 self._halo_f()
                 s.phase_field()
                 if self.world > 1:
                     self._exchange("phi")
-                if events is not None:
-                    events[k][0].record(self.stream)
-                s.collide()
+                s.collide_boundary()           # planes next to the faces; joins the streams
                 if events is not None:
                     events[k][1].record(self.stream)
 
