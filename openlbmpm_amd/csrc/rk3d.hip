@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -31,6 +32,8 @@ constexpr int Q = 19;
 __device__ __forceinline__ constexpr double wq(int i) { return i == 0 ? 1. / 3. : (i < 7 ? 1. / 18. : 1. / 36.); }
 __device__ __forceinline__ constexpr double bq(int i) { return i == 0 ? -1. / 3. : (i < 7 ? 1. / 18. : 1. / 36.); }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 struct RK3Dev {
     int nx, ny, nzl, pitch;
     unsigned plane_bytes;        // bytes of one [y][x] plane of doubles
@@ -44,6 +47,12 @@ struct RK3Dev {
     double *diag;                // [5][vol] rhoR, rhoB, vx, vy, vz or nullptr
     double ak, beta, cR, cB, solidPhi, vzR, vzB, rhoOutR, rhoOutB;   // cX = 1 / (2 (tauX - 1/2))
     int first, fill;
+    // compact storage (layout 1): only fluid cells are stored, see "compact storage" below
+    const u32x4 *seg;                 // [rows][nseg] {fluid mask lo, hi, j of the first fluid cell, fluid(x0-1) | fluid(x0+64) << 1 | pad << 2}, rows = (nzl+2)*ny
+    const u32x4 *seg2;                // [rows][nseg] {j of cell x0-1, j of cell x0+64 (periodic), -, -}
+    const unsigned long long *pstart; // [nzl+3] fluid cells before plane zl
+    unsigned long long *dbg;          // phase timing of the marching kernel (LBMPM_RK3D_TIMING=1), else nullptr
+    int nseg;
 };
 
 // ---- addressing.  Populations are stored plane-major, f[zl][colour][q][y][x]: everything a node
@@ -183,6 +192,153 @@ __device__ __forceinline__ void node_state3(const RK3Dev &p, const Cell &c, int 
     finish_state3(p, zl, fR, fB, rR, rB);
 }
 
+
+// ======================================================================= compact storage
+// Only fluid cells are stored.  Cells are numbered plane by plane, inside a plane tile by tile
+// (64 x 8 cells, the footprint of a block of the marching kernel), inside a tile row by row in x
+// order (j = index inside the plane); every tile's run starts on a 128-byte line and is padded to
+// a whole number of lines, so a block writes complete lines only (partial lines cost a
+// read-modify-write, see collide_store).  Populations lie plane-major with the two colours side by
+// side, f[zl][q][j] = {red, blue}: as in the dense layout everything a node touches sits within 57
+// population blocks of three consecutive planes and is addressed as <uniform base> + <32-bit
+// offset>, and one 16-byte access per direction moves both colours.  No neighbour table: per row
+// segment of 64 cells there is one 64-bit fluid mask and the j of its first fluid cell, and
+// j(x) = first + popcount(mask below x).  A wave owns one row segment, so the words are
+// wave-uniform: the popcount is v_mbcnt and "is the upstream cell fluid" is the mask itself used
+// as a lane mask.  HBM moves fluid cells only.
+constexpr int DIRT[27] = {-1, 16, -1, 12, 6, 13, -1, 17, -1, 8, 4, 9, 2, 0, 1, 10, 3, 7, -1, 18, -1, 14, 5, 11, -1, 15, -1};   // [(cz+1)*9 + (cy+1)*3 + cx+1]
+constexpr int TILE_ROWS = 8;        // rows per tile of the cell numbering
+
+struct RowTab {
+    unsigned long long m;           // fluid bits of the segment
+    unsigned first;                 // j of the segment's first fluid cell
+    unsigned lbit, rbit, jl, jr;    // fluid bit and j of the cells x0-1 and x0+64 (periodic in x)
+    unsigned pad;                   // cells of padding behind this segment's run (last row of a tile only)
+};
+
+// segment records {mask lo, mask hi, first, lbit | rbit << 1 | pad << 2} and {jl, jr, -, -}
+template <bool UNI>
+__device__ __forceinline__ RowTab make_row(u32x4 sg, u32x4 nb)
+{
+    if (UNI) {
+        sg.x = __builtin_amdgcn_readfirstlane(sg.x); sg.y = __builtin_amdgcn_readfirstlane(sg.y);
+        sg.z = __builtin_amdgcn_readfirstlane(sg.z); sg.w = __builtin_amdgcn_readfirstlane(sg.w);
+        nb.x = __builtin_amdgcn_readfirstlane(nb.x); nb.y = __builtin_amdgcn_readfirstlane(nb.y);
+    }
+    RowTab t;
+    t.m = ((unsigned long long)sg.y << 32) | sg.x;
+    t.first = sg.z; t.lbit = sg.w & 1u; t.rbit = (sg.w >> 1) & 1u; t.pad = sg.w >> 2;
+    t.jl = nb.x; t.jr = nb.y;
+    return t;
+}
+
+// rows straight from the tables in global memory (set-up, boundary-plane and diagnostics kernels)
+struct GlobalRows {
+    const RK3Dev &p;
+    int x, y;
+    __device__ __forceinline__ RowTab operator()(int zl, int ry) const
+    {
+        const size_t r = ((size_t)zl * p.ny + wrapi(y + ry, p.ny)) * p.nseg + (x >> 6);
+        return make_row<false>(p.seg[r], p.seg2[r]);
+    }
+};
+
+// number of set bits of M below bit b (UNI: b is the lane id, M wave-uniform)
+template <bool UNI>
+__device__ __forceinline__ unsigned bits_below(unsigned long long M, unsigned b)
+{
+    if (UNI) return __builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
+    return (unsigned)__popcll(M & ((1ull << b) - 1ull));
+}
+template <bool UNI>
+__device__ __forceinline__ bool bit_of(unsigned long long M, unsigned b)
+{
+    if (UNI) return __builtin_amdgcn_inverse_ballot_w64(M);
+    return (M >> b) & 1ull;
+}
+
+// j and fluid bit of the cell dx to the right of bit b of the segment (periodic in x)
+template <bool UNI>
+__device__ __forceinline__ void row_cell(const RowTab &t, int dx, unsigned b, unsigned &j, bool &fl)
+{
+    if (dx == 0) {
+        fl = bit_of<UNI>(t.m, b);
+        j = t.first + bits_below<UNI>(t.m, b);
+    } else if (dx < 0) {
+        const unsigned long long M = (t.m << 1) | (unsigned long long)t.lbit;
+        fl = bit_of<UNI>(M, b);
+        j = b == 0u ? t.jl : t.first - t.lbit + bits_below<UNI>(M, b);
+    } else {
+        const unsigned long long M = (t.m >> 1) | ((unsigned long long)t.rbit << 63);
+        fl = bit_of<UNI>(M, b);
+        j = b == 63u ? t.jr : t.first + bits_below<UNI>(t.m, b) + (bit_of<UNI>(t.m, b) ? 1u : 0u);
+    }
+}
+
+struct PlaneAddr {               // of the three planes around the plane that is pulled
+    const char *base;            // population 0 of the plane below
+    unsigned off[3], cnt[3];     // byte offset of the three planes' blocks from base, fluid cells per plane
+};
+
+__device__ __forceinline__ PlaneAddr plane_addr(const RK3Dev &p, const double *f, int zl)
+{
+    PlaneAddr a;
+    const unsigned long long p0 = p.pstart[zl - 1], p1 = p.pstart[zl], p2 = p.pstart[zl + 1], p3 = p.pstart[zl + 2];
+    a.base = reinterpret_cast<const char *>(f) + (size_t)p0 * (Q * 16);
+    a.cnt[0] = (unsigned)(p1 - p0); a.cnt[1] = (unsigned)(p2 - p1); a.cnt[2] = (unsigned)(p3 - p2);
+    a.off[0] = 0u; a.off[1] = a.cnt[0] * (unsigned)(Q * 16); a.off[2] = a.off[1] + a.cnt[1] * (unsigned)(Q * 16);
+    return a;
+}
+__device__ __forceinline__ double2 ldg2(const char *uniform_base, unsigned off) { return *reinterpret_cast<const double2 *>(uniform_base + off); }
+
+// pull of the node at bit b (cell x) of the row that `rows(zl, 0)` describes, which must be fluid
+// there; also returns the node's own j.  Bounce-back as in pull3: a non-fluid upstream cell
+// redirects the load to the opposite population of the node itself.
+template <bool FIRST, bool UNI, typename Rows>
+__device__ __forceinline__ void pull3c(const RK3Dev &p, const Rows &rows, int x, int zl, unsigned b, double fR[Q], double fB[Q], unsigned &own_j)
+{
+    constexpr int OPP[Q] = LBMPM_D3Q19_OPP;
+    const PlaneAddr a = plane_addr(p, p.fin, zl);
+    {
+        const RowTab t = rows(zl, 0);
+        own_j = t.first + bits_below<UNI>(t.m, b);
+    }
+    const unsigned own16 = own_j * 16u;
+    if (FIRST) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const double2 v = ldg2(a.base, a.off[1] + (unsigned)i * a.cnt[1] * 16u + own16);
+            fR[i] = v.x;
+            fB[i] = v.y;
+        }
+        return;
+    }
+#pragma unroll
+    for (int rz = -1; rz <= 1; ++rz)
+#pragma unroll
+        for (int ry = -1; ry <= 1; ++ry) {
+            const RowTab t = rows(zl + rz, ry);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int i = DIRT[(1 - rz) * 9 + (1 - ry) * 3 + (1 - dx)];      // the direction that arrives from (dx, ry, rz)
+                if (i < 0) continue;
+                unsigned off;
+                if (i == 0) off = a.off[1] + own16;
+                else {
+                    unsigned j;
+                    bool fl;
+                    row_cell<UNI>(t, dx, b, j, fl);
+                    const unsigned up = a.off[1 + rz] + (unsigned)i * a.cnt[1 + rz] * 16u + j * 16u;
+                    const unsigned back = a.off[1] + (unsigned)OPP[i] * a.cnt[1] * 16u + own16;
+                    off = fl ? up : back;
+                }
+                const double2 v = ldg2(a.base, off);
+                fR[i] = v.x;
+                fB[i] = v.y;
+            }
+        }
+}
+
 constexpr int BX3 = 64, BY3 = 4;
 
 // K1: phase field of the streamed, boundary-corrected lattice on the planes zl0 .. zl0+gridDim.z-1
@@ -216,8 +372,9 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3d_phase_field(RK3Dev p, int zl0)
 // the colour densities and the colour gradient; stores the post-collision populations of plane zl.
 // Lanes of non-fluid cells whose 128-byte line holds fluid store zeros: partially written
 // lines cost the memory system a read-modify-write (measured: +35 % kernel time at porosity 0.65).
-__device__ __forceinline__ void collide_store(const RK3Dev &p, int zl, unsigned own, bool fluid, const double ft_in[Q],
-                                              double rR, double rB, double gx, double gy, double gz)
+template <bool COMPACT = false>   // COMPACT: {red, blue} pairs, 16 bytes per node and direction
+__device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsigned stride, unsigned own, bool fluid,
+                                              const double ft_in[Q], double rR, double rB, double gx, double gy, double gz)
 {
 #pragma clang fp contract(fast)      // fused multiply-adds here (the 2-D kernels stay uncontracted for bit parity with the reference)
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
@@ -227,8 +384,10 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, int zl, unsigned 
         const double t = ft_in[i];
         mx += (double)CX[i] * t; my += (double)CY[i] * t; mz += (double)CZ[i] * t;
     }
-    // five divisions per node instead of three per direction: reciprocals once, products after
-    // (differs from the division form of oracle/rk3d_oracle.c by rounding only; tests bound it)
+    // Arithmetic organised for the hardware, not after the reference's statement order (the oracle
+    // keeps that; the tests bound the rounding difference): five divisions per node, and the
+    // directions in opposite pairs, whose equilibrium, perturbation and recolouring terms differ
+    // in sign only.
     const double rho = rR + rB, irho = 1. / rho;
     const double ux = mx * irho, uy = my * irho, uz = mz * irho, usq = ux * ux + uy * uy + uz * uz;
     const double phi = (rR - rB) * irho;
@@ -236,20 +395,31 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, int zl, unsigned 
     const double g2 = gx * gx + gy * gy + gz * gz, gn = sqrt(g2);
     const double ig2 = g2 != 0. ? 1. / g2 : 0., ign = gn * ig2;
     const double kR = rR * irho, kB = rB * irho, arc = p.beta * rR * rB * irho * irho, akgn = p.ak * gn;
-    char *red = const_cast<char *>(plane_ptr(p.fout, p, zl)), *blue = red + (size_t)Q * p.plane_bytes;
+    const double c0 = 1. - 1.5 * usq;
+    char *blue = red + (size_t)Q * stride;       // red = population 0 of the node's plane, stride = bytes between populations
+    auto put = [&](int i, double g, double a) {
+        if (COMPACT) {
+            double2 v;
+            v.x = fluid ? kR * g + a : 0.; v.y = fluid ? kB * g - a : 0.;
+            *reinterpret_cast<double2 *>(red + (size_t)i * stride + own) = v;
+        } else {
+            stg(red + (size_t)i * stride, own, fluid ? kR * g + a : 0.);
+            stg(blue + (size_t)i * stride, own, fluid ? kB * g - a : 0.);
+        }
+    };
+    // relaxation as f - (f - feq) omega: a node at equilibrium stays there bit for bit
+    put(0, (ft_in[0] - (ft_in[0] - (rho * wq(0)) * c0) * omega) - akgn * bq(0), 0.);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) {
+    for (int i = 1; i < Q; i += 2) {             // i and i + 1 are opposite
+        const double w = wq(i), ien = i < 7 ? 1. : 0.70710678118654752440;
         const double eu = (double)CX[i] * ux + (double)CY[i] * uy + (double)CZ[i] * uz;
-        const double feq = rho * wq(i) * (1. + 3. * eu + 4.5 * eu * eu - 1.5 * usq);
-        double ft = ft_in[i];
-        ft = ft - (ft - feq) * omega;
         const double eg = (double)CX[i] * gx + (double)CY[i] * gy + (double)CZ[i] * gz;
-        ft += akgn * (wq(i) * (eg * eg) * ig2 - bq(i));
-        const double ien = (i == 0) ? 0. : (i < 7 ? 1. : 0.70710678118654752440);
-        const double a = arc * wq(i) * (eg * ien * ign);
-        stg(red + (size_t)i * p.plane_bytes, own, fluid ? kR * ft + a : 0.);
-        stg(blue + (size_t)i * p.plane_bytes, own, fluid ? kB * ft - a : 0.);
-        __builtin_amdgcn_sched_barrier(0);      // one direction's temporaries at a time: registers are the scarce resource here
+        const double sym = (rho * w) * (c0 + 4.5 * eu * eu), odd = (3. * rho * w) * eu;
+        const double pert = (akgn * w * ig2) * (eg * eg) - akgn * bq(i);
+        const double a = (arc * w * ien * ign) * eg;
+        put(i, (ft_in[i] - (ft_in[i] - (sym + odd)) * omega) + pert, a);
+        put(i + 1, (ft_in[i + 1] - (ft_in[i + 1] - (sym - odd)) * omega) + pert, -a);
+        __builtin_amdgcn_sched_barrier(0);      // one pair's temporaries at a time: registers are the scarce resource here
     }
 }
 
@@ -287,7 +457,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3d_collide(RK3Dev p)
     double ft[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) ft[i] = fR[i] + fB[i];
-    collide_store(p, zl, c.o[1][1], fluid, ft, rR, rB, gx, gy, gz);
+    collide_store(p, const_cast<char *>(plane_ptr(p.fout, p, zl)), p.plane_bytes, c.o[1][1], fluid, ft, rR, rB, gx, gy, gz);
 }
 
 // Fused time step (default): one block owns a TX x TY column of nodes and marches along z.
@@ -409,10 +579,296 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
                     gy += 3. * wq(i) * (double)CY[i] * ph;
                     gz += 3. * wq(i) * (double)CZ[i] * ph;
                 }
-                collide_store(p, z, own_off, isfl, ft, rRz, rBz, gx, gy, gz);
+                collide_store(p, const_cast<char *>(plane_ptr(p.fout, p, z)), p.plane_bytes, own_off, isfl, ft, rRz, rBz, gx, gy, gz);
             }
         }
         fluid = (mo >> 31) && z + 1 >= 1 && z + 1 <= p.nzl;
+    }
+}
+
+
+// ---------------------------------------------------------------- compact-storage kernels
+// K1 on compact storage (boundary planes of a slab, diagnostics)
+__global__ __launch_bounds__(BX3 *BY3) void rk3dc_phase_field(RK3Dev p, int zl0)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + zl0;
+    if (y >= p.ny || x >= p.nx) return;
+    const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    double fR[Q], fB[Q], rR, rB;
+    unsigned j;
+    const GlobalRows rows{p, x, y};
+    if (p.first) pull3c<true, false>(p, rows, x, source_plane(p, zl), (unsigned)(x & 63), fR, fB, j);
+    else pull3c<false, false>(p, rows, x, source_plane(p, zl), (unsigned)(x & 63), fR, fB, j);
+    finish_state3(p, zl, fR, fB, rR, rB);
+    p.phi[idx] = (rR - rB) / (rR + rB);
+    if (p.diag) {
+        constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+        double mx = 0., my = 0., mz = 0.;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const double t = fR[i] + fB[i];
+            mx += (double)CX[i] * t; my += (double)CY[i] * t; mz += (double)CZ[i] * t;
+        }
+        const double rho = rR + rB;
+        p.diag[idx] = rR; p.diag[p.vol + idx] = rB;
+        p.diag[2 * p.vol + idx] = mx / rho; p.diag[3 * p.vol + idx] = my / rho; p.diag[4 * p.vol + idx] = mz / rho;
+    }
+}
+
+// the rows around a tile, staged in LDS ahead of their use: [ring slot][tile row - 2 .. TY + 1][segment tx-1, tx, tx+1][record 0, 1]
+template <int TY>
+struct TileRows {
+    static constexpr int ROWS = TY + 4, SLOTS = 8;
+    const u32x4 (*ring)[ROWS][6];
+    int lrow, k;                 // this lane's row inside the staged rows, its segment slot
+    bool uni;
+    template <bool UNI>
+    __device__ __forceinline__ RowTab get(int zl, int ry) const
+    {
+        const u32x4 *r = ring[zl & (SLOTS - 1)][lrow + ry];
+        return make_row<UNI>(r[2 * k], r[2 * k + 1]);
+    }
+};
+template <int TY, bool UNI>
+struct TileRowsU {
+    TileRows<TY> t;
+    __device__ __forceinline__ RowTab operator()(int zl, int ry) const { return t.template get<UNI>(zl, ry); }
+};
+
+// phase field of a cell of plane zl for the ring (compact storage); for a fluid node of an owned
+// plane also the pulled, boundary-corrected populations, densities and the node's j
+template <bool FIRST, bool UNI, typename Rows>
+__device__ __forceinline__ double ring_phi_c(const RK3Dev &p, const Rows &rows, int x, int y, int zl, unsigned b, bool &fluid,
+                                             double fR[Q], double fB[Q], double &rR, double &rB, unsigned &j)
+{
+    fluid = false;
+    if (zl == 0 || zl == p.nzl + 1) return (p.phi + (size_t)zl * p.plane2)[(size_t)y * p.pitch + x];   // neighbour rank's plane (or outside: solidPhi)
+    const RowTab t = rows(zl, 0);
+    fluid = bit_of<UNI>(t.m, b);
+    if (!fluid) return p.solidPhi;
+    j = t.first + bits_below<UNI>(t.m, b);
+    unsigned js;
+    pull3c<FIRST, UNI>(p, rows, x, source_plane(p, zl), b, fR, fB, js);
+    finish_state3(p, zl, fR, fB, rR, rB);
+    return (rR - rB) / (rR + rB);
+}
+
+// the marching kernel of rk3d_fused on compact storage (TX = 64: a wave owns one row segment)
+template <int TY, bool FIRST>
+__global__ __launch_bounds__(64 * TY, 768 / (64 * TY)) void rk3dc_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last)
+{
+    constexpr int TX = 64;
+    using M = March<TX, TY>;
+    using TR = TileRows<TY>;
+    constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+    __shared__ double sphi[M::RING][M::FY][M::FX];
+    __shared__ double park[Q][M::NT];
+    __shared__ u32x4 srow[TR::SLOTS][TR::ROWS][6];
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int tx = slot % tilesX, r = slot / tilesX, ty = xcd * rows_per_xcd + r % rows_per_xcd, chunk = r / rows_per_xcd;
+    if (ty >= tilesY) return;
+    const int tid = threadIdx.x, lx = tid % TX, ly = tid / TX;
+    const int x = tx * TX + lx, y = ty * TY + ly;
+    const bool own = y < p.ny;                                     // nx is a multiple of 64 here
+    const int yo = ring_coord(y, p.ny);                            // row ny of a cut tile = row 0, rim of row ny-1
+    const bool has_own = yo >= 0;
+    // rim cell of this thread: bottom row, top row (one wave each), then the two columns (corners included)
+    int hlx = 0, hly = 0, hx = 0, hy = 0;
+    bool has_rim = false;
+    if (tid < M::NH) {
+        if (tid < 2 * TX) { hlx = 1 + tid % TX; hly = tid < TX ? 0 : M::FY - 1; }
+        else { const int k = tid - 2 * TX; hlx = k < M::FY ? 0 : M::FX - 1; hly = k % M::FY; }
+        hx = ring_coord(tx * TX + hlx - 1, p.nx);
+        hy = ring_coord(ty * TY + hly - 1, p.ny);
+        has_rim = hx >= 0 && hy >= 0;
+    }
+    const TileRowsU<TY, true> rows_own{{srow, ly + 2, 1, true}};
+    const TileRowsU<TY, true> rows_rimrow{{srow, hly + 1, 1, true}};
+    const TileRowsU<TY, false> rows_rimcol{{srow, hly + 1, hlx == 0 ? 0 : 2, false}};
+    const int za = z_first + chunk * chunk_len, zb = min(za + chunk_len - 1, z_last);
+    const int expm = p.fill >= 1000 ? p.fill - 1000 : 0;     // TEMPORARY experiment switches
+    if (expm & 1) has_rim = false;
+    // Row records are staged two march steps ahead of their first use: fetched into a register
+    // during one step, written to LDS at the top of the next (so nobody waits for that fetch),
+    // read from the step after.  72 lanes, one 16-byte record each.
+    auto fetch_rows = [&](int zl) -> u32x4 {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (tid < TR::ROWS * 6 && zl >= 0 && zl <= p.nzl + 1) {
+            const int row = tid / 6, k = tid % 6;
+            int yy = (ty * TY - 2 + row) % p.ny;
+            if (yy < 0) yy += p.ny;
+            int sg = tx - 1 + (k >> 1);
+            sg = sg < 0 ? sg + p.nseg : (sg >= p.nseg ? sg - p.nseg : sg);
+            const size_t rr = ((size_t)zl * p.ny + yy) * p.nseg + sg;
+            v = (k & 1) ? p.seg2[rr] : p.seg[rr];
+        }
+        return v;
+    };
+    auto put_rows = [&](int zl, u32x4 v) {
+        if (tid < TR::ROWS * 6) const_cast<u32x4 &>(srow[zl & (TR::SLOTS - 1)][tid / 6][tid % 6]) = v;
+    };
+    for (int zl = za - 3; zl <= za + 2; ++zl) put_rows(zl, fetch_rows(zl));
+    u32x4 staged = fetch_rows(za + 3);
+    // Software pipeline of the own cells: the pulls of plane z + 2 are issued before the barrier and
+    // the collision of plane z, and consumed at the top of the next march step (the reduced state
+    // sits in the LDS park meanwhile, so the pulls in flight are all the registers carry).
+    bool fluid = false, fl_raw = false;         // node of the parked plane / of the plane in flight is fluid
+    bool padz = false, pad_raw = false;         // idle lane that writes line padding for that plane
+    unsigned jz = 0, j_raw = 0;                 // their j
+    double rR = 1., rB = 1.;                    // densities of the parked plane
+    double rawR[Q], rawB[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { park[i][tid] = 1.; rawR[i] = 0.; rawB[i] = 0.; }
+    __syncthreads();
+    auto issue = [&](int zl) {                  // pulls of the own cell of plane zl
+        fl_raw = false; pad_raw = false;
+        if (!has_own || zl < 1 || zl > p.nzl) return;
+        const RowTab t = rows_own(zl, 0);
+        fl_raw = bit_of<true>(t.m, (unsigned)lx);
+        if (!fl_raw) {
+            // the first `pad` idle lanes of the last row of a tile write the zeros that complete the tile's last line
+            const unsigned rank = bits_below<true>(~t.m, (unsigned)lx);
+            pad_raw = own && rank < t.pad;
+            j_raw = t.first + (unsigned)__popcll(t.m) + rank;
+            return;
+        }
+        j_raw = t.first + bits_below<true>(t.m, (unsigned)lx);
+        unsigned js;
+        pull3c<FIRST, true>(p, rows_own, x, source_plane(p, zl), (unsigned)lx, rawR, rawB, js);
+    };
+    issue(za - 1);
+
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    const bool timed = p.dbg && bid == 8 * 3 && (tid == 0 || tid == 64 * (TY - 1));
+    auto stamp = [&](int k) { if (timed) { const unsigned long long t = clock64(); tacc[k] += t - tprev; tprev = t; } };
+    if (timed) tprev = clock64();
+    for (int z = za - 2; z <= zb; ++z) {
+        put_rows(z + 5, staged);                // read from the next march step on
+        staged = fetch_rows(z + 6);
+        // ---- plane z + 1, rim cells: phase field only
+        if (tid < 2 * TX) {
+            if (has_rim) {
+                double fR[Q], fB[Q], a, c;
+                bool f;
+                unsigned j;
+                sphi[(z + 1) & (M::RING - 1)][hly][hlx] = ring_phi_c<FIRST, true>(p, rows_rimrow, hx, hy, z + 1, (unsigned)(tid % TX), f, fR, fB, a, c, j);
+            }
+        } else if (has_rim) {
+            double fR[Q], fB[Q], a, c;
+            bool f;
+            unsigned j;
+            sphi[(z + 1) & (M::RING - 1)][hly][hlx] = ring_phi_c<FIRST, false>(p, rows_rimcol, hx, hy, z + 1, (unsigned)(hx & 63), f, fR, fB, a, c, j);
+        }
+        stamp(0);
+        // ---- plane z + 1, own cell (pulled during the previous march step): boundary rules, phase
+        //      field into the ring, reduced state into the park (which still holds plane z: swap)
+        double ft[Q];
+        const double rRz = rR, rBz = rB;
+        const unsigned jzz = jz;
+        const bool fluidn = fl_raw;
+        {
+            double rRn = 1., rBn = 1., ph = p.solidPhi;
+            if (z + 1 == 0 || z + 1 == p.nzl + 1) { if (has_own) ph = (p.phi + (size_t)(z + 1) * p.plane2)[(size_t)yo * p.pitch + x]; }
+            else if (fluidn) {
+                finish_state3(p, z + 1, rawR, rawB, rRn, rBn);
+                ph = (rRn - rBn) / (rRn + rBn);
+            }
+            if (has_own) sphi[(z + 1) & (M::RING - 1)][ly + 1][lx + 1] = ph;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                ft[i] = park[i][tid];
+                double t = rawR[i] + rawB[i];
+                asm volatile("" : "+v"(t));      // here, not later: frees the pull registers for the next plane
+                park[i][tid] = t;
+            }
+            rR = rRn; rB = rBn; jz = j_raw;
+        }
+        const bool padzz = padz;
+        padz = pad_raw;
+        stamp(1);
+        // ---- pulls of plane z + 2 into flight
+        if (z + 2 <= zb + 1) issue(z + 2);
+        else { fl_raw = false; pad_raw = false; }
+        stamp(2);
+        __syncthreads();
+        stamp(3);
+        // ---- plane z: collide
+        if (z >= za && fluid && own && (expm & 2)) {
+            const unsigned long long p0 = p.pstart[z], p1 = p.pstart[z + 1];
+            const unsigned cnt = (unsigned)(p1 - p0);
+            char *o = reinterpret_cast<char *>(p.fout) + (size_t)p0 * (Q * 16);
+            if (!(expm & 4)) for (int i = 0; i < Q; ++i) { double2 v; v.x = ft[i]; v.y = rRz; *reinterpret_cast<double2 *>(o + (size_t)i * cnt * 16u + jzz * 16u) = v; }
+            else if (ft[3] == 12345.) *reinterpret_cast<double *>(o) = rBz;
+        } else
+        if (z >= za && ((fluid && own) || padzz)) {
+            double gx = 0., gy = 0., gz = 0.;
+#pragma unroll
+            for (int i = 1; i < Q; ++i) {
+                const double ph = sphi[(z + CZ[i]) & (M::RING - 1)][ly + 1 + CY[i]][lx + 1 + CX[i]];
+                gx += 3. * wq(i) * (double)CX[i] * ph;
+                gy += 3. * wq(i) * (double)CY[i] * ph;
+                gz += 3. * wq(i) * (double)CZ[i] * ph;
+            }
+            const unsigned long long p0 = p.pstart[z], p1 = p.pstart[z + 1];
+            const unsigned cnt = (unsigned)(p1 - p0);
+            collide_store<true>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * (Q * 16), cnt * 16u, jzz * 16u, fluid, ft, rRz, rBz, gx, gy, gz);
+        }
+        fluid = fluidn;
+        stamp(4);
+    }
+    if (timed)
+        for (int k = 0; k < 5; ++k) p.dbg[(tid == 0 ? 0 : 5) + k] = tacc[k];
+}
+
+// halo packing on compact storage: the five populations (both colours) that cross each cut, as
+// contiguous runs of the outermost owned planes
+__global__ void rk3dc_pack(RK3Dev p, const double *f, double *send_up, double *send_dn)
+{
+    constexpr int UP[5] = {5, 11, 14, 15, 18}, DN[5] = {6, 12, 13, 16, 17};
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long pt = p.pstart[p.nzl], pb = p.pstart[1];
+    const size_t ct = (size_t)(p.pstart[p.nzl + 1] - pt), cb = (size_t)(p.pstart[2] - pb);
+    const double2 *f2 = reinterpret_cast<const double2 *>(f);
+    double2 *up = reinterpret_cast<double2 *>(send_up), *dn = reinterpret_cast<double2 *>(send_dn);
+    for (int j = 0; j < 5; ++j) {
+        if (k < ct) up[(size_t)j * ct + k] = f2[(size_t)pt * Q + (size_t)UP[j] * ct + k];
+        if (k < cb) dn[(size_t)j * cb + k] = f2[(size_t)pb * Q + (size_t)DN[j] * cb + k];
+    }
+}
+
+__global__ void rk3dc_unpack(RK3Dev p, double *f, const double *recv_from_below, const double *recv_from_above, int have_below,
+                             int have_above)
+{
+    constexpr int UP[5] = {5, 11, 14, 15, 18}, DN[5] = {6, 12, 13, 16, 17};
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long pl = p.pstart[0], ph = p.pstart[p.nzl + 1];
+    const size_t cl = (size_t)(p.pstart[1] - pl), ch = (size_t)(p.pstart[p.nzl + 2] - ph);
+    double2 *f2 = reinterpret_cast<double2 *>(f);
+    const double2 *lo = reinterpret_cast<const double2 *>(recv_from_below), *hi = reinterpret_cast<const double2 *>(recv_from_above);
+    for (int j = 0; j < 5; ++j) {
+        if (have_below && k < cl) f2[(size_t)pl * Q + (size_t)UP[j] * cl + k] = lo[(size_t)j * cl + k];
+        if (have_above && k < ch) f2[(size_t)ph * Q + (size_t)DN[j] * ch + k] = hi[(size_t)j * ch + k];
+    }
+}
+
+__global__ void rk3dc_init_rest(RK3Dev p, const double *rho_r, const double *rho_b, double *f)
+{
+    const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
+    if (x >= p.nx || y >= p.ny) return;
+    if (!(p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
+    const GlobalRows rows{p, x, y};
+    const RowTab t = rows(zl, 0);
+    const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
+    const size_t sd = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
+    const double a = rho_r[sd], b = rho_b[sd];
+    const unsigned long long p0 = p.pstart[zl];
+    const size_t cnt = (size_t)(p.pstart[zl + 1] - p0);
+    double2 *pl = reinterpret_cast<double2 *>(f) + (size_t)p0 * Q;
+    for (int i = 0; i < Q; ++i) {
+        double2 v;
+        v.x = wq(i) * a; v.y = wq(i) * b;
+        pl[(size_t)i * cnt + j] = v;
     }
 }
 
@@ -500,6 +956,14 @@ struct lbmpm_rk3d {
     double *fA = nullptr, *fB = nullptr, *phi = nullptr, *diag = nullptr;
     double *send_up = nullptr, *send_dn = nullptr, *recv_below = nullptr, *recv_above = nullptr;
     std::vector<uint8_t> h_domain;   // owned planes only, [nzl][ny][nx]
+    // compact storage (fluid cells only): default whenever nx is a multiple of 64; LBMPM_RK3D_LAYOUT=dense overrides
+    bool compact = false;
+    int nseg = 0;
+    size_t ncells = 0;               // stored cells, halo planes included
+    unsigned long long *pstart = nullptr;
+    uint32_t *seg = nullptr, *seg2 = nullptr;        // 4 words per record
+    unsigned long long *dbg = nullptr;
+    std::vector<unsigned long long> h_pstart;
     bool streamed = false;
     int variant = 0, tile = 0, chunk_len = 32, fill = 16, boundary = 8;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL / _BOUNDARY
     hipStream_t aux = nullptr;       // second stream for the interior planes (lbmpm_rk3d_collide_interior)
@@ -516,6 +980,7 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     RK3Dev p{};
     p.nx = c->nx; p.ny = c->ny; p.nzl = c->nzl; p.pitch = c->pitch; p.plane2 = c->plane2; p.vol = c->vol;
     p.plane_bytes = (unsigned)(c->plane2 * sizeof(double));
+    p.seg = reinterpret_cast<const u32x4 *>(c->seg); p.seg2 = reinterpret_cast<const u32x4 *>(c->seg2); p.pstart = c->pstart; p.nseg = c->nseg; p.dbg = c->dbg;
     p.z0 = (int)c->cfg.z_offset; p.nzg = (int)c->cfg.nz_global;
     p.flags = c->flags; p.solidnbr = c->solidnbr; p.fin = c->fA; p.fout = c->fB; p.phi = c->phi; p.diag = nullptr;
     p.ak = (c->cfg.ak_r + c->cfg.ak_b) * 0.5; p.beta = c->cfg.beta; p.cR = 1. / (2. * (c->cfg.tau_r - 0.5)); p.cB = 1. / (2. * (c->cfg.tau_b - 0.5));
@@ -560,7 +1025,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_CHUNK")) chunk_len = atoi(e) > 0 ? atoi(e) : 32;
     if (const char *e = getenv("LBMPM_RK3D_FILL")) fill = atoi(e);
     LBMPM_REQUIRE(variant == 0 || variant == 1, "lbmpm_rk3d_create: variant must be 0 (fused) or 1 (split)");
-    LBMPM_REQUIRE(fill == 0 || fill == 4 || fill == 8 || fill == 16 || fill == 32 || fill == 64,
+    LBMPM_REQUIRE(fill >= 1000 || fill == 0 || fill == 4 || fill == 8 || fill == 16 || fill == 32 || fill == 64,
                   "LBMPM_RK3D_FILL must be 0 or a power of two <= 64");
     LBMPM_HIP_TRY(hipSetDevice(cfg->device));
     lbmpm_rk3d *c = new (std::nothrow) lbmpm_rk3d();
@@ -569,6 +1034,8 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny; c->nzl = (int)cfg->nz_local;
     c->variant = variant; c->tile = tile; c->chunk_len = chunk_len; c->fill = fill;
     if (const char *e = getenv("LBMPM_RK3D_BOUNDARY")) c->boundary = atoi(e) >= 2 ? atoi(e) : 2;
+    c->compact = variant == 0 && c->nx % 64 == 0;
+    if (const char *e = getenv("LBMPM_RK3D_LAYOUT")) if (!strcmp(e, "dense")) c->compact = false;
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
     c->vol = c->plane2 * (size_t)(c->nzl + 2);
@@ -591,8 +1058,65 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
 #define TRY_RC(e) do { rc = (e); if (rc != LBMPM_OK) { lbmpm_rk3d_destroy(c); return rc; } } while (0)
     TRY_RC(dev_alloc(c, &c->flags, c->vol));
     TRY_RC(dev_alloc(c, &c->solidnbr, c->vol));
-    TRY_RC(dev_alloc(c, &c->fA, 2 * Q * c->vol));
-    TRY_RC(dev_alloc(c, &c->fB, 2 * Q * c->vol));
+    std::vector<uint32_t> hseg, hseg2;
+    if (c->compact) {
+        // segment records of the compact storage; numbering: plane, tile (64 x TILE_ROWS), row, x
+        c->nseg = c->nx / 64;
+        const int ns = c->nseg;
+        const size_t rows = (size_t)(c->nzl + 2) * c->ny;
+        hseg.assign(rows * ns * 4, 0u);
+        hseg2.assign(rows * ns * 4, 0u);
+        c->h_pstart.assign(c->nzl + 3, 0ull);
+        unsigned long long total = 0;
+        std::vector<unsigned long long> m((size_t)c->ny * ns);
+        std::vector<unsigned> first((size_t)c->ny * ns);
+        for (int z = 0; z < c->nzl + 2; ++z) {
+            c->h_pstart[z] = total;
+            for (int y = 0; y < c->ny; ++y)
+                for (int sg = 0; sg < ns; ++sg) {
+                    const uint8_t *fl = hflags.data() + (size_t)z * c->plane2 + (size_t)y * c->pitch + sg * 64;
+                    unsigned long long w = 0;
+                    for (int b = 0; b < 64; ++b)
+                        if (fl[b]) w |= 1ull << b;
+                    m[(size_t)y * ns + sg] = w;
+                }
+            unsigned j = 0;
+            for (int y0 = 0; y0 < c->ny; y0 += TILE_ROWS)
+                for (int sg = 0; sg < ns; ++sg) {
+                    int last = -1;
+                    for (int y = y0; y < y0 + TILE_ROWS && y < c->ny; ++y) {
+                        first[(size_t)y * ns + sg] = j;
+                        j += (unsigned)__builtin_popcountll(m[(size_t)y * ns + sg]);
+                        last = y;
+                    }
+                    const unsigned pad = (8u - (j & 7u)) & 7u;          // whole 128-byte lines per tile run
+                    hseg[(((size_t)z * c->ny + last) * ns + sg) * 4 + 3] = pad << 2;
+                    j += pad;
+                }
+            for (int y = 0; y < c->ny; ++y)
+                for (int sg = 0; sg < ns; ++sg) {
+                    const size_t r = ((size_t)z * c->ny + y) * ns + sg;
+                    const int sl = sg > 0 ? sg - 1 : ns - 1, sr = sg + 1 < ns ? sg + 1 : 0;
+                    const unsigned long long ml = m[(size_t)y * ns + sl], mr = m[(size_t)y * ns + sr];
+                    hseg[r * 4 + 0] = (uint32_t)m[(size_t)y * ns + sg];
+                    hseg[r * 4 + 1] = (uint32_t)(m[(size_t)y * ns + sg] >> 32);
+                    hseg[r * 4 + 2] = first[(size_t)y * ns + sg];
+                    hseg[r * 4 + 3] |= (uint32_t)(ml >> 63) | ((uint32_t)(mr & 1ull) << 1);
+                    hseg2[r * 4 + 0] = first[(size_t)y * ns + sl] + (unsigned)__builtin_popcountll(ml) - 1u;   // j of cell x0-1 (if fluid)
+                    hseg2[r * 4 + 1] = first[(size_t)y * ns + sr];                                             // j of cell x0+64 (if fluid)
+                }
+            total += j;
+        }
+        c->h_pstart[c->nzl + 2] = total;
+        c->ncells = (size_t)total;
+        TRY_RC(dev_alloc(c, &c->seg, hseg.size()));
+        TRY_RC(dev_alloc(c, &c->seg2, hseg2.size()));
+        TRY_RC(dev_alloc(c, &c->pstart, c->h_pstart.size()));
+        if (getenv("LBMPM_RK3D_TIMING")) TRY_RC(dev_alloc(c, &c->dbg, 16));
+    }
+    const size_t fcount = c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol;
+    TRY_RC(dev_alloc(c, &c->fA, fcount));
+    TRY_RC(dev_alloc(c, &c->fB, fcount));
     TRY_RC(dev_alloc(c, &c->phi, c->vol));
     TRY_RC(dev_alloc(c, &c->send_up, 10 * c->plane2));
     TRY_RC(dev_alloc(c, &c->send_dn, 10 * c->plane2));
@@ -600,6 +1124,9 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     TRY_RC(dev_alloc(c, &c->recv_above, 10 * c->plane2));
 #undef TRY_RC
     hipError_t e = hipMemcpyAsync(c->flags, hflags.data(), c->vol, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && c->compact) e = hipMemcpyAsync(c->seg, hseg.data(), hseg.size() * sizeof(hseg[0]), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && c->compact) e = hipMemcpyAsync(c->seg2, hseg2.data(), hseg2.size() * sizeof(hseg2[0]), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && c->compact) e = hipMemcpyAsync(c->pstart, c->h_pstart.data(), c->h_pstart.size() * sizeof(c->h_pstart[0]), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { set_error("flags upload failed: %s", hipGetErrorString(e)); lbmpm_rk3d_destroy(c); return LBMPM_ERR_HIP; }
     RK3Dev p = make_dev(c);
@@ -617,7 +1144,7 @@ extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (void *ptr : {(void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->phi, (void *)c->diag,
+    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->dbg, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->phi, (void *)c->diag,
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
@@ -643,16 +1170,24 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
 {
     LBMPM_REQUIRE(c && rho_r && rho_b, "lbmpm_rk3d_set_density: null argument");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
-    // stage the two density fields in the (idle) second population buffer, expand on the device
+    // stage the two density fields on the device, expand there
     const size_t n = (size_t)c->nx * c->ny * c->nzl;
-    double *stage = c->fB;
-    LBMPM_HIP_TRY(hipMemcpyAsync(stage, rho_r, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    LBMPM_HIP_TRY(hipMemcpyAsync(stage + n, rho_b, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    LBMPM_HIP_TRY(hipMemsetAsync(c->fA, 0, 2 * Q * c->vol * sizeof(double), c->stream));
-    RK3Dev p = make_dev(c);
-    rk3d_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
-    LBMPM_HIP_TRY(hipGetLastError());
-    LBMPM_HIP_TRY(hipMemsetAsync(c->fB, 0, 2 * Q * c->vol * sizeof(double), c->stream));
+    const size_t fbytes = (c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol) * sizeof(double);
+    double *stage = nullptr;
+    LBMPM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&stage), 2 * n * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(stage, rho_r, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(stage + n, rho_b, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->fA, 0, fbytes, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->fB, 0, fbytes, c->stream);
+    if (e == hipSuccess) {
+        RK3Dev p = make_dev(c);
+        if (c->compact) rk3dc_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
+        else rk3d_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(stage);
+    if (e != hipSuccess) { set_error("lbmpm_rk3d_set_density: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     c->streamed = false;
     c->steps = 0;
@@ -664,7 +1199,9 @@ extern "C" int lbmpm_rk3d_pack_halo(lbmpm_rk3d *c)
     LBMPM_REQUIRE(c, "null context");
     RK3Dev p = make_dev(c);
     const int threads = 256;
-    rk3d_pack<<<dim3((unsigned)((c->plane2 + threads - 1) / threads)), dim3(threads), 0, c->stream>>>(p, c->fA, c->send_up, c->send_dn);
+    const dim3 grid((unsigned)((c->plane2 + threads - 1) / threads));
+    if (c->compact) rk3dc_pack<<<grid, dim3(threads), 0, c->stream>>>(p, c->fA, c->send_up, c->send_dn);
+    else rk3d_pack<<<grid, dim3(threads), 0, c->stream>>>(p, c->fA, c->send_up, c->send_dn);
     LBMPM_HIP_TRY(hipGetLastError());
     return LBMPM_OK;
 }
@@ -674,8 +1211,9 @@ extern "C" int lbmpm_rk3d_unpack_halo(lbmpm_rk3d *c, int have_below, int have_ab
     LBMPM_REQUIRE(c, "null context");
     RK3Dev p = make_dev(c);
     const int threads = 256;
-    rk3d_unpack<<<dim3((unsigned)((c->plane2 + threads - 1) / threads)), dim3(threads), 0, c->stream>>>(
-        p, c->fA, c->recv_below, c->recv_above, have_below, have_above);
+    const dim3 grid((unsigned)((c->plane2 + threads - 1) / threads));
+    if (c->compact) rk3dc_unpack<<<grid, dim3(threads), 0, c->stream>>>(p, c->fA, c->recv_below, c->recv_above, have_below, have_above);
+    else rk3d_unpack<<<grid, dim3(threads), 0, c->stream>>>(p, c->fA, c->recv_below, c->recv_above, have_below, have_above);
     LBMPM_HIP_TRY(hipGetLastError());
     return LBMPM_OK;
 }
@@ -687,14 +1225,16 @@ extern "C" int lbmpm_rk3d_phase_field(lbmpm_rk3d *c, int with_diagnostics)
     if (with_diagnostics && !c->diag) { const int rc = dev_alloc(c, &c->diag, 5 * c->vol); if (rc) return rc; }
     RK3Dev p = make_dev(c);
     p.diag = with_diagnostics ? c->diag : nullptr;
-    if (c->variant == 1 || with_diagnostics) {
-        rk3d_phase_field<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, 1);
-    } else {
+    auto k1 = [&](int planes, int zl0) {
+        if (c->compact) rk3dc_phase_field<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3, planes), dim3(BX3, BY3), 0, c->stream>>>(p, zl0);
+        else rk3d_phase_field<<<grid3(c, planes), dim3(BX3, BY3), 0, c->stream>>>(p, zl0);
+    };
+    if (c->variant == 1 || with_diagnostics) k1(c->nzl, 1);
+    else {
         // fused variant: the marching kernel computes the phase field itself; only the planes a
         // neighbour rank needs are produced here
-        if (c->cfg.z_offset > 0) rk3d_phase_field<<<grid3(c, 1), dim3(BX3, BY3), 0, c->stream>>>(p, 1);
-        if (c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global && (c->nzl > 1 || c->cfg.z_offset == 0))
-            rk3d_phase_field<<<grid3(c, 1), dim3(BX3, BY3), 0, c->stream>>>(p, c->nzl);
+        if (c->cfg.z_offset > 0) k1(1, 1);
+        if (c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global && (c->nzl > 1 || c->cfg.z_offset == 0)) k1(1, c->nzl);
     }
     LBMPM_HIP_TRY(hipGetLastError());
     return LBMPM_OK;
@@ -711,10 +1251,25 @@ void launch_fused(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, i
     else rk3d_fused<TX, TY, false><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
 }
 
+template <int TY>
+void launch_fused_c(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last)
+{
+    const int tilesX = c->nseg, tilesY = (c->ny + TY - 1) / TY, rpx = (tilesY + 7) / 8;
+    const int nchunks = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
+    const dim3 grid((unsigned)(8 * tilesX * rpx * nchunks)), block(64 * TY);
+    if (p.first) rk3dc_fused<TY, true><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+    else rk3dc_fused<TY, false><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+}
+
 // planes z_first..z_last of the time step on stream st
 void launch_step_range(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last)
 {
     if (z_last < z_first) return;
+    if (c->compact) {
+        if (c->tile == 1) launch_fused_c<4>(c, p, st, z_first, z_last);
+        else launch_fused_c<8>(c, p, st, z_first, z_last);
+        return;
+    }
     if (c->tile == 1) launch_fused<64, 4>(c, p, st, z_first, z_last);        // 3 blocks/CU, 55 % rim
     else if (c->tile == 2) launch_fused<32, 8>(c, p, st, z_first, z_last);
     else launch_fused<64, 8>(c, p, st, z_first, z_last);                     // default: 1 block/CU, 29 % rim
@@ -845,12 +1400,15 @@ extern "C" int lbmpm_rk3d_sync(lbmpm_rk3d *c)
 extern "C" int lbmpm_rk3d_buffer(lbmpm_rk3d *c, int which, void **ptr, int64_t *bytes)
 {
     LBMPM_REQUIRE(c && ptr && bytes, "lbmpm_rk3d_buffer: null argument");
-    const int64_t fb = (int64_t)(10 * c->plane2 * sizeof(double)), pb = (int64_t)(c->plane2 * sizeof(double));
+    const int64_t pb = (int64_t)(c->plane2 * sizeof(double));
+    // compact storage moves the fluid cells of the plane only (the two sides of a cut hold the same plane)
+    auto fb = [&](int zl) { return c->compact ? (int64_t)((c->h_pstart[zl + 1] - c->h_pstart[zl]) * 10 * sizeof(double))
+                                              : (int64_t)(10 * c->plane2 * sizeof(double)); };
     switch (which) {
-        case LBMPM_RK3D_BUF_F_SEND_UP: *ptr = c->send_up; *bytes = fb; return LBMPM_OK;
-        case LBMPM_RK3D_BUF_F_SEND_DOWN: *ptr = c->send_dn; *bytes = fb; return LBMPM_OK;
-        case LBMPM_RK3D_BUF_F_RECV_FROM_BELOW: *ptr = c->recv_below; *bytes = fb; return LBMPM_OK;
-        case LBMPM_RK3D_BUF_F_RECV_FROM_ABOVE: *ptr = c->recv_above; *bytes = fb; return LBMPM_OK;
+        case LBMPM_RK3D_BUF_F_SEND_UP: *ptr = c->send_up; *bytes = fb(c->nzl); return LBMPM_OK;
+        case LBMPM_RK3D_BUF_F_SEND_DOWN: *ptr = c->send_dn; *bytes = fb(1); return LBMPM_OK;
+        case LBMPM_RK3D_BUF_F_RECV_FROM_BELOW: *ptr = c->recv_below; *bytes = fb(0); return LBMPM_OK;
+        case LBMPM_RK3D_BUF_F_RECV_FROM_ABOVE: *ptr = c->recv_above; *bytes = fb(c->nzl + 1); return LBMPM_OK;
         case LBMPM_RK3D_BUF_PHI_SEND_UP: *ptr = c->phi + (size_t)c->nzl * c->plane2; *bytes = pb; return LBMPM_OK;
         case LBMPM_RK3D_BUF_PHI_SEND_DOWN: *ptr = c->phi + c->plane2; *bytes = pb; return LBMPM_OK;
         case LBMPM_RK3D_BUF_PHI_RECV_FROM_BELOW: *ptr = c->phi; *bytes = pb; return LBMPM_OK;
@@ -889,7 +1447,16 @@ extern "C" int lbmpm_rk3d_get_field(lbmpm_rk3d *c, int field, double *out)
     return LBMPM_OK;
 }
 
+// tuning aid (LBMPM_RK3D_TIMING=1): shader-clock ticks one block spent per phase, wave 0 then the last wave
+extern "C" int lbmpm_rk3d_debug_timing(lbmpm_rk3d *c, unsigned long long *out10)
+{
+    LBMPM_REQUIRE(c && out10 && c->dbg, "no timing buffer (set LBMPM_RK3D_TIMING=1 before create, compact storage only)");
+    LBMPM_HIP_TRY(hipMemcpyAsync(out10, c->dbg, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return LBMPM_OK;
+}
+
 extern "C" int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *c) { return c ? c->nfluid : 0; }
 extern "C" int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *c) { return c ? c->steps : 0; }
 extern "C" int64_t lbmpm_rk3d_device_bytes(const lbmpm_rk3d *c) { return c ? c->bytes : 0; }
-extern "C" const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *c) { return (c && c->variant == 1) ? "rk3d_collide" : "rk3d_fused"; }
+extern "C" const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *c) { return !c ? "" : (c->variant == 1 ? "rk3d_collide" : (c->compact ? "rk3dc_fused" : "rk3d_fused")); }

@@ -72,6 +72,48 @@ def test_kernel_schedules_agree_bitwise(env, monkeypatch):
     ref.close(); c.close()
 
 
+def test_compact_storage_vs_oracle():
+    """nx a multiple of 64 selects the compact (fluid-cells-only) storage"""
+    from openlbmpm_amd.rk3d import RK3DCluster
+    from oracle.rk3d import RK3DOracle
+    dom, rR, rB = _case(nx=128, ny=21, nz=30, seed=5)
+    par = dict(tauR=1.0, tauB=0.8)
+    c = RK3DCluster(dom, 1, par)
+    assert c.slabs[0].dominant_kernel == "rk3dc_fused"
+    c.set_density(rR, rB)
+    o = RK3DOracle(dom, rR, rB, par)
+    for n in (1, 14):
+        c.step(n); o.run(n)
+        c.observe(); o.macro()
+        for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz"):
+            e = rel_err(c.get(f), o.field(f))
+            assert e < TOL, "field %s rel err %.3e after %d steps" % (f, e, c.slabs[0].steps_done)
+    c.close()
+
+
+@pytest.mark.parametrize("env,k", [({}, 2), ({}, 3), ({"LBMPM_RK3D_BOUNDARY": "2"}, 3), ({"LBMPM_RK3D_TILE": "1"}, 1),
+                                   ({"LBMPM_RK3D_CHUNK": "7"}, 2)],
+                         ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
+def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch):
+    from openlbmpm_amd.rk3d import RK3DCluster
+    dom, rR, rB = _case(nx=64, ny=19, nz=41, seed=12)
+    monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")
+    ref = RK3DCluster(dom, 1)
+    assert ref.slabs[0].dominant_kernel == "rk3d_fused"
+    ref.set_density(rR, rB)
+    ref.step(11); ref.observe()
+    monkeypatch.delenv("LBMPM_RK3D_LAYOUT")
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    c = RK3DCluster(dom, k)
+    assert c.slabs[0].dominant_kernel == "rk3dc_fused"
+    c.set_density(rR, rB)
+    c.step(11); c.observe()
+    for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz"):
+        assert np.array_equal(ref.get(f), c.get(f)), f
+    ref.close(); c.close()
+
+
 def test_single_slab_convenience_equals_phases():
     from openlbmpm_amd.rk3d import RK3DCluster, RK3DSlab
     dom, rR, rB = _case(nx=24, ny=12, nz=20, seed=2)
