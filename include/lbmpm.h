@@ -308,8 +308,6 @@ int lbmpm_rk3d_sync(lbmpm_rk3d *ctx);
 int lbmpm_rk3d_buffer(lbmpm_rk3d *ctx, int which, void **device_ptr, int64_t *bytes);
 /* owned planes [nz_local][ny][nx] */
 int lbmpm_rk3d_get_field(lbmpm_rk3d *ctx, int field, double *out);
-/* tuning aid, needs LBMPM_RK3D_TIMING=1 at create: shader-clock ticks of one block per phase */
-int lbmpm_rk3d_debug_timing(lbmpm_rk3d *ctx, unsigned long long *out10);
 int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *ctx);
 int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *ctx);
 const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *ctx);

@@ -51,7 +51,6 @@ struct RK3Dev {
     const u32x4 *seg;                 // [rows][nseg] {fluid mask lo, hi, j of the first fluid cell, fluid(x0-1) | fluid(x0+64) << 1 | pad << 2}, rows = (nzl+2)*ny
     const u32x4 *seg2;                // [rows][nseg] {j of cell x0-1, j of cell x0+64 (periodic), -, -}
     const unsigned long long *pstart; // [nzl+3] fluid cells before plane zl
-    unsigned long long *dbg;          // phase timing of the marching kernel (LBMPM_RK3D_TIMING=1), else nullptr
     int nseg;
 };
 
@@ -687,8 +686,6 @@ __global__ __launch_bounds__(64 * TY, 768 / (64 * TY)) void rk3dc_fused(RK3Dev p
     const TileRowsU<TY, true> rows_rimrow{{srow, hly + 1, 1, true}};
     const TileRowsU<TY, false> rows_rimcol{{srow, hly + 1, hlx == 0 ? 0 : 2, false}};
     const int za = z_first + chunk * chunk_len, zb = min(za + chunk_len - 1, z_last);
-    const int expm = p.fill >= 1000 ? p.fill - 1000 : 0;     // TEMPORARY experiment switches
-    if (expm & 1) has_rim = false;
     // Row records are staged two march steps ahead of their first use: fetched into a register
     // during one step, written to LDS at the top of the next (so nobody waits for that fetch),
     // read from the step after.  72 lanes, one 16-byte record each.
@@ -739,10 +736,6 @@ __global__ __launch_bounds__(64 * TY, 768 / (64 * TY)) void rk3dc_fused(RK3Dev p
     };
     issue(za - 1);
 
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
-    const bool timed = p.dbg && bid == 8 * 3 && (tid == 0 || tid == 64 * (TY - 1));
-    auto stamp = [&](int k) { if (timed) { const unsigned long long t = clock64(); tacc[k] += t - tprev; tprev = t; } };
-    if (timed) tprev = clock64();
     for (int z = za - 2; z <= zb; ++z) {
         put_rows(z + 5, staged);                // read from the next march step on
         staged = fetch_rows(z + 6);
@@ -760,7 +753,6 @@ __global__ __launch_bounds__(64 * TY, 768 / (64 * TY)) void rk3dc_fused(RK3Dev p
             unsigned j;
             sphi[(z + 1) & (M::RING - 1)][hly][hlx] = ring_phi_c<FIRST, false>(p, rows_rimcol, hx, hy, z + 1, (unsigned)(hx & 63), f, fR, fB, a, c, j);
         }
-        stamp(0);
         // ---- plane z + 1, own cell (pulled during the previous march step): boundary rules, phase
         //      field into the ring, reduced state into the park (which still holds plane z: swap)
         double ft[Q];
@@ -786,21 +778,11 @@ __global__ __launch_bounds__(64 * TY, 768 / (64 * TY)) void rk3dc_fused(RK3Dev p
         }
         const bool padzz = padz;
         padz = pad_raw;
-        stamp(1);
         // ---- pulls of plane z + 2 into flight
         if (z + 2 <= zb + 1) issue(z + 2);
         else { fl_raw = false; pad_raw = false; }
-        stamp(2);
         __syncthreads();
-        stamp(3);
         // ---- plane z: collide
-        if (z >= za && fluid && own && (expm & 2)) {
-            const unsigned long long p0 = p.pstart[z], p1 = p.pstart[z + 1];
-            const unsigned cnt = (unsigned)(p1 - p0);
-            char *o = reinterpret_cast<char *>(p.fout) + (size_t)p0 * (Q * 16);
-            if (!(expm & 4)) for (int i = 0; i < Q; ++i) { double2 v; v.x = ft[i]; v.y = rRz; *reinterpret_cast<double2 *>(o + (size_t)i * cnt * 16u + jzz * 16u) = v; }
-            else if (ft[3] == 12345.) *reinterpret_cast<double *>(o) = rBz;
-        } else
         if (z >= za && ((fluid && own) || padzz)) {
             double gx = 0., gy = 0., gz = 0.;
 #pragma unroll
@@ -815,10 +797,7 @@ __global__ __launch_bounds__(64 * TY, 768 / (64 * TY)) void rk3dc_fused(RK3Dev p
             collide_store<true>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * (Q * 16), cnt * 16u, jzz * 16u, fluid, ft, rRz, rBz, gx, gy, gz);
         }
         fluid = fluidn;
-        stamp(4);
     }
-    if (timed)
-        for (int k = 0; k < 5; ++k) p.dbg[(tid == 0 ? 0 : 5) + k] = tacc[k];
 }
 
 // halo packing on compact storage: the five populations (both colours) that cross each cut, as
@@ -962,7 +941,6 @@ struct lbmpm_rk3d {
     size_t ncells = 0;               // stored cells, halo planes included
     unsigned long long *pstart = nullptr;
     uint32_t *seg = nullptr, *seg2 = nullptr;        // 4 words per record
-    unsigned long long *dbg = nullptr;
     std::vector<unsigned long long> h_pstart;
     bool streamed = false;
     int variant = 0, tile = 0, chunk_len = 32, fill = 16, boundary = 8;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL / _BOUNDARY
@@ -980,7 +958,7 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     RK3Dev p{};
     p.nx = c->nx; p.ny = c->ny; p.nzl = c->nzl; p.pitch = c->pitch; p.plane2 = c->plane2; p.vol = c->vol;
     p.plane_bytes = (unsigned)(c->plane2 * sizeof(double));
-    p.seg = reinterpret_cast<const u32x4 *>(c->seg); p.seg2 = reinterpret_cast<const u32x4 *>(c->seg2); p.pstart = c->pstart; p.nseg = c->nseg; p.dbg = c->dbg;
+    p.seg = reinterpret_cast<const u32x4 *>(c->seg); p.seg2 = reinterpret_cast<const u32x4 *>(c->seg2); p.pstart = c->pstart; p.nseg = c->nseg;
     p.z0 = (int)c->cfg.z_offset; p.nzg = (int)c->cfg.nz_global;
     p.flags = c->flags; p.solidnbr = c->solidnbr; p.fin = c->fA; p.fout = c->fB; p.phi = c->phi; p.diag = nullptr;
     p.ak = (c->cfg.ak_r + c->cfg.ak_b) * 0.5; p.beta = c->cfg.beta; p.cR = 1. / (2. * (c->cfg.tau_r - 0.5)); p.cB = 1. / (2. * (c->cfg.tau_b - 0.5));
@@ -1025,7 +1003,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_CHUNK")) chunk_len = atoi(e) > 0 ? atoi(e) : 32;
     if (const char *e = getenv("LBMPM_RK3D_FILL")) fill = atoi(e);
     LBMPM_REQUIRE(variant == 0 || variant == 1, "lbmpm_rk3d_create: variant must be 0 (fused) or 1 (split)");
-    LBMPM_REQUIRE(fill >= 1000 || fill == 0 || fill == 4 || fill == 8 || fill == 16 || fill == 32 || fill == 64,
+    LBMPM_REQUIRE(fill == 0 || fill == 4 || fill == 8 || fill == 16 || fill == 32 || fill == 64,
                   "LBMPM_RK3D_FILL must be 0 or a power of two <= 64");
     LBMPM_HIP_TRY(hipSetDevice(cfg->device));
     lbmpm_rk3d *c = new (std::nothrow) lbmpm_rk3d();
@@ -1112,7 +1090,6 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
         TRY_RC(dev_alloc(c, &c->seg, hseg.size()));
         TRY_RC(dev_alloc(c, &c->seg2, hseg2.size()));
         TRY_RC(dev_alloc(c, &c->pstart, c->h_pstart.size()));
-        if (getenv("LBMPM_RK3D_TIMING")) TRY_RC(dev_alloc(c, &c->dbg, 16));
     }
     const size_t fcount = c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol;
     TRY_RC(dev_alloc(c, &c->fA, fcount));
@@ -1144,7 +1121,7 @@ extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->dbg, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->phi, (void *)c->diag,
+    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->phi, (void *)c->diag,
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
@@ -1444,15 +1421,6 @@ extern "C" int lbmpm_rk3d_get_field(lbmpm_rk3d *c, int field, double *out)
                 const size_t s = (size_t)z * hp + (size_t)y * c->nx + x;
                 out[s] = c->h_domain[s] == 1 ? h[(size_t)(z + 1) * c->plane2 + (size_t)y * c->pitch + x] : 0.0;
             }
-    return LBMPM_OK;
-}
-
-// tuning aid (LBMPM_RK3D_TIMING=1): shader-clock ticks one block spent per phase, wave 0 then the last wave
-extern "C" int lbmpm_rk3d_debug_timing(lbmpm_rk3d *c, unsigned long long *out10)
-{
-    LBMPM_REQUIRE(c && out10 && c->dbg, "no timing buffer (set LBMPM_RK3D_TIMING=1 before create, compact storage only)");
-    LBMPM_HIP_TRY(hipMemcpyAsync(out10, c->dbg, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     return LBMPM_OK;
 }
 

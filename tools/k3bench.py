@@ -19,11 +19,6 @@ def run(dom, label, steps=20):
     print("%-28s fluid %.1fM  step %.3f ms  collide %.3f ms  MLUPS %.0f  collide GB/s(alg) %.0f" % (
         label, nf / 1e6, ms_total / steps, ms_dom / steps, nf * steps / ms_total / 1e3,
         608.0 * nf / (ms_dom / steps * 1e-3) / 1e9), flush=True)
-    if os.environ.get("LBMPM_RK3D_TIMING"):
-        import ctypes as C
-        buf = (C.c_uint64 * 10)()
-        if s._L.lbmpm_rk3d_debug_timing(s._h, buf) == 0:
-            print("   phase ticks wave0: %s   last wave: %s" % (list(buf[:5]), list(buf[5:])), flush=True)
     s.close()
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
