@@ -41,7 +41,10 @@ def pmc_traffic(kernel, workload_tag):
     (profiles/pmc_traffic.json), or None when no profile matches this exact workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            rec = json.load(fh)["kernels"].get(kernel)
+            recs = json.load(fh)["kernels"]
+        rec = recs.get(kernel)
+        if rec and rec.get("workload") != workload_tag:      # other template instance of the same kernel (tracer on/off)
+            rec = next((r for k, r in recs.items() if k.startswith(kernel) and r.get("workload") == workload_tag), None)
     except (OSError, ValueError, KeyError):
         return None
     if not rec or rec.get("workload") != workload_tag:

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the FETCH_SIZE and WRITE_SIZE summaries written by
+tools/rocprof_summary.py --pmc (separate rocprofv3 passes).
+
+traffic = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): the x2 on FETCH_SIZE is the gfx950 correction of
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section), calibrated there on 16-byte-per-lane streaming
+reads; rk3dc_fused reads 16 B per lane, the 2-D kernels read 8 B per lane (their read side is an
+upper estimate).  WRITE_SIZE is taken as reported (it matches the algorithmic write bytes of
+these kernels to within 2 %)."""
+import json
+import re
+import sys
+
+WORKLOADS = {"rk3dc_fused": "c5 512x512x512", "rk3d_fused": "c5 512x512x512", "rk3d_collide": "c5 512x512x512",
+             "rk3d_phase_field": "c5 512x512x512", "rk2d_fused": None, "sc2d_fused": "c3 2048x2048"}
+
+
+def parse(path, counter):
+    out = {}
+    for line in open(path):
+        m = re.match(r"^(.*?)\s+%s\s+(\d+)\s+([0-9.]+)\s*$" % counter, line.rstrip())
+        if m:
+            out[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
+    return out
+
+
+def short(name):
+    m = re.search(r"(rk3dc?_\w+|rk2d_\w+|sc2d_\w+)", name)
+    return m.group(1) if m else name
+
+
+def main():
+    fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
+    kernels = {}
+    for name, (n, f) in fetch.items():
+        k = short(name)
+        if k not in WORKLOADS or "true" in name.split(k)[1][:20] and k.endswith("fused") and "rk3d" in k:
+            continue                      # first-step instantiation of the 3-D kernel: one launch only
+        w = write.get(name, (0, 0.0))[1]
+        rec = {"launches_profiled": n, "fetch_size_kb": f, "write_size_kb": w,
+               "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0, "workload": WORKLOADS[k]}
+        if k == "rk2d_fused":             # c2 (no tracer) and c4 (tracer) are different template instances
+            rec["workload"] = "c4 2048x2048" if re.search(r"rk2d_fused<(true|false), true", name) else "c2 1024x1024"
+            k = "rk2d_fused" if rec["workload"].startswith("c2") else "rk2d_fused[tracer]"
+        kernels[k] = rec
+    print(json.dumps({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+                                "`python bench.py --steps 10 --warmup 2 --no-cpu-baseline`, MI355X (tools/profile_round.sh)",
+                      "correction": "traffic = 2*FETCH_SIZE + WRITE_SIZE (KB -> B); x2 = the guide's gfx950 FETCH_SIZE correction "
+                                    "(calibrated on 16-B lanes; exact for rk3dc_fused, upper estimate for the 8-B-lane 2-D kernels)",
+                      "kernels": kernels}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
