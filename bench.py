@@ -52,6 +52,17 @@ def pmc_traffic(kernel, workload_tag):
     return rec["traffic_bytes_per_launch"]
 
 
+def measured_hbm(device):
+    """copy / read-only GB/s of this device over 2 x 4 GiB (context for roofline.frac, which is quoted
+    against the 8 TB/s specification)"""
+    import ctypes as C
+    from openlbmpm_amd import _lib
+    a, b = C.c_double(0), C.c_double(0)
+    if _lib.lib().lbmpm_hbm_stream_test(int(device), 4 << 30, 5, C.byref(a), C.byref(b)) != 0:
+        return None
+    return {"copy_GBs": round(a.value, 1), "read_GBs": round(b.value, 1), "bytes_per_buffer": 4 << 30}
+
+
 # ----------------------------------------------------------------------------- workloads
 def build_c2(nx, ny, device):
     from openlbmpm_amd.rk2d import RK2DSolver
@@ -194,7 +205,7 @@ def main():
         dom = c5_domain(size)
         nz = size[2]
         nfluid_global = int(dom.sum())
-        z0, nzl = partition_z(nz, world)[rank]
+        z0, nzl = RK3DDistributed.partition(dom, world)[rank]       # equal fluid cells per rank
         rR, rB = c5_densities(dom[z0:z0 + nzl], z0, nz)
         m0_local = float((rR + rB).sum())
         if world == 1:
@@ -255,6 +266,7 @@ def main():
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
                              "traffic": pmc_traffic(dom_kernel, "c5 %dx%dx%d" % size) if world == 1 else None,
                              "kernel": dom_kernel,
+                             "measured_stream_ceiling": measured_hbm(local_rank) if world == 1 else None,
                              "note": None if world == 1 else "N>1: the kernel runs as interior + boundary launches on two "
                                      "streams under the halo exchange; avg_launch_ms brackets the whole step, exchange included",
                              "avg_launch_ms": round(per_launch_ms, 5),
@@ -314,6 +326,7 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
                              "traffic": pmc_traffic(solver.dominant_kernel, "%s %dx%d" % ((wl,) + size)),
+                             "measured_stream_ceiling": measured_hbm(local_rank),
                              "kernel": solver.dominant_kernel, "avg_launch_ms": round(per_launch_ms, 6),
                              "algorithmic_bytes_per_launch": B_ALG[wl] * nfluid},
             }

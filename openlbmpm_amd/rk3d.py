@@ -7,7 +7,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import F64P, U8P, RK3DConfig, check
-from .slab import partition_z, neighbour_exchange, local_exchange, DeviceBuffer
+from .slab import partition_z, partition_z_balanced, neighbour_exchange, local_exchange, DeviceBuffer
 
 FIELDS = dict(phi=0, rhoR=1, rhoB=2, vx=3, vy=4, vz=5)
 BUF = dict(f_send_up=0, f_send_down=1, f_recv_below=2, f_recv_above=3,
@@ -193,16 +193,24 @@ class RK3DCluster:
 class RK3DDistributed:
     """One slab per process/GPU; halos over torch.distributed P2P (RCCL over xGMI)."""
 
-    def __init__(self, is_domain_global, params=None, device=0, group=None):
+    def __init__(self, is_domain_global, params=None, device=0, group=None, balance=True):
         import torch.distributed as dist
         self.rank, self.world, self.group = dist.get_rank(group), dist.get_world_size(group), group
-        z0, n = partition_z(is_domain_global.shape[0], self.world)[self.rank]
+        z0, n = self.partition(is_domain_global, self.world, balance)[self.rank]
         self.z0, self.nzl = z0, n
         import torch
         self._torch = torch
         self.slab = RK3DSlab(is_domain_global, z0, n, params, device)
         self.stream = torch.cuda.Stream(device)
         self.slab.use_torch_stream(self.stream)
+
+    @staticmethod
+    def partition(is_domain_global, world, balance=True):
+        """z-ranges of the ranks: equal fluid cells per rank (default) or equal planes"""
+        if not balance or world == 1:
+            return partition_z(is_domain_global.shape[0], world)
+        counts = (np.asarray(is_domain_global) == 1).reshape(is_domain_global.shape[0], -1).sum(axis=1)
+        return partition_z_balanced(counts, world)
 
     def set_density(self, rhoR_global, rhoB_global):
         self.slab.set_density(rhoR_global[self.z0:self.z0 + self.nzl], rhoB_global[self.z0:self.z0 + self.nzl])

@@ -21,6 +21,27 @@ def partition_z(nz_global, world):
     return out
 
 
+def partition_z_balanced(fluid_per_plane, world, min_planes=2):
+    """Contiguous z-ranges with (nearly) equal numbers of FLUID cells: the time of a slab is
+    proportional to its fluid cells, and the all-fluid buffer planes at both ends of a porous
+    sample would otherwise make the end ranks ~8 % slower than the rest.
+    Every rank derives the same cuts from the same mask; no communication."""
+    w = [int(v) for v in fluid_per_plane]
+    nz = len(w)
+    if world < 1 or nz < min_planes * world:
+        raise ValueError("cannot cut %d planes into %d slabs of >= %d planes" % (nz, world, min_planes))
+    total, cuts, acc, z = float(sum(w)), [0], 0.0, 0
+    for r in range(1, world):
+        target = total * r / world
+        lo, hi = cuts[-1] + min_planes, nz - min_planes * (world - r)
+        while z < hi and (z < lo or acc + w[z] * 0.5 <= target):
+            acc += w[z]
+            z += 1
+        cuts.append(z)
+    cuts.append(nz)
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+
+
 def neighbour_exchange(send_up, send_down, recv_from_below, recv_from_above, rank, world, group=None):
     """Every rank sends `send_up` to rank+1 (which receives it in `recv_from_below`) and
     `send_down` to rank-1 (received in `recv_from_above`).  No wrap-around: the global lattice is

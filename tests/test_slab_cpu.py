@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from openlbmpm_amd.slab import partition_z, neighbour_exchange, local_exchange
+from openlbmpm_amd.slab import partition_z, partition_z_balanced, neighbour_exchange, local_exchange
 
 
 def test_partition_covers_and_orders():
@@ -81,3 +81,21 @@ def test_neighbour_exchange_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(r, True) for r in range(world)]
+
+
+def test_balanced_partition_equalises_fluid_cells():
+    rng = np.random.default_rng(3)
+    w = np.full(512, 170000); w[:10] = 262144; w[-10:] = 262144
+    w = w + rng.integers(-3000, 3000, size=512)
+    for world in (1, 2, 3, 4, 8):
+        parts = partition_z_balanced(w, world)
+        assert parts[0][0] == 0 and sum(n for _, n in parts) == 512
+        assert all(parts[r][0] + parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+        assert all(n >= 2 for _, n in parts)
+        loads = [int(w[z0:z0 + n].sum()) for z0, n in parts]
+        assert max(loads) <= 1.01 * (w.sum() / world) + w.max()
+    # degenerate: all fluid in one plane still leaves every rank its two planes
+    w = np.zeros(16, dtype=int); w[5] = 100
+    assert all(n >= 2 for _, n in partition_z_balanced(w, 8))
+    with pytest.raises(ValueError):
+        partition_z_balanced(np.ones(7), 4)
