@@ -1,0 +1,84 @@
+"""Driver counterpart of the reference's RKCG2D/Transport2DRK.py (own code): tracers carried by the
+colour-gradient two-phase flow, class Transport2DRK(pathIniFile).runTransport2DMPMCRKNew().
+
+The reference file does not parse and its `transportsetup.ini` is not
+shipped; key names are the ones its constructor reads (Transport2DRK.py:31-311,
+openlbmpm_amd/config.read_transport).  Kept: the flow set-up of RKColorGradientLBM; the initial
+concentration rules (Transport2DRK.py:413-452: tracer 0 = 1 below the top buffer rows for
+generated geometries, every tracer = 1 in the 10 top rows for image geometries); initial
+distribution g_i = w_i C (:466-469); one tracer sub-step inside every flow step at the place the
+reference does it (:1341-1418, fused into the flow kernel here); record cadence
+`(iStep-1) % TimeInterval == 0`; flow datasets of SimulationResultsRK.h5 and
+`/TransportMacro/TracerConcType<k>in<record>` of ConcentrationResults.h5 (:651-661).
+Note the two views inside one record: the flow arrays are the state at the START of step iStep
+(after streaming and boundary kernels, :1302-1312), the concentrations the state AFTER the tracer
+update of that same step (:1418-1432).
+"""
+import numpy as np
+
+from . import config
+from .RKD2Q9 import RKColorGradientLBM
+from .results import ResultFile
+from .rk2d import RK2DSolver
+
+
+class Transport2DRK(RKColorGradientLBM):
+    def __init__(self, pathIniFile, output_dir=None, image=None, device=0):
+        RKColorGradientLBM.__init__(self, pathIniFile, output_dir=output_dir, image=image, device=device)
+        self.tr = config.read_transport(pathIniFile)
+        self.numTracers = self.tr["num_tracers"]
+
+    def initializeTransportDomain(self):
+        """Transport2DRK.py:399-469"""
+        p, t = self.par, self.tr
+        ny, nx = self.isDomain.shape
+        rows = np.arange(ny)[:, None]
+        fluid = self.isDomain == 1
+        conc = np.zeros((self.numTracers, ny, nx))
+        if p["image"]:
+            conc[:, (fluid & (rows >= ny - 10))] = 1.0
+        else:
+            conc[0, (fluid & (rows <= ny - p["nbuf"]))] = 1.0
+        # [InitialCondition] TracerConc is read by the reference (:199-206) but never applied
+        self.tracerConc = conc
+
+    def runTransport2DMPMCRKNew(self, progress=None):
+        p, t = self.par, self.tr
+        if p["tension_type"] != "CSF":
+            raise config.ConfigError("the coupled loop uses the CSF colour-gradient flow (Transport2DRK.py:1434-1485)")
+        self.initializeDomainBorder()
+        self.initializeDomainCondition()
+        self.initializeTransportDomain()
+        keys = ("sigma", "theta", "wetting", "beta", "delta", "tauR", "tauB", "tautype", "relax", "inlet", "outlet",
+                "vyR", "vyB", "rhoBH", "rhoRH", "rhoBL", "rhoRL")
+        solver = RK2DSolver(self.isDomain, {k: p[k] for k in keys}, device=self.device)
+        solver.set_macro(self.fluidsRhoR, self.fluidsRhoB)
+        n = self.numTracers
+        solver.configure_tracers(diffX=tuple(t["diffX"]), diffY=tuple(t["diffY"]), dXY=t["dXY"], dYX=t["dYX"],
+                                 beta=(t["beta"],) * n, crit=0.5, inlet_conc=tuple(t["inlet_conc"]),
+                                 free_outlet=True, dirichlet_inlet=True)
+        for k in range(n):
+            solver.set_tracer(k, self.tracerConc[k])
+        flow = ResultFile(self.output_dir, "SimulationResultsRK",
+                          (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity")))
+        conc = ResultFile(self.output_dir, "ConcentrationResults", (("TransportMacro", "MacroData"),))
+        self.result_path, self.concentration_path = flow.path, conc.path
+        done = 0
+        while done < self.timeSteps:
+            if done % self.timeInterval == 0:
+                k = self.records
+                self._record(solver, flow)              # flow view at the start of step done + 1
+                solver.step(1)
+                done += 1
+                for i in range(n):                      # concentrations after the tracer update of that step
+                    self.tracerConc[i] = solver.get_tracer(i)
+                    conc.write("TransportMacro", "TracerConcType%gin%g" % (i, k), self.tracerConc[i])
+            m = min(self.timeInterval - done % self.timeInterval, self.timeSteps - done) if done % self.timeInterval else 0
+            if m:
+                solver.step(m)
+                done += m
+            if progress:
+                progress(done)
+        solver.sync()
+        self.solver = solver
+        return self.result_path, self.concentration_path

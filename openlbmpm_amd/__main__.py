@@ -2,6 +2,7 @@
 
     python -m openlbmpm_amd rk  <ini-dir> [--out DIR] [--steps N] [--device D]
     python -m openlbmpm_amd sc  <ini-dir> [--out DIR] [--steps N] [--device D]
+    python -m openlbmpm_amd tr  <ini-dir> ...      colour gradient + tracers (RKtwophasesetup2D.ini + transportsetup.ini)
 """
 import argparse
 import sys
@@ -10,7 +11,7 @@ import time
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m openlbmpm_amd")
-    ap.add_argument("model", choices=["rk", "sc"], help="rk = colour gradient (RKtwophasesetup2D.ini); "
+    ap.add_argument("model", choices=["rk", "sc", "tr"], help="rk = colour gradient (RKtwophasesetup2D.ini); "
                                                        "sc = Shan-Chen / EFS (twophasesetup.ini + efs2D.ini|shanchen2D.ini)")
     ap.add_argument("ini_dir")
     ap.add_argument("--out", default=None, help="result directory (default ~/LBMResults)")
@@ -24,6 +25,13 @@ def main(argv=None):
         if a.steps is not None:
             sim.timeSteps = a.steps
         path = sim.runRKColorGradient2D()
+        steps, nodes = sim.timeSteps, sim.voidSpace
+    elif a.model == "tr":
+        from .Transport2DRK import Transport2DRK
+        sim = Transport2DRK(a.ini_dir, output_dir=a.out, device=a.device)
+        if a.steps is not None:
+            sim.timeSteps = a.steps
+        path = " and ".join(sim.runTransport2DMPMCRKNew())
         steps, nodes = sim.timeSteps, sim.voidSpace
     else:
         from .ShanChenD2Q9 import ShanChenD2Q9

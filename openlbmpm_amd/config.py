@@ -139,3 +139,44 @@ def read_sc2d(ini_dir):
         raise ConfigError("ExplicitScheme 8/10 (higher isotropy) is not built yet")
     p["steps"] = m.int("Time", "numberTimeStep")
     return p
+
+
+def read_transport(ini_dir):
+    """transportsetup.ini -> dict (keys consumed by Transport2DRK.py:31-311; the file itself is not
+    shipped with the reference).  Only the combinations its working loop runTransport2DMPMCRKNew
+    can execute are accepted: multiphase flow system, D2Q5, MRT, no reaction, Dirichlet (Inamuro)
+    inlet, free-flow outlet."""
+    c = Ini(os.path.join(ini_dir, "transportsetup.ini"))
+    p = {}
+    if c.str("SystemType", "Option") != "MPMC":
+        raise ConfigError("[SystemType] Option: only 'MPMC' (tracers in the two-phase flow) is part of the GPU path")
+    if c.str("SystemType", "Reaction") != "no":
+        raise ConfigError("[SystemType] Reaction = 'yes' is not built (SURVEY.md section 8f-4)")
+    p["precipitation"] = c.str("SystemType", "Precipitation")
+    if c.int("SystemType", "NumberSchemes") != 5:
+        raise ConfigError("[SystemType] NumberSchemes: only the D2Q5 scheme is on the working path (Transport2DRK.py:1343-1384)")
+    n = c.int("TransportParameters", "NumberTracers")
+    if not 1 <= n <= 4:
+        raise ConfigError("[TransportParameters] NumberTracers must be 1..4")
+    p["num_tracers"] = n
+    p["diffJ"] = c.floats("TransportParameters", "DiffusionJ", n)
+    p["tau"] = c.floats("TransportParameters", "Tau", n)
+    p["beta"] = c.float("TransportParameters", "BetaInterface")
+    if c.str("BoundaryCondition", "InletType") != "Dirichlet":
+        raise ConfigError("[BoundaryCondition] InletType: only 'Dirichlet' (calInamuroConstConcBoundary) is called by the loop")
+    p["inlet_conc"] = c.floats("BoundaryCondition", "ConcentrationInlet", n)
+    if c.str("BoundaryCondition", "OutletType") != "FreeFlow":
+        raise ConfigError("[BoundaryCondition] OutletType: only 'FreeFlow' (calFreeConcBoundary3) is called by the loop")
+    p["init_type"] = c.str("InitialCondition", "Type")
+    if p["init_type"] == "Homogeneous":
+        p["init_conc"] = c.floats("InitialCondition", "TracerConc", n)
+    p["fluid"] = c.int("FluidForTransport", "FluidType")
+    if c.str("RelaxationType", "Relaxation") != "MRT":
+        raise ConfigError("[RelaxationType] Relaxation: the D2Q5 path is MRT (calCollisionTransportLinearEqlMRTGPU)")
+    p["diffX"] = c.floats("TransportMRT", "DiffusionX", n)
+    p["diffY"] = c.floats("TransportMRT", "DiffusionY", n)
+    # the reference indexes these two by tracer when reading and uses the whole list as a scalar
+    # when filling S (Transport2DRK.py:334-335): one value for all tracers is what it can run with
+    p["dXY"] = c.floats("TransportMRT", "DiffusionXY", n)[0]
+    p["dYX"] = c.floats("TransportMRT", "DiffusionYX", n)[0]
+    return p

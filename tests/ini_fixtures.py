@@ -146,3 +146,44 @@ def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirich
         fh.write(MODEL_INI.format(section="EFSParameters" if efs else "ShanChenParameters", bg=0.02 if efs else 0.06,
                                   G=0.20 if efs else 3.8, Gs0=-0.14 if efs else -0.40, Gs1=0.14 if efs else 0.40,
                                   outlet=outlet, vy1=-5.03e-4 if efs else -1.01e-3, steps=steps))
+
+
+TRANSPORT_INI = """[SystemType]
+Option = 'MPMC'
+Reaction = 'no'
+Precipitation = 'no'
+NumberSchemes = 5
+
+[TransportParameters]
+NumberTracers = 2
+DiffusionJ = 0.3333333333333333, 0.3333333333333333
+Tau = 1.0, 1.0
+BetaInterface = 0.8
+
+[BoundaryCondition]
+InletType = 'Dirichlet'
+ConcentrationInlet = 1.0, 0.25
+OutletType = 'FreeFlow'
+
+[InitialCondition]
+Type = 'Homogeneous'
+TracerConc = 1.0, 0.5
+
+[FluidForTransport]
+FluidType = 0
+
+[RelaxationType]
+Relaxation = 'MRT'
+
+[TransportMRT]
+DiffusionX = 0.16666666666666666, 0.12
+DiffusionY = 0.16666666666666666, 0.2
+DiffusionXY = 0.01, 0.01
+DiffusionYX = 0.02, 0.02
+"""
+
+
+def write_transport(d):
+    import os
+    with open(os.path.join(d, "transportsetup.ini"), "w") as fh:
+        fh.write(TRANSPORT_INI)

@@ -37,3 +37,16 @@ def test_sc_ini(tmp_path, inter):
     p = config.read_sc2d(str(tmp_path))
     assert p["inter"] == inter and p["steps"] == 300 and (p["tau0"], p["tau1"]) == (1.0, 1.0)
     assert p["G"] == (0.20 if inter == "EFS" else 3.8)
+
+
+def test_transport_ini(tmp_path):
+    from ini_fixtures import write_transport, TRANSPORT_INI
+    from openlbmpm_amd import config
+    write_transport(str(tmp_path))
+    t = config.read_transport(str(tmp_path))
+    assert t["num_tracers"] == 2 and t["diffX"] == [1. / 6., 0.12] and t["dXY"] == 0.01 and t["beta"] == 0.8
+    for old, new in (("'MPMC'", "'Single'"), ("NumberSchemes = 5", "NumberSchemes = 9"), ("'FreeFlow'", "'Dirichlet'"),
+                     ("Reaction = 'no'", "Reaction = 'yes'"), ("0.12", "0.12, 0.3")):
+        (tmp_path / "transportsetup.ini").write_text(TRANSPORT_INI.replace(old, new))
+        with pytest.raises(config.ConfigError):
+            config.read_transport(str(tmp_path))

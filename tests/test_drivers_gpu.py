@@ -41,6 +41,40 @@ def test_sc_driver_records_match_reference(tmp_path):
             assert rel_err(res["/" + name % rec], g) < 1e-9, name % rec
 
 
+def test_transport_driver_records_match_coupled_oracle(tmp_path):
+    """Transport2DRK counterpart: flow records as the RK driver writes them, concentration records =
+    state after the tracer update of the recording step (Transport2DRK.py:1418-1432)"""
+    from ini_fixtures import write_transport
+    from openlbmpm_amd.Transport2DRK import Transport2DRK
+    from openlbmpm_amd.results import load_results
+    from oracle.tr import CoupledOracle
+    write_rk(str(tmp_path), nx=20, ny=48, steps=60, interval=25)
+    write_transport(str(tmp_path))
+    sim = Transport2DRK(str(tmp_path), output_dir=str(tmp_path / "out"))
+    flow_path, conc_path = sim.runTransport2DMPMCRKNew()
+    assert sim.records == 3
+    res = load_results(conc_path)
+    # the same run in the oracle
+    ref = Transport2DRK(str(tmp_path), output_dir=str(tmp_path / "out2"))
+    ref.initializeDomainBorder(); ref.initializeDomainCondition(); ref.initializeTransportDomain()
+    p, t = ref.par, ref.tr
+    keys = ("sigma", "theta", "wetting", "beta", "delta", "tauR", "tauB", "tautype", "relax", "inlet", "outlet",
+            "vyR", "vyB", "rhoBH", "rhoRH", "rhoBL", "rhoRL")
+    o = CoupledOracle(ref.isDomain, {k: p[k] for k in keys}, ref.fluidsRhoR, ref.fluidsRhoB, ref.tracerConc,
+                      dict(diffX=tuple(t["diffX"]), diffY=tuple(t["diffY"]), dXY=t["dXY"], dYX=t["dYX"], beta=(t["beta"],) * 2,
+                           crit=0.5, inlet_conc=tuple(t["inlet_conc"]), free_outlet=True, dirichlet_inlet=True))
+    sel = ref.isDomain.reshape(-1) == 1
+    done = 0
+    for rec in range(3):
+        o.run(rec * 25 + 1 - done); done = rec * 25 + 1
+        for k in range(2):
+            got = res["/TransportMacro/TracerConcType%din%d" % (k, rec)].reshape(-1)[sel]
+            assert rel_err(got, o.C[k]) < 1e-9, (k, rec)
+    assert ref.tracerConc[1].max() == 0.0 and abs(ref.tracerConc[0].max() - 1.0) < 1e-15   # Transport2DRK.py:417-424
+    flow = load_results(flow_path)
+    assert "/FluidMacro/FluidDensityRin2" in flow and "/FluidVelocity/FluidVelocityYAt2" in flow
+
+
 def test_cli_runs(tmp_path):
     from openlbmpm_amd.__main__ import main
     write_sc(str(tmp_path), inter="EFS", steps=40, relax="MRT")
