@@ -26,8 +26,11 @@ def load_structure_image(path):
 
 
 class RKColorGradientLBM:
-    def __init__(self, pathIniFile, output_dir=None, image=None, device=0):
+    def __init__(self, pathIniFile, output_dir=None, image=None, device=0, initial_dir=None):
         self.pathIni = pathIniFile
+        self.initial_dir = initial_dir or os.path.expanduser("~/LBMInitial")
+        self.fluidPDFR = self.fluidPDFB = None
+        self.physicalVX = self.physicalVY = None
         self.par = config.read_rk2d(pathIniFile)
         self.output_dir = output_dir or os.path.expanduser("~/LBMResults")
         self.device = device
@@ -53,9 +56,61 @@ class RKColorGradientLBM:
     def initializeDomainCondition(self):
         p = self.par
         if p["cycle"]:
-            raise config.ConfigError("IsCycle = 'yes' (restart from ~/LBMInitial) is not wired up yet")
+            self._initial_state_from_files()
+            return
         self.fluidsRhoR, self.fluidsRhoB = initial_densities_rk(self.isDomain, p["image"], p["nbuf"],
                                                                  p["rho0R"], p["rho0B"])
+
+    def _initial_state_from_files(self):
+        """[CyclesSetup] IsCycle = 'yes' (drainage-imbibition cycles, RKD2Q9.py:491-559): start from the
+        results of a previous run kept in ~/LBMInitial."""
+        from .results import load_results
+        p = self.par
+
+        def find(stem):
+            for ext in (".h5", ".npz"):
+                f = os.path.join(self.initial_dir, stem + ext)
+                if os.path.isfile(f):
+                    return load_results(f)
+            raise config.ConfigError("IsCycle = 'yes': no %s.h5/.npz in %s" % (stem, self.initial_dir))
+
+        def need(d, key):
+            if key not in d:
+                raise config.ConfigError("IsCycle = 'yes': dataset %s missing" % key)
+            a = np.array(d[key], dtype=np.float64)
+            if a.shape[:2] != self.isDomain.shape:
+                raise config.ConfigError("IsCycle = 'yes': %s has shape %s, the domain is %s" % (key, a.shape, self.isDomain.shape))
+            return a
+
+        if not p["image"]:
+            # last record of SimulationResultsRK; top 20 rows refilled with blue; f = f_eq(rho, u) (:492-508)
+            d, k = find("SimulationResultsRK"), p["last_step"]
+            self.fluidsRhoR = need(d, "/FluidMacro/FluidDensityRin%d" % k)
+            self.fluidsRhoB = need(d, "/FluidMacro/FluidDensityBin%d" % k)
+            self.physicalVX = need(d, "/FluidVelocity/FluidVelocityXAt%d" % k)
+            self.physicalVY = need(d, "/FluidVelocity/FluidVelocityYAt%d" % k)
+            self.fluidsRhoR[-20:, :] = 0.0
+            self.fluidsRhoB[-20:, :] = p["rho0B"]
+            solid = self.isDomain != 1
+            for a in (self.fluidsRhoR, self.fluidsRhoB, self.physicalVX, self.physicalVY):
+                a[solid] = 0.0
+        else:
+            # cycleInitialRK: populations taken over, colours swapped in the top buffer rows (:532-556)
+            d, nb = find("cycleInitialRK"), p["nbuf"]
+            rR, rB = need(d, "/FluidMacro/FluidDensityR"), need(d, "/FluidMacro/FluidDensityB")
+            fR, fB = need(d, "/FluidPDF/FluidPDFR"), need(d, "/FluidPDF/FluidPDFB")
+            self.fluidsRhoR, self.fluidsRhoB = rR.copy(), rB.copy()
+            self.fluidPDFR, self.fluidPDFB = fR.copy(), fB.copy()
+            self.fluidsRhoR[-nb:], self.fluidsRhoB[-nb:] = rB[-nb:], rR[-nb:]
+            self.fluidPDFR[-nb:], self.fluidPDFB[-nb:] = fB[-nb:], fR[-nb:]
+            self.physicalVX = need(d, "/FluidVelocity/FluidVelocityX")
+            self.physicalVY = need(d, "/FluidVelocity/FluidVelocityY")
+
+    def _upload_initial_state(self, solver):
+        if self.fluidPDFR is not None:
+            solver.set_pdf(self.fluidPDFR, self.fluidPDFB)
+        else:
+            solver.set_macro(self.fluidsRhoR, self.fluidsRhoB, self.physicalVX, self.physicalVY)
 
     # -- run
     def runRKColorGradient2D(self, progress=None):
@@ -65,7 +120,7 @@ class RKColorGradientLBM:
         keys = ("sigma", "theta", "wetting", "beta", "delta", "tauR", "tauB", "tautype", "relax", "inlet", "outlet",
                 "vyR", "vyB", "rhoBH", "rhoRH", "rhoBL", "rhoRL")
         solver = RK2DSolver(self.isDomain, {k: p[k] for k in keys}, device=self.device)
-        solver.set_macro(self.fluidsRhoR, self.fluidsRhoB)
+        self._upload_initial_state(solver)
         out = ResultFile(self.output_dir, "SimulationResultsRK",
                          (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity")))
         self.result_path = out.path

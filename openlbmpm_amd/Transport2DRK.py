@@ -52,7 +52,7 @@ class Transport2DRK(RKColorGradientLBM):
         keys = ("sigma", "theta", "wetting", "beta", "delta", "tauR", "tauB", "tautype", "relax", "inlet", "outlet",
                 "vyR", "vyB", "rhoBH", "rhoRH", "rhoBL", "rhoRL")
         solver = RK2DSolver(self.isDomain, {k: p[k] for k in keys}, device=self.device)
-        solver.set_macro(self.fluidsRhoR, self.fluidsRhoB)
+        self._upload_initial_state(solver)
         n = self.numTracers
         solver.configure_tracers(diffX=tuple(t["diffX"]), diffY=tuple(t["diffY"]), dXY=t["dXY"], dYX=t["dYX"],
                                  beta=(t["beta"],) * n, crit=0.5, inlet_conc=tuple(t["inlet_conc"]),

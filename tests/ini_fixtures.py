@@ -68,8 +68,8 @@ Type = '{relax}'
 ;;MRT
 
 [CyclesSetup]
-IsCycle = 'no'
-LastStep = 100
+IsCycle = '{cycle}'
+LastStep = {last}
 """
 
 TWOPHASE_INI = """[PictureSetup]
@@ -131,10 +131,10 @@ numberTimeStep = {steps}
 """
 
 
-def write_rk(d, nx=20, ny=48, steps=60, interval=25, relax="MRT"):
+def write_rk(d, nx=20, ny=48, steps=60, interval=25, relax="MRT", cycle="no", last=100):
     import os
     with open(os.path.join(d, "RKtwophasesetup2D.ini"), "w") as fh:
-        fh.write(RK_INI.format(nx=nx, ny=ny, steps=steps, interval=interval, relax=relax))
+        fh.write(RK_INI.format(nx=nx, ny=ny, steps=steps, interval=interval, relax=relax, cycle=cycle, last=last))
 
 
 def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirichlet"):

@@ -75,6 +75,34 @@ def test_transport_driver_records_match_coupled_oracle(tmp_path):
     assert "/FluidMacro/FluidDensityRin2" in flow and "/FluidVelocity/FluidVelocityYAt2" in flow
 
 
+def test_restart_from_previous_results(tmp_path):
+    """[CyclesSetup] IsCycle = 'yes' (RKD2Q9.py:491-508): densities and velocities of record LastStep,
+    top 20 rows refilled with blue, populations at equilibrium"""
+    import shutil
+    from openlbmpm_amd.RKD2Q9 import RKColorGradientLBM
+    from openlbmpm_amd.results import load_results
+    first = tmp_path / "first"; first.mkdir()
+    write_rk(str(first), nx=20, ny=64, steps=60, interval=25)
+    a = RKColorGradientLBM(str(first), output_dir=str(tmp_path / "out1"))
+    path = a.runRKColorGradient2D()
+    init = tmp_path / "LBMInitial"; init.mkdir()
+    shutil.copy(path, str(init))
+    second = tmp_path / "second"; second.mkdir()
+    write_rk(str(second), nx=20, ny=64, steps=30, interval=25, cycle="yes", last=2)
+    b = RKColorGradientLBM(str(second), output_dir=str(tmp_path / "out2"), initial_dir=str(init))
+    b.initializeDomainBorder(); b.initializeDomainCondition()
+    old = load_results(path)
+    assert np.array_equal(b.fluidsRhoR[:-20], old["/FluidMacro/FluidDensityRin2"][:-20])
+    assert np.array_equal(b.physicalVY, old["/FluidVelocity/FluidVelocityYAt2"])
+    assert b.fluidsRhoR[-20:].max() == 0.0 and b.fluidsRhoB[-20:, 1:-1].min() > 0.0
+    b2 = RKColorGradientLBM(str(second), output_dir=str(tmp_path / "out2"), initial_dir=str(init))
+    res = load_results(b2.runRKColorGradient2D())
+    r0 = res["/FluidMacro/FluidDensityRin0"] + res["/FluidMacro/FluidDensityBin0"]
+    assert np.isfinite(r0).all() and abs(r0.sum() - (b.fluidsRhoR + b.fluidsRhoB).sum()) / r0.sum() < 1e-3
+    with pytest.raises(Exception):
+        RKColorGradientLBM(str(second), output_dir=str(tmp_path / "o3"), initial_dir=str(tmp_path / "nowhere")).runRKColorGradient2D()
+
+
 def test_cli_runs(tmp_path):
     from openlbmpm_amd.__main__ import main
     write_sc(str(tmp_path), inter="EFS", steps=40, relax="MRT")
