@@ -214,6 +214,10 @@ typedef struct lbmpm_sc2d_config {
     double inlet_velocity_y[2];/* [VelocityBoundary] velocityY                             */
     int32_t device;
     int32_t variant;           /* 0 = default                                              */
+    int32_t force_scheme;      /* [ForceScheme] ExplicitScheme: 4 (also 0), 8 or 10 (EFS only).
+                                  8: boundary rows one row further inside + two ghost rows;
+                                  10: no boundary kernels (as the reference's loop); both run as
+                                  two sweeps per step instead of the fused kernel              */
 } lbmpm_sc2d_config;
 
 typedef struct lbmpm_sc2d lbmpm_sc2d;

@@ -135,8 +135,9 @@ def read_sc2d(ini_dir):
                           "(the Dirichlet inlet references undefined attributes, ShanChenD2Q9.py:1497)")
     p["outlet"] = m.str("BoundaryDefinition", "BoundaryTypeOutlet")
     p["vy0"], p["vy1"] = m.floats("VelocityBoundary", "velocityY", 2)
-    if p["inter"] == "EFS" and m.int("ForceScheme", "ExplicitScheme") != 4:
-        raise ConfigError("ExplicitScheme 8/10 (higher isotropy) is not built yet")
+    p["scheme"] = m.int("ForceScheme", "ExplicitScheme") if p["inter"] == "EFS" else 4
+    if p["scheme"] not in (4, 8, 10):
+        raise ConfigError("[ForceScheme] ExplicitScheme must be 4, 8 or 10")
     p["steps"] = m.int("Time", "numberTimeStep")
     return p
 

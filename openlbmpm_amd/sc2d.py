@@ -16,7 +16,7 @@ FIELDS = dict(f0=0, f1=1, rho0=2, rho1=3, vx=4, vy=5, Fx0=6, Fx1=7, Fy0=8, Fy1=9
 
 # parameter names follow the reference ini files (twophasesetup.ini, efs2D.ini / shanchen2D.ini)
 DEFAULT_PARAMS = dict(inter="EFS", relax="SRT", tau0=1.0, tau1=1.0, G=0.20, Gs0=-0.14, Gs1=0.14,
-                      outlet="Dirichlet", vy0=0.0, vy1=-5.03e-4)
+                      outlet="Dirichlet", vy0=0.0, vy1=-5.03e-4, scheme=4)
 
 
 def _f64(a):
@@ -52,6 +52,7 @@ class SC2DSolver:
         cfg.outlet_type = 0 if p["outlet"] == "Dirichlet" else 1
         cfg.inlet_velocity_y[0], cfg.inlet_velocity_y[1] = p["vy0"], p["vy1"]
         cfg.device = int(device); cfg.variant = 0
+        cfg.force_scheme = int(p["scheme"])
         self._h = C.c_void_p()
         check(L.lbmpm_sc2d_create(C.byref(cfg), dom.ctypes.data_as(U8P), C.byref(self._h)), "lbmpm_sc2d_create")
         self._L = L

@@ -56,11 +56,12 @@ class _Sim(C.Structure):
                 ("tau", C.c_double * 2), ("G", C.c_double * 4), ("Gs", C.c_double * 2),
                 ("vyIn", C.c_double * 2), ("mrt", C.c_int), ("outletType", C.c_int), ("Lam", F64P)] + \
                [(n, F64P) for n in ("f", "fOld", "fNew", "rho", "psi", "Fx", "Fy", "ux", "uy", "feq",
-                                    "ff", "fM", "ffM", "vx", "vy")]
+                                    "ff", "fM", "ffM", "vx", "vy")] + \
+               [("scheme", C.c_int), ("nbrX", I64P), ("wX", C.c_double * 36)]
 
 
 DEFAULT_PARAMS = dict(inter="EFS", relax="SRT", rho0=1.0, rho1=1.0, bg0=0.02, bg1=0.02, tau0=1.0, tau1=1.0,
-                      G=0.20, Gs0=-0.14, Gs1=0.14, outlet="Dirichlet", vy0=0.0, vy1=-5.03e-4)
+                      G=0.20, Gs0=-0.14, Gs1=0.14, outlet="Dirichlet", vy0=0.0, vy1=-5.03e-4, scheme=4)
 
 
 def initial_densities(dom, image, p):
@@ -122,6 +123,16 @@ class SCOracle:
         for name in ("f", "fOld", "fNew", "rho", "psi", "Fx", "Fy", "ux", "uy", "feq", "ff", "fM", "ffM",
                      "vx", "vy"):
             setattr(s, name, _p(getattr(self, name), F64P))
+        s.scheme = int(p["scheme"])
+        if s.scheme not in (4, 8, 10):
+            raise ValueError("ExplicitScheme must be 4, 8 or 10")
+        if s.scheme != 4:
+            nn = 24 if s.scheme == 8 else 36
+            self.nbrX = np.empty(nn * N, np.int64)
+            L.sc_fill_neighbors_iso(C.c_int64(N), C.c_int64(nx), C.c_int64(ny), C.c_int(nn), _p(self.fluidNodes, I64P),
+                                    _p(newidx, I64P), _p(self.nbrX, I64P))
+            s.nbrX = _p(self.nbrX, I64P)
+            L.sc_iso_weights(C.c_int(s.scheme), s.wX)
         self._s, self._L = s, L
         self.iterations = 0
         if self.efs:

@@ -100,14 +100,15 @@ void sc_stream(i64 N, const i64 *nbr, double *f, double *fNew)
     }
 }
 
-/* O:839-863 constantVelocityZouHeBoundaryHigher (row ny-2, per component) */
-void sc_inlet_velocity(i64 N, i64 nx, i64 ny, const double *vyIn, const i64 *fluidNodes,
-                       double *rho, double *f)
+/* O:839-863 constantVelocityZouHeBoundaryHigher (row ny-2, per component); O:868-895 ...Higher8 is
+ * the same on row ny-3 */
+void sc_inlet_velocity_row(i64 N, i64 nx, i64 row, const double *vyIn, const i64 *fluidNodes,
+                           double *rho, double *f)
 {
     PARFOR
     for (i64 n = 0; n < N; ++n) {
         i64 loc = fluidNodes[n];
-        if (!(loc < (ny - 1) * nx && loc >= (ny - 2) * nx)) continue;
+        if (!(loc < (row + 1) * nx && loc >= row * nx)) continue;
         for (int k = 0; k < NF; ++k) {
             double *g = &F(f, k, n, 0);
             R(rho, k, n) = (g[0] + g[1] + g[3] + 2. * (g[2] + g[5] + g[6])) / (1. + vyIn[k]);
@@ -118,14 +119,15 @@ void sc_inlet_velocity(i64 N, i64 nx, i64 ny, const double *vyIn, const i64 *flu
     }
 }
 
-/* O:710-738 ghostPointsConstantVelocityInlet (row ny-1 <- S neighbour, rho summed) */
-void sc_ghost_inlet(i64 N, i64 nx, i64 ny, const i64 *fluidNodes, const i64 *nbr, double *rho,
-                    double *f)
+/* O:710-738 ghostPointsConstantVelocityInlet (row ny-1 <- S neighbour, rho summed); O:897-956
+ * ghostPointsConstantVelocity8 / 82 are the same on rows ny-2, then ny-1 */
+void sc_ghost_inlet_row(i64 N, i64 nx, i64 row, const i64 *fluidNodes, const i64 *nbr, double *rho,
+                        double *f)
 {
     PARFOR
     for (i64 n = 0; n < N; ++n) {
         i64 loc = fluidNodes[n];
-        if (!(loc < ny * nx && loc >= (ny - 1) * nx)) continue;
+        if (!(loc < (row + 1) * nx && loc >= row * nx)) continue;
         i64 L = nbr[8 * n + 3];
         for (int k = 0; k < NF; ++k) {
             double *g = &F(f, k, n, 0);
@@ -137,13 +139,13 @@ void sc_ghost_inlet(i64 N, i64 nx, i64 ny, const i64 *fluidNodes, const i64 *nbr
 
 /* O:555-585 constantPressureZouHeBoundaryLower: densities HARD-CODED to (1.0, 0.02);
  * the densityL argument is ignored (reference quirk, replicated). */
-void sc_outlet_pressure(i64 N, i64 nx, const i64 *fluidNodes, double *rho, double *f)
-{
+void sc_outlet_pressure_row(i64 N, i64 nx, i64 row, const i64 *fluidNodes, double *rho, double *f)
+{   /* row 1: ...Lower; row 2: O:590-620 ...Lower8 */
     static const double dens[2] = {1.0, 0.02};
     PARFOR
     for (i64 n = 0; n < N; ++n) {
         i64 loc = fluidNodes[n];
-        if (!(loc >= nx && loc < 2 * nx)) continue;
+        if (!(loc >= row * nx && loc < (row + 1) * nx)) continue;
         for (int k = 0; k < NF; ++k) {
             double *g = &F(f, k, n, 0);
             double d = dens[k];
@@ -156,13 +158,14 @@ void sc_outlet_pressure(i64 N, i64 nx, const i64 *fluidNodes, double *rho, doubl
     }
 }
 
-/* O:743-770 ghostPointsConstantPressureOutlet (row 0 <- N neighbour, rho summed) */
-void sc_ghost_outlet(i64 N, i64 nx, const i64 *fluidNodes, const i64 *nbr, double *rho, double *f)
+/* O:743-770 ghostPointsConstantPressureOutlet (row 0 <- N neighbour, rho summed); O:775-836
+ * ghostPointsConstantPressureOutlet8 / 82 are the same on rows 1, then 0 */
+void sc_ghost_outlet_row(i64 N, i64 nx, i64 row, const i64 *fluidNodes, const i64 *nbr, double *rho, double *f)
 {
     PARFOR
     for (i64 n = 0; n < N; ++n) {
         i64 loc = fluidNodes[n];
-        if (!(loc < nx)) continue;
+        if (!(loc >= row * nx && loc < (row + 1) * nx)) continue;
         i64 H = nbr[8 * n + 1];
         for (int k = 0; k < NF; ++k) {
             double *g = &F(f, k, n, 0);
@@ -171,6 +174,15 @@ void sc_ghost_outlet(i64 N, i64 nx, const i64 *fluidNodes, const i64 *nbr, doubl
         }
     }
 }
+
+void sc_inlet_velocity(i64 N, i64 nx, i64 ny, const double *vyIn, const i64 *fluidNodes, double *rho, double *f)
+{ sc_inlet_velocity_row(N, nx, ny - 2, vyIn, fluidNodes, rho, f); }
+void sc_ghost_inlet(i64 N, i64 nx, i64 ny, const i64 *fluidNodes, const i64 *nbr, double *rho, double *f)
+{ sc_ghost_inlet_row(N, nx, ny - 1, fluidNodes, nbr, rho, f); }
+void sc_outlet_pressure(i64 N, i64 nx, const i64 *fluidNodes, double *rho, double *f)
+{ sc_outlet_pressure_row(N, nx, 1, fluidNodes, rho, f); }
+void sc_ghost_outlet(i64 N, i64 nx, const i64 *fluidNodes, const i64 *nbr, double *rho, double *f)
+{ sc_ghost_outlet_row(N, nx, 0, fluidNodes, nbr, rho, f); }
 
 /* O:960-1038 convectiveOutletGPU / Ghost2GPU / Ghost3GPU (original SC): row <- N neighbour */
 void sc_outlet_copy_row(i64 N, i64 nx, i64 row, const i64 *fluidNodes, const i64 *nbr, double *f,
@@ -300,6 +312,95 @@ void sc_efs_force4(i64 N, const i64 *nbr, const double *G, const double *Gs, con
     }
 }
 
+
+/* ---- higher-isotropy force stencils, [ForceScheme] ExplicitScheme = 8 | 10
+ * neighbour order of fillNeighboringNodesISO8 / ISO10 (E:392-486, :488-625): the 8 D2Q9 neighbours,
+ * distance-2 axis, (2,2) diagonals, the 8 knight moves, then (ISO10) distance-3 axis and the 8 (3,1) moves */
+static const int ISO_DX[36] = {1, 0, -1, 0, 1, -1, -1, 1, 2, 0, -2, 0, 2, -2, -2, 2, 2, 1, -1, -2, -2, -1, 1, 2,
+                               3, 0, -3, 0, 3, 1, -1, -3, -3, -1, 1, 3};
+static const int ISO_DY[36] = {0, 1, 0, -1, 1, 1, -1, -1, 0, 2, 0, -2, 2, 2, -2, -2, 1, 2, 2, 1, -1, -2, -2, -1,
+                               0, 3, 0, -3, 1, 3, 3, 1, -1, -3, -3, -1};
+
+void sc_fill_neighbors_iso(i64 N, i64 nx, i64 ny, int nn, const i64 *fluidNodes, const i64 *newidx, i64 *out)
+{
+    for (i64 n = 0; n < N; ++n) {
+        i64 i = fluidNodes[n] / nx, j = fluidNodes[n] % nx;
+        for (int m = 0; m < nn; ++m) {
+            i64 ii = (i + ISO_DY[m] + ny) % ny, jj = (j + ISO_DX[m] + nx) % nx;
+            out[nn * n + m] = newidx[ii * nx + jj];
+        }
+    }
+}
+
+/* weightInter8 / weightInter10, D:1677-1689 */
+void sc_iso_weights(int scheme, double *w)
+{
+    if (scheme == 8) {
+        for (int m = 0; m < 4; ++m) { w[m] = 4. / 21.; w[4 + m] = 4. / 45.; w[8 + m] = 1. / 60.; w[12 + m] = 1. / 5040.; }
+        for (int m = 16; m < 24; ++m) w[m] = 2. / 315.;
+    } else {
+        for (int m = 0; m < 4; ++m) { w[m] = 262. / 1785.; w[4 + m] = 93. / 1190.; w[8 + m] = 7. / 340.; w[12 + m] = 9. / 9520.; w[24 + m] = 2. / 5355.; }
+        for (int m = 16; m < 24; ++m) w[m] = 6. / 595.;
+        for (int m = 28; m < 36; ++m) w[m] = 1. / 7140.;
+    }
+}
+
+/* line-of-sight rule of the far neighbours (the `if` in front of every block of E:627-955 / :957-1377): a
+ * neighbour at distance 2 counts only if the nearest neighbour on the way to it is fluid, a knight-move
+ * neighbour if one of the two nearest neighbours on the way is, distance 3 if the whole path is */
+static int iso_gate(const i64 *nb, int m)
+{
+    static const int K2[8][2] = {{0, 4}, {1, 4}, {1, 5}, {2, 5}, {2, 6}, {3, 6}, {3, 7}, {0, 7}};
+    static const int K3[8][4] = {{4, 16, 0, 8}, {1, 9, 4, 17}, {1, 9, 5, 18}, {2, 10, 5, 19},
+                                 {2, 10, 6, 20}, {3, 11, 6, 21}, {3, 11, 7, 22}, {0, 8, 7, 23}};
+#define FL(k) (nb[k] != -1)
+    if (!FL(m)) return 0;
+    if (m < 8) return 1;
+    if (m < 16) return FL(m - 8);
+    if (m < 24) return FL(K2[m - 16][0]) || FL(K2[m - 16][1]);
+    if (m < 28) return FL(m - 24) && FL(m - 16);
+    return (FL(K3[m - 28][0]) && FL(K3[m - 28][1])) || (FL(K3[m - 28][2]) && FL(K3[m - 28][3]));
+#undef FL
+}
+
+/* E:627-955 calExplicit8thOrderScheme, E:957-1377 calExplicit10thOrderScheme: fluid neighbour n adds
+ * -|e| 6 w_n G_ij psi_i (psi_j(n) - psi_j) sign(e) per axis (scheme 10: psi_j(n) alone); a missing neighbour adds the solid term
+ * -1/9 (axis) / -1/36 (diagonal) Gs_i psi_i sign(e) for the 8 nearest neighbours only */
+void sc_efs_force_iso(i64 N, int nn, const i64 *nbrX, const double *w, const double *G, const double *Gs,
+                      const double *psi, double *Fx, double *Fy)
+{
+    PARFOR
+    for (i64 n = 0; n < N; ++n) {
+        double fx[NF], fy[NF];
+        for (int i = 0; i < NF; ++i) { fx[i] = 0.0; fy[i] = 0.0; }
+        for (int m = 0; m < nn; ++m) {
+            i64 q = nbrX[nn * n + m];
+            int dx = ISO_DX[m], dy = ISO_DY[m];
+            if (iso_gate(nbrX + nn * n, m)) {
+                for (int i = 0; i < NF; ++i)
+                    for (int j = 0; j < NF; ++j) {
+                        /* scheme 8 differences psi_j(n) - psi_j, scheme 10 uses the plain product (E:1009 ff.) */
+                        double d = nn == 36 ? R(psi, j, q) : R(psi, j, q) - R(psi, j, n), sx = dx > 0 ? 1. : -1., sy = dy > 0 ? 1. : -1.;
+                        if (dx == 1 || dx == -1) fx[i] += -6.0 * w[m] * G[i * NF + j] * R(psi, i, n) * (d) * (sx);
+                        if (dx == 2 || dx == -2) fx[i] += -2. * 6.0 * w[m] * G[i * NF + j] * R(psi, i, n) * (d) * (sx);
+                        if (dx == 3 || dx == -3) fx[i] += -3. * 6.0 * w[m] * G[i * NF + j] * R(psi, i, n) * (d) * (sx);
+                        if (dy == 1 || dy == -1) fy[i] += -6.0 * w[m] * G[i * NF + j] * R(psi, i, n) * (d) * (sy);
+                        if (dy == 2 || dy == -2) fy[i] += -2. * 6.0 * w[m] * G[i * NF + j] * R(psi, i, n) * (d) * (sy);
+                        if (dy == 3 || dy == -3) fy[i] += -3. * 6.0 * w[m] * G[i * NF + j] * R(psi, i, n) * (d) * (sy);
+                    }
+            } else if (m < 8 && q == -1) {
+                for (int i = 0; i < NF; ++i) {
+                    double c = m < 4 ? -1. / 9. : -1. / 36.;
+                    if (dx != 0) fx[i] += c * Gs[i] * R(psi, i, n) * (dx > 0 ? 1. : -1.);
+                    if (dy != 0) fy[i] += c * Gs[i] * R(psi, i, n) * (dy > 0 ? 1. : -1.);
+                }
+            }
+        }
+        for (int i = 0; i < NF; ++i) { R(Fx, i, n) = fx[i]; R(Fy, i, n) = fy[i]; }
+    }
+}
+
+
 /* E:340-363 calEquilibriumVEFGPU (SRT: weights 1/tau_k) and E:1426-1449
  * transformEquilibriumVelocity (MRT: weights conserveS_k) */
 void sc_efs_ueq(i64 N, const double *wk /* 1/tau_k or conserveS_k */, int divide, const double *rho,
@@ -403,13 +504,18 @@ typedef struct {
     int mrt, outletType /*0 Dirichlet 1 Convective*/;
     const double *Lam;   /* [2][9][9], MRT only */
     double *f, *fOld, *fNew, *rho, *psi, *Fx, *Fy, *ux, *uy, *feq, *ff, *fM, *ffM, *vx, *vy;
+    int scheme;          /* 4, 8 or 10 ([ForceScheme] ExplicitScheme) */
+    const i64 *nbrX;     /* [N][24] or [N][36] for scheme 8 / 10 */
+    double wX[36];
 } sc_sim;
 
 static void sc_efs_force_chain(sc_sim *s)
 {   /* D:2039-2087 == D:1714-1768: psi, F, u_eq, f_eq, F_i */
     i64 N = s->N;
     memcpy(s->psi, s->rho, sizeof(double) * NF * N);            /* O:99-106 psi = rho */
-    sc_efs_force4(N, s->nbr, s->G, s->Gs, s->psi, s->Fx, s->Fy);
+    if (s->scheme == 8) sc_efs_force_iso(N, 24, s->nbrX, s->wX, s->G, s->Gs, s->psi, s->Fx, s->Fy);
+    else if (s->scheme == 10) sc_efs_force_iso(N, 36, s->nbrX, s->wX, s->G, s->Gs, s->psi, s->Fx, s->Fy);
+    else sc_efs_force4(N, s->nbr, s->G, s->Gs, s->psi, s->Fx, s->Fy);
     if (!s->mrt) sc_efs_ueq(N, s->tau, 1, s->rho, s->Fx, s->Fy, s->f, s->ux, s->uy);
     else { double ones[NF] = {1., 1.}; sc_efs_ueq(N, ones, 0, s->rho, s->Fx, s->Fy, s->f, s->ux, s->uy); }
     sc_efs_feq(N, s->rho, s->ux, s->uy, s->feq);
@@ -418,21 +524,26 @@ static void sc_efs_force_chain(sc_sim *s)
 
 static void sc_efs_bcs(sc_sim *s, int in_loop)
 {
-    i64 N = s->N;
-    if (in_loop && s->outletType == 1) {          /* D:1913-1930 */
+    i64 N = s->N, ny = s->ny;
+    /* scheme 8 applies the same rules one row further inside and refreshes two ghost rows
+     * (D:1798-1808, :1837-1849, :1942-1953, :1994-2020); scheme 10 has no boundary kernel in either place */
+    const int sh = s->scheme == 8 ? 1 : 0, on = s->scheme != 10;
+    if (in_loop && s->outletType == 1) {          /* D:1913-1930 (not scheme dependent) */
         sc_outlet_convective_row(N, s->nx, 2, s->fluidNodes, s->nbr, s->f, s->fOld, s->rho, s->vy);
         sc_outlet_convective_row(N, s->nx, 1, s->fluidNodes, s->nbr, s->f, s->fOld, s->rho, s->vy);
         sc_outlet_convective_row(N, s->nx, 0, s->fluidNodes, s->nbr, s->f, s->fOld, s->rho, s->vy);
     }
-    if (in_loop && s->outletType == 0) {          /* D:1931-1941 */
-        sc_outlet_pressure(N, s->nx, s->fluidNodes, s->rho, s->f);
-        sc_ghost_outlet(N, s->nx, s->fluidNodes, s->nbr, s->rho, s->f);
+    if (in_loop && s->outletType == 0 && on) {    /* D:1931-1953 */
+        sc_outlet_pressure_row(N, s->nx, 1 + sh, s->fluidNodes, s->rho, s->f);
+        for (int r = sh; r >= 0; --r) sc_ghost_outlet_row(N, s->nx, r, s->fluidNodes, s->nbr, s->rho, s->f);
     }
-    sc_inlet_velocity(N, s->nx, s->ny, s->vyIn, s->fluidNodes, s->rho, s->f);       /* D:1990 / :1811 */
-    sc_ghost_inlet(N, s->nx, s->ny, s->fluidNodes, s->nbr, s->rho, s->f);           /* D:2008 / :1826 */
-    if (!in_loop && s->outletType == 0) {         /* pre-loop order: inlet first, D:1827-1838 */
-        sc_outlet_pressure(N, s->nx, s->fluidNodes, s->rho, s->f);
-        sc_ghost_outlet(N, s->nx, s->fluidNodes, s->nbr, s->rho, s->f);
+    if (on) {
+        sc_inlet_velocity_row(N, s->nx, ny - 2 - sh, s->vyIn, s->fluidNodes, s->rho, s->f);       /* D:1990 / :1811 */
+        for (int r = ny - 1 - sh; r <= ny - 1; ++r) sc_ghost_inlet_row(N, s->nx, r, s->fluidNodes, s->nbr, s->rho, s->f);
+    }
+    if (!in_loop && s->outletType == 0 && on) {   /* pre-loop order: inlet first, D:1827-1849 */
+        sc_outlet_pressure_row(N, s->nx, 1 + sh, s->fluidNodes, s->rho, s->f);
+        for (int r = sh; r >= 0; --r) sc_ghost_outlet_row(N, s->nx, r, s->fluidNodes, s->nbr, s->rho, s->f);
     }
 }
 

@@ -81,7 +81,7 @@ velocityY = {vy0},{vy1}
 PressureInlet = 0.0, 0.0
 PressureOutlet = 1.0, 0.0
 [ForceScheme]
-ExplicitScheme = 4
+ExplicitScheme = {scheme}
 [BodyForce]
 Option = 'no'
 forceXG = 0.0
@@ -92,7 +92,7 @@ numberTimeStep = {steps}
 
 DEFAULTS = dict(image='no', nx=20, ny=48, inter='EFS', relax='SRT', rho0=1.0, rho1=1.0, bg0=0.02, bg1=0.02,
                 tau0=1.0, tau1=1.0, G=0.20, Gs0=-0.14, Gs1=0.14, outlet='Dirichlet', vy0=0.0, vy1=-5.03e-4,
-                steps=60)
+                steps=60, scheme=4)
 
 
 def porous_image(nx, ny, seed, n_discs, rmin, rmax):
@@ -113,6 +113,12 @@ SCENARIOS = {
     "efs_srt_convective": (dict(steps=60, outlet='Convective', tau0=0.9, tau1=1.1), (0, 1, 60), None),
     "efs_mrt_porous": (dict(steps=60, relax='MRT', image='yes'), (0, 1, 60),
                        dict(nx=34, ny=44, seed=5, n_discs=9, rmin=2.0, rmax=4.5)),
+    # higher-isotropy force stencils (efs2D.ini [ForceScheme] ExplicitScheme = 8 | 10): scheme 8 moves the
+    # boundary rows one row inwards and keeps two ghost rows; scheme 10 has no boundary kernels in the loop
+    "efs_srt_iso8": (dict(steps=60, scheme=8), (0, 1, 60), None),
+    "efs_mrt_iso8_porous": (dict(steps=60, scheme=8, relax='MRT', tau0=1.0, tau1=0.8, image='yes'), (0, 1, 60),
+                            dict(nx=34, ny=44, seed=5, n_discs=9, rmin=2.0, rmax=4.5)),
+    "efs_srt_iso10": (dict(steps=40, scheme=10), (0, 1, 40), None),
     "sc_srt_convective": (dict(steps=80, inter='ShanChen', G=3.8, Gs0=-0.40, Gs1=0.40, bg0=0.06, bg1=0.06,
                                outlet='Convective', vy1=-1.01e-3), (1, 2, 10, 80), None),
     "sc_srt_porous": (dict(steps=60, inter='ShanChen', G=2.6, Gs0=-0.20, Gs1=0.20, bg0=0.15, bg1=0.15,

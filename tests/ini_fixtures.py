@@ -119,7 +119,7 @@ PressureInlet = 0.0, 0.0
 PressureOutlet = 1.0, 0.0
 
 [ForceScheme]
-ExplicitScheme = 4
+ExplicitScheme = {scheme}
 
 [BodyForce]
 Option = 'no'
@@ -137,7 +137,7 @@ def write_rk(d, nx=20, ny=48, steps=60, interval=25, relax="MRT", cycle="no", la
         fh.write(RK_INI.format(nx=nx, ny=ny, steps=steps, interval=interval, relax=relax, cycle=cycle, last=last))
 
 
-def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirichlet"):
+def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirichlet", scheme=4):
     import os
     with open(os.path.join(d, "twophasesetup.ini"), "w") as fh:
         fh.write(TWOPHASE_INI.format(nx=nx, ny=ny, inter=inter, relax=relax))
@@ -145,7 +145,7 @@ def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirich
     with open(os.path.join(d, "efs2D.ini" if efs else "shanchen2D.ini"), "w") as fh:
         fh.write(MODEL_INI.format(section="EFSParameters" if efs else "ShanChenParameters", bg=0.02 if efs else 0.06,
                                   G=0.20 if efs else 3.8, Gs0=-0.14 if efs else -0.40, Gs1=0.14 if efs else 0.40,
-                                  outlet=outlet, vy1=-5.03e-4 if efs else -1.01e-3, steps=steps))
+                                  outlet=outlet, vy1=-5.03e-4 if efs else -1.01e-3, steps=steps, scheme=scheme))
 
 
 TRANSPORT_INI = """[SystemType]

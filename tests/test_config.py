@@ -50,3 +50,13 @@ def test_transport_ini(tmp_path):
         (tmp_path / "transportsetup.ini").write_text(TRANSPORT_INI.replace(old, new))
         with pytest.raises(config.ConfigError):
             config.read_transport(str(tmp_path))
+
+
+def test_force_scheme_key(tmp_path):
+    write_sc(str(tmp_path), inter="EFS", scheme=8)
+    assert config.read_sc2d(str(tmp_path))["scheme"] == 8
+    write_sc(str(tmp_path), inter="EFS", scheme=6)
+    with pytest.raises(config.ConfigError):
+        config.read_sc2d(str(tmp_path))
+    write_sc(str(tmp_path), inter="ShanChen", scheme=10)       # original Shan-Chen ignores the key
+    assert config.read_sc2d(str(tmp_path))["scheme"] == 4

@@ -103,6 +103,19 @@ def test_restart_from_previous_results(tmp_path):
         RKColorGradientLBM(str(second), output_dir=str(tmp_path / "o3"), initial_dir=str(tmp_path / "nowhere")).runRKColorGradient2D()
 
 
+def test_sc_driver_with_iso8_scheme_matches_reference(tmp_path):
+    """[ForceScheme] ExplicitScheme = 8 through the driver: the run ends where the reference's ends"""
+    from openlbmpm_amd.ShanChenD2Q9 import ShanChenD2Q9
+    d = np.load([f for f in golden_files("sc_") if f.endswith("sc_efs_srt_iso8.npz")][0])
+    write_sc(str(tmp_path), inter="EFS", nx=20, ny=48, steps=60, scheme=8)
+    sim = ShanChenD2Q9(str(tmp_path), output_dir=str(tmp_path / "out"))
+    sim.runTypeSCmodel()
+    sel = d["isDomain"].reshape(-1) == 1
+    for k in (0, 1):
+        got = sim.solver.get("rho%d" % k).reshape(-1)[sel]
+        assert rel_err(got, d["s60_rho"][k]) < 1e-9
+
+
 def test_cli_runs(tmp_path):
     from openlbmpm_amd.__main__ import main
     write_sc(str(tmp_path), inter="EFS", steps=40, relax="MRT")
