@@ -22,6 +22,23 @@ __device__ const double VX[5] = {0., 1., -1., 0., 0.};
 __device__ const double VY[5] = {0., 0., 0., 1., -1.};
 __device__ const double WT5[5] = {1. / 3., 1. / 6., 1. / 6., 1. / 6., 1. / 6.};
 __device__ const int OPP5[5] = {0, 2, 1, 4, 3};
+// neighbour order of fillNeighboringNodesISO8 / ISO10 (ExplicitD2Q9GPU.py:392, :488)
+__device__ const int ISO_DX[36] = {1, 0, -1, 0, 1, -1, -1, 1, 2, 0, -2, 0, 2, -2, -2, 2, 2, 1, -1, -2, -2, -1, 1, 2,
+                                   3, 0, -3, 0, 3, 1, -1, -3, -3, -1, 1, 3};
+__device__ const int ISO_DY[36] = {0, 1, 0, -1, 1, 1, -1, -1, 0, 2, 0, -2, 2, 2, -2, -2, 1, 2, 2, 1, -1, -2, -2, -1,
+                                   0, 3, 0, -3, 1, 3, 3, 1, -1, -3, -3, -1};
+// line-of-sight rule of the far neighbours (the `if` in front of every block of E:627-955 / :957-1377)
+__device__ int iso_gate(const i64 *nb, int m)
+{
+    const int K2[8][2] = {{0, 4}, {1, 4}, {1, 5}, {2, 5}, {2, 6}, {3, 6}, {3, 7}, {0, 7}};
+    const int K3[8][4] = {{4, 16, 0, 8}, {1, 9, 4, 17}, {1, 9, 5, 18}, {2, 10, 5, 19}, {2, 10, 6, 20}, {3, 11, 6, 21}, {3, 11, 7, 22}, {0, 8, 7, 23}};
+    if (nb[m] == -1) return 0;
+    if (m < 8) return 1;
+    if (m < 16) return nb[m - 8] != -1;
+    if (m < 24) return nb[K2[m - 16][0]] != -1 || nb[K2[m - 16][1]] != -1;
+    if (m < 28) return nb[m - 24] != -1 && nb[m - 16] != -1;
+    return (nb[K3[m - 28][0]] != -1 && nb[K3[m - 28][1]] != -1) || (nb[K3[m - 28][2]] != -1 && nb[K3[m - 28][3]] != -1);
+}
 
 #define NF 2
 #define F(f, k, n, j) (f)[((size_t)(k) * N + (n)) * 9 + (j)]

@@ -323,6 +323,7 @@ static const int ISO_DY[36] = {0, 1, 0, -1, 1, 1, -1, -1, 0, 2, 0, -2, 2, 2, -2,
 
 void sc_fill_neighbors_iso(i64 N, i64 nx, i64 ny, int nn, const i64 *fluidNodes, const i64 *newidx, i64 *out)
 {
+    PARFOR
     for (i64 n = 0; n < N; ++n) {
         i64 i = fluidNodes[n] / nx, j = fluidNodes[n] % nx;
         for (int m = 0; m < nn; ++m) {

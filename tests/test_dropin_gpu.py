@@ -139,7 +139,7 @@ def test_colour_gradient_loop_with_reference_launch_statements(dropin):
         RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](totalNodes, xDimension, o.rhoR, deviceFluidRhoB, deviceColorValue)
 
 
-@pytest.mark.parametrize("scenario", ["efs_srt_dirichlet", "efs_mrt_dirichlet", "efs_srt_convective"])
+@pytest.mark.parametrize("scenario", ["efs_srt_dirichlet", "efs_mrt_dirichlet", "efs_srt_convective", "efs_srt_iso8", "efs_srt_iso10"])
 def test_explicit_forcing_loop_with_reference_launch_statements(dropin, scenario):
     cuda, _, OPT, EXP, _ = dropin
     from oracle.sc import SCOracle, simple_geometry, collision_matrices
@@ -174,7 +174,18 @@ def test_explicit_forcing_loop_with_reference_launch_statements(dropin, scenario
     dTau = cuda.to_device(tau)
     dG = cuda.to_device(np.array([[0., par["G"]], [par["G"], 0.]])); dGs = cuda.to_device(np.array([par["Gs0"], par["Gs1"]]))
     dEX = cuda.to_device(np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.])); dEY = cuda.to_device(np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.]))
-    dWI = cuda.to_device(np.array([1. / 3.] * 4 + [1. / 12.] * 4)); dW = cuda.to_device(w9)
+    scheme = int(par.get("scheme", 4))
+    weights = {4: [1. / 3.] * 4 + [1. / 12.] * 4,
+               8: [4. / 21.] * 4 + [4. / 45.] * 4 + [1. / 60.] * 4 + [1. / 5040.] * 4 + [2. / 315.] * 8,
+               10: [262. / 1785.] * 4 + [93. / 1190.] * 4 + [7. / 340.] * 4 + [9. / 9520.] * 4 + [6. / 595.] * 8 +
+                   [2. / 5355.] * 4 + [1. / 7140.] * 8}[scheme]          # ShanChenD2Q9.py:1675-1689
+    dWI = cuda.to_device(np.array(weights)); dW = cuda.to_device(w9)
+    if scheme == 8:
+        dNbrX = cuda.to_device(np.zeros(24 * N, dtype=np.int64))
+        EXP.fillNeighboringNodesISO8[grid1D, tpb](N, nx, ny, xDimension, dFluidIndices, dIdx, dNbrX)
+    elif scheme == 10:
+        dNbrX = cuda.to_device(np.zeros(36 * N, dtype=np.int64))
+        EXP.fillNeighboringNodesISO10[grid1D, tpb](N, nx, ny, xDimension, dFluidIndices, dIdx, dNbrX)
     dVelY = cuda.to_device(np.array([par["vy0"], par["vy1"]]))
     mrt = par["relax"] == "MRT"
     if mrt:
@@ -183,7 +194,12 @@ def test_explicit_forcing_loop_with_reference_launch_statements(dropin, scenario
 
     def chain():
         OPT.calFluidPotentialGPUEql[grid1D, tpb](N, typesFluids, xDimension, dRho, dPot)
-        EXP.calExplicit4thOrderScheme[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbr, dWI, dG, dGs, dPot, dFx, dFy)
+        if scheme == 4:
+            EXP.calExplicit4thOrderScheme[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbr, dWI, dG, dGs, dPot, dFx, dFy)
+        elif scheme == 8:
+            EXP.calExplicit8thOrderScheme[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbrX, dWI, dG, dGs, dPot, dFx, dFy)
+        else:
+            EXP.calExplicit10thOrderScheme[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbrX, dWI, dG, dGs, dPot, dFx, dFy)
         if mrt:
             EXP.transformEquilibriumVelocity[grid1D, tpb](N, typesFluids, xDimension, dEX, dEY, dRho, dFx, dFy, dPDF,
                                                           dConserveS, dEqVX, dEqVY)
@@ -192,13 +208,23 @@ def test_explicit_forcing_loop_with_reference_launch_statements(dropin, scenario
         EXP.calEquilibriumFuncEFGPU[grid1D, tpb](N, typesFluids, xDimension, dW, dEX, dEY, dRho, dEqVX, dEqVY, dFeq)
         EXP.calForceDistrGPU[grid1D, tpb](N, typesFluids, xDimension, dEX, dEY, dEqVX, dEqVY, dRho, dFx, dFy, dFeq, dFF)
 
-    def inlet():
-        OPT.constantVelocityZouHeBoundaryHigher[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dVelY, dFluidIndices, dRho, dPDF)
-        OPT.ghostPointsConstantVelocityInlet[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+    def inlet():                      # ShanChenD2Q9.py:1794-1825, :1989-2020
+        if scheme == 4:
+            OPT.constantVelocityZouHeBoundaryHigher[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dVelY, dFluidIndices, dRho, dPDF)
+            OPT.ghostPointsConstantVelocityInlet[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+        if scheme == 8:
+            OPT.constantVelocityZouHeBoundaryHigher8[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dVelY, dFluidIndices, dRho, dPDF)
+            OPT.ghostPointsConstantVelocity8[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+            OPT.ghostPointsConstantVelocity82[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
 
-    def outlet_dirichlet():
-        OPT.constantPressureZouHeBoundaryLower[grid1D, tpb](N, typesFluids, nx, xDimension, 1.002, dFluidIndices, dRho, dPDF)
-        OPT.ghostPointsConstantPressureOutlet[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+    def outlet_dirichlet():           # :1826-1849, :1931-1953
+        if scheme == 4:
+            OPT.constantPressureZouHeBoundaryLower[grid1D, tpb](N, typesFluids, nx, xDimension, 1.002, dFluidIndices, dRho, dPDF)
+            OPT.ghostPointsConstantPressureOutlet[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+        elif scheme == 8:
+            OPT.constantPressureZouHeBoundaryLower8[grid1D, tpb](N, typesFluids, nx, xDimension, 1.002, dFluidIndices, dRho, dPDF)
+            OPT.ghostPointsConstantPressureOutlet8[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+            OPT.ghostPointsConstantPressureOutlet82[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dRho, dPDF)
 
     # pre-loop, ShanChenD2Q9.py:1714-1849
     chain()

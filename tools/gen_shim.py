@@ -85,13 +85,26 @@ SPEC = [
  ("sc", "calStreaming2GPU", O + ":539", "totalNum:i numFluids:i xDim:i fluidPDFNew:D fluidPDF:D",
   "sc_check_nf(numFluids); launch_sc_stream2(st, totalNum, fluidPDFNew, fluidPDF)"),
  ("sc", "constantPressureZouHeBoundaryLower", O + ":555", "totalNodes:i numFluids:i nx:i xDim:i densityL:d fluidNodes:I fluidRho:D fluidPDF:D",
-  "sc_check_nf(numFluids); launch_sc_outlet_pressure(st, totalNodes, nx, fluidNodes, fluidRho, fluidPDF)"),
+  "sc_check_nf(numFluids); launch_sc_outlet_pressure_row(st, totalNodes, nx, 1, fluidNodes, fluidRho, fluidPDF)"),
+ # scheme 8: the same rules one row further inside, two ghost rows
+ ("sc", "constantPressureZouHeBoundaryLower8", O + ":590", "totalNodes:i numFluids:i nx:i xDim:i densityL:d fluidNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_outlet_pressure_row(st, totalNodes, nx, 2, fluidNodes, fluidRho, fluidPDF)"),
+ ("sc", "ghostPointsConstantPressureOutlet8", O + ":775", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_ghost_outlet_row(st, totalNodes, nx, 1, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
+ ("sc", "ghostPointsConstantPressureOutlet82", O + ":807", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_ghost_outlet_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
+ ("sc", "constantVelocityZouHeBoundaryHigher8", O + ":868", "totalNodes:i numFluids:i nx:i ny:i xDim:i specificVY:D fluidNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_inlet_velocity_row(st, totalNodes, nx, ny - 3, specificVY, fluidNodes, fluidRho, fluidPDF)"),
+ ("sc", "ghostPointsConstantVelocity8", O + ":897", "totalNodes:i numFluids:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_ghost_inlet_row(st, totalNodes, nx, ny - 2, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
+ ("sc", "ghostPointsConstantVelocity82", O + ":927", "totalNodes:i numFluids:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_ghost_inlet_row(st, totalNodes, nx, ny - 1, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
  ("sc", "ghostPointsConstantVelocityInlet", O + ":710", "totalNodes:i numFluids:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
-  "sc_check_nf(numFluids); launch_sc_ghost_inlet(st, totalNodes, nx, ny, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
+  "sc_check_nf(numFluids); launch_sc_ghost_inlet_row(st, totalNodes, nx, ny - 1, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
  ("sc", "ghostPointsConstantPressureOutlet", O + ":743", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
-  "sc_check_nf(numFluids); launch_sc_ghost_outlet(st, totalNodes, nx, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
+  "sc_check_nf(numFluids); launch_sc_ghost_outlet_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
  ("sc", "constantVelocityZouHeBoundaryHigher", O + ":839", "totalNodes:i numFluids:i nx:i ny:i xDim:i specificVY:D fluidNodes:I fluidRho:D fluidPDF:D",
-  "sc_check_nf(numFluids); launch_sc_inlet_velocity(st, totalNodes, nx, ny, specificVY, fluidNodes, fluidRho, fluidPDF)"),
+  "sc_check_nf(numFluids); launch_sc_inlet_velocity_row(st, totalNodes, nx, ny - 2, specificVY, fluidNodes, fluidRho, fluidPDF)"),
  ("sc", "convectiveOutletGPU", O + ":960", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidRho:D",
   "sc_check_nf(numFluids); launch_sc_outlet_copy_row(st, totalNodes, nx, 2, fluidNodes, neighboringNodes, fluidPDFNew, fluidRho)"),
  ("sc", "convectiveOutletGhost2GPU", O + ":988", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidRho:D",
@@ -108,6 +121,14 @@ SPEC = [
   "sc_check_nf(numFluids); launch_sc_interaction_collision(st, totalNodes, tau, interCoeff, interSolid, fluidRho, fluidPotential, fluidPDF, neighboringNodes, forceX, forceY)"),
  ("sc", "calExplicit4thOrderScheme", E + ":51", "totalNodes:i numFluids:i xDim:i fluidNodes:I neighboringNodes:I weightInter:D interactionCoeff:D interactionSolid:D fluidPotential:D forceX:D forceY:D",
   "sc_check_nf(numFluids); launch_sc_efs_force4(st, totalNodes, neighboringNodes, interactionCoeff, interactionSolid, fluidPotential, forceX, forceY)"),
+ ("sc", "fillNeighboringNodesISO8", E + ":392", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
+  "launch_sc_fill_neighbors_iso(st, totalNodes, nx, ny, 24, fluidNodes, domainNewIndex, neighboringNodes)"),
+ ("sc", "fillNeighboringNodesISO10", E + ":488", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
+  "launch_sc_fill_neighbors_iso(st, totalNodes, nx, ny, 36, fluidNodes, domainNewIndex, neighboringNodes)"),
+ ("sc", "calExplicit8thOrderScheme", E + ":627", "totalNodes:i numFluids:i xDim:i fluidNodes:I neighboringNodes:I weightInter:D interactionCoeff:D interactionSolid:D fluidPotential:D forceX:D forceY:D",
+  "sc_check_nf(numFluids); launch_sc_efs_force_iso(st, totalNodes, 24, neighboringNodes, weightInter, interactionCoeff, interactionSolid, fluidPotential, forceX, forceY)"),
+ ("sc", "calExplicit10thOrderScheme", E + ":957", "totalNodes:i numFluids:i xDim:i fluidNodes:I neighboringNodes:I weightInter:D interactionCoeff:D interactionSolid:D fluidPotential:D forceX:D forceY:D",
+  "sc_check_nf(numFluids); launch_sc_efs_force_iso(st, totalNodes, 36, neighboringNodes, weightInter, interactionCoeff, interactionSolid, fluidPotential, forceX, forceY)"),
  ("sc", "calEquilibriumFuncEFGPU", E + ":227", "totalNum:i numFluids:i xDim:i weightCoeff:D EX:D EY:D fluidRho:D equilibriumVX:D equilibriumVY:D fEq:D",
   "sc_check_nf(numFluids); launch_sc_efs_feq(st, totalNum, fluidRho, equilibriumVX, equilibriumVY, fEq)"),
  ("sc", "calForceDistrGPU", E + ":255", "totalNodes:i numFluids:i xDim:i EX:D EY:D equilibriumVX:D equilibriumVY:D fluidRho:D forceX:D forceY:D fEq:D fForce:D",
