@@ -73,7 +73,9 @@ enum { LBMPM_RELAX_SRT = 0, LBMPM_RELAX_MRT = 1 };
 enum { LBMPM_INLET_VELOCITY = 0,      /* BoundaryTypeInlet 'Neumann'   */
        LBMPM_INLET_PRESSURE = 1 };    /* BoundaryTypeInlet 'Dirichlet' */
 enum { LBMPM_OUTLET_PRESSURE = 0,     /* BoundaryTypeOutlet 'Dirichlet'  */
-       LBMPM_OUTLET_CONVECTIVE = 1 }; /* BoundaryTypeOutlet 'Convective' */
+       LBMPM_OUTLET_CONVECTIVE = 1,   /* BoundaryTypeOutlet 'Convective' */
+       LBMPM_OUTLET_NONE = 2 };       /* sc2d only: no boundary kernels at all, inlet included: fully periodic box
+                                         (the static-droplet Laplace case of the reference's CPU path SimpleD2Q9) */
 
 typedef struct lbmpm_rk2d_config {
     int64_t nx, ny;            /* xDomain, yDomain (incl. ghost rows 0 and ny-1)            */

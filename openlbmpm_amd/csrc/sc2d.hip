@@ -627,7 +627,7 @@ SCDev make_dev(const lbmpm_sc2d *c)
     p.vyIn[0] = c->cfg.inlet_velocity_y[0]; p.vyIn[1] = c->cfg.inlet_velocity_y[1];
     p.model = c->cfg.model; p.mrt = c->cfg.relaxation == LBMPM_RELAX_MRT; p.outlet = c->cfg.outlet_type;
     p.first = c->streamed ? 0 : 1; p.keep_force = c->keep_force ? 1 : 0;
-    p.scheme = c->scheme; p.sh = c->scheme == 8 ? 1 : 0; p.nobc = c->scheme == 10 ? 1 : 0;
+    p.scheme = c->scheme; p.sh = c->scheme == 8 ? 1 : 0; p.nobc = (c->scheme == 10 || c->cfg.outlet_type == LBMPM_OUTLET_NONE) ? 1 : 0;
     p.psi = c->psi;
     return p;
 }
@@ -737,7 +737,7 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
         set_error("the original Shan-Chen path is SRT only in the reference (ShanChenD2Q9.py:1584)");
         return LBMPM_ERR_UNSUPPORTED;
     }
-    LBMPM_REQUIRE(cfg->outlet_type == 0 || cfg->outlet_type == 1, "bad outlet_type %d", cfg->outlet_type);
+    LBMPM_REQUIRE(cfg->outlet_type >= 0 && cfg->outlet_type <= 2, "bad outlet_type %d", cfg->outlet_type);
     LBMPM_REQUIRE(cfg->tau[0] > 0.5 && cfg->tau[1] > 0.5, "FluidsTau must exceed 0.5");
     LBMPM_REQUIRE(cfg->variant == 0, "variant must be 0");
     LBMPM_REQUIRE(cfg->force_scheme == 0 || cfg->force_scheme == 4 || cfg->force_scheme == 8 || cfg->force_scheme == 10,

@@ -40,7 +40,7 @@ class SC2DSolver:
             raise ValueError("InteractionType must be 'ShanChen' or 'EFS'")
         if p["relax"] not in ("SRT", "MRT"):
             raise ValueError("RelaxationType must be 'SRT' or 'MRT' ('TRT' is a stub in the reference)")
-        if p["outlet"] not in ("Dirichlet", "Convective"):
+        if p["outlet"] not in ("Dirichlet", "Convective", "Periodic"):
             raise ValueError("BoundaryTypeOutlet must be 'Dirichlet' or 'Convective'")
         cfg = SC2DConfig()
         cfg.nx, cfg.ny = self.nx, self.ny
@@ -49,7 +49,7 @@ class SC2DSolver:
         cfg.tau[0], cfg.tau[1] = p["tau0"], p["tau1"]
         cfg.g_fluid = p["G"]
         cfg.g_solid[0], cfg.g_solid[1] = p["Gs0"], p["Gs1"]
-        cfg.outlet_type = 0 if p["outlet"] == "Dirichlet" else 1
+        cfg.outlet_type = {"Dirichlet": 0, "Convective": 1, "Periodic": 2}[p["outlet"]]     # Periodic: no boundary kernels (API only)
         cfg.inlet_velocity_y[0], cfg.inlet_velocity_y[1] = p["vy0"], p["vy1"]
         cfg.device = int(device); cfg.variant = 0
         cfg.force_scheme = int(p["scheme"])

@@ -118,7 +118,7 @@ class SCOracle:
         s.Gs[0], s.Gs[1] = p["Gs0"], p["Gs1"]
         s.vyIn[0], s.vyIn[1] = p["vy0"], p["vy1"]
         s.mrt = 1 if p["relax"] == "MRT" else 0
-        s.outletType = 0 if p["outlet"] == "Dirichlet" else 1
+        s.outletType = {"Dirichlet": 0, "Convective": 1, "Periodic": 2}[p["outlet"]]
         s.Lam = _p(self.Lam, F64P)
         for name in ("f", "fOld", "fNew", "rho", "psi", "Fx", "Fy", "ux", "uy", "feq", "ff", "fM", "ffM",
                      "vx", "vy"):

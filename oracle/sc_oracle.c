@@ -502,7 +502,7 @@ typedef struct {
     i64 N, nx, ny;
     const i64 *fluidNodes, *nbr;
     double tau[NF], G[NF * NF], Gs[NF], vyIn[NF];
-    int mrt, outletType /*0 Dirichlet 1 Convective*/;
+    int mrt, outletType /*0 Dirichlet 1 Convective 2 none (periodic box)*/;
     const double *Lam;   /* [2][9][9], MRT only */
     double *f, *fOld, *fNew, *rho, *psi, *Fx, *Fy, *ux, *uy, *feq, *ff, *fM, *ffM, *vx, *vy;
     int scheme;          /* 4, 8 or 10 ([ForceScheme] ExplicitScheme) */
@@ -528,7 +528,7 @@ static void sc_efs_bcs(sc_sim *s, int in_loop)
     i64 N = s->N, ny = s->ny;
     /* scheme 8 applies the same rules one row further inside and refreshes two ghost rows
      * (D:1798-1808, :1837-1849, :1942-1953, :1994-2020); scheme 10 has no boundary kernel in either place */
-    const int sh = s->scheme == 8 ? 1 : 0, on = s->scheme != 10;
+    const int sh = s->scheme == 8 ? 1 : 0, on = s->scheme != 10 && s->outletType != 2;   /* 2: periodic box, no boundary kernels */
     if (in_loop && s->outletType == 1) {          /* D:1913-1930 (not scheme dependent) */
         sc_outlet_convective_row(N, s->nx, 2, s->fluidNodes, s->nbr, s->f, s->fOld, s->rho, s->vy);
         sc_outlet_convective_row(N, s->nx, 1, s->fluidNodes, s->nbr, s->f, s->fOld, s->rho, s->vy);
@@ -579,8 +579,10 @@ void sc_efs_run(sc_sim *s, i64 n) { for (i64 k = 0; k < n; ++k) sc_efs_iter(s); 
 void sc_sc_iter(sc_sim *s)
 {
     i64 N = s->N;
-    sc_inlet_velocity(N, s->nx, s->ny, s->vyIn, s->fluidNodes, s->rho, s->f);
-    sc_ghost_inlet(N, s->nx, s->ny, s->fluidNodes, s->nbr, s->rho, s->f);
+    if (s->outletType != 2) {        /* 2: periodic box (static-droplet case), boundary kernels skipped */
+        sc_inlet_velocity(N, s->nx, s->ny, s->vyIn, s->fluidNodes, s->rho, s->f);
+        sc_ghost_inlet(N, s->nx, s->ny, s->fluidNodes, s->nbr, s->rho, s->f);
+    }
     sc_rho(N, s->rho, s->f);
     memcpy(s->psi, s->rho, sizeof(double) * NF * N);
     sc_interaction_collision(N, s->tau, s->G, s->Gs, s->rho, s->psi, s->f, s->nbr, s->Fx, s->Fy);
