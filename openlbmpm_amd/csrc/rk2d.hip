@@ -839,6 +839,7 @@ int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
             // tile-shape sweep on MI355X (1024^2): 64x8 / 1 node per thread is the
             // default; the others stay selectable for tuning (LBMPM_RK2D_SHAPE)
             case 1: launch_fused_shape<FusedShape<16, 2>>(c, p); break;
+            case 3: launch_fused_shape<FusedShape<4, 1>>(c, p); break;
             case 2: launch_fused_shape<FusedShape<16, 1>>(c, p); break;
             default: launch_fused_shape<FusedShape<8, 1>>(c, p); break;
         }

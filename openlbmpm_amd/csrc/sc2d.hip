@@ -322,7 +322,7 @@ __device__ __forceinline__ void chain_collide(const SCDev &p, double f0[9], doub
 }
 
 // ---------------------------------------------------------------- fused step kernel
-constexpr int TW = 64, TH = 8, HALO = 1, RW = TW + 2 * HALO, RH = TH + 2 * HALO, THREADS = TW * TH;
+constexpr int TW = 64, TH = 4, HALO = 1, RW = TW + 2 * HALO, RH = TH + 2 * HALO, THREADS = TW * TH;
 
 template <bool MRT>
 __global__ __launch_bounds__(THREADS) void sc2d_fused(SCDev p, int tiles_x)
