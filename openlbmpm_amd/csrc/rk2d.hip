@@ -819,6 +819,15 @@ void launch_fused_shape(lbmpm_rk2d *c, const RKDev &p)
     else rk2d_fused<false, false, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
 }
 
+template <typename SH>
+void launch_fused_tracer(lbmpm_rk2d *c, const RKDev &p)
+{
+    const int tiles_x = (c->nx + SH::TW - 1) / SH::TW, tiles_y = (c->ny + SH::TH - 1) / SH::TH;
+    const dim3 g(tiles_x * tiles_y), b(SH::THREADS);
+    if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2d_fused<true, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+    else rk2d_fused<false, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+}
+
 int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
 {
     RKDev p = make_dev(c);
@@ -829,11 +838,9 @@ int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
         const bool ev = timed && c->pool.take(&e0, &e1);
         if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
         if (c->ntr > 0) {
-            using SH = FusedShape<8, 1>;
-            const int tiles_x = (c->nx + SH::TW - 1) / SH::TW, tiles_y = (c->ny + SH::TH - 1) / SH::TH;
-            const dim3 g(tiles_x * tiles_y), b(SH::THREADS);
-            if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2d_fused<true, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
-            else rk2d_fused<false, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+            // the tracer variant needs 157 VGPRs: 64 x 4 tiles keep three independent blocks on a CU
+            if (c->shape == 0) launch_fused_tracer<FusedShape<4, 1>>(c, p);
+            else launch_fused_tracer<FusedShape<8, 1>>(c, p);
         } else
         switch (c->shape) {
             // tile-shape sweep on MI355X (1024^2): 64x8 / 1 node per thread is the
