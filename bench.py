@@ -151,7 +151,7 @@ def cpu_baseline_c5(edge=128, target_seconds=12.0):
     nfl = int(dom.sum())
     o.run(1)
     t0 = time.perf_counter(); o.run(1); dt = time.perf_counter() - t0
-    n = max(1, min(100, int(target_seconds / max(dt, 1e-6))))
+    n = max(1, min(2000, int(target_seconds / max(dt, 1e-6))))       # about 12 s of CPU work
     t0 = time.perf_counter(); o.run(n); el = time.perf_counter() - t0
     return dict(value=round(nfl * n / el / 1e6, 3), unit="MLUPS", cores=int(lib().rk_oracle_threads()), kind="port",
                 sample="c5 model on a %d^3 porous sample (same generator/parameters), %d steps of "
