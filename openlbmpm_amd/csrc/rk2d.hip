@@ -489,7 +489,7 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
 }
 
 template <bool MRT, bool TRACER, typename SH>
-__global__ __launch_bounds__(SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
+__global__ __launch_bounds__(SH::THREADS, 1024 / SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
 {
     constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
     constexpr int RW = SH::RW, RH = SH::RH;

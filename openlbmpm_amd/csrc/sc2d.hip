@@ -325,7 +325,7 @@ __device__ __forceinline__ void chain_collide(const SCDev &p, double f0[9], doub
 constexpr int TW = 64, TH = 4, HALO = 1, RW = TW + 2 * HALO, RH = TH + 2 * HALO, THREADS = TW * TH;
 
 template <bool MRT>
-__global__ __launch_bounds__(THREADS) void sc2d_fused(SCDev p, int tiles_x)
+__global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
 {
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
     __shared__ double s_psi0[RH * RW];
