@@ -655,7 +655,7 @@ __device__ __forceinline__ double ring_phi_c(const RK3Dev &p, const Rows &rows, 
 
 // the marching kernel of rk3d_fused on compact storage (TX = 64: a wave owns one row segment)
 template <int TY, bool FIRST>
-__global__ __launch_bounds__(64 * TY, 768 / (64 * TY)) void rk3dc_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last)
+__global__ __launch_bounds__(64 * TY, 512 / (64 * TY)) void rk3dc_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last)
 {
     constexpr int TX = 64;
     using M = March<TX, TY>;

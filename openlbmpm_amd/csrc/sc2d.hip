@@ -173,9 +173,7 @@ __device__ __forceinline__ void sc_force_iso(const SCDev &p, int x, int y, const
     const int nn = s10 ? 36 : 24;
     size_t nidx[36];
     unsigned long long fl = 0;
-#pragma unroll
-    for (int m = 0; m < 36; ++m) {
-        if (m >= nn) break;
+    for (int m = 0; m < nn; ++m) {
         int yy = y + DY[m], xx = x + DX[m];
         yy = yy < 0 ? yy + p.ny : (yy >= p.ny ? yy - p.ny : yy);
         xx = xx < 0 ? xx + p.nx : (xx >= p.nx ? xx - p.nx : xx);
@@ -184,9 +182,7 @@ __device__ __forceinline__ void sc_force_iso(const SCDev &p, int x, int y, const
     }
     auto F = [&](int k) { return (fl >> k) & 1ull; };
     double fx[2] = {0., 0.}, fy[2] = {0., 0.};
-#pragma unroll
-    for (int m = 0; m < 36; ++m) {
-        if (m >= nn) break;
+    for (int m = 0; m < nn; ++m) {
         bool on = F(m);
         if (on && m >= 8) {
             if (m < 16) on = F(m - 8);

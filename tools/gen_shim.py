@@ -73,11 +73,11 @@ SPEC = [
  ("sc", "fillNeighboringNodes", O + ":22", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
   "launch_rk_fill_neighbors(st, totalNodes, nx, ny, fluidNodes, domainNewIndex, neighboringNodes)"),
  ("sc", "savePDFLastStep", O + ":70", "totalNodes:i numFluids:i xDim:i fluidPDF:D fluidPDFOld:D",
-  "sc_check_nf(numFluids); hipMemcpyAsync(fluidPDFOld, fluidPDF, sizeof(double) * 2 * 9 * (size_t)totalNodes, hipMemcpyDeviceToDevice, st)"),
+  "sc_check_nf(numFluids); LBMPM_HIP_TRY(hipMemcpyAsync(fluidPDFOld, fluidPDF, sizeof(double) * 2 * 9 * (size_t)totalNodes, hipMemcpyDeviceToDevice, st))"),
  ("sc", "calFluidRhoGPU", O + ":84", "totalNodes:i numFluids:i xDim:i fluidRho:D fluidPDF:D",
   "sc_check_nf(numFluids); launch_sc_rho(st, totalNodes, fluidRho, fluidPDF)"),
  ("sc", "calFluidPotentialGPUEql", O + ":99", "totalNodes:i numFluids:i xDim:i fluidRho:D fluidPotential:D",
-  "sc_check_nf(numFluids); hipMemcpyAsync(fluidPotential, fluidRho, sizeof(double) * 2 * (size_t)totalNodes, hipMemcpyDeviceToDevice, st)"),
+  "sc_check_nf(numFluids); LBMPM_HIP_TRY(hipMemcpyAsync(fluidPotential, fluidRho, sizeof(double) * 2 * (size_t)totalNodes, hipMemcpyDeviceToDevice, st))"),
  ("sc", "calPhysicalVelocity", O + ":156", "totalNodes:i numFluids:i xDim:i fluidPDF:D fluidRho:D forceX:D forceY:D velocityPX:D velocityPY:D",
   "sc_check_nf(numFluids); launch_sc_physical_velocity(st, totalNodes, fluidPDF, fluidRho, forceX, forceY, velocityPX, velocityPY)"),
  ("sc", "calStreaming1GPU", O + ":452", "totalNum:i numFluids:i xDim:i fluidNodes:I neighboringNodes:I fluidPDF:D fluidPDFNew:D",
