@@ -12,7 +12,17 @@ __device__ __forceinline__ int wrapm(int v, int n)
     return v < 0 ? v + n : v;
 }
 
-// Pull-streaming of two D2Q9 lattices stored as f[c][q][y*pitch + x] (c = 0,1).
+// The two D2Q9 lattices of a solver (red/blue, component 0/1) are stored side by side,
+// f[q][y*pitch + x] = {f_0, f_1}: one 16-byte access per direction moves both.
+__host__ __device__ __forceinline__ size_t fslot(size_t plane, int q, size_t node, int c) { return ((size_t)q * plane + node) * 2 + (size_t)c; }
+__device__ __forceinline__ void store_pair(double *f, size_t plane, int q, size_t node, double a, double b)
+{
+    double2 v;
+    v.x = a; v.y = b;
+    reinterpret_cast<double2 *>(f)[(size_t)q * plane + node] = v;
+}
+
+// Pull-streaming of the two lattices.
 // Equivalent to the reference's push + in-place half-way bounce-back
 // (AcceleratedRKGPU2D.py:340-417, OptimizedD2Q9GPU.py:452-550).  P needs the members
 // nx, ny, pitch, plane, solidnbr, fin, first.
@@ -21,29 +31,27 @@ __device__ __forceinline__ void pull_node(const P &p, int x, int y, double f0[9]
 {
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY, OPP[9] = LBMPM_D2Q9_OPP;
     const size_t idx = (size_t)y * p.pitch + x;
-    const double *fr = p.fin;
-    const double *fb = p.fin + 9 * p.plane;
+    const double2 *f2 = reinterpret_cast<const double2 *>(p.fin);
     // p.first: the state is already "post-streaming" (initial condition) -> read in place
     const bool first = p.first != 0;
     const unsigned sn = first ? 0u : p.solidnbr[idx];
-    // All 18 loads are issued without waiting for the solid-neighbour byte (solid nodes hold
+    // All 9 loads are issued without waiting for the solid-neighbour byte (solid nodes hold
     // finite junk that is never used); the rare bounce-back links are patched afterwards.
-    f0[0] = fr[idx];
-    f1[0] = fb[idx];
+    { const double2 v = f2[idx]; f0[0] = v.x; f1[0] = v.y; }
 #pragma unroll
     for (int i = 1; i < 9; ++i) {
         const int xs = wrapi(x - EX[i], p.nx), ys = wrapi(y - EY[i], p.ny);
         const size_t s = first ? idx : (size_t)ys * p.pitch + xs;
-        f0[i] = fr[i * p.plane + s];
-        f1[i] = fb[i * p.plane + s];
+        const double2 v = f2[i * p.plane + s];
+        f0[i] = v.x; f1[i] = v.y;
     }
     if (sn != 0) {
 #pragma unroll
         for (int i = 1; i < 9; ++i) {
             const int o = OPP[i];
             if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
-                f0[i] = fr[o * p.plane + idx];
-                f1[i] = fb[o * p.plane + idx];
+                const double2 v = f2[o * p.plane + idx];
+                f0[i] = v.x; f1[i] = v.y;
             }
         }
     }

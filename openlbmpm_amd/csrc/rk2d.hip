@@ -5,7 +5,7 @@
 // include/lbmpm.h for the kernel-by-kernel list and DESIGN.md for the data layout.
 //
 // Layout (HBM): dense grid, structure of arrays, direction-major:
-//     f[c][q][y*pitch + x]   c in {R,B}, q in 0..8, float64, two ping-pong buffers
+//     f[q][y*pitch + x] = {f_R, f_B}   q in 0..8, float64 pairs, two ping-pong buffers
 //     solidnbr[y*pitch + x]  uint8, bit (i-1) set <=> node + e_i is NOT fluid (periodic wrap)
 //     flags[y*pitch + x]     uint8, bit0 = fluid
 //     F[2][..]   CSF force of the last step (the reference's velocity lags it by one step)
@@ -396,9 +396,8 @@ __global__ __launch_bounds__(BX *BY) void rk2d_collide_stream(RKDev p)
     if (p.diag) { p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K; }
     collide<MRT>(p, fT, rR, rB, phi, vx, vy, Fx, Fy);
     recolor(p.beta, fT, rR, rB, gx, gy, fR, fB);
-    double *fr = p.fout, *fb = p.fout + 9 * p.plane;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { fr[i * p.plane + idx] = fR[i]; fb[i * p.plane + idx] = fB[i]; }
+    for (int i = 0; i < 9; ++i) lbmpm_dev::store_pair(p.fout, p.plane, i, idx, fR[i], fB[i]);
 }
 
 // ---------------------------------------------------------------- fused schedule
@@ -666,9 +665,8 @@ __global__ __launch_bounds__(SH::THREADS, 1024 / SH::THREADS) void rk2d_fused(RK
         }
         p.F[idx] = Fx;
         p.F[p.plane + idx] = Fy;
-        double *fr = p.fout, *fb = p.fout + 9 * p.plane;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { fr[i * p.plane + idx] = fR[i]; fb[i * p.plane + idx] = fB[i]; }
+        for (int i = 0; i < 9; ++i) lbmpm_dev::store_pair(p.fout, p.plane, i, idx, fR[i], fB[i]);
     }
 }
 
@@ -1004,8 +1002,8 @@ extern "C" int lbmpm_rk2d_set_pdf(lbmpm_rk2d *c, const double *pdf_r, const doub
             const size_t s = ((size_t)y * c->nx + x) * 9, d = (size_t)y * c->pitch + x;
             if (c->h_domain[(size_t)y * c->nx + x] != 1) continue;
             for (int i = 0; i < 9; ++i) {
-                h[i * c->plane + d] = pdf_r[s + i];
-                h[(9 + i) * c->plane + d] = pdf_b[s + i];
+                h[lbmpm_dev::fslot(c->plane, i, d, 0)] = pdf_r[s + i];
+                h[lbmpm_dev::fslot(c->plane, i, d, 1)] = pdf_b[s + i];
             }
         }
     LBMPM_HIP_TRY(hipMemcpyAsync(c->fA, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));

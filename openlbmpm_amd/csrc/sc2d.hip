@@ -6,7 +6,7 @@
 // list.  "O:" = ShanChen2D/OptimizedD2Q9GPU.py, "E:" = ShanChen2D/ExplicitD2Q9GPU.py,
 // "D:" = ShanChen2D/ShanChenD2Q9.py.
 //
-// Layout: dense SoA f[k][q][y*pitch+x] (k = component), ping-pong; solidnbr / flags bytes as
+// Layout: dense f[q][y*pitch+x] = {f_0, f_1} (both components side by side), ping-pong; solidnbr / flags bytes as
 // in rk2d.hip.  State between steps = post-collision populations at their own node.
 // One fused kernel per time step: a 64x8 tile + 1-node halo recomputes rho_k (= psi_k) of the
 // streamed, boundary-corrected lattice into LDS, then every node evaluates the
@@ -409,9 +409,8 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
     if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
     }
     // non-fluid lanes of a line that holds fluid write zeros into their dead slots (full-line stores)
-    double *o0 = p.fout, *o1 = p.fout + 9 * p.plane;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) { o0[j * p.plane + idx] = f0[j]; o1[j * p.plane + idx] = f1[j]; }
+    for (int j = 0; j < 9; ++j) store_pair(p.fout, p.plane, j, idx, f0[j], f1[j]);
 }
 
 // ---------------------------------------------------------------- schemes 8 / 10: two sweeps per step
@@ -467,7 +466,7 @@ __global__ __launch_bounds__(256) void sc2d_iso_collide(SCDev p)
     chain_collide<MRT>(p, f0, f1, rho, Fx, Fy, ueqx, ueqy);
     if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
 #pragma unroll
-    for (int j = 0; j < 9; ++j) { p.fout[j * p.plane + idx] = f0[j]; p.fout[(9 + j) * p.plane + idx] = f1[j]; }
+    for (int j = 0; j < 9; ++j) store_pair(p.fout, p.plane, j, idx, f0[j], f1[j]);
 }
 
 // SC end-of-iteration view (D:1624-1629): streamed populations + outlet copies, rho, u with the
@@ -499,7 +498,7 @@ __global__ __launch_bounds__(256) void sc2d_init_psi(SCDev p)
     const size_t idx = (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
     double a = 0., b = 0.;
-    for (int j = 0; j < 9; ++j) { a += p.fin[j * p.plane + idx]; b += p.fin[(9 + j) * p.plane + idx]; }
+    for (int j = 0; j < 9; ++j) { a += p.fin[fslot(p.plane, j, idx, 0)]; b += p.fin[fslot(p.plane, j, idx, 1)]; }
     p.psi[idx] = a; p.psi[p.plane + idx] = b;
 }
 
@@ -515,7 +514,7 @@ __global__ __launch_bounds__(256) void sc2d_init_chain(SCDev p)
     if (!(p.flags[idx] & 1)) return;
     const unsigned sn = p.solidnbr[idx];
     double f0[9], f1[9], nb0[9], nb1[9];
-    for (int j = 0; j < 9; ++j) { f0[j] = p.fin[j * p.plane + idx]; f1[j] = p.fin[(9 + j) * p.plane + idx]; }
+    for (int j = 0; j < 9; ++j) { f0[j] = p.fin[fslot(p.plane, j, idx, 0)]; f1[j] = p.fin[fslot(p.plane, j, idx, 1)]; }
     const double rho[2] = {p.psi[idx], p.psi[p.plane + idx]};
     for (int i = 1; i < 9; ++i) {
         const size_t n = (size_t)wrapi(y + EY[i], p.ny) * p.pitch + wrapi(x + EX[i], p.nx);
@@ -541,7 +540,7 @@ __global__ __launch_bounds__(256) void sc2d_init_chain(SCDev p)
             const size_t o = (size_t)(9 * k + j) * p.plane + idx;
             p.scrA[o] = feq;
             p.scrB[o] = ff;
-            p.fout[o] = f[k][j] - 1. / 2. * ff;          // transformPDFGPU E:278-288
+            p.fout[fslot(p.plane, j, idx, k)] = f[k][j] - 1. / 2. * ff;          // transformPDFGPU E:278-288
         }
 }
 
@@ -561,7 +560,7 @@ __global__ __launch_bounds__(256) void sc2d_init_collide(SCDev p)
     if (bc && p.outlet == LBMPM_OUTLET_PRESSURE && y <= p.sh) ys = 1 + p.sh;
     const size_t s = (size_t)ys * p.pitch + x;
     double f0[9], f1[9];
-    for (int j = 0; j < 9; ++j) { f0[j] = p.fin[j * p.plane + s]; f1[j] = p.fin[(9 + j) * p.plane + s]; }
+    for (int j = 0; j < 9; ++j) { f0[j] = p.fin[fslot(p.plane, j, s, 0)]; f1[j] = p.fin[fslot(p.plane, j, s, 1)]; }
     if (bc && ys == p.ny - 2 - p.sh) { bc_inlet(p.vyIn[0], f0); bc_inlet(p.vyIn[1], f1); }
     if (bc && p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1 + p.sh) { bc_outlet(1.0, f0); bc_outlet(0.02, f1); }
     if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2) {
@@ -582,10 +581,10 @@ __global__ __launch_bounds__(256) void sc2d_init_collide(SCDev p)
         if (MRT) {
             double rl[9];
             mrt_relax(d, 1. / p.tau[k], rl);
-            for (int j = 0; j < 9; ++j) p.fout[(size_t)(9 * k + j) * p.plane + idx] = f[k][j] + rl[j] + 1. * ff[j];
+            for (int j = 0; j < 9; ++j) p.fout[fslot(p.plane, j, idx, k)] = f[k][j] + rl[j] + 1. * ff[j];
         } else {
             const double om = 1. / p.tau[k];
-            for (int j = 0; j < 9; ++j) p.fout[(size_t)(9 * k + j) * p.plane + idx] = f[k][j] + om * d[j] + 1. * ff[j];
+            for (int j = 0; j < 9; ++j) p.fout[fslot(p.plane, j, idx, k)] = f[k][j] + om * d[j] + 1. * ff[j];
         }
     }
 }
@@ -806,7 +805,7 @@ extern "C" int lbmpm_sc2d_set_pdf(lbmpm_sc2d *c, const double *pdf0, const doubl
         for (int x = 0; x < c->nx; ++x) {
             if (c->h_domain[(size_t)y * c->nx + x] != 1) continue;
             const size_t s = ((size_t)y * c->nx + x) * 9, d = (size_t)y * c->pitch + x;
-            for (int i = 0; i < 9; ++i) { h[i * c->plane + d] = pdf0[s + i]; h[(9 + i) * c->plane + d] = pdf1[s + i]; }
+            for (int i = 0; i < 9; ++i) { h[fslot(c->plane, i, d, 0)] = pdf0[s + i]; h[fslot(c->plane, i, d, 1)] = pdf1[s + i]; }
         }
     LBMPM_HIP_TRY(hipMemcpyAsync(c->fA, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     LBMPM_HIP_TRY(hipMemsetAsync(c->F, 0, 4 * c->plane * sizeof(double), c->stream));
