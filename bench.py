@@ -259,8 +259,9 @@ def main():
                            "fluid_nodes": nfluid_global, "lattice_nodes": int(np.prod(size)),
                            "parallelism": "z-slabs x%d, RCCL p2p halo (5 populations x 2 colours + phi per face)" % world
                                           if world > 1 else "1 gpu",
-                           "kernel_schedule": "one fused z-marching kernel per step (pull, phase field in an LDS ring, collide, store)"
-                                              if dom_kernel == "rk3d_fused" else "phase_field + collide (split-2)",
+                           "kernel_schedule": "one fused z-marching kernel per step (pull, phase field in an LDS ring, collide, store), "
+                                              + ("compact storage: fluid cells only" if dom_kernel == "rk3dc_fused" else "dense storage")
+                                              if "fused" in dom_kernel else "phase_field + collide (split-2)",
                            "parity": "unpinned (no 3-D code in the reference); checked against oracle/rk3d_oracle.c"},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
