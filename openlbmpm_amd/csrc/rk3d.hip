@@ -7,11 +7,18 @@
 // oracle/rk3d_oracle.c and DESIGN.md).  PARITY UNPINNED against the reference; pinned
 // against the independent CPU statement oracle/rk3d_oracle.c.
 //
-// Layout per rank: dense, plane-major SoA f[zl][colour][q][y][x], zl = 0..nzl+1 where zl = 1..nzl
-// are the owned planes and zl = 0 / nzl+1 are halo planes holding the neighbour rank's outermost
-// plane (only the five populations that cross the cut are ever filled / read).  x, y periodic;
-// z not (planes 0 and nz-1 of the global lattice are boundary ghost planes).
-// One time step = [f halo exchange] -> phase_field -> [phi halo exchange] -> collide.
+// Two storage layouts per rank (zl = 0..nzl+1: owned planes 1..nzl + one halo plane on each side that
+// holds the neighbour rank's outermost plane; only the five populations that cross the cut are
+// ever filled / read there; x, y periodic, z not: planes 0 and nz-1 of the global lattice are
+// boundary ghost planes):
+//   compact (default when nx % 64 == 0): fluid cells only, f[zl][q][j] = {red, blue}, see
+//       "compact storage" below -> kernels rk3dc_*
+//   dense: plane-major SoA f[zl][colour][q][y][x] -> kernels rk3d_*
+// and two schedules: fused (default; one z-marching kernel per step that keeps the phase field in
+// an LDS ring) and split (variant 1, dense only: phase_field sweep + collide sweep).
+// One time step of a slab = [f halo exchange] -> phase field of the face planes -> [phi halo
+// exchange] -> collide; lbmpm_rk3d_collide_interior / _boundary overlap the exchanges with the
+// planes that do not depend on them.
 #include "lbmpm_common.h"
 #include "d2q9_device.h"
 
@@ -621,7 +628,6 @@ struct TileRows {
     static constexpr int ROWS = TY + 4, SLOTS = 8;
     const u32x4 (*ring)[ROWS][6];
     int lrow, k;                 // this lane's row inside the staged rows, its segment slot
-    bool uni;
     template <bool UNI>
     __device__ __forceinline__ RowTab get(int zl, int ry) const
     {
@@ -682,9 +688,9 @@ __global__ __launch_bounds__(64 * TY, 512 / (64 * TY)) void rk3dc_fused(RK3Dev p
         hy = ring_coord(ty * TY + hly - 1, p.ny);
         has_rim = hx >= 0 && hy >= 0;
     }
-    const TileRowsU<TY, true> rows_own{{srow, ly + 2, 1, true}};
-    const TileRowsU<TY, true> rows_rimrow{{srow, hly + 1, 1, true}};
-    const TileRowsU<TY, false> rows_rimcol{{srow, hly + 1, hlx == 0 ? 0 : 2, false}};
+    const TileRowsU<TY, true> rows_own{{srow, ly + 2, 1}};
+    const TileRowsU<TY, true> rows_rimrow{{srow, hly + 1, 1}};
+    const TileRowsU<TY, false> rows_rimcol{{srow, hly + 1, hlx == 0 ? 0 : 2}};
     const int za = z_first + chunk * chunk_len, zb = min(za + chunk_len - 1, z_last);
     // Row records are staged two march steps ahead of their first use: fetched into a register
     // during one step, written to LDS at the top of the next (so nobody waits for that fetch),
