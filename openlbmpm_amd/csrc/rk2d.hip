@@ -488,7 +488,7 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
 }
 
 template <bool MRT, bool TRACER, typename SH>
-__global__ __launch_bounds__(SH::THREADS, 1024 / SH::THREADS) void rk2d_fused(RKDev p, int tiles_x)
+__global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rk2d_fused(RKDev p, int tiles_x)
 {
     constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
     constexpr int RW = SH::RW, RH = SH::RH;
@@ -836,8 +836,8 @@ int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
         const bool ev = timed && c->pool.take(&e0, &e1);
         if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
         if (c->ntr > 0) {
-            // the tracer variant needs 157 VGPRs: 64 x 4 tiles keep three independent blocks on a CU
-            if (c->shape == 0) launch_fused_tracer<FusedShape<4, 1>>(c, p);
+            // registers are capped at 128 (amdgpu_waves_per_eu on the kernel): two 64 x 8 blocks share a CU
+            if (c->shape == 3) launch_fused_tracer<FusedShape<4, 1>>(c, p);
             else launch_fused_tracer<FusedShape<8, 1>>(c, p);
         } else
         switch (c->shape) {
