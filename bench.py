@@ -57,10 +57,11 @@ def measured_hbm(device):
     against the 8 TB/s specification)"""
     import ctypes as C
     from openlbmpm_amd import _lib
-    a, b = C.c_double(0), C.c_double(0)
-    if _lib.lib().lbmpm_hbm_stream_test(int(device), 4 << 30, 5, C.byref(a), C.byref(b)) != 0:
+    a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+    if _lib.lib().lbmpm_hbm_stream_test(int(device), 4 << 30, 5, C.byref(a), C.byref(b), C.byref(c)) != 0:
         return None
-    return {"copy_GBs": round(a.value, 1), "read_GBs": round(b.value, 1), "bytes_per_buffer": 4 << 30}
+    return {"copy_GBs": round(a.value, 1), "read_GBs": round(b.value, 1), "inplace_update_GBs": round(c.value, 1),
+            "bytes_per_buffer": 4 << 30}
 
 
 # ----------------------------------------------------------------------------- workloads

@@ -45,9 +45,10 @@ const char *lbmpm_last_error(void);
 const char *lbmpm_version(void);
 /* number of visible HIP devices, or a negative status */
 int lbmpm_device_count(void);
-/* measured HBM ceiling of the device for the roofline: copy (read + write) and read-only GB/s over
- * two buffers of bytes_per_buffer each (choose them far larger than the 256 MB Infinity Cache) */
-int lbmpm_hbm_stream_test(int device, int64_t bytes_per_buffer, int reps, double *copy_gbs, double *read_gbs);
+/* measured HBM ceiling of the device for the roofline: copy (read + write, two buffers), read-only and
+ * in-place update (read + write of the same lines; may be NULL) GB/s over buffers of
+ * bytes_per_buffer each (choose them far larger than the 256 MB Infinity Cache) */
+int lbmpm_hbm_stream_test(int device, int64_t bytes_per_buffer, int reps, double *copy_gbs, double *read_gbs, double *inplace_gbs);
 
 /* ------------------------------------------------------------------------------------
  * Colour-gradient D2Q9 two-phase solver with continuum-surface-force (CSF) tension.

@@ -102,7 +102,7 @@ _SIGNATURES = {
     "lbmpm_rk3d_phase_field": (C.c_int, [C.c_void_p, C.c_int]),
     "lbmpm_rk3d_collide": (C.c_int, [C.c_void_p]),
     "lbmpm_rk3d_collide_interior": (C.c_int, [C.c_void_p]),
-    "lbmpm_hbm_stream_test": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "lbmpm_hbm_stream_test": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lbmpm_rk3d_collide_boundary": (C.c_int, [C.c_void_p]),
     "lbmpm_rk3d_step": (C.c_int, [C.c_void_p, C.c_int64]),
     "lbmpm_rk3d_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),

@@ -89,55 +89,85 @@ __global__ void setup_solidnbr(int nx, int ny, int pitch, const uint8_t *flags, 
 // The ceiling the lattice kernels are measured against: plain copy (1 read + 1 write) and a
 // read-only sum over buffers far larger than L2 + Infinity Cache, 16 bytes per lane.
 namespace {
+// four independent 16-byte accesses in flight per lane
 __global__ __launch_bounds__(256) void stream_copy(const double2 *__restrict__ a, double2 *__restrict__ b, size_t n)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const double2 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+        b[i] = v0; b[i + stride] = v1; b[i + 2 * stride] = v2; b[i + 3 * stride] = v3;
+    }
+    for (; i < n; i += stride) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void stream_scale(double2 *__restrict__ a, size_t n)      // in place: 1 read + 1 write of the same lines
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        double2 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+        v0.x *= 1.0001; v1.x *= 1.0001; v2.x *= 1.0001; v3.x *= 1.0001;
+        a[i] = v0; a[i + stride] = v1; a[i + 2 * stride] = v2; a[i + 3 * stride] = v3;
+    }
+    for (; i < n; i += stride) { double2 v = a[i]; v.x *= 1.0001; a[i] = v; }
 }
 __global__ __launch_bounds__(256) void stream_read(const double2 *__restrict__ a, double *out, size_t n)
 {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double s = 0.;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const double2 v = a[i]; s += v.x + v.y; }
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const double2 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+        s += (v0.x + v0.y) + (v1.x + v1.y) + (v2.x + v2.y) + (v3.x + v3.y);
+    }
+    for (; i < n; i += stride) { const double2 v = a[i]; s += v.x + v.y; }
     if (s == 12345.678) out[0] = s;      // keeps the loads alive, never true for the zero-filled buffer
 }
 }  // namespace
 
-extern "C" int lbmpm_hbm_stream_test(int device, int64_t bytes_per_buffer, int reps, double *copy_gbs, double *read_gbs)
+extern "C" int lbmpm_hbm_stream_test(int device, int64_t bytes_per_buffer, int reps, double *copy_gbs, double *read_gbs, double *inplace_gbs)
 {
     LBMPM_REQUIRE(bytes_per_buffer >= (1 << 20) && reps >= 1 && copy_gbs && read_gbs, "lbmpm_hbm_stream_test: bad argument");
     LBMPM_HIP_TRY(hipSetDevice(device));
     const size_t n = (size_t)bytes_per_buffer / sizeof(double2);
     double2 *a = nullptr, *b = nullptr;
     hipStream_t st = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&a), n * sizeof(double2));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(double2));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventCreate(&e2);
+    if (e == hipSuccess) e = hipEventCreate(&e3);
     if (e == hipSuccess) e = hipMemsetAsync(a, 0, n * sizeof(double2), st);
     if (e == hipSuccess) e = hipMemsetAsync(b, 0, n * sizeof(double2), st);
     if (e == hipSuccess) {
-        const dim3 grid(256 * 16), block(256);
+        const dim3 grid(256 * 32), block(256);
         stream_copy<<<grid, block, 0, st>>>(a, b, n);          // warm-up
         (void)hipEventRecord(e0, st);
         for (int r = 0; r < reps; ++r) stream_copy<<<grid, block, 0, st>>>(a, b, n);
         (void)hipEventRecord(e1, st);
         for (int r = 0; r < reps; ++r) stream_read<<<grid, block, 0, st>>>(a, reinterpret_cast<double *>(b), n);
         (void)hipEventRecord(e2, st);
+        for (int r = 0; r < reps; ++r) stream_scale<<<grid, block, 0, st>>>(b, n);
+        (void)hipEventRecord(e3, st);
         e = hipStreamSynchronize(st);
         if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        float m0 = 0.f, m1 = 0.f;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
         (void)hipEventElapsedTime(&m0, e0, e1);
         (void)hipEventElapsedTime(&m1, e1, e2);
+        (void)hipEventElapsedTime(&m2, e2, e3);
+        if (inplace_gbs) *inplace_gbs = 2.0 * (double)(n * sizeof(double2)) * reps / (m2 * 1e-3) / 1e9;
         *copy_gbs = 2.0 * (double)(n * sizeof(double2)) * reps / (m0 * 1e-3) / 1e9;
         *read_gbs = (double)(n * sizeof(double2)) * reps / (m1 * 1e-3) / 1e9;
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (e2) (void)hipEventDestroy(e2);
+    if (e3) (void)hipEventDestroy(e3);
     if (st) (void)hipStreamDestroy(st);
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
