@@ -169,6 +169,10 @@ typedef struct lbmpm_tracer_config {
     double inlet_concentration[4];  /* [BoundaryCondition] ConcentrationInlet             */
     int32_t dirichlet_inlet;        /* InletType 'Dirichlet' (Inamuro) on ghost row ny-1  */
     int32_t free_outlet;            /* OutletType 'Freeflow' on row 0                     */
+    double reaction_rate;           /* [Reaction] ReactionRate (first value): A + B -> C between tracers 0, 1, 2
+                                       (calReactionTracersGPU, AccelerateTransport2DRK.py:95); 0 = no reaction */
+    double diffusion_j[4];          /* [TransportParameters] DiffusionJ: rest weight J_0 of every tracer; the
+                                       reaction source is spread with J_0, (1-J_0)/4 x 4 (Transport2DRK.py:404) */
 } lbmpm_tracer_config;
 
 int lbmpm_rk2d_tracer_configure(lbmpm_rk2d *ctx, const lbmpm_tracer_config *cfg);

@@ -56,7 +56,8 @@ class Transport2DRK(RKColorGradientLBM):
         n = self.numTracers
         solver.configure_tracers(diffX=tuple(t["diffX"]), diffY=tuple(t["diffY"]), dXY=t["dXY"], dYX=t["dYX"],
                                  beta=(t["beta"],) * n, crit=0.5, inlet_conc=tuple(t["inlet_conc"]),
-                                 free_outlet=True, dirichlet_inlet=True)
+                                 free_outlet=True, dirichlet_inlet=True, reaction_rate=t["reaction_rate"],
+                                 diffJ=tuple(t["diffJ"]))
         for k in range(n):
             solver.set_tracer(k, self.tracerConc[k])
         flow = ResultFile(self.output_dir, "SimulationResultsRK",

@@ -37,7 +37,8 @@ class TracerConfig(C.Structure):
     _fields_ = [("num_tracers", C.c_int32), ("diffusion_x", C.c_double * 4), ("diffusion_y", C.c_double * 4),
                 ("diffusion_xy", C.c_double), ("diffusion_yx", C.c_double), ("beta_interface", C.c_double * 4),
                 ("criteria_rho", C.c_double), ("inlet_concentration", C.c_double * 4),
-                ("dirichlet_inlet", C.c_int32), ("free_outlet", C.c_int32)]
+                ("dirichlet_inlet", C.c_int32), ("free_outlet", C.c_int32),
+                ("reaction_rate", C.c_double), ("diffusion_j", C.c_double * 4)]
 
 
 class SC2DConfig(C.Structure):

@@ -151,8 +151,14 @@ def read_transport(ini_dir):
     p = {}
     if c.str("SystemType", "Option") != "MPMC":
         raise ConfigError("[SystemType] Option: only 'MPMC' (tracers in the two-phase flow) is part of the GPU path")
-    if c.str("SystemType", "Reaction") != "no":
-        raise ConfigError("[SystemType] Reaction = 'yes' is not built (SURVEY.md section 8f-4)")
+    p["reaction_rate"] = 0.0
+    if c.str("SystemType", "Reaction") == "yes":
+        # A + B -> C between tracers 0, 1, 2; the kernel uses the first rate only (AccelerateTransport2DRK.py:105-107)
+        nr = c.int("Reaction", "NumberReaction")
+        rates = c.floats("Reaction", "ReactionRate")
+        if nr < 1 or len(rates) < 1:
+            raise ConfigError("[Reaction] needs NumberReaction >= 1 and ReactionRate")
+        p["reaction_rate"] = rates[0]
     p["precipitation"] = c.str("SystemType", "Precipitation")
     if c.int("SystemType", "NumberSchemes") != 5:
         raise ConfigError("[SystemType] NumberSchemes: only the D2Q5 scheme is on the working path (Transport2DRK.py:1343-1384)")
@@ -160,6 +166,8 @@ def read_transport(ini_dir):
     if not 1 <= n <= 4:
         raise ConfigError("[TransportParameters] NumberTracers must be 1..4")
     p["num_tracers"] = n
+    if p["reaction_rate"] and n != 3:
+        raise ConfigError("[SystemType] Reaction = 'yes' couples exactly three tracers (NumberTracers = 3)")
     p["diffJ"] = c.floats("TransportParameters", "DiffusionJ", n)
     p["tau"] = c.floats("TransportParameters", "Tau", n)
     p["beta"] = c.float("TransportParameters", "BetaInterface")

@@ -46,6 +46,7 @@ struct RKDev {
     double *gout;
     double trCrit;
     double trM[25], trA[4][25], trBeta[4], trCb[4];
+    double trRate, trJ[4];   // reaction A + B -> C between tracers 0, 1, 2 (rate 0 = off); J_0 of every tracer
 };
 
 // ---------------------------------------------------------------- boundary rows
@@ -437,9 +438,9 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
     double ux = 0., uy = 0., un = 0.;
     if (gn > 1.0e-8) { ux = -gx / gn; uy = -gy / gn; un = sqrt(ux * ux + uy * uy); }
     const double ind = (rhoR > p.trCrit) ? -(1. - 1.) : -(1. - 0.);
-    for (int t = 0; t < p.ntr; ++t) {
+    // streamed, inlet-corrected populations of tracer t at this node
+    auto pull_g = [&](int t, double g[5]) {
         const double *gi = p.gin + (size_t)t * 5 * p.plane;
-        double g[5];
         g[0] = gi[own];
 #pragma unroll
         for (int j = 1; j < 5; ++j) {
@@ -454,6 +455,21 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
             const double u = (p.trCb[t] - sm) / W5[4];
             g[4] = W5[4] * u;
         }
+    };
+    // reaction A + B -> C (calReactionTracersGPU T:95-111): source k C_0 C_1, needs the concentrations of
+    // tracers 0 and 1 before any tracer is updated (their populations are pulled again in the loop: L1 hits)
+    double src = 0.;
+    if (p.trRate != 0.) {
+        double ga[5], gb[5];
+        pull_g(0, ga); pull_g(1, gb);
+        double ca = 0., cb = 0.;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { ca += ga[j]; cb += gb[j]; }
+        src = p.trRate * ca * cb;
+    }
+    for (int t = 0; t < p.ntr; ++t) {
+        double g[5];
+        pull_g(t, g);
         double C = 0.;
 #pragma unroll
         for (int j = 0; j < 5; ++j) C += g[j];
@@ -477,12 +493,16 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
             d[j] = v;
         }
         double *go = p.gout + (size_t)t * 5 * p.plane;
-        go[idx] = g[0] + d[0];
+        const double S = (p.trRate != 0.) ? (t == 2 ? src : -src) : 0.;        // tracers 0, 1 consumed, 2 produced
+        const double J0 = p.trJ[t], J1 = (1. - p.trJ[t]) / 4.;
+        if (p.trRate != 0.) go[idx] = (g[0] + d[0]) + J0 * S;
+        else go[idx] = g[0] + d[0];
 #pragma unroll
         for (int j = 1; j < 5; ++j) {
             double c = 0.;
             if (un > 1.0e-8) c = ((double)VX5[j] * ux + (double)VY5[j] * uy) / (1. * un);
-            go[j * p.plane + idx] = (g[j] + d[j]) + p.trBeta[t] * ind * (W5[j] * C) * c;
+            const double v = (g[j] + d[j]) + p.trBeta[t] * ind * (W5[j] * C) * c;
+            go[j * p.plane + idx] = (p.trRate != 0.) ? v + J1 * S : v;
         }
     }
 }
@@ -775,6 +795,7 @@ struct lbmpm_rk2d {
     int ntr = 0, trFree = 0, trDirichlet = 0;
     double *gA = nullptr, *gB = nullptr;
     double trCrit = 0.5, trM[25] = {0}, trA[4][25] = {{0}}, trBeta[4] = {0}, trCb[4] = {0};
+    double trRate = 0., trJ[4] = {1. / 3., 1. / 3., 1. / 3., 1. / 3.};
     int shape = 0;            // fused tile shape (LBMPM_RK2D_SHAPE, tuning only)
     bool streamed = false;    // false: fA holds the initial (already "post-streaming") state
     bool diag_valid = false;
@@ -803,6 +824,7 @@ RKDev make_dev(const lbmpm_rk2d *c)
     p.trCrit = c->trCrit;
     memcpy(p.trM, c->trM, sizeof(p.trM)); memcpy(p.trA, c->trA, sizeof(p.trA));
     memcpy(p.trBeta, c->trBeta, sizeof(p.trBeta)); memcpy(p.trCb, c->trCb, sizeof(p.trCb));
+    p.trRate = c->trRate; memcpy(p.trJ, c->trJ, sizeof(p.trJ));
     return p;
 }
 
@@ -1208,7 +1230,10 @@ extern "C" int lbmpm_rk2d_tracer_configure(lbmpm_rk2d *c, const lbmpm_tracer_con
             }
         c->trBeta[k] = t->beta_interface[k];
         c->trCb[k] = t->inlet_concentration[k];
+        c->trJ[k] = t->diffusion_j[k];
     }
+    LBMPM_REQUIRE(t->reaction_rate == 0. || t->num_tracers == 3, "the reaction couples exactly three tracers (A + B -> C)");
+    c->trRate = t->reaction_rate;
     c->trCrit = t->criteria_rho; c->trFree = t->free_outlet ? 1 : 0; c->trDirichlet = t->dirichlet_inlet ? 1 : 0;
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->gA) { (void)hipFree(c->gA); (void)hipFree(c->gB); c->gA = c->gB = nullptr; c->bytes -= (int64_t)(2 * c->ntr * 5 * c->plane * sizeof(double)); }

@@ -101,7 +101,7 @@ class RK2DSolver:
 
     # -- tracer transport (BASELINE config 4)
     def configure_tracers(self, diffX=(1. / 6.,), diffY=(1. / 6.,), dXY=0.0, dYX=0.0, beta=(1.0,), crit=0.5,
-                          inlet_conc=(1.0,), free_outlet=True, dirichlet_inlet=True):
+                          inlet_conc=(1.0,), free_outlet=True, dirichlet_inlet=True, reaction_rate=0.0, diffJ=None):
         """D2Q5-MRT tracers advected by the flow (keys of the reference's transportsetup.ini,
         Transport2DRK.py:35-311)."""
         n = len(diffX)
@@ -114,6 +114,12 @@ class RK2DSolver:
             t.beta_interface[k], t.inlet_concentration[k] = beta[k], inlet_conc[k]
         t.diffusion_xy, t.diffusion_yx, t.criteria_rho = dXY, dYX, crit
         t.dirichlet_inlet, t.free_outlet = int(dirichlet_inlet), int(free_outlet)
+        t.reaction_rate = float(reaction_rate)           # A + B -> C between tracers 0, 1, 2
+        dj = tuple(diffJ) if diffJ is not None else (1. / 3.,) * n
+        if len(dj) != n:
+            raise ValueError("diffJ needs one value per tracer")
+        for k in range(n):
+            t.diffusion_j[k] = dj[k]
         check(self._L.lbmpm_rk2d_tracer_configure(self._h, C.byref(t)), "lbmpm_rk2d_tracer_configure")
         self.num_tracers = n
 

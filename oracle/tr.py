@@ -39,11 +39,11 @@ class _Tr(C.Structure):
     _fields_ = [("N", C.c_int64), ("nx", C.c_int64), ("ny", C.c_int64), ("nT", C.c_int), ("freeOutlet", C.c_int),
                 ("dirichletInlet", C.c_int), ("fluidNodes", I64P), ("nbr4", I64P), ("M", F64P), ("A", F64P),
                 ("beta", F64P), ("cb", F64P), ("crit", C.c_double), ("g", F64P), ("gNew", F64P), ("C", F64P),
-                ("ind", F64P)]
+                ("ind", F64P), ("reaction", C.c_int), ("rate", C.c_double * 1), ("J", C.c_double * 20)]
 
 
 DEFAULT_TRACER = dict(diffX=(1. / 6.,), diffY=(1. / 6.,), dXY=0.0, dYX=0.0, beta=(1.0,), crit=0.5,
-                      inlet_conc=(1.0,), free_outlet=True, dirichlet_inlet=True)
+                      inlet_conc=(1.0,), free_outlet=True, dirichlet_inlet=True, reaction_rate=0.0, diffJ=None)
 
 
 class CoupledOracle:
@@ -78,6 +78,15 @@ class CoupledOracle:
         s.M, s.A, s.beta, s.cb = _p(self.M, F64P), _p(self.A, F64P), _p(self.beta, F64P), _p(self.cb, F64P)
         s.crit = t["crit"]
         s.g, s.gNew, s.C, s.ind = _p(self.g, F64P), _p(self.gNew, F64P), _p(self.C, F64P), _p(self.ind, F64P)
+        s.reaction = 1 if t["reaction_rate"] else 0
+        if s.reaction:
+            if nT != 3:
+                raise ValueError("the reaction couples exactly three tracers")
+            s.rate[0] = t["reaction_rate"]
+            dj = t["diffJ"] or (1. / 3.,) * nT
+            for i in range(nT):
+                for j in range(5):
+                    s.J[5 * i + j] = dj[i] if j == 0 else (1. - dj[i]) / 4.
         self._s, self._L = s, L
 
     def run(self, n):

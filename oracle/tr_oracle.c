@@ -160,6 +160,21 @@ void tr_inlet_inamuro(i64 N, int nT, i64 ny, i64 nx, const i64 *fluidNodes, cons
     }
 }
 
+/* T:95-111 calReactionTracersGPU: A + B -> C between tracers 0, 1 (consumed) and 2 (produced);
+ * source k C_0 C_1 spread over the populations with the weights J (diffJED, TD:404-410) */
+void tr_reaction(i64 N, int nT, const double *rate, const double *J /*[nT][5]*/, const double *C, double *g)
+{
+    PARFOR
+    for (i64 n = 0; n < N; ++n) {
+        double S[3];
+        S[0] = -rate[0] * C[0 * N + n] * C[1 * N + n];
+        S[1] = -rate[0] * C[0 * N + n] * C[1 * N + n];
+        S[2] = rate[0] * C[0 * N + n] * C[1 * N + n];
+        for (int i = 0; i < nT; ++i)
+            for (int j = 0; j < 5; ++j) g[((i64)i * N + n) * 5 + j] = g[((i64)i * N + n) * 5 + j] + J[i * 5 + j] * S[i];
+    }
+}
+
 typedef struct {
     i64 N, nx, ny;
     int nT, freeOutlet, dirichletInlet;
@@ -167,6 +182,8 @@ typedef struct {
     const double *M, *A, *beta, *cb;
     double crit;
     double *g, *gNew, *C, *ind;
+    int reaction;            /* [SystemType] Reaction = 'yes' (needs nT == 3) */
+    double rate[1], J[4 * 5];
 } tr_sim;
 
 /* tracer sub-step of the coupled loop, TD:1341-1418 (D2Q5, MRT): uses rhoR, physical velocity and
@@ -176,6 +193,7 @@ void tr_substep(tr_sim *s, const double *rhoR, const double *vx, const double *v
     tr_indicator(s->N, s->crit, s->ind, rhoR);
     tr_collide_mrt(s->N, s->nT, vx, vy, s->C, s->g, s->M, s->A);
     tr_interface(s->N, s->nT, s->beta, s->ind, Gx, Gy, s->C, s->g);
+    if (s->reaction) tr_reaction(s->N, s->nT, s->rate, s->J, s->C, s->g);       /* TD:1358-1362 */
     if (s->freeOutlet) tr_free_outlet(s->N, s->nT, s->nx, s->fluidNodes, s->nbr4, s->g);
     tr_stream(s->N, s->nT, s->nbr4, s->g, s->gNew);
     if (s->dirichletInlet) tr_inlet_inamuro(s->N, s->nT, s->ny, s->nx, s->fluidNodes, s->cb, s->g);

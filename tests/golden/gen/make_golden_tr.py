@@ -102,6 +102,21 @@ def main():
     g5 = g4.copy()
     T.calInamuroConstConcBoundary[grid, block](N, xDim, nT, ny, nx, fluidNodes, nbr, cb, w, g5)
     out.update(ina_cb=cb, ina_in_g=g4.copy(), ina_out_g=g5.copy())
+    # reaction between tracers (A + B -> C, Transport2DRK.py:1358-1362 / AccelerateTransport2DRK.py:95-111)
+    n3 = 3
+    g6 = rng.uniform(0.02, 0.3, size=(n3, N, 5))
+    conc3 = rng.uniform(0.0, 1.0, size=(n3, N))
+    diffJ = np.array([1. / 3., 0.3, 0.4])
+    diffJED = np.zeros([n3, 5])                      # statements of Transport2DRK.py:404-410
+    for i in range(5):
+        if i == 0:
+            diffJED[:, i] = diffJ[:]
+        else:
+            diffJED[:, i] = (1. - diffJ[:]) / 4.
+    rate = np.array([0.05])
+    g7 = g6.copy()
+    T.calReactionTracersGPU[grid, block](N, n3, xDim, rate, diffJED, conc3, g7)
+    out.update(rea_rate=rate, rea_J=diffJED, rea_diffJ=diffJ, rea_conc=conc3, rea_in_g=g6.copy(), rea_out_g=g7.copy())
     np.savez_compressed(os.path.join(OUT, "tr_kernels.npz"), **out)
     refenv.say("tr_kernels: N=%d" % N)
 

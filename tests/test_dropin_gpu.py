@@ -294,3 +294,6 @@ def test_tracer_kernels_against_reference_vectors(dropin):
     assert np.array_equal(dG.copy_to_host(), d["str_out_g"])
     TR.calInamuroConstConcBoundary[cfg](N, xDim, nT, ny, nx, dFl, dNbr, dev(d["ina_cb"]), w, dG)
     assert rel_err(dG.copy_to_host(), d["ina_out_g"]) < 1e-13
+    dG3 = dev(d["rea_in_g"])                    # reaction between three tracers
+    TR.calReactionTracersGPU[cfg](N, 3, xDim, dev(d["rea_rate"]), dev(d["rea_J"]), dev(d["rea_conc"]), dG3)
+    assert rel_err(dG3.copy_to_host(), d["rea_out_g"]) < 1e-13

@@ -58,6 +58,16 @@ def test_each_kernel():
     assert rel_err(g, d["ina_out_g"]) < TOL
 
 
+def test_reaction_kernel():
+    g = np.ascontiguousarray(d["rea_in_g"])
+    L.tr_reaction(C.c_int64(N), C.c_int(3), P(np.ascontiguousarray(d["rea_rate"])), P(np.ascontiguousarray(d["rea_J"])),
+                  P(np.ascontiguousarray(d["rea_conc"])), P(g))
+    assert rel_err(g, d["rea_out_g"]) < TOL
+    # A + B -> C: what the two reactants lose the product gains (sum_j J_ij = 1)
+    dg = (g - d["rea_in_g"]).sum(axis=2)
+    assert np.allclose(dg[0], dg[1], rtol=0, atol=1e-15) and np.allclose(dg[0], -dg[2], rtol=0, atol=1e-15)
+
+
 def test_coupled_loop_conserves_tracer_in_closed_box():
     """no inlet/outlet for the tracer: total tracer mass is conserved by collide + interface +
     stream (bounce-back) to round-off, whatever the flow does."""

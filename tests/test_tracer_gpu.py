@@ -49,6 +49,34 @@ def test_two_tracers_vs_coupled_oracle(porous):
     s.close()
 
 
+def test_three_tracers_with_reaction_vs_coupled_oracle():
+    """[SystemType] Reaction = 'yes': A + B -> C between tracers 0, 1, 2 (calReactionTracersGPU)"""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from oracle.tr import CoupledOracle
+    dom, rR, rB, conc = _case(True)
+    conc = np.stack([conc[0], conc[1] * 3.0, np.zeros_like(conc[0])])
+    flow = dict(theta=70.0, tauR=1.0, tauB=0.8)
+    tr = dict(diffX=(1. / 6., 0.12, 0.15), diffY=(1. / 6., 0.2, 0.15), dXY=0.01, dYX=0.02, beta=(1.0, 0.6, 0.8), crit=0.5,
+              inlet_conc=(1.0, 0.25, 0.0), free_outlet=True, dirichlet_inlet=True, reaction_rate=0.05,
+              diffJ=(1. / 3., 0.3, 0.4))
+    s = RK2DSolver(dom, flow)
+    s.set_macro(rR, rB)
+    s.configure_tracers(**tr)
+    for k in range(3):
+        s.set_tracer(k, conc[k])
+    o = CoupledOracle(dom, flow, rR, rB, conc, tr)
+    for n in (1, 2, 40):
+        s.step(n); o.run(n)
+        for k in range(3):
+            e = rel_err(s.get_tracer(k, compact=True), o.C[k])
+            assert e < 1e-9, "tracer %d rel err %.3e after %d steps" % (k, e, s.steps_done)
+    assert o.C[2].max() > 1e-4          # the product tracer started from zero
+    with pytest.raises(Exception):
+        s2 = RK2DSolver(dom, flow)
+        s2.configure_tracers(reaction_rate=0.1)      # one tracer cannot react
+    s.close()
+
+
 def test_tracer_mass_conserved_without_open_boundaries():
     from openlbmpm_amd.rk2d import RK2DSolver
     dom, rR, rB, conc = _case(True)

@@ -150,6 +150,8 @@ SPEC = [
  # ---------------- tracer transport
  ("tr", "fillNeighboringNodesTransport", T + ":51", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
   "launch_tr_fill_neighbors(st, totalNodes, nx, ny, fluidNodes, domainNewIndex, neighboringNodes)"),
+ ("tr", "calReactionTracersGPU", T + ":95", "totalNodes:i numTracers:i xDim:i reactionRate:D diffJcoeffs:D tracerConc:D tracerPDF:D",
+  "launch_tr_reaction(st, totalNodes, (int)numTracers, reactionRate, diffJcoeffs, tracerConc, tracerPDF)"),
  ("tr", "calConcentrationGPU", T + ":78", "totalNodes:i numTracers:i xDim:i numSchemes:i tracerConc:D tracerPDF:D",
   "tr_check_q5(numSchemes); launch_tr_concentration(st, totalNodes, (int)numTracers, tracerConc, tracerPDF)"),
  ("tr", "calCollisionTransportLinearEqlMRTGPU", T + ":535", "totalNodes:i xDim:i numTracers:i unitVX:D unitVY:D velocityVX:D velocityVY:D tracerConc:D tracerPDF:D transportM:D inverseRelaxationMS:D weightsCoeff:D",
