@@ -82,10 +82,12 @@ __device__ __forceinline__ int xcd_tile(int b, int nb)
 // store zeros into their (dead) slots with the same instruction, so the line leaves L2 complete:
 // partially written lines cost the memory system a read-modify-write (measured on the D3Q19
 // kernel: +35 % kernel time at porosity 0.65).  Must be reached by whole waves.
+// LANES = lanes per 128-byte line: 8 for the 16-byte population pairs, 16 for 8-byte side arrays.
+template <int LANES = 16>
 __device__ __forceinline__ bool line_has_active(bool active, unsigned lane)
 {
     const unsigned long long m = __ballot(active);
-    return ((m >> (lane & 48u)) & 0xFFFFull) != 0;
+    return ((m >> (lane & (64u - LANES))) & ((1ull << LANES) - 1ull)) != 0;
 }
 
 }  // namespace lbmpm_dev

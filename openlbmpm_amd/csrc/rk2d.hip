@@ -648,7 +648,9 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     for (int m = 0; m < NT; ++m) {
         const int x = tx0 + lx, y = ty0 + ly + m * TY;
         // non-fluid lanes of a 128-byte line that holds fluid write zeros into their dead slots
-        if (!(lbmpm_dev::line_has_active(act[m], tid & 63) && x < p.nx && y < p.ny)) continue;
+        // (8 lanes per line for the 16-byte population pairs, 16 for the 8-byte force planes)
+        const bool line8 = lbmpm_dev::line_has_active<8>(act[m], tid & 63);
+        if (!(lbmpm_dev::line_has_active<16>(act[m], tid & 63) && x < p.nx && y < p.ny)) continue;
         const size_t idx = (size_t)y * p.pitch + x;
         double fR[9], fB[9], Fx = 0., Fy = 0.;
 #pragma unroll
@@ -685,8 +687,10 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         }
         p.F[idx] = Fx;
         p.F[p.plane + idx] = Fy;
+        if (line8) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) lbmpm_dev::store_pair(p.fout, p.plane, i, idx, fR[i], fB[i]);
+            for (int i = 0; i < 9; ++i) lbmpm_dev::store_pair(p.fout, p.plane, i, idx, fR[i], fB[i]);
+        }
     }
 }
 

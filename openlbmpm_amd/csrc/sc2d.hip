@@ -365,7 +365,7 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
         s_psi1[ry * RW + rx] = b;
     }
     __syncthreads();
-    const bool line = lbmpm_dev::line_has_active(act, tid & 63) && inside;
+    const bool line = lbmpm_dev::line_has_active<8>(act, tid & 63) && inside;     // populations: 16 bytes per lane
     if (!line) return;
     if (!act) {
 #pragma unroll
