@@ -1,0 +1,82 @@
+"""Error behaviour of the C ABI on a GPU box: every misuse returns a negative
+status with a message in lbmpm_last_error(); nothing aborts, nothing falls back to a CPU path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rk2d_rejects_bad_configurations_and_shapes():
+    from openlbmpm_amd._lib import LbmpmError
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.geometry import simple_geometry
+    dom = simple_geometry(20, 40)
+    with pytest.raises((LbmpmError, ValueError, KeyError)):
+        RK2DSolver(dom, dict(tauR=0.4))                       # tau <= 1/2
+    with pytest.raises((LbmpmError, ValueError, KeyError)):
+        RK2DSolver(dom, dict(wetting=7))                      # unknown WettingType
+    s = RK2DSolver(dom, None)
+    with pytest.raises(TypeError):
+        s.set_macro(np.zeros((3, 3)), np.zeros((3, 3)))       # wrong shape
+    with pytest.raises(LbmpmError) as e:
+        s.get_tracer(0)                                       # no tracer configured
+    assert "tracer" in str(e.value)
+    s.set_macro(np.where(dom == 1, 1.0, 0.0), np.zeros(dom.shape))
+    s.step(2)
+    with pytest.raises(LbmpmError):
+        s.configure_tracers()
+        s.set_tracer(0, np.zeros(dom.shape))                  # tracer state must be set before the first step
+    s.close()
+
+
+def test_sc2d_rejects_bad_configurations():
+    from openlbmpm_amd._lib import LbmpmError
+    from openlbmpm_amd.sc2d import SC2DSolver
+    from openlbmpm_amd.geometry import simple_geometry
+    dom = simple_geometry(20, 48)
+    with pytest.raises((LbmpmError, ValueError)):
+        SC2DSolver(dom, dict(inter="ShanChen", relax="MRT"))  # MRT exists for the explicit forcing scheme only
+    with pytest.raises((LbmpmError, ValueError)):
+        SC2DSolver(dom, dict(inter="ShanChen", scheme=8))     # iso-8 force belongs to EFS
+    with pytest.raises((LbmpmError, ValueError)):
+        SC2DSolver(dom, dict(scheme=6))
+    s = SC2DSolver(dom, dict(inter="EFS"))
+    s.set_density(np.where(dom == 1, 1.0, 0.0), np.where(dom == 1, 0.02, 0.0))
+    s.step(1)
+    with pytest.raises(LbmpmError) as e:
+        s.get("rho0")                                         # EFS densities need the diagnostics switch
+    assert "diagnostics" in str(e.value)
+    s.close()
+
+
+def test_rk3d_protocol_misuse_is_reported():
+    from openlbmpm_amd import _lib
+    from openlbmpm_amd._lib import LbmpmError
+    from openlbmpm_amd.rk3d import RK3DSlab
+    from openlbmpm_amd.geometry import porous_spheres, initial_densities_rk3d
+    dom = porous_spheres(64, 16, 40, porosity=0.7, rmin=3.0, rmax=6.0, seed=3, nbuf=5)
+    rR, rB = initial_densities_rk3d(dom, 5)
+    with pytest.raises(LbmpmError):
+        RK3DSlab(dom, 30, 20)                                 # slab outside the lattice
+    with pytest.raises(LbmpmError):
+        RK3DSlab(dom, 0, 40, params=dict(tauR=0.5))
+    top = RK3DSlab(dom, 20, 20)
+    top.set_density(rR[20:], rB[20:])
+    with pytest.raises(LbmpmError) as e:
+        top.step_single(1)                                    # a slab cannot step alone: it needs its neighbour's halo
+    assert "single-slab" in str(e.value)
+    top.collide_interior()
+    with pytest.raises(LbmpmError):
+        top.collide()                                         # the step was opened with collide_interior
+    top.collide_boundary()
+    with pytest.raises(LbmpmError) as e:
+        top.get("rhoR")                                       # densities exist after phase_field(diagnostics=True) only
+    assert "phase_field" in str(e.value)
+    with pytest.raises(KeyError):
+        top.buffer("no_such_buffer")
+    ptr, n = C.c_void_p(), C.c_int64(0)
+    assert _lib.lib().lbmpm_rk3d_buffer(top._h, 99, C.byref(ptr), C.byref(n)) < 0
+    assert b"unknown buffer" in _lib.lib().lbmpm_last_error()
+    top.close()
