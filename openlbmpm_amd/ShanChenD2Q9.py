@@ -18,8 +18,9 @@ from .sc2d import SC2DSolver
 
 
 class ShanChenD2Q9:
-    def __init__(self, pathIniFile, output_dir=None, image=None, device=0, record_every=None):
+    def __init__(self, pathIniFile, output_dir=None, image=None, device=0, record_every=None, initial_dir=None):
         self.path = pathIniFile
+        self.initial_dir = initial_dir or os.path.expanduser("~/LBMInitial")
         self.par = config.read_sc2d(pathIniFile)
         self.output_dir = output_dir or os.path.expanduser("~/LBMResults")
         self.device, self._image = device, image
@@ -47,6 +48,26 @@ class ShanChenD2Q9:
         r = np.zeros((2, self.ny, self.nx))
         r[0][fluid & lower] = p["rho0"]; r[1][fluid & lower] = p["bg1"]
         r[1][fluid & ~lower] = p["rho1"]; r[0][fluid & ~lower] = p["bg0"]
+        if p["cycle"]:
+            # next drainage / imbibition cycle (ShanChenD2Q9.py:788-815): the old fluid keeps its last recorded
+            # distribution below the top 30 rows, the new fluid fills those rows; populations at rest
+            from .results import load_results
+            old = None
+            for ext in (".h5", ".npz"):
+                f = os.path.join(self.initial_dir, "SimulationResults" + ext)
+                if os.path.isfile(f):
+                    old = load_results(f)
+                    break
+            key = "/FluidMacro/FluidDensityType0in%d" % p["last_step"]
+            if old is None or key not in old:
+                raise config.ConfigError("[DICycles] Option = 'yes': %s of SimulationResults not found in %s" % (key, self.initial_dir))
+            prev = np.asarray(old[key], dtype=np.float64)
+            if prev.shape != self.isDomain.shape:
+                raise config.ConfigError("[DICycles]: recorded density has shape %s, the domain is %s" % (prev.shape, self.isDomain.shape))
+            top = ii >= self.ny - 30
+            r[0] = np.where(top, p["bg0"], prev)
+            r[1] = np.where(top, p["rho1"], p["bg1"])
+            r[:, ~fluid] = 0.0
         self.fluidsDensity = r
 
     def runTypeSCmodel(self, progress=None):

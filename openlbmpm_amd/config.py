@@ -123,6 +123,10 @@ def read_sc2d(ini_dir):
     p["relax"] = c.str("RelaxationType", "Type")
     if c.str("DuplicateDomain", "Option", default="'no'") == "yes":
         raise ConfigError("DuplicateDomain prompts interactively in the reference; not supported")
+    p["cycle"] = c.str("DICycles", "Option", default="'no'") == "yes"          # ShanChenD2Q9.py:148-157
+    p["last_step"] = c.int("DICycles", "LastStep", default=0)
+    if p["cycle"] and not p["image"]:
+        raise ConfigError("[DICycles] Option = 'yes' initialises pore-image domains only (ShanChenD2Q9.py:788)")
     m = Ini(os.path.join(ini_dir, "efs2D.ini" if p["inter"] == "EFS" else "shanchen2D.ini"))
     sec = "EFSParameters" if p["inter"] == "EFS" else "ShanChenParameters"
     p["rho0"], p["rho1"] = m.floats("FluidProperties", "InitialDensities", 2)

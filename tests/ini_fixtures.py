@@ -73,7 +73,7 @@ LastStep = {last}
 """
 
 TWOPHASE_INI = """[PictureSetup]
-Exist = 'no'
+Exist = '{image}'
 [SeparationBorder]
 xGrid = {nx}
 yGrid = {ny}
@@ -91,8 +91,8 @@ Type = '{relax}'
 [DuplicateDomain]
 Option = 'no'
 [DICycles]
-Option = 'no'
-LastStep =  1105
+Option = '{cycle}'
+LastStep =  {last}
 """
 
 MODEL_INI = """[FluidProperties]
@@ -137,10 +137,11 @@ def write_rk(d, nx=20, ny=48, steps=60, interval=25, relax="MRT", cycle="no", la
         fh.write(RK_INI.format(nx=nx, ny=ny, steps=steps, interval=interval, relax=relax, cycle=cycle, last=last))
 
 
-def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirichlet", scheme=4):
+def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirichlet", scheme=4, image="no", cycle="no",
+             last=0):
     import os
     with open(os.path.join(d, "twophasesetup.ini"), "w") as fh:
-        fh.write(TWOPHASE_INI.format(nx=nx, ny=ny, inter=inter, relax=relax))
+        fh.write(TWOPHASE_INI.format(nx=nx, ny=ny, inter=inter, relax=relax, image=image, cycle=cycle, last=last))
     efs = inter == "EFS"
     with open(os.path.join(d, "efs2D.ini" if efs else "shanchen2D.ini"), "w") as fh:
         fh.write(MODEL_INI.format(section="EFSParameters" if efs else "ShanChenParameters", bg=0.02 if efs else 0.06,

@@ -116,6 +116,37 @@ def test_sc_driver_with_iso8_scheme_matches_reference(tmp_path):
         assert rel_err(got, d["s60_rho"][k]) < 1e-9
 
 
+def test_sc_next_cycle_starts_from_previous_records(tmp_path):
+    """[DICycles] Option = 'yes' (ShanChenD2Q9.py:788-815): old fluid from the record LastStep below the top 30 rows,
+    new fluid in the top 30 rows"""
+    import shutil
+    from openlbmpm_amd.ShanChenD2Q9 import ShanChenD2Q9
+    from openlbmpm_amd.results import load_results
+    from openlbmpm_amd.geometry import porous_disks
+    img = np.where(porous_disks(40, 60, porosity=0.75, rmin=2.0, rmax=4.0, seed=2) == 1, 255.0, 0.0)
+    first = tmp_path / "first"; first.mkdir()
+    write_sc(str(first), inter="EFS", steps=40, image="yes")
+    a = ShanChenD2Q9(str(first), output_dir=str(tmp_path / "o1"), image=img)
+    path = a.runTypeSCmodel()
+    init = tmp_path / "LBMInitial"; init.mkdir()
+    shutil.copy(path, str(init))
+    second = tmp_path / "second"; second.mkdir()
+    write_sc(str(second), inter="EFS", steps=10, image="yes", cycle="yes", last=0)
+    b = ShanChenD2Q9(str(second), output_dir=str(tmp_path / "o2"), image=img, initial_dir=str(init))
+    b.initializeDomainBorder(); b.initializeDomainCondition()
+    old = load_results(path)["/FluidMacro/FluidDensityType0in0"]
+    fluid = b.isDomain == 1
+    assert np.array_equal(b.fluidsDensity[0][:-30][fluid[:-30]], old[:-30][fluid[:-30]])
+    assert np.all(b.fluidsDensity[1][-30:][fluid[-30:]] == b.par["rho1"]) and np.all(b.fluidsDensity[0][-30:][fluid[-30:]] == b.par["bg0"])
+    b2 = ShanChenD2Q9(str(second), output_dir=str(tmp_path / "o2"), image=img, initial_dir=str(init))
+    res = load_results(b2.runTypeSCmodel())
+    assert np.isfinite(res["/FluidMacro/FluidDensityType0in0"]).all()
+    from openlbmpm_amd import config
+    write_sc(str(second), inter="EFS", steps=10, image="no", cycle="yes")
+    with pytest.raises(config.ConfigError):
+        ShanChenD2Q9(str(second))
+
+
 def test_cli_runs(tmp_path):
     from openlbmpm_amd.__main__ import main
     write_sc(str(tmp_path), inter="EFS", steps=40, relax="MRT")
