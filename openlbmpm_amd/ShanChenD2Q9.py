@@ -18,9 +18,11 @@ from .sc2d import SC2DSolver
 
 
 class ShanChenD2Q9:
-    def __init__(self, pathIniFile, output_dir=None, image=None, device=0, record_every=None, initial_dir=None):
+    def __init__(self, pathIniFile, output_dir=None, image=None, device=0, record_every=None, initial_dir=None,
+                 duplicate=None):
         self.path = pathIniFile
         self.initial_dir = initial_dir or os.path.expanduser("~/LBMInitial")
+        self.duplicate = duplicate            # (x, y) copies of the pore image, overrides the ini
         self.par = config.read_sc2d(pathIniFile)
         self.output_dir = output_dir or os.path.expanduser("~/LBMResults")
         self.device, self._image = device, image
@@ -35,7 +37,7 @@ class ShanChenD2Q9:
             if img is None:
                 from .RKD2Q9 import load_structure_image
                 img = load_structure_image(os.path.expanduser("~/StructureImage/structure.png"))
-            self.isDomain = image_domain(img, 20, 0.5)
+            self.isDomain = image_domain(img, 20, 0.5, duplicate=self.duplicate or p["duplicate"])
         else:
             self.isDomain = simple_geometry(p["nx"], p["ny"])
         self.ny, self.nx = self.isDomain.shape

@@ -121,8 +121,11 @@ def read_sc2d(ini_dir):
     if p["inter"] not in ("ShanChen", "EFS"):
         raise ConfigError("InteractionType must be 'ShanChen' or 'EFS'")
     p["relax"] = c.str("RelaxationType", "Type")
+    p["duplicate"] = None
     if c.str("DuplicateDomain", "Option", default="'no'") == "yes":
-        raise ConfigError("DuplicateDomain prompts interactively in the reference; not supported")
+        # the reference asks for the two numbers with input() (ShanChenD2Q9.py:573-574); here they are two more
+        # keys of the same section, or the `duplicate=` argument of the driver
+        p["duplicate"] = (c.int("DuplicateDomain", "xDirectionNumber", default=1), c.int("DuplicateDomain", "yDirectionNumber", default=1))
     p["cycle"] = c.str("DICycles", "Option", default="'no'") == "yes"          # ShanChenD2Q9.py:148-157
     p["last_step"] = c.int("DICycles", "LastStep", default=0)
     if p["cycle"] and not p["image"]:

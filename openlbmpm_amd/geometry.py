@@ -12,15 +12,31 @@ def simple_geometry(nx, ny):
     return dom
 
 
-def image_domain(image, num_buffering_layers, ratio_top_to_bottom):
+def expand_image_domain(array, x_number, y_number):
+    """[DuplicateDomain] Option = 'yes' (ShanChenD2Q9.py:513-541): tile the cropped image x_number x y_number
+    times, every second copy mirrored so that pores stay connected across the seams."""
+    a = np.asarray(array)
+    if x_number < 1 or y_number < 1:
+        raise ValueError("duplication numbers must be >= 1")
+    rows = []
+    for i in range(int(y_number)):
+        base = a if i % 2 == 0 else np.flipud(a)
+        rows.append(np.hstack([base if j % 2 == 0 else np.fliplr(base) for j in range(int(x_number))]))
+    return np.vstack(rows)
+
+
+def image_domain(image, num_buffering_layers, ratio_top_to_bottom, duplicate=None):
     """Binary pore image (0 = solid) -> isDomain following RKD2Q9.py:373-414 and :432-443:
-    crop to the bounding box of solid pixels, force the first/last column solid, then add
-    2*numBufferingLayers all-void rows, int(2*n*ratio) of them before row 0."""
+    crop to the bounding box of solid pixels, [duplicate = (x_number, y_number): mirror-tile it,
+    ShanChenD2Q9.py:569-576], force the first/last column solid, then add 2*numBufferingLayers
+    all-void rows, int(2*n*ratio) of them before row 0."""
     img = np.asarray(image, dtype=np.float64)
     ys, xs = np.nonzero(img == 0.0)
     if ys.size == 0:
         raise ValueError("image has no solid (zero) pixel")
     eff = np.array(img[ys.min():ys.max() + 1, xs.min():xs.max() + 1], copy=True)
+    if duplicate is not None:
+        eff = np.array(expand_image_domain(eff, duplicate[0], duplicate[1]), copy=True)
     eff[:, 0] = 0.0
     eff[:, -1] = 0.0
     n_before = int(2 * num_buffering_layers * ratio_top_to_bottom)

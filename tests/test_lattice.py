@@ -42,3 +42,18 @@ def test_recolouring_cosine_identity():
     for ex, ey in zip(EX[1:], EY[1:]):
         en = np.hypot(ex, ey)
         assert abs((ex * g[0] + ey * g[1]) / (en * gn) * en - (ex * g[0] + ey * g[1]) / gn) < 1e-15
+
+
+def test_duplicated_pore_image_is_mirror_tiled():
+    """[DuplicateDomain] Option = 'yes' (ShanChenD2Q9.py:513-541)"""
+    import numpy as np
+    from openlbmpm_amd.geometry import expand_image_domain, image_domain
+    a = np.arange(12.0).reshape(3, 4)
+    e = expand_image_domain(a, 3, 2)
+    assert e.shape == (6, 12)
+    assert np.array_equal(e[:3, :4], a) and np.array_equal(e[:3, 4:8], a[:, ::-1]) and np.array_equal(e[:3, 8:], a)
+    assert np.array_equal(e[3:, :4], a[::-1]) and np.array_equal(e[3:, 4:8], a[::-1, ::-1])
+    img = np.full((10, 8), 255.0); img[0, 0] = 0.0; img[-1, -1] = 0.0; img[4:6, 3:5] = 0.0
+    d1, d2 = image_domain(img, 20, 0.5), image_domain(img, 20, 0.5, duplicate=(2, 3))
+    assert d1.shape == (50, 8) and d2.shape == (70, 16)
+    assert d2[:, 0].sum() == 40 and d2[:, -1].sum() == 40          # side walls, buffer rows stay open
