@@ -1,0 +1,137 @@
+"""Physics checks of the HIP solvers (through the C ABI), independent of the oracle:
+
+  * Laplace's law for a static droplet -- D3Q19: dp = 2 sigma / R with the perturbation operator's
+    sigma = 2/9 (A_R + A_B) tau (Liu, Valocchi & Kang 2012); D2Q9 CSF: dp = sigma / R with the
+    SurfaceTension of the ini file; pressure = rho / 3;
+  * static contact angle of a sessile droplet from its spherical-cap shape -- D3Q19: cos(theta) =
+    phi_s = (SolidRhoR - SolidRhoB) / (SolidRhoR + SolidRhoB); D2Q9: the ContactAngle of the ini.
+
+The D3Q19 path has no reference code to be pinned to: these tests are what
+ties its oracle-checked arithmetic to the physics the model is meant to reproduce.  Tolerances
+(3 % on dp, 4-6 degrees) are what a diffuse interface 4-5 cells wide allows at these radii.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _crossing(profile, coord):
+    """first zero crossing (+ -> -) of a sampled profile, linear interpolation"""
+    for i in range(len(profile) - 1):
+        if profile[i] > 0 >= profile[i + 1]:
+            return coord[i] + (coord[i + 1] - coord[i]) * profile[i] / (profile[i] - profile[i + 1])
+    raise AssertionError("no interface found along the sampled line")
+
+
+def _cap_angle(height, widths):
+    """contact angle of a spherical cap of height `height`; `widths` are the half-widths in the
+    first two fluid layers (half a cell and 1.5 cells from the wall), extrapolated to the wall"""
+    a = widths[0] + 0.5 * (widths[0] - widths[1])
+    radius = (a * a + height * height) / (2.0 * height)
+    return float(np.degrees(np.arccos(1.0 - height / radius)))
+
+
+# ----------------------------------------------------------------------------- D3Q19
+
+RK3D_CLOSED = dict(velocityZR=0.0, velocityZB=0.0, densityRL=1e-8, densityBL=1.0)
+
+
+@pytest.mark.parametrize("radius", [10, 14, 18])
+def test_d3q19_laplace_law(radius):
+    from openlbmpm_amd.rk3d import RK3DSlab
+    n, ak, tau = 64, 7.0e-3, 1.0
+    dom = np.ones((n, n, n), dtype=np.uint8)
+    z, y, x = np.mgrid[0:n, 0:n, 0:n]
+    c = (n - 1) / 2.0
+    r = np.sqrt((x - c) ** 2 + (y - c) ** 2 + (z - c) ** 2)
+    s = RK3DSlab(dom, 0, n, dict(RK3D_CLOSED, AkR=ak, AkB=ak, tauR=tau, tauB=tau))
+    s.set_density(np.where(r < radius, 1.0, 1e-8), np.where(r < radius, 1e-8, 1.0))
+    s.step_single(4000)
+    s.phase_field(diagnostics=True)
+    rho, phi = s.get("rhoR") + s.get("rhoB"), s.get("phi")
+    speed = np.sqrt(s.get("vx") ** 2 + s.get("vy") ** 2 + s.get("vz") ** 2)
+    s.close()
+    R = (3.0 * float((phi > 0).sum()) / (4.0 * np.pi)) ** (1.0 / 3.0)
+    assert abs(R - radius) < 0.5                                     # the droplet neither grows nor dissolves
+    dp = (rho[r < R - 4].mean() - rho[(r > R + 6) & (z > 6) & (z < n - 7)].mean()) / 3.0
+    sigma = 2.0 / 9.0 * (2 * ak) * tau
+    assert abs(dp / (2.0 * sigma / R) - 1.0) < 0.03, (R, dp, 2.0 * sigma / R)
+    assert speed.max() < 5e-4                                        # spurious currents stay small
+
+
+@pytest.mark.parametrize("phi_s", [-0.5, 0.0, 0.5])
+def test_d3q19_contact_angle(phi_s):
+    from openlbmpm_amd.rk3d import RK3DSlab
+    nx, ny, nz, wall, radius = 96, 48, 96, 4, 18
+    dom = np.ones((nz, ny, nx), dtype=np.uint8)
+    dom[:, :wall, :] = 0
+    z, y, x = np.mgrid[0:nz, 0:ny, 0:nx]
+    cx, cz = (nx - 1) / 2.0, (nz - 1) / 2.0
+    inside = ((x - cx) ** 2 + (z - cz) ** 2 + (y - (wall - 0.5)) ** 2 < radius ** 2) & (dom == 1)
+    s = RK3DSlab(dom, 0, nz, dict(RK3D_CLOSED, SolidRhoR=(1 + phi_s) / 2, SolidRhoB=(1 - phi_s) / 2))
+    s.set_density(np.where(inside, 1.0, 1e-8) * dom, np.where(inside, 1e-8, 1.0) * dom)
+    s.step_single(20000)
+    s.phase_field(diagnostics=True)
+    phi = s.get("phi")
+    s.close()
+    iz, ix = int(round(cz)), int(round(cx))
+    height = _crossing(phi[iz, wall:, ix], np.arange(wall, ny) - (wall - 0.5))
+    widths = [_crossing(phi[iz, wall + k, ix:], np.arange(ix, nx) - cx) for k in (0, 1)]
+    theta = _cap_angle(height, widths)
+    assert abs(theta - np.degrees(np.arccos(phi_s))) < 4.0, (phi_s, theta, height, widths)
+
+
+# ----------------------------------------------------------------------------- D2Q9 CSF
+
+# no inflow; convective outlet (the pressure outlet re-colours what it lets back in)
+RK2D_CLOSED = dict(vyR=0.0, vyB=0.0, rhoRH=5e-8, rhoBH=1.0, rhoBL=1.0, rhoRL=5e-8, inlet="Neumann", outlet="Convective")
+
+
+def _channel(nx, ny):
+    dom = np.ones((ny, nx), dtype=np.uint8)
+    dom[:, 0] = dom[:, -1] = 0
+    return dom
+
+
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+@pytest.mark.parametrize("radius", [16, 24])
+def test_d2q9_laplace_law(radius, relax):
+    from openlbmpm_amd.rk2d import RK2DSolver
+    n, sigma = 128, 0.01
+    dom = _channel(n, n)
+    y, x = np.mgrid[0:n, 0:n]
+    c = (n - 1) / 2.0
+    r = np.hypot(x - c, y - c)
+    s = RK2DSolver(dom, dict(RK2D_CLOSED, sigma=sigma, relax=relax, theta=90.0), diagnostics=True)
+    s.set_macro(np.where(r < radius, 1.0, 5e-8) * dom, np.where(r < radius, 5e-8, 1.0) * dom)
+    s.step(20000)
+    rho, phi = s.get("rhoR") + s.get("rhoB"), s.get("phi")
+    s.close()
+    R = np.sqrt(float((phi[8:n - 8] > 0).sum()) / np.pi)              # (the inlet row itself is red)
+    assert abs(R - radius) < 0.5
+    dp = (rho[r < R - 5].mean() - rho[(r > R + 8) & (dom == 1) & (y > 8) & (y < n - 9)].mean()) / 3.0
+    assert abs(dp / (sigma / R) - 1.0) < 0.03, (R, dp, sigma / R)
+
+
+@pytest.mark.parametrize("wetting,theta", [(1, 60.0), (1, 90.0), (1, 120.0), (2, 60.0)])
+def test_d2q9_contact_angle(wetting, theta):
+    """WettingType 1 measures ContactAngle through the red droplet; type 2 through the blue fluid
+    (the two types give mirror-image results for theta and 180 - theta)."""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    nx, ny, radius = 128, 192, 30
+    dom = _channel(nx, ny)
+    y, x = np.mgrid[0:ny, 0:nx]
+    cy = (ny - 1) / 2.0
+    inside = ((x - 0.5) ** 2 + (y - cy) ** 2 < radius ** 2) & (dom == 1)
+    s = RK2DSolver(dom, dict(RK2D_CLOSED, sigma=0.01, relax="MRT", theta=theta, wetting=wetting), diagnostics=True)
+    s.set_macro(np.where(inside, 1.0, 5e-8) * dom, np.where(inside, 5e-8, 1.0) * dom)
+    s.step(60000)
+    phi = s.get("phi")
+    s.close()
+    iy = int(round(cy))
+    height = _crossing(phi[iy, 1:nx - 1], np.arange(1, nx - 1) - 0.5)
+    widths = [_crossing(phi[iy:, 1 + k], np.arange(iy, ny) - cy) for k in (0, 1)]
+    got = _cap_angle(height, widths)
+    expect = theta if wetting == 1 else 180.0 - theta
+    assert abs(got - expect) < 6.0, (wetting, theta, got, height, widths)
