@@ -3,6 +3,7 @@
   * Laplace's law for a static droplet -- D3Q19: dp = 2 sigma / R with the perturbation operator's
     sigma = 2/9 (A_R + A_B) tau (Liu, Valocchi & Kang 2012); D2Q9 CSF: dp = sigma / R with the
     SurfaceTension of the ini file; pressure = rho / 3;
+  * D2Q5 tracer: variance of a Gaussian blob grows by 2 D t;
   * static contact angle of a sessile droplet from its spherical-cap shape -- D3Q19: cos(theta) =
     phi_s = (SolidRhoR - SolidRhoB) / (SolidRhoR + SolidRhoB); D2Q9: the ContactAngle of the ini.
 
@@ -135,3 +136,34 @@ def test_d2q9_contact_angle(wetting, theta):
     got = _cap_angle(height, widths)
     expect = theta if wetting == 1 else 180.0 - theta
     assert abs(got - expect) < 6.0, (wetting, theta, got, height, widths)
+
+
+# ----------------------------------------------------------------------------- D2Q5 tracer
+
+@pytest.mark.parametrize("dx,dy", [(1.0 / 6.0, 1.0 / 6.0), (0.1, 0.2), (0.05, 0.25)])
+def test_d2q5_tracer_diffuses_at_the_configured_rate(dx, dy):
+    """A Gaussian blob in quiescent blue fluid: the variance along x / y grows by 2 D t with the
+    DiffusionX / DiffusionY of transportsetup.ini, the mass and the centre stay put."""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    nx, ny, steps = 128, 160, 500
+    dom = _channel(nx, ny)
+    y, x = np.mgrid[0:ny, 0:nx]
+    top = y >= ny - 12
+    s = RK2DSolver(dom, dict(vyR=0.0, vyB=0.0, outlet="Convective"))
+    s.set_macro(np.where(top, 1.0, 0.0) * dom, np.where(~top, 1.0, 0.0) * dom)
+    s.configure_tracers(diffX=(dx,), diffY=(dy,), free_outlet=False, dirichlet_inlet=False)
+    c0 = np.exp(-((x - 63.5) ** 2 + (y - 70.0) ** 2) / (2 * 6.0 ** 2)) * dom * ~top
+    s.set_tracer(0, c0)
+    s.step(steps)
+    c1 = s.get_tracer(0)
+    s.close()
+
+    def moments(c):
+        m = c.sum(); mx, my = (c * x).sum() / m, (c * y).sum() / m
+        return m, mx, my, (c * (x - mx) ** 2).sum() / m, (c * (y - my) ** 2).sum() / m
+
+    a, b = moments(c0), moments(c1)
+    assert abs(b[0] - a[0]) / a[0] < 1e-11
+    assert abs(b[1] - a[1]) < 0.02 and abs(b[2] - a[2]) < 0.02
+    assert abs((b[3] - a[3]) / (2 * steps) / dx - 1.0) < 0.01, ((b[3] - a[3]) / (2 * steps), dx)
+    assert abs((b[4] - a[4]) / (2 * steps) / dy - 1.0) < 0.01, ((b[4] - a[4]) / (2 * steps), dy)
