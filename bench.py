@@ -142,21 +142,21 @@ def cpu_baseline_c2(nx, ny, target_seconds=10.0):
                 sample="c2 %dx%d capillary, %d steps of oracle/rk_oracle.c (OpenMP), %.1f s" % (nx, ny, n, el))
 
 
-def cpu_baseline_c5(edge=128, target_seconds=12.0):
+def cpu_baseline_c5(relax, edge=128, target_seconds=12.0):
     from oracle.rk3d import RK3DOracle
     from oracle import lib
     from openlbmpm_amd.geometry import porous_spheres
     dom = porous_spheres(edge, edge, edge, porosity=0.65, rmin=6.0, rmax=20.0, seed=SEED, nbuf=10)
     rR, rB = c5_densities(dom, 0, edge)
-    o = RK3DOracle(dom, rR, rB)
+    o = RK3DOracle(dom, rR, rB, dict(relax=relax))
     nfl = int(dom.sum())
     o.run(1)
     t0 = time.perf_counter(); o.run(1); dt = time.perf_counter() - t0
     n = max(1, min(2000, int(target_seconds / max(dt, 1e-6))))       # about 12 s of CPU work
     t0 = time.perf_counter(); o.run(n); el = time.perf_counter() - t0
     return dict(value=round(nfl * n / el / 1e6, 3), unit="MLUPS", cores=int(lib().rk_oracle_threads()), kind="port",
-                sample="c5 model on a %d^3 porous sample (same generator/parameters), %d steps of "
-                       "oracle/rk3d_oracle.c (OpenMP), %.1f s" % (edge, n, el))
+                sample="c5 model (%s) on a %d^3 porous sample (same generator/parameters), %d steps of "
+                       "oracle/rk3d_oracle.c (OpenMP), %.1f s" % (relax, edge, n, el))
 
 
 # ----------------------------------------------------------------------------- main
@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="c5", choices=["c5", "c2", "c3", "c4"])
     ap.add_argument("--size", type=int, nargs="+", default=None, help="c5: NX NY NZ; c2/c3: NX NY")
+    ap.add_argument("--relax", default="MRT", choices=["MRT", "SRT"],
+                    help="c5 relaxation: BASELINE.json names the MRT configuration; the shipped ini says 'SRT' with ';;MRT' beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -210,7 +212,7 @@ def main():
         rR, rB = c5_densities(dom[z0:z0 + nzl], z0, nz)
         m0_local = float((rR + rB).sum())
         if world == 1:
-            slab = RK3DSlab(dom, 0, nz, device=local_rank)
+            slab = RK3DSlab(dom, 0, nz, dict(relax=args.relax), device=local_rank)
             slab.set_density(rR, rB)
             del rR, rB
             slab.step_single(warmup)
@@ -224,7 +226,7 @@ def main():
             nfl_local, dom_kernel = slab.num_fluid_nodes, slab.dominant_kernel
             slab.close()
         else:
-            d = RK3DDistributed(dom, device=local_rank)
+            d = RK3DDistributed(dom, dict(relax=args.relax), device=local_rank)
             d.slab.set_density(rR, rB)
             del rR, rB
             d.step(warmup)
@@ -254,9 +256,9 @@ def main():
                 "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
                 "ms_per_step": round(wall * 1e3 / steps, 5), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": "c5: D3Q19 colour gradient (perturbation operator, SRT; RKtwophasesetup3D.ini "
+                "config": {"workload": "c5: D3Q19 colour gradient (perturbation operator, %s; RKtwophasesetup3D.ini "
                                        "parameters), %dx%dx%d synthetic porous medium (spheres r 6-20, porosity 0.65, "
-                                       "10 buffer planes, side walls), seed %d" % (size + (SEED,)),
+                                       "10 buffer planes, side walls), seed %d" % ((args.relax,) + size + (SEED,)),
                            "fluid_nodes": nfluid_global, "lattice_nodes": int(np.prod(size)),
                            "parallelism": "z-slabs x%d, RCCL p2p halo (5 populations x 2 colours + phi per face)" % world
                                           if world > 1 else "1 gpu",
@@ -288,7 +290,7 @@ def main():
                     s.close()
                 out["secondary"] = sec
             if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline_c5()
+                out["cpu_baseline"] = cpu_baseline_c5(args.relax)
     else:
         size = tuple(args.size) if args.size else ((1024, 1024) if wl == "c2" else (2048, 2048))
         steps = args.steps if args.steps is not None else (2000 if wl == "c2" else 500)

@@ -285,6 +285,9 @@ typedef struct lbmpm_rk3d_config {
     double outlet_rho_r, outlet_rho_b; /* densityRL, densityBL                     */
     int32_t device;
     int32_t variant;
+    int32_t relaxation;         /* [RelaxationType] Type: 0 'SRT', 1 'MRT' (RKtwophasesetup3D.ini:53-55;
+                                 * D3Q19 moment basis of d'Humieres et al. 2002: s_e 1.19, s_eps = s_pi 1.4,
+                                 * s_q = s_m 1.2, stress moments at 1/tau) */
 } lbmpm_rk3d_config;
 
 typedef struct lbmpm_rk3d lbmpm_rk3d;

@@ -3,6 +3,7 @@
     python -m openlbmpm_amd rk  <ini-dir> [--out DIR] [--steps N] [--device D]
     python -m openlbmpm_amd sc  <ini-dir> [--out DIR] [--steps N] [--device D]
     python -m openlbmpm_amd tr  <ini-dir> ...      colour gradient + tracers (RKtwophasesetup2D.ini + transportsetup.ini)
+    python -m openlbmpm_amd rk3d <ini-dir> ...     D3Q19 colour gradient (RKtwophasesetup3D.ini); under torchrun: z-slabs, one per GPU
 """
 import argparse
 import sys
@@ -11,7 +12,7 @@ import time
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m openlbmpm_amd")
-    ap.add_argument("model", choices=["rk", "sc", "tr"], help="rk = colour gradient (RKtwophasesetup2D.ini); "
+    ap.add_argument("model", choices=["rk", "sc", "tr", "rk3d"], help="rk = colour gradient (RKtwophasesetup2D.ini); "
                                                        "sc = Shan-Chen / EFS (twophasesetup.ini + efs2D.ini|shanchen2D.ini)")
     ap.add_argument("ini_dir")
     ap.add_argument("--out", default=None, help="result directory (default ~/LBMResults)")
@@ -25,6 +26,22 @@ def main(argv=None):
         if a.steps is not None:
             sim.timeSteps = a.steps
         path = sim.runRKColorGradient2D()
+        steps, nodes = sim.timeSteps, sim.voidSpace
+    elif a.model == "rk3d":
+        import os
+        from .RKColorGradientD3Q19 import RKColorGradient3D
+        device = a.device
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:          # launched by torchrun: one rank per GPU
+            import torch
+            import torch.distributed as dist
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(device)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        sim = RKColorGradient3D(a.ini_dir, output_dir=a.out, device=device)
+        if a.steps is not None:
+            sim.timeSteps = a.steps
+        path = sim.runRKColorGradient3D()
         steps, nodes = sim.timeSteps, sim.voidSpace
     elif a.model == "tr":
         from .Transport2DRK import Transport2DRK

@@ -108,6 +108,46 @@ def read_rk2d(ini_dir):
     return p
 
 
+def read_rk3d(ini_dir):
+    """RKtwophasesetup3D.ini -> dict.  The module that consumed this file (RKColorGradientD3Q19,
+    main.py:22) is not in the reference tree; the keys are read by name as the ini spells them."""
+    c = Ini(os.path.join(ini_dir, "RKtwophasesetup3D.ini"))
+    p = {}
+    p["image"] = c.str("ImageSetup", "Existance", default="'no'") == "yes"
+    if not p["image"]:
+        p["nx"] = c.int("DomainSize", "xDomain"); p["ny"] = c.int("DomainSize", "yDomain")
+        p["nz"] = c.int("DomainSize", "zDomain")
+    for k in ("AlphaR", "AlphaB"):
+        if c.float("RKParameters", k, default=0.0) != 0.0:
+            raise ConfigError("[RKParameters] %s != 0 (density-ratio rest weights) is not supported" % k)
+    p["AkR"] = c.float("RKParameters", "AkR"); p["AkB"] = c.float("RKParameters", "AkB")
+    p["beta"] = c.float("RKParameters", "BetaThickness")
+    p["tauR"] = c.float("FluidParameters", "TauR"); p["tauB"] = c.float("FluidParameters", "TauB")
+    p["rho0R"] = c.float("FluidParameters", "InitialRhoR", default=1.0)
+    p["rho0B"] = c.float("FluidParameters", "InitialRhoB", default=1.0)
+    p["SolidRhoR"] = c.float("BoundariesSetup", "SolidRhoR"); p["SolidRhoB"] = c.float("BoundariesSetup", "SolidRhoB")
+    if p["SolidRhoR"] + p["SolidRhoB"] == 0.0:
+        raise ConfigError("[BoundariesSetup] SolidRhoR + SolidRhoB must not be zero")
+    if c.str("BoundaryCondition", "BoundaryTypeInlet") != "Neumann" or c.str("BoundaryCondition", "NeumannType", default="'ZouHe'") != "ZouHe":
+        raise ConfigError("3-D inlet: only BoundaryTypeInlet = 'Neumann' with NeumannType = 'ZouHe'")
+    if c.str("BoundaryCondition", "BoundaryTypeOutlet") != "Dirichlet":
+        raise ConfigError("3-D outlet: only BoundaryTypeOutlet = 'Dirichlet'")
+    p["velocityZR"] = c.float("BoundaryCondition", "velocityZR", default=0.0)
+    p["velocityZB"] = c.float("BoundaryCondition", "velocityZB", default=0.0)
+    p["densityBL"] = c.float("BoundaryCondition", "densityBL", default=1.0)
+    p["densityRL"] = c.float("BoundaryCondition", "densityRL", default=1.0)
+    if c.str("GradientType", "Type", default="'Isotropic'") != "Isotropic":
+        raise ConfigError("[GradientType] Type: only 'Isotropic'")
+    p["steps"] = c.int("TimeSteps", "TimeSteps")
+    p["interval"] = c.int("TimeSteps", "TimeInterval", default=0)       # not in the shipped file
+    p["relax"] = c.str("RelaxationType", "Type", default="'SRT'")
+    if p["relax"] not in ("SRT", "MRT"):
+        raise ConfigError("[RelaxationType] Type must be 'SRT' or 'MRT'")
+    if c.str("CyclesSetup", "IsCycle", default="'no'") == "yes":
+        raise ConfigError("[CyclesSetup] IsCycle = 'yes' is not supported in 3-D")
+    return p
+
+
 def read_sc2d(ini_dir):
     """twophasesetup.ini + efs2D.ini | shanchen2D.ini -> dict (ShanChenD2Q9.py:42-157, :172-499)."""
     c = Ini(os.path.join(ini_dir, "twophasesetup.ini"))

@@ -19,6 +19,7 @@
 // One time step of a slab = [f halo exchange] -> phase field of the face planes -> [phi halo
 // exchange] -> collide; lbmpm_rk3d_collide_interior / _boundary overlap the exchanges with the
 // planes that do not depend on them.
+#include <type_traits>
 #include "lbmpm_common.h"
 #include "d2q9_device.h"
 
@@ -54,6 +55,7 @@ struct RK3Dev {
     double *diag;                // [5][vol] rhoR, rhoB, vx, vy, vz or nullptr
     double ak, beta, cR, cB, solidPhi, vzR, vzB, rhoOutR, rhoOutB;   // cX = 1 / (2 (tauX - 1/2))
     int first, fill;
+    int mrt;                     // 0: BGK, 1: MRT (d'Humieres D3Q19 basis) on the colour-blind populations
     // compact storage (layout 1): only fluid cells are stored, see "compact storage" below
     const u32x4 *seg;                 // [rows][nseg] {fluid mask lo, hi, j of the first fluid cell, fluid(x0-1) | fluid(x0+64) << 1 | pad << 2}, rows = (nzl+2)*ny
     const u32x4 *seg2;                // [rows][nseg] {j of cell x0-1, j of cell x0+64 (periodic), -, -}
@@ -374,11 +376,26 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3d_phase_field(RK3Dev p, int zl0)
     }
 }
 
+// rows of the D3Q19 moment basis (d'Humieres et al. 2002) that relax at their own rates, as functions
+// of the direction; all fold to constants in the unrolled loops
+__device__ __forceinline__ constexpr double mrt_c2(int i) { return i == 0 ? 0. : (i < 7 ? 1. : 2.); }
+__device__ __forceinline__ constexpr double mrt_e(int i) { return 19. * mrt_c2(i) - 30.; }
+__device__ __forceinline__ constexpr double mrt_eps(int i) { return (21. * mrt_c2(i) * mrt_c2(i) - 53. * mrt_c2(i) + 24.) / 2.; }
+__device__ __forceinline__ constexpr double mrt_pixx(int i)
+{
+    constexpr int CX[Q] = LBMPM_D3Q19_CX;
+    return (3. * mrt_c2(i) - 5.) * (3. * (double)(CX[i] * CX[i]) - mrt_c2(i));
+}
+__device__ __forceinline__ constexpr double mrt_piww(int i)
+{
+    constexpr int CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+    return (3. * mrt_c2(i) - 5.) * (double)(CY[i] * CY[i] - CZ[i] * CZ[i]);
+}
 // BGK + perturbation + recolouring of one node from the colour-blind populations ft = fR + fB,
 // the colour densities and the colour gradient; stores the post-collision populations of plane zl.
 // Lanes of non-fluid cells whose 128-byte line holds fluid store zeros: partially written
 // lines cost the memory system a read-modify-write (measured: +35 % kernel time at porosity 0.65).
-template <bool COMPACT = false>   // COMPACT: {red, blue} pairs, 16 bytes per node and direction
+template <bool COMPACT, bool MRT>   // COMPACT: {red, blue} pairs, 16 bytes per node and direction; MRT: [RelaxationType] Type
 __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsigned stride, unsigned own, bool fluid,
                                               const double ft_in[Q], double rR, double rB, double gx, double gy, double gz)
 {
@@ -402,6 +419,30 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     const double ig2 = g2 != 0. ? 1. / g2 : 0., ign = gn * ig2;
     const double kR = rR * irho, kB = rB * irho, arc = p.beta * rR * rB * irho * irho, akgn = p.ak * gn;
     const double c0 = 1. - 1.5 * usq;
+    // MRT ([RelaxationType] Type = 'MRT'): f -= M^-1 S M (f - feq) in the D3Q19 basis of d'Humieres et al. 2002
+    // with s_e = 1.19, s_eps = s_pi = 1.4, the third-order moments q and m at 1.2 and the stress
+    // moments at omega.  (d'Humieres' s_m = 1.98 is unstable next to the Zou-He planes; see the oracle.)
+    // d = f - feq has no mass and no momentum, so
+    //   even part: Delta = omega d + sum_k (s_k - omega) M_k (M_k . d) / |M_k|^2 over k = e, eps, pi_xx, pi_ww
+    //              (the moments see only the sums of opposite pairs),
+    //   odd part:  everything that is not momentum relaxes at 1.2, i.e. the pair differences do.
+    double kev[4] = {0., 0., 0., 0.};
+    const double hodd = MRT ? 0.5 * (1.2 - omega) : 0.;
+    if (MRT) {
+        // private copies of u: the equilibrium terms of this pass must not be kept (18 registers) for the next
+        double vx = ux, vy = uy, vz = uz, v0 = c0;
+        asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz), "+v"(v0));
+        const double d0 = ft_in[0] - (rho * wq(0)) * v0;
+        kev[0] = -30. * d0; kev[1] = 12. * d0;
+#pragma unroll
+        for (int i = 1; i < Q; i += 2) {
+            const double eu = (double)CX[i] * vx + (double)CY[i] * vy + (double)CZ[i] * vz;
+            const double sp = (ft_in[i] + ft_in[i + 1]) - 2. * ((rho * wq(i)) * (v0 + 4.5 * eu * eu));
+            kev[0] += mrt_e(i) * sp; kev[1] += mrt_eps(i) * sp; kev[2] += mrt_pixx(i) * sp; kev[3] += mrt_piww(i) * sp;
+        }
+        kev[0] *= (1.19 - omega) * (1. / 2394.); kev[1] *= (1.4 - omega) * (1. / 252.);
+        kev[2] *= (1.4 - omega) * (1. / 72.);    kev[3] *= (1.4 - omega) * (1. / 24.);
+    }
     char *blue = red + (size_t)Q * stride;       // red = population 0 of the node's plane, stride = bytes between populations
     auto put = [&](int i, double g, double a) {
         if (COMPACT) {
@@ -414,7 +455,7 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
         }
     };
     // relaxation as f - (f - feq) omega: a node at equilibrium stays there bit for bit
-    put(0, (ft_in[0] - (ft_in[0] - (rho * wq(0)) * c0) * omega) - akgn * bq(0), 0.);
+    put(0, ((ft_in[0] - (ft_in[0] - (rho * wq(0)) * c0) * omega) - (MRT ? -30. * kev[0] + 12. * kev[1] : 0.)) - akgn * bq(0), 0.);
 #pragma unroll
     for (int i = 1; i < Q; i += 2) {             // i and i + 1 are opposite
         const double w = wq(i), ien = i < 7 ? 1. : 0.70710678118654752440;
@@ -423,8 +464,13 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
         const double sym = (rho * w) * (c0 + 4.5 * eu * eu), odd = (3. * rho * w) * eu;
         const double pert = (akgn * w * ig2) * (eg * eg) - akgn * bq(i);
         const double a = (arc * w * ien * ign) * eg;
-        put(i, (ft_in[i] - (ft_in[i] - (sym + odd)) * omega) + pert, a);
-        put(i + 1, (ft_in[i + 1] - (ft_in[i + 1] - (sym - odd)) * omega) + pert, -a);
+        double ev = 0., od = 0.;
+        if (MRT) {
+            ev = mrt_e(i) * kev[0] + mrt_eps(i) * kev[1] + mrt_pixx(i) * kev[2] + mrt_piww(i) * kev[3];
+            od = hodd * ((ft_in[i] - ft_in[i + 1]) - 2. * odd);
+        }
+        put(i, ((ft_in[i] - (ft_in[i] - (sym + odd)) * omega) - (ev + od)) + pert, a);
+        put(i + 1, ((ft_in[i + 1] - (ft_in[i + 1] - (sym - odd)) * omega) - (ev - od)) + pert, -a);
         __builtin_amdgcn_sched_barrier(0);      // one pair's temporaries at a time: registers are the scarce resource here
     }
 }
@@ -440,6 +486,7 @@ __device__ __forceinline__ bool line_has_fluid(bool fluid, unsigned lane, int fi
 
 // K2 of the split variant: stream + boundaries again, colour gradient from the global phase field,
 // collision, store
+template <bool MRT>
 __global__ __launch_bounds__(BX3 *BY3) void rk3d_collide(RK3Dev p)
 {
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
@@ -463,7 +510,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3d_collide(RK3Dev p)
     double ft[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) ft[i] = fR[i] + fB[i];
-    collide_store(p, const_cast<char *>(plane_ptr(p.fout, p, zl)), p.plane_bytes, c.o[1][1], fluid, ft, rR, rB, gx, gy, gz);
+    collide_store<false, MRT>(p, const_cast<char *>(plane_ptr(p.fout, p, zl)), p.plane_bytes, c.o[1][1], fluid, ft, rR, rB, gx, gy, gz);
 }
 
 // Fused time step (default): one block owns a TX x TY column of nodes and marches along z.
@@ -506,7 +553,7 @@ __device__ __forceinline__ double ring_phi(const RK3Dev &p, const Cell &c, int z
     return (rR - rB) / (rR + rB);
 }
 
-template <int TX, int TY, bool FIRST>
+template <int TX, int TY, bool FIRST, bool MRT>
 __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last)
 {
     using M = March<TX, TY>;
@@ -585,7 +632,7 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
                     gy += 3. * wq(i) * (double)CY[i] * ph;
                     gz += 3. * wq(i) * (double)CZ[i] * ph;
                 }
-                collide_store(p, const_cast<char *>(plane_ptr(p.fout, p, z)), p.plane_bytes, own_off, isfl, ft, rRz, rBz, gx, gy, gz);
+                collide_store<false, MRT>(p, const_cast<char *>(plane_ptr(p.fout, p, z)), p.plane_bytes, own_off, isfl, ft, rRz, rBz, gx, gy, gz);
             }
         }
         fluid = (mo >> 31) && z + 1 >= 1 && z + 1 <= p.nzl;
@@ -660,7 +707,7 @@ __device__ __forceinline__ double ring_phi_c(const RK3Dev &p, const Rows &rows, 
 }
 
 // the marching kernel of rk3d_fused on compact storage (TX = 64: a wave owns one row segment)
-template <int TY, bool FIRST>
+template <int TY, bool FIRST, bool MRT>
 __global__ __launch_bounds__(64 * TY, 512 / (64 * TY)) void rk3dc_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last)
 {
     constexpr int TX = 64;
@@ -800,7 +847,7 @@ __global__ __launch_bounds__(64 * TY, 512 / (64 * TY)) void rk3dc_fused(RK3Dev p
             }
             const unsigned long long p0 = p.pstart[z], p1 = p.pstart[z + 1];
             const unsigned cnt = (unsigned)(p1 - p0);
-            collide_store<true>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * (Q * 16), cnt * 16u, jzz * 16u, fluid, ft, rRz, rBz, gx, gy, gz);
+            collide_store<true, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * (Q * 16), cnt * 16u, jzz * 16u, fluid, ft, rRz, rBz, gx, gy, gz);
         }
         fluid = fluidn;
     }
@@ -972,6 +1019,7 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     p.rhoOutR = c->cfg.outlet_rho_r; p.rhoOutB = c->cfg.outlet_rho_b;
     p.first = c->streamed ? 0 : 1;
     p.fill = c->fill;
+    p.mrt = c->cfg.relaxation;
     return p;
 }
 
@@ -1009,6 +1057,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_CHUNK")) chunk_len = atoi(e) > 0 ? atoi(e) : 32;
     if (const char *e = getenv("LBMPM_RK3D_FILL")) fill = atoi(e);
     LBMPM_REQUIRE(variant == 0 || variant == 1, "lbmpm_rk3d_create: variant must be 0 (fused) or 1 (split)");
+    LBMPM_REQUIRE(cfg->relaxation == 0 || cfg->relaxation == 1, "lbmpm_rk3d_create: relaxation must be 0 (SRT) or 1 (MRT)");
     LBMPM_REQUIRE(fill == 0 || fill == 4 || fill == 8 || fill == 16 || fill == 32 || fill == 64,
                   "LBMPM_RK3D_FILL must be 0 or a power of two <= 64");
     LBMPM_HIP_TRY(hipSetDevice(cfg->device));
@@ -1224,14 +1273,24 @@ extern "C" int lbmpm_rk3d_phase_field(lbmpm_rk3d *c, int with_diagnostics)
 }
 
 namespace {
+// run f(bool_constant<a>, bool_constant<b>): two run-time switches -> template arguments
+template <typename F>
+void dispatch2(bool a, bool b, F &&f)
+{
+    if (a) { if (b) f(std::true_type{}, std::true_type{}); else f(std::true_type{}, std::false_type{}); }
+    else   { if (b) f(std::false_type{}, std::true_type{}); else f(std::false_type{}, std::false_type{}); }
+}
+
 template <int TX, int TY>
 void launch_fused(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last)
 {
     const int tilesX = (c->nx + TX - 1) / TX, tilesY = (c->ny + TY - 1) / TY, rpx = (tilesY + 7) / 8;
     const int nchunks = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
     const dim3 grid((unsigned)(8 * tilesX * rpx * nchunks)), block(TX * TY);
-    if (p.first) rk3d_fused<TX, TY, true><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
-    else rk3d_fused<TX, TY, false><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+    auto go = [&](auto first, auto mrt) {
+        rk3d_fused<TX, TY, decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+    };
+    dispatch2(p.first != 0, p.mrt != 0, go);
 }
 
 template <int TY>
@@ -1240,8 +1299,10 @@ void launch_fused_c(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first,
     const int tilesX = c->nseg, tilesY = (c->ny + TY - 1) / TY, rpx = (tilesY + 7) / 8;
     const int nchunks = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
     const dim3 grid((unsigned)(8 * tilesX * rpx * nchunks)), block(64 * TY);
-    if (p.first) rk3dc_fused<TY, true><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
-    else rk3dc_fused<TY, false><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+    auto go = [&](auto first, auto mrt) {
+        rk3dc_fused<TY, decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+    };
+    dispatch2(p.first != 0, p.mrt != 0, go);
 }
 
 // planes z_first..z_last of the time step on stream st
@@ -1271,7 +1332,10 @@ extern "C" int lbmpm_rk3d_collide(lbmpm_rk3d *c)
     LBMPM_REQUIRE(c, "null context");
     LBMPM_REQUIRE(!c->interior_pending, "lbmpm_rk3d_collide after lbmpm_rk3d_collide_interior: finish the step with lbmpm_rk3d_collide_boundary");
     RK3Dev p = make_dev(c);
-    if (c->variant == 1) rk3d_collide<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p);
+    if (c->variant == 1) {
+        if (p.mrt) rk3d_collide<true><<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p);
+        else rk3d_collide<false><<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p);
+    }
     else launch_step_range(c, p, c->stream, 1, c->nzl);
     LBMPM_HIP_TRY(hipGetLastError());
     finish_step(c);

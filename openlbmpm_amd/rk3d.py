@@ -15,7 +15,7 @@ BUF = dict(f_send_up=0, f_send_down=1, f_recv_below=2, f_recv_above=3,
 
 # names follow IniFiles/RKtwophasesetup3D.ini
 DEFAULT_PARAMS = dict(AkR=7.0e-3, AkB=7.0e-3, beta=1.0, tauR=1.0, tauB=1.0, SolidRhoR=0.7, SolidRhoB=0.0,
-                      velocityZR=0.0, velocityZB=-1.0e-4, densityRL=1.0e-8, densityBL=1.0)
+                      velocityZR=0.0, velocityZB=-1.0e-4, densityRL=1.0e-8, densityBL=1.0, relax="SRT")
 
 
 class RK3DSlab:
@@ -43,7 +43,9 @@ class RK3DSlab:
         cfg.solid_phi = (p["SolidRhoR"] - p["SolidRhoB"]) / (p["SolidRhoR"] + p["SolidRhoB"])
         cfg.inlet_vz_r, cfg.inlet_vz_b = p["velocityZR"], p["velocityZB"]
         cfg.outlet_rho_r, cfg.outlet_rho_b = p["densityRL"], p["densityBL"]
-        cfg.device, cfg.variant = int(device), 0
+        if p["relax"] not in ("SRT", "MRT"):
+            raise ValueError("RelaxationType must be 'SRT' or 'MRT'")
+        cfg.device, cfg.variant, cfg.relaxation = int(device), 0, int(p["relax"] == "MRT")
         self._h = C.c_void_p()
         check(L.lbmpm_rk3d_create(C.byref(cfg), halo.ctypes.data_as(U8P), C.byref(self._h)), "lbmpm_rk3d_create")
         self._L = L

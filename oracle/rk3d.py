@@ -14,11 +14,12 @@ class _Sim(C.Structure):
     _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64), ("dom", U8P)] + \
                [(n, C.c_double) for n in ("akR", "akB", "beta", "tauR", "tauB", "solidPhi", "vzR", "vzB",
                                           "rhoOutR", "rhoOutB")] + \
+               [("mrt", C.c_int)] + \
                [(n, F64P) for n in ("fR", "fB", "gR", "gB", "rhoR", "rhoB", "phi", "vx", "vy", "vz", "Gx", "Gy", "Gz")]
 
 
 DEFAULT_PARAMS = dict(AkR=7.0e-3, AkB=7.0e-3, beta=1.0, tauR=1.0, tauB=1.0, SolidRhoR=0.7, SolidRhoB=0.0,
-                      velocityZR=0.0, velocityZB=-1.0e-4, densityRL=1.0e-8, densityBL=1.0)
+                      velocityZR=0.0, velocityZB=-1.0e-4, densityRL=1.0e-8, densityBL=1.0, relax="SRT")
 
 
 class RK3DOracle:
@@ -39,6 +40,7 @@ class RK3DOracle:
         s.akR, s.akB, s.beta, s.tauR, s.tauB = p["AkR"], p["AkB"], p["beta"], p["tauR"], p["tauB"]
         s.solidPhi = (p["SolidRhoR"] - p["SolidRhoB"]) / (p["SolidRhoR"] + p["SolidRhoB"])
         s.vzR, s.vzB, s.rhoOutR, s.rhoOutB = p["velocityZR"], p["velocityZB"], p["densityRL"], p["densityBL"]
+        s.mrt = 1 if p["relax"] == "MRT" else 0
         self._names = ("fR", "fB", "gR", "gB", "rhoR", "rhoB", "phi", "vx", "vy", "vz", "Gx", "Gy", "Gz")
         for name in self._names:
             setattr(s, name, getattr(self, "_" + name).ctypes.data_as(F64P))

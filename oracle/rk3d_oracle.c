@@ -11,6 +11,10 @@
  *                     phi_s = (SolidRhoR-SolidRhoB)/(SolidRhoR+SolidRhoB)
  *                     (AcceleratedRKGPU2D.py:1199-1219)
  *   BGK on f_R, f_B   tau = 1/2 + 1/((1+phi)/(2(tauR-1/2)) + (1-phi)/(2(tauB-1/2)))   (A:1144-1160)
+ *   MRT option        ([RelaxationType] Type = 'MRT', RKtwophasesetup3D.ini:53-55) as the 2-D MRT
+ *                     kernel does it: f_tot -= M^-1 S M (f_tot - f_eq) (A:1938-2025), with the D3Q19
+ *                     moment basis of d'Humieres et al. 2002, rates s_e 1.19, s_eps 1.4, s_pi 1.4, s_q = s_m 1.2
+ *                     (his s_m = 1.98 is unstable at the open planes), conserved moments 0, stress moments 1/tau
  *   perturbation      f += (AkR+AkB)/2 |G| (w_i (e_i.G)^2/|G|^2 - B_i)                 (A:1225-1239)
  *                     with the D3Q19 B_i of Liu, Valocchi & Kang 2012: -1/3, 1/18, 1/36
  *   recolouring       f_R = rhoR/rho f + beta rhoR rhoB/rho^2 w_i cos(theta_i)         (A:1241-1267)
@@ -47,6 +51,7 @@ typedef struct {
     i64 nx, ny, nz;
     const uint8_t *dom;          /* [nz][ny][nx] 1 = fluid */
     double akR, akB, beta, tauR, tauB, solidPhi, vzR, vzB, rhoOutR, rhoOutB;
+    int mrt;
     double *fR, *fB, *gR, *gB;   /* [nz*ny*nx][19] current / scratch */
     double *rhoR, *rhoB, *phi, *vx, *vy, *vz, *Gx, *Gy, *Gz;
 } rk3d_sim;
@@ -133,9 +138,68 @@ static void rk3d_bc_and_macro(rk3d_sim *s)
     }
 }
 
+/* D3Q19 moment basis of d'Humieres, Ginzburg, Krafczyk, Lallemand & Luo (2002): rows
+ * rho, e, eps, jx, qx, jy, qy, jz, qz, 3pxx, 3pixx, pww, piww, pxy, pyz, pxz, mx, my, mz */
+static void mrt_basis(double M[Q][Q])
+{
+    for (int i = 0; i < Q; ++i) {
+        double x = CX[i], y = CY[i], z = CZ[i], c2 = x * x + y * y + z * z;
+        M[0][i] = 1.;
+        M[1][i] = 19. * c2 - 30.;
+        M[2][i] = (21. * c2 * c2 - 53. * c2 + 24.) / 2.;
+        M[3][i] = x;  M[4][i] = (5. * c2 - 9.) * x;
+        M[5][i] = y;  M[6][i] = (5. * c2 - 9.) * y;
+        M[7][i] = z;  M[8][i] = (5. * c2 - 9.) * z;
+        M[9][i] = 3. * x * x - c2;   M[10][i] = (3. * c2 - 5.) * (3. * x * x - c2);
+        M[11][i] = y * y - z * z;    M[12][i] = (3. * c2 - 5.) * (y * y - z * z);
+        M[13][i] = x * y; M[14][i] = y * z; M[15][i] = x * z;
+        M[16][i] = (y * y - z * z) * x; M[17][i] = (z * z - x * x) * y; M[18][i] = (x * x - y * y) * z;
+    }
+}
+
+/* d <- M^-1 S M d; the rows of M are mutually orthogonal, so M^-1 = M^T diag(1/|row|^2) */
+static void mrt_relax_with(const double M[Q][Q], const double S[Q], double d[Q])
+{
+    double m[Q], out[Q];
+    for (int k = 0; k < Q; ++k) {
+        double acc = 0., nrm = 0.;
+        for (int i = 0; i < Q; ++i) { acc += M[k][i] * d[i]; nrm += M[k][i] * M[k][i]; }
+        m[k] = S[k] * acc / nrm;
+    }
+    for (int i = 0; i < Q; ++i) {
+        double acc = 0.;
+        for (int k = 0; k < Q; ++k) acc += M[k][i] * m[k];
+        out[i] = acc;
+    }
+    for (int i = 0; i < Q; ++i) d[i] = out[i];
+}
+
+/* s_e, s_eps, s_q, s_pi, s_m.  d'Humieres' own s_m = 1.98 lets a mode grow at the Zou-He planes (a 24^3
+ * static droplet is gone after ~1500 steps; tests/test_oracle_rk3d.py); the two third-order moment
+ * families therefore share 1.2. */
+static double RATES[5] = {1.19, 1.4, 1.2, 1.4, 1.2};
+void rk3d_set_mrt_rates_public(const double *r) { for (int i = 0; i < 5; ++i) RATES[i] = r[i]; }
+static void mrt_relax(const double M[Q][Q], double inv_tau, double d[Q])
+{
+    const double S[Q] = {0., RATES[0], RATES[1], 0., RATES[2], 0., RATES[2], 0., RATES[2], inv_tau, RATES[3], inv_tau, RATES[3],
+                         inv_tau, inv_tau, inv_tau, RATES[4], RATES[4], RATES[4]};
+    mrt_relax_with(M, S, d);
+}
+
+/* test hooks: the basis itself, and d <- M^-1 diag(S) M d for any S */
+void rk3d_mrt_basis_public(double *M19x19) { mrt_basis((double (*)[Q])M19x19); }
+void rk3d_mrt_relax_public(const double *S, double *d)
+{
+    double M[Q][Q];
+    mrt_basis(M);
+    mrt_relax_with(M, S, d);
+}
+
 static void rk3d_collide_stream(rk3d_sim *s)
 {
     i64 nx = s->nx, ny = s->ny, nz = s->nz, pl = nx * ny;
+    double M[Q][Q];
+    mrt_basis(M);
     PARFOR
     for (i64 z = 0; z < nz; ++z)
         for (i64 y = 0; y < ny; ++y)
@@ -160,11 +224,19 @@ static void rk3d_collide_stream(rk3d_sim *s)
                 double tau = 0.5 + 1. / ((1. + phi) / (2. * (s->tauR - 0.5)) + (1. - phi) / (2. * (s->tauB - 0.5)));
                 double ux = s->vx[n], uy = s->vy[n], uz = s->vz[n], usq = ux * ux + uy * uy + uz * uz;
                 double *r = s->fR + Q * n, *b = s->fB + Q * n;
+                double dm[Q];
+                if (s->mrt) {
+                    for (int i = 0; i < Q; ++i) {
+                        double eu = CX[i] * ux + CY[i] * uy + CZ[i] * uz;
+                        dm[i] = (r[i] + b[i]) - rho * WT(i) * (1. + 3. * eu + 4.5 * eu * eu - 1.5 * usq);
+                    }
+                    mrt_relax(M, 1. / tau, dm);
+                }
                 for (int i = 0; i < Q; ++i) {
                     double eu = CX[i] * ux + CY[i] * uy + CZ[i] * uz;
                     double feq = rho * WT(i) * (1. + 3. * eu + 4.5 * eu * eu - 1.5 * usq);
                     double ft = r[i] + b[i];
-                    ft = ft - (ft - feq) / tau;
+                    ft = s->mrt ? ft - dm[i] : ft - (ft - feq) / tau;
                     double eg = CX[i] * gx + CY[i] * gy + CZ[i] * gz;
                     if (g2 != 0.) ft += (s->akR + s->akB) * 0.5 * gn * (WT(i) * (eg * eg) / g2 - BI(i));
                     double en = sqrt((double)(CX[i] * CX[i] + CY[i] * CY[i] + CZ[i] * CZ[i]));

@@ -188,3 +188,68 @@ def write_transport(d):
     import os
     with open(os.path.join(d, "transportsetup.ini"), "w") as fh:
         fh.write(TRANSPORT_INI)
+
+
+# key spellings of IniFiles/RKtwophasesetup3D.ini (own values)
+RK3D_INI = """[ImageSetup]
+Existance = 'no'
+
+[DomainSize]
+xDomain = {nx}
+yDomain = {ny}
+zDomain = {nz}
+
+[RKParameters]
+AlphaR = {alpha}
+AlphaB = 0.
+BetaThickness = 1.
+AkR = 7.0e-3
+AkB = 7.0e-3
+DeltaValue = 0.98
+
+[FluidParameters]
+TauR = 1.0
+TauB = 0.9
+InitialRhoR = 1.0
+InitialRhoB = 1.0
+
+[BoundariesSetup]
+SolidRhoR = 0.7
+SolidRhoB = 0.0
+
+[BoundaryCondition]
+BoundaryTypeInlet = 'Neumann'
+NeumannType = 'ZouHe'
+velocityZR = 0.0
+;;-2.5e-4
+velocityZB = -1.0e-4
+BoundaryTypeOutlet = 'Dirichlet'
+densityBL = 1.0
+densityRL = 1.0e-8
+
+[GradientType]
+Type = 'Isotropic'
+;;'Isotropic'
+
+[TimeSteps]
+TimeSteps = {steps}
+
+[Parallelism]
+Parallel = 'yes'
+xDimension = 128
+ThreadsNum = 32
+
+[RelaxationType]
+Type = '{relax}'
+;;MRT
+
+[CyclesSetup]
+IsCycle = 'no'
+LastStep = 350
+"""
+
+
+def write_rk3d(d, nx=32, ny=32, nz=96, steps=1000, relax="SRT", alpha="0."):
+    import os
+    with open(os.path.join(d, "RKtwophasesetup3D.ini"), "w") as fh:
+        fh.write(RK3D_INI.format(nx=nx, ny=ny, nz=nz, steps=steps, relax=relax, alpha=alpha))

@@ -60,3 +60,18 @@ def test_force_scheme_key(tmp_path):
         config.read_sc2d(str(tmp_path))
     write_sc(str(tmp_path), inter="ShanChen", scheme=10)       # original Shan-Chen ignores the key
     assert config.read_sc2d(str(tmp_path))["scheme"] == 4
+
+
+def test_rk3d_ini(tmp_path):
+    from ini_fixtures import write_rk3d
+    write_rk3d(str(tmp_path), relax="MRT")
+    p = config.read_rk3d(str(tmp_path))
+    assert (p["nx"], p["ny"], p["nz"], p["steps"]) == (32, 32, 96, 1000)
+    assert p["relax"] == "MRT" and p["AkR"] == 7.0e-3 and p["tauB"] == 0.9 and p["velocityZB"] == -1.0e-4
+    assert p["SolidRhoR"] == 0.7 and p["densityRL"] == 1.0e-8 and not p["image"]
+    write_rk3d(str(tmp_path), alpha="0.2")
+    with pytest.raises(config.ConfigError):
+        config.read_rk3d(str(tmp_path))
+    write_rk3d(str(tmp_path), relax="TRT")
+    with pytest.raises(config.ConfigError):
+        config.read_rk3d(str(tmp_path))

@@ -38,15 +38,16 @@ def _cap_angle(height, widths):
 RK3D_CLOSED = dict(velocityZR=0.0, velocityZB=0.0, densityRL=1e-8, densityBL=1.0)
 
 
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
 @pytest.mark.parametrize("radius", [10, 14, 18])
-def test_d3q19_laplace_law(radius):
+def test_d3q19_laplace_law(radius, relax):
     from openlbmpm_amd.rk3d import RK3DSlab
     n, ak, tau = 64, 7.0e-3, 1.0
     dom = np.ones((n, n, n), dtype=np.uint8)
     z, y, x = np.mgrid[0:n, 0:n, 0:n]
     c = (n - 1) / 2.0
     r = np.sqrt((x - c) ** 2 + (y - c) ** 2 + (z - c) ** 2)
-    s = RK3DSlab(dom, 0, n, dict(RK3D_CLOSED, AkR=ak, AkB=ak, tauR=tau, tauB=tau))
+    s = RK3DSlab(dom, 0, n, dict(RK3D_CLOSED, AkR=ak, AkB=ak, tauR=tau, tauB=tau, relax=relax))
     s.set_density(np.where(r < radius, 1.0, 1e-8), np.where(r < radius, 1e-8, 1.0))
     s.step_single(4000)
     s.phase_field(diagnostics=True)

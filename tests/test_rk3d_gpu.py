@@ -18,11 +18,12 @@ def _case(nx=40, ny=21, nz=38, seed=4):
     return dom, rR, rB
 
 
-def test_single_slab_vs_oracle():
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+def test_single_slab_vs_oracle(relax):
     from openlbmpm_amd.rk3d import RK3DCluster
     from oracle.rk3d import RK3DOracle
     dom, rR, rB = _case()
-    par = dict(tauR=1.0, tauB=0.8)
+    par = dict(tauR=1.0, tauB=0.8, relax=relax)
     c = RK3DCluster(dom, 1, par)
     c.set_density(rR, rB)
     o = RK3DOracle(dom, rR, rB, par)
@@ -72,12 +73,13 @@ def test_kernel_schedules_agree_bitwise(env, monkeypatch):
     ref.close(); c.close()
 
 
-def test_compact_storage_vs_oracle():
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+def test_compact_storage_vs_oracle(relax):
     """nx a multiple of 64 selects the compact (fluid-cells-only) storage"""
     from openlbmpm_amd.rk3d import RK3DCluster
     from oracle.rk3d import RK3DOracle
     dom, rR, rB = _case(nx=128, ny=21, nz=30, seed=5)
-    par = dict(tauR=1.0, tauB=0.8)
+    par = dict(tauR=1.0, tauB=0.8, relax=relax)
     c = RK3DCluster(dom, 1, par)
     assert c.slabs[0].dominant_kernel == "rk3dc_fused"
     c.set_density(rR, rB)
@@ -112,6 +114,42 @@ def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch):
     for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz"):
         assert np.array_equal(ref.get(f), c.get(f)), f
     ref.close(); c.close()
+
+
+@pytest.mark.parametrize("env,k", [({"LBMPM_RK3D_LAYOUT": "dense"}, 1), ({"LBMPM_RK3D_LAYOUT": "dense", "LBMPM_RK3D_VARIANT": "1"}, 2),
+                                   ({}, 3), ({"LBMPM_RK3D_TILE": "1", "LBMPM_RK3D_CHUNK": "6"}, 2)],
+                         ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
+def test_mrt_schedules_agree_bitwise(env, k, monkeypatch):
+    """MRT relaxation: dense / compact storage, split sweeps, slab decomposition -- one arithmetic"""
+    from openlbmpm_amd.rk3d import RK3DCluster
+    dom, rR, rB = _case(nx=64, ny=19, nz=41, seed=12)
+    par = dict(relax="MRT", tauR=0.9, tauB=0.7)
+    ref = RK3DCluster(dom, 1, par)
+    ref.set_density(rR, rB)
+    ref.step(11); ref.observe()
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    c = RK3DCluster(dom, k, par)
+    c.set_density(rR, rB)
+    c.step(11); c.observe()
+    for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz"):
+        assert np.array_equal(ref.get(f), c.get(f)), f
+    ref.close(); c.close()
+
+
+def test_mrt_differs_from_srt_and_unknown_relaxation_is_rejected():
+    from openlbmpm_amd.rk3d import RK3DCluster
+    dom, rR, rB = _case(nx=24, ny=12, nz=20, seed=2)
+    out = []
+    for relax in ("SRT", "MRT"):
+        c = RK3DCluster(dom, 1, dict(relax=relax))
+        c.set_density(rR, rB)
+        c.step(6); c.observe()
+        out.append(c.get("vz"))
+        c.close()
+    assert np.abs(out[0] - out[1]).max() > 1e-9
+    with pytest.raises(ValueError):
+        RK3DCluster(dom, 1, dict(relax="TRT"))
 
 
 def test_single_slab_convenience_equals_phases():

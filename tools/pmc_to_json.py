@@ -34,14 +34,16 @@ def main():
     kernels = {}
     for name, (n, f) in fetch.items():
         k = short(name)
-        if k not in WORKLOADS or "true" in name.split(k)[1][:20] and k.endswith("fused") and "rk3d" in k:
-            continue                      # first-step instantiation of the 3-D kernel: one launch only
+        if k not in WORKLOADS:
+            continue
         w = write.get(name, (0, 0.0))[1]
         rec = {"launches_profiled": n, "fetch_size_kb": f, "write_size_kb": w,
                "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0, "workload": WORKLOADS[k]}
         if k == "rk2d_fused":             # c2 (no tracer) and c4 (tracer) are different template instances
             rec["workload"] = "c4 2048x2048" if re.search(r"rk2d_fused<(true|false), true", name) else "c2 1024x1024"
             k = "rk2d_fused" if rec["workload"].startswith("c2") else "rk2d_fused[tracer]"
+        if k in kernels and kernels[k]["launches_profiled"] >= n:
+            continue                      # e.g. the first-step instantiation of the 3-D kernel: one launch only
         kernels[k] = rec
     print(json.dumps({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                                 "`python bench.py --steps 10 --warmup 2 --no-cpu-baseline`, MI355X (tools/profile_round.sh)",
