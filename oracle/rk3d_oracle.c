@@ -163,7 +163,7 @@ static void mrt_relax_with(const double M[Q][Q], const double S[Q], double d[Q])
     double m[Q], out[Q];
     for (int k = 0; k < Q; ++k) {
         double acc = 0., nrm = 0.;
-        for (int i = 0; i < Q; ++i) { acc += M[k][i] * d[i]; nrm += M[k][i] * M[k][i]; }
+        for (int i = 0; i < Q; ++i) { acc += M[k][i] * d[i]; nrm += M[k][i] * M[k][i]; }   /* |row|^2: small integers, exact */
         m[k] = S[k] * acc / nrm;
     }
     for (int i = 0; i < Q; ++i) {
