@@ -2,8 +2,10 @@
 (RKD2Q9.py:348-357, :938-957; ShanChenD2Q9.py:503-511, :940-955).
 
 Backend: PyTables or h5py when importable (same file layout as the reference's `tables` calls);
-otherwise a `.npz` whose keys are the HDF5 paths (`/FluidMacro/FluidDensityRin0`, ...), so that
-post-processing only has to swap the loader.
+else the HDF5 C library itself through ctypes (openlbmpm_amd/_hdf5.py: still a real .h5 with the
+same groups and datasets); only when no HDF5 is present at all a `.npz` whose keys are the HDF5
+paths (`/FluidMacro/FluidDensityRin0`, ...), so that post-processing only has to swap the loader.
+`LBMPM_RESULT_BACKEND=tables|h5py|libhdf5|npz` forces one.
 """
 import os
 
@@ -11,6 +13,11 @@ import numpy as np
 
 
 def _backend():
+    forced = os.environ.get("LBMPM_RESULT_BACKEND")
+    if forced:
+        if forced not in ("tables", "h5py", "libhdf5", "npz"):
+            raise ValueError("LBMPM_RESULT_BACKEND must be tables, h5py, libhdf5 or npz")
+        return forced
     try:
         import tables  # noqa: F401
         return "tables"
@@ -20,7 +27,9 @@ def _backend():
         import h5py  # noqa: F401
         return "h5py"
     except ImportError:
-        return "npz"
+        pass
+    from . import _hdf5
+    return "libhdf5" if _hdf5.available() else "npz"
 
 
 class ResultFile:
@@ -41,6 +50,9 @@ class ResultFile:
             with h5py.File(self.path, "w") as f:
                 for g, _ in self.groups:
                     f.create_group(g)
+        elif self.backend == "libhdf5":
+            from . import _hdf5
+            _hdf5.create(self.path, self.groups)
 
     def write(self, group, name, array):
         array = np.asarray(array)
@@ -53,6 +65,9 @@ class ResultFile:
             import h5py
             with h5py.File(self.path, "a") as f:
                 f["/%s/%s" % (group, name)] = array
+        elif self.backend == "libhdf5":
+            from . import _hdf5
+            _hdf5.write(self.path, "/%s/%s" % (group, name), array)
         else:
             self._npz["/%s/%s" % (group, name)] = np.array(array, copy=True)
             np.savez_compressed(self.path, **self._npz)
@@ -70,7 +85,13 @@ def load_results(path):
             f.visititems(lambda n, o: out.__setitem__("/" + n, o[()]) if hasattr(o, "shape") else None)
         return out
     except ImportError:
+        pass
+    try:
         import tables as tb
+    except ImportError:
+        from . import _hdf5
+        return _hdf5.read_all(path)
+    else:
         out = {}
         f = tb.open_file(path, "r")
         for node in f.walk_nodes("/", "Array"):
