@@ -1,6 +1,7 @@
 """Closed forms used by the HIP kernels instead of the reference's dense 9x9 loops, checked
 against the matrices the reference builds (RKD2Q9.py:308-340, SimpleD2Q9.py:107-124)."""
 import numpy as np
+import pytest
 
 from oracle.rk import mrt_matrices
 from oracle.sc import transformation_matrix
@@ -57,3 +58,18 @@ def test_duplicated_pore_image_is_mirror_tiled():
     d1, d2 = image_domain(img, 20, 0.5), image_domain(img, 20, 0.5, duplicate=(2, 3))
     assert d1.shape == (50, 8) and d2.shape == (70, 16)
     assert d2[:, 0].sum() == 40 and d2[:, -1].sum() == 40          # side walls, buffer rows stay open
+
+
+def test_structure_image_file_is_read_as_greyscale(tmp_path):
+    """the PNG the reference drivers read from ~/StructureImage (RKD2Q9.py:382, ShanChenD2Q9.py:549):
+    0 = solid, anything else = pore, through the same crop / wall / buffer rules as an array"""
+    PIL = pytest.importorskip("PIL.Image")
+    from openlbmpm_amd.RKD2Q9 import load_structure_image
+    from openlbmpm_amd.geometry import image_domain
+    rng = np.random.default_rng(1)
+    img = (rng.random((40, 30)) > 0.3).astype(np.uint8) * 255
+    path = str(tmp_path / "structure.png")
+    PIL.fromarray(img).save(path)
+    back = load_structure_image(path)
+    assert back.shape == img.shape and np.array_equal(back > 0, img > 0)
+    assert np.array_equal(image_domain(back, 6, 0.5), image_domain(img.astype(np.float64), 6, 0.5))
