@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 from . import config
-from .geometry import initial_densities_rk3d
+from .geometry import initial_densities_rk3d, voxel_domain
 from .results import ResultFile
 from .rk3d import RK3DSlab, RK3DDistributed
 
@@ -30,11 +30,13 @@ def duct(nx, ny, nz):
 
 
 class RKColorGradient3D:
-    def __init__(self, pathIniFile, output_dir=None, domain=None, device=0, record_every=None, num_buffering_layers=10):
+    def __init__(self, pathIniFile, output_dir=None, domain=None, device=0, record_every=None, num_buffering_layers=10,
+                 structure_path=None):
         self.pathIni = pathIniFile
         self.par = config.read_rk3d(pathIniFile)
         self.output_dir = output_dir or os.path.expanduser("~/LBMResults3D")       # main.py:28
         self.device, self._domain, self.nbuf = device, domain, int(num_buffering_layers)
+        self.structure_path = structure_path
         self.timeSteps = self.par["steps"]
         self.timeInterval = record_every or self.par["interval"] or max(1, self.timeSteps // 10)
         self.records = 0
@@ -46,8 +48,12 @@ class RKColorGradient3D:
             if self.isDomain.ndim != 3:
                 raise TypeError("domain must be a [nz][ny][nx] array")
         elif p["image"]:
-            raise config.ConfigError("[ImageSetup] Existance = 'yes': pass the voxel array as `domain=` (the reference "
-                                     "ships no 3-D image reader)")
+            # the reference ships no 3-D image reader; a NumPy voxel file next to where its 2-D drivers look
+            # for structure.png (non-zero = pore), framed like the 2-D images are
+            path = self.structure_path or os.path.expanduser("~/StructureImage/structure3D.npy")
+            if not os.path.isfile(path):
+                raise config.ConfigError("[ImageSetup] Existance = 'yes': voxel file %s not found (or pass `domain=`)" % path)
+            self.isDomain = voxel_domain(np.load(path), self.nbuf)
         else:
             self.isDomain = duct(p["nx"], p["ny"], p["nz"])
         self.zDomain, self.yDomain, self.xDomain = self.isDomain.shape

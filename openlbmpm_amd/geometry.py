@@ -123,6 +123,21 @@ def porous_spheres(nx, ny, nz, porosity=0.65, rmin=6.0, rmax=20.0, seed=20260928
     return (~solid).astype(np.uint8)
 
 
+def voxel_domain(voxels, nbuf=10, walls=True):
+    """isDomain [nz + 2 nbuf][ny][nx] from a voxel array (non-zero = pore): the image rules of
+    RKD2Q9.py:407-414 carried to 3-D as in porous_spheres -- solid side walls around the sample,
+    `nbuf` all-fluid buffer planes added below and above it."""
+    v = np.asarray(voxels)
+    if v.ndim != 3:
+        raise TypeError("voxels must be a [nz][ny][nx] array")
+    core = (v != 0).astype(np.uint8)
+    if walls:
+        core[:, :, 0] = core[:, :, -1] = 0
+        core[:, 0, :] = core[:, -1, :] = 0
+    buf = np.ones((int(nbuf),) + core.shape[1:], dtype=np.uint8)
+    return np.ascontiguousarray(np.concatenate([buf, core, buf], axis=0))
+
+
 def initial_densities_rk3d(is_domain, nbuf, rho_r=1.0, rho_b=1.0):
     """3-D analogue of RKD2Q9.py:511-531: red below the top buffer planes, blue in them."""
     nz = is_domain.shape[0]

@@ -73,3 +73,15 @@ def test_structure_image_file_is_read_as_greyscale(tmp_path):
     back = load_structure_image(path)
     assert back.shape == img.shape and np.array_equal(back > 0, img > 0)
     assert np.array_equal(image_domain(back, 6, 0.5), image_domain(img.astype(np.float64), 6, 0.5))
+
+
+def test_voxel_domain_frames_a_sample_like_the_2d_image_rules():
+    from openlbmpm_amd.geometry import voxel_domain
+    rng = np.random.default_rng(2)
+    vox = (rng.random((12, 9, 11)) > 0.4).astype(np.uint8) * 7
+    dom = voxel_domain(vox, nbuf=3)
+    assert dom.shape == (18, 9, 11) and dom.dtype == np.uint8
+    assert dom[:3].all() and dom[-3:].all()                                   # buffer planes: all fluid
+    core = dom[3:-3]
+    assert not core[:, 0, :].any() and not core[:, -1, :].any() and not core[:, :, 0].any() and not core[:, :, -1].any()
+    assert np.array_equal(core[:, 1:-1, 1:-1], (vox != 0)[:, 1:-1, 1:-1])
