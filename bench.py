@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-B_ALG = {"c2": 288.0, "c3": 288.0, "c4": 368.0, "c5": 608.0}   # algorithmic bytes / lattice update
+B_ALG = {"c1": 288.0, "c2": 288.0, "c3": 288.0, "c4": 368.0, "c5": 608.0}   # algorithmic bytes / lattice update
 SEED = 20260928
 
 
@@ -105,6 +105,24 @@ def build_c4(nx, ny, device):
     return s, float((rR + rB).sum()), lambda: float((s.get("rhoR") + s.get("rhoB")).sum())
 
 
+C1_PAR = dict(inter="ShanChen", relax="SRT", tau0=1.0, tau1=1.0, G=3.8, Gs0=-0.40, Gs1=0.40, outlet="Periodic", vy0=0.0, vy1=0.0)
+
+
+def c1_fields(n=128, radius=20):
+    """BASELINE configs[0]: original Shan-Chen static droplet, fully periodic box (shanchen2D.ini parameters)"""
+    yy, xx = np.mgrid[0:n, 0:n]
+    inside = (xx - n / 2) ** 2 + (yy - n / 2) ** 2 <= radius * radius
+    return np.ones((n, n), dtype=np.uint8), np.where(inside, 1.0, 0.06), np.where(inside, 0.06, 1.0)
+
+
+def build_c1(nx, ny, device):
+    from openlbmpm_amd.sc2d import SC2DSolver
+    dom, r0, r1 = c1_fields(nx)
+    s = SC2DSolver(dom, C1_PAR, device=device)
+    s.set_density(r0, r1)
+    return s, float((r0 + r1).sum()), None
+
+
 def c5_domain(n):
     from openlbmpm_amd.geometry import porous_spheres
     nx, ny, nz = n
@@ -157,6 +175,22 @@ def cpu_baseline_c5(relax, edge=128, target_seconds=12.0):
     return dict(value=round(nfl * n / el / 1e6, 3), unit="MLUPS", cores=int(lib().rk_oracle_threads()), kind="port",
                 sample="c5 model (%s) on a %d^3 porous sample (same generator/parameters), %d steps of "
                        "oracle/rk3d_oracle.c (OpenMP), %.1f s" % (relax, edge, n, el))
+
+
+def cpu_baseline_simple_d2q9(target_seconds=6.0):
+    """the 'repo's own CPU path' line: configs[0] in the shape of the reference's SimpleD2Q9 (whole-array NumPy,
+    one thread), see oracle/simple_d2q9.py"""
+    from oracle.simple_d2q9 import SimpleD2Q9SC
+    dom, r0, r1 = c1_fields(128)
+    s = SimpleD2Q9SC(dom, r0, r1, tau=(1.0, 1.0), G=3.8, Gs=(-0.40, 0.40))
+    s.run(2)
+    t0 = time.perf_counter(); s.run(5); dt = (time.perf_counter() - t0) / 5
+    n = max(5, min(400, int(target_seconds / max(dt, 1e-6))))
+    t0 = time.perf_counter(); s.run(n); el = time.perf_counter() - t0
+    assert np.isfinite(s.rho[0]).all()
+    return dict(value=round(128 * 128 * n / el / 1e6, 3), unit="MLUPS", cores=1, kind="port",
+                sample="configs[0] (original Shan-Chen, 128x128 periodic static droplet), %d steps of oracle/simple_d2q9.py "
+                       "(NumPy, SimpleD2Q9-shaped; the reference's own CPU loop does not run), %.1f s" % (n, el))
 
 
 # ----------------------------------------------------------------------------- main
@@ -278,10 +312,10 @@ def main():
             }
             if world == 1 and not args.no_secondary:
                 sec = []
-                for name, build, size2 in (("c2", build_c2, (1024, 1024)), ("c3", build_c3, (2048, 2048)),
-                                           ("c4", build_c4, (2048, 2048))):
+                for name, build, size2 in (("c1", build_c1, (128, 128)), ("c2", build_c2, (1024, 1024)),
+                                           ("c3", build_c3, (2048, 2048)), ("c4", build_c4, (2048, 2048))):
                     s, _, _ = build(size2[0], size2[1], local_rank)
-                    k = 1000 if name == "c2" else 300
+                    k = 1000 if name in ("c1", "c2") else 300
                     w, mt, md = time_solver_2d(s, k, k // 10)
                     nf = s.num_fluid_nodes
                     sec.append({"workload": name, "value": round(nf * k / w / 1e6, 2), "unit": "MLUPS",
@@ -291,6 +325,7 @@ def main():
                 out["secondary"] = sec
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_c5(args.relax)
+                out["cpu_baseline_reference_shape"] = cpu_baseline_simple_d2q9()
     else:
         size = tuple(args.size) if args.size else ((1024, 1024) if wl == "c2" else (2048, 2048))
         steps = args.steps if args.steps is not None else (2000 if wl == "c2" else 500)

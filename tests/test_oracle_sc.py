@@ -48,3 +48,27 @@ def test_time_loop_matches_reference(path):
         for f in fields:
             e = rel_err(getattr(o, alias.get(f, f)), d["s%d_%s" % (k, f)])
             assert e < 1e-11, "%s snapshot %d field %s rel err %.3e" % (os.path.basename(path), k, f, e)
+
+
+def test_simple_d2q9_shaped_numpy_baseline_equals_the_c_oracle():
+    """oracle/simple_d2q9.py (whole-array NumPy in the shape of the reference's CPU path, the
+    'repo's own CPU path' line of bench.py) == sc_oracle.c with the boundary kernels skipped, on
+    a periodic box with a droplet and a solid block (bounce-back + solid adhesion)."""
+    from oracle.simple_d2q9 import SimpleD2Q9SC
+    from oracle.sc import SCOracle
+    par = dict(inter="ShanChen", relax="SRT", tau0=1.0, tau1=1.0, G=3.8, Gs0=-0.40, Gs1=0.40, outlet="Periodic",
+               vy0=0.0, vy1=0.0, rho0=1.0, rho1=1.0, bg0=0.06, bg1=0.06)
+    n = 48
+    yy, xx = np.mgrid[0:n, 0:n]
+    ins = (xx - n / 2) ** 2 + (yy - n / 2) ** 2 <= 64
+    dom = np.ones((n, n), dtype=np.uint8)
+    dom[8:12, 5:9] = 0
+    r0 = np.where(ins, 1.0, 0.06) * dom; r1 = np.where(ins, 0.06, 1.0) * dom
+    s = SimpleD2Q9SC(dom, r0, r1)
+    o = SCOracle(dom, par, rho_init=np.stack([r0, r1]))
+    fl = dom.ravel() == 1
+    for k in (1, 59):
+        s.run(k); o.run(k)
+        for c in range(2):
+            assert rel_err(s.rho[c].ravel()[fl], o.rho[c]) < 1e-11
+            assert rel_err(np.moveaxis(s.particleDisFunc[c], 0, -1).reshape(-1, 9)[fl], o.f[c]) < 1e-11
