@@ -294,6 +294,7 @@ def main():
                                        "parameters), %dx%dx%d synthetic porous medium (spheres r 6-20, porosity 0.65, "
                                        "10 buffer planes, side walls), seed %d" % ((args.relax,) + size + (SEED,)),
                            "fluid_nodes": nfluid_global, "lattice_nodes": int(np.prod(size)),
+                           "mlups_total_lattice": round(float(np.prod(size)) * steps / wall / 1e6, 2),
                            "parallelism": "z-slabs x%d, RCCL p2p halo (5 populations x 2 colours + phi per face)" % world
                                           if world > 1 else "1 gpu",
                            "kernel_schedule": "one fused z-marching kernel per step (pull, phase field in an LDS ring, collide, store), "
