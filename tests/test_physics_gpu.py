@@ -3,6 +3,7 @@
   * Laplace's law for a static droplet -- D3Q19: dp = 2 sigma / R with the perturbation operator's
     sigma = 2/9 (A_R + A_B) tau (Liu, Valocchi & Kang 2012); D2Q9 CSF: dp = sigma / R with the
     SurfaceTension of the ini file; pressure = rho / 3;
+  * D3Q19 single-phase duct flow: Zou-He inlet velocity, constant flux, rectangular-duct Poiseuille profile;
   * D2Q5 tracer: variance of a Gaussian blob grows by 2 D t;
   * static contact angle of a sessile droplet from its spherical-cap shape -- D3Q19: cos(theta) =
     phi_s = (SolidRhoR - SolidRhoB) / (SolidRhoR + SolidRhoB); D2Q9: the ContactAngle of the ini.
@@ -60,6 +61,39 @@ def test_d3q19_laplace_law(radius, relax):
     sigma = 2.0 / 9.0 * (2 * ak) * tau
     assert abs(dp / (2.0 * sigma / R) - 1.0) < 0.03, (R, dp, 2.0 * sigma / R)
     assert speed.max() < 5e-4                                        # spurious currents stay small
+
+
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+def test_d3q19_duct_flow_inlet_flux_and_poiseuille_profile(relax):
+    """Single-phase flow through a square duct driven by the Zou-He velocity plane: the inlet plane moves
+    at velocityZB, the mass flux is the same through every cross-section, and the developed profile is
+    the series solution of the rectangular duct (half-way bounce-back walls)."""
+    from openlbmpm_amd.rk3d import RK3DSlab
+    from openlbmpm_amd.RKColorGradientD3Q19 import duct
+    nx = ny = 26; nz = 64; v = -1.0e-3
+    dom = duct(nx, ny, nz)
+    # blue-wetting walls (phi_s = -1 = the fluid's phi): no colour gradient at the walls, a truly single-phase case
+    s = RK3DSlab(dom, 0, nz, dict(relax=relax, velocityZR=0.0, velocityZB=v, densityRL=1e-8, densityBL=1.0,
+                                  SolidRhoR=0.0, SolidRhoB=0.7))
+    s.set_density(1e-8 * dom, dom.astype(np.float64))
+    s.step_single(8000)
+    s.phase_field(diagnostics=True)
+    rho, uz, ux = s.get("rhoR") + s.get("rhoB"), s.get("vz"), s.get("vx")
+    s.close()
+    inlet = uz[nz - 2][dom[nz - 2] == 1]
+    assert np.abs(inlet / v - 1.0).max() < 1e-6
+    flux = (rho * uz).sum(axis=(1, 2))[2:nz - 2]
+    assert np.abs(flux / flux.mean() - 1.0).max() < 1e-4
+    a = nx - 2.0                                            # wall to wall, half-way between solid and fluid nodes
+    xs = np.arange(1, nx - 1) - 0.5 - a / 2
+    X, Y = np.meshgrid(xs, xs)
+    series = np.zeros_like(X)
+    for n in range(1, 60, 2):
+        k = n * np.pi / a
+        series += (-1) ** ((n - 1) // 2) / n ** 3 * (1 - np.cosh(k * Y) / np.cosh(k * a / 2)) * np.cos(k * X)
+    mid = uz[nz // 2, 1:-1, 1:-1]
+    assert np.abs(mid / mid.mean() - series / series.mean()).max() < 0.005
+    assert np.abs(ux[nz // 2]).max() < 0.02 * abs(v), np.abs(ux[nz // 2]).max()      # developed: (almost) no cross flow at mid-length
 
 
 @pytest.mark.parametrize("phi_s", [-0.5, 0.0, 0.5])
