@@ -1049,6 +1049,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     LBMPM_REQUIRE(cfg->z_offset >= 0 && cfg->z_offset + cfg->nz_local <= cfg->nz_global, "slab [%lld, %lld) outside 0..%lld",
                   (long long)cfg->z_offset, (long long)(cfg->z_offset + cfg->nz_local), (long long)cfg->nz_global);
     LBMPM_REQUIRE(cfg->tau_r > 0.5 && cfg->tau_b > 0.5, "TauR/TauB must exceed 0.5");
+    LBMPM_REQUIRE(cfg->outlet_rho_r > 0. && cfg->outlet_rho_b > 0., "densityRL/densityBL must be positive (the Zou-He outlet divides by them; the shipped ini uses 1e-8 for the absent colour)");
     LBMPM_REQUIRE((double)cfg->nx * cfg->ny * (cfg->nz_local + 2) < 2.0e9, "slab too large for 32-bit plane indices");
     LBMPM_REQUIRE((double)(cfg->nx + 31) * cfg->ny * 8.0 * 6 * Q < 4.0e9, "xy plane too large: 114 planes must fit 32-bit byte offsets (about 4.3M cells per plane)");
     int variant = cfg->variant, tile = 0, chunk_len = 32, fill = 16;

@@ -62,6 +62,9 @@ def test_rk3d_protocol_misuse_is_reported():
         RK3DSlab(dom, 30, 20)                                 # slab outside the lattice
     with pytest.raises(LbmpmError):
         RK3DSlab(dom, 0, 40, params=dict(tauR=0.5))
+    with pytest.raises(LbmpmError) as e:
+        RK3DSlab(dom, 0, 40, params=dict(densityRL=0.0))      # the outlet rule divides by it
+    assert "densityRL" in str(e.value)
     top = RK3DSlab(dom, 20, 20)
     top.set_density(rR[20:], rB[20:])
     with pytest.raises(LbmpmError) as e:
