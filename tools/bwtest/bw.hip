@@ -222,6 +222,28 @@ __global__ __launch_bounds__(TPB) void copy_march_db(const double2 *__restrict__
     for (; p < p1; ++p) { st(v, p); if (p + 1 < p1) ld(v, p + 1); }
 }
 
+
+// M: marching copy of 19 streams where the 19 directions of a cell are split over NG wave groups of the workgroup:
+//    TPB threads = (TPB / NG) cells x NG groups; group g (whole waves) moves directions g, g + NG, ...
+template <int NQ, int TPB, int NG>
+__global__ __launch_bounds__(TPB) void copy_march_split(const double2 *__restrict__ a, double2 *__restrict__ b, size_t cpp, int tiles, int planes, int len)
+{
+    constexpr int CELLS = TPB / NG, PER = (NQ + NG - 1) / NG;
+    const int chunk = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int g = threadIdx.x / CELLS;
+    const size_t cell = (size_t)tile * CELLS + threadIdx.x % CELLS;
+    if (cell >= cpp) return;
+    const int p0 = chunk * len, p1 = min(planes, p0 + len);
+    for (int p = p0; p < p1; ++p) {
+        const size_t o = (size_t)p * NQ * cpp + cell;
+        double2 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int q = g + k * NG; if (q < NQ) v[k] = a[o + q * cpp]; }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int q = g + k * NG; if (q < NQ) b[o + q * cpp] = v[k]; }
+    }
+}
+
 template <typename F>
 double time_it(F f, int reps)
 {
@@ -326,6 +348,18 @@ int main()
         runl("L double-buffered staggered, 512 thr", [&] { copy_march_db<19, 512, true><<<g512, 512>>>(a, b, cpp, (int)(cpp / 512), planes, len); });
         runl("L double-buffered burst, 256 thr", [&] { copy_march_db<19, 256, false><<<g256, 256>>>(a, b, cpp, (int)(cpp / 256), planes, len); });
         runl("L double-buffered staggered, 256 thr", [&] { copy_march_db<19, 256, true><<<g256, 256>>>(a, b, cpp, (int)(cpp / 256), planes, len); });
+    }
+    {
+        const size_t cpp = 172032; const int len = 32, nq = 19;
+        const int planes = (int)(n / ((size_t)nq * cpp));
+        auto runm = [&](const char *nm, auto launch) { const double t = time_it(launch, 5); printf("%-60s %7.0f GB/s\n", nm, 2.0 * 16 * nq * cpp * planes / t / 1e9); fflush(stdout); };
+        const int nch = (planes + len - 1) / len;
+        runm("M split over 1 group  (512 thr = 512 cells)", [&] { copy_march_split<19, 512, 1><<<(unsigned)(cpp / 512 * nch), 512>>>(a, b, cpp, (int)(cpp / 512), planes, len); });
+        runm("M split over 2 groups (512 thr = 256 cells)", [&] { copy_march_split<19, 512, 2><<<(unsigned)(cpp / 256 * nch), 512>>>(a, b, cpp, (int)(cpp / 256), planes, len); });
+        runm("M split over 4 groups (512 thr = 128 cells)", [&] { copy_march_split<19, 512, 4><<<(unsigned)(cpp / 128 * nch), 512>>>(a, b, cpp, (int)(cpp / 128), planes, len); });
+        runm("M split over 8 groups (512 thr = 64 cells)", [&] { copy_march_split<19, 512, 8><<<(unsigned)(cpp / 64 * nch), 512>>>(a, b, cpp, (int)(cpp / 64), planes, len); });
+        runm("M split over 4 groups (1024 thr = 256 cells)", [&] { copy_march_split<19, 1024, 4><<<(unsigned)(cpp / 256 * nch), 1024>>>(a, b, cpp, (int)(cpp / 256), planes, len); });
+        runm("M split over 2 groups (1024 thr = 512 cells)", [&] { copy_march_split<19, 1024, 2><<<(unsigned)(cpp / 512 * nch), 1024>>>(a, b, cpp, (int)(cpp / 512), planes, len); });
     }
     return 0;
 }
