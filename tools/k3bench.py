@@ -11,7 +11,7 @@ import bench
 def run(dom, label, steps=20):
     nz = dom.shape[0]
     rR, rB = bench.c5_densities(dom, 0, nz)
-    s = RK3DSlab(dom, 0, nz)
+    s = RK3DSlab(dom, 0, nz, dict(relax=os.environ.get("LBMPM_K3_RELAX", "SRT")))
     s.set_density(rR, rB)
     s.step_single(3); s.sync()
     ms_total, ms_dom = s.step_timed(steps)
