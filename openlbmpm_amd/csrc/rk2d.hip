@@ -954,6 +954,7 @@ extern "C" int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is
             hflags[(size_t)y * c->pitch + x] = v;
             c->nfluid += v;
         }
+    if (c->nfluid == 0) { set_error("lbmpm_rk2d_create: the domain has no fluid node (is_domain == 1 marks fluid)"); delete c; return LBMPM_ERR_INVALID; }
     int rc = LBMPM_OK;
 #define TRY_RC(e) do { rc = (e); if (rc != LBMPM_OK) { lbmpm_rk2d_destroy(c); return rc; } } while (0)
     {

@@ -1083,6 +1083,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
                 hflags[(size_t)z * c->plane2 + (size_t)y * c->pitch + x] = v;
                 if (z >= 1 && z <= c->nzl) c->nfluid += v;
             }
+    if (c->nfluid == 0) { set_error("lbmpm_rk3d_create: the slab has no fluid node (is_domain == 1 marks fluid); cut the lattice elsewhere"); delete c; return LBMPM_ERR_INVALID; }
     {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return LBMPM_ERR_HIP; }

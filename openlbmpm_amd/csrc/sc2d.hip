@@ -755,6 +755,7 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
             hflags[(size_t)y * c->pitch + x] = v;
             c->nfluid += v;
         }
+    if (c->nfluid == 0) { set_error("lbmpm_sc2d_create: the domain has no fluid node (is_domain == 1 marks fluid)"); delete c; return LBMPM_ERR_INVALID; }
     {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return LBMPM_ERR_HIP; }

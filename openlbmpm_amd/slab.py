@@ -3,8 +3,8 @@
 Pure torch / Python: no lattice arithmetic here.  The same code path serves
   * one process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI) and
   * CPU tensors over gloo in the tests (tests/test_slab_cpu.py).
+torch is imported where it is used: a single-slab run never loads it.
 """
-import torch
 
 
 def partition_z(nz_global, world):
@@ -47,6 +47,7 @@ def neighbour_exchange(send_up, send_down, recv_from_below, recv_from_above, ran
     `send_down` to rank-1 (received in `recv_from_above`).  No wrap-around: the global lattice is
     not periodic in z.  Point-to-point only (ncclSend/ncclRecv pairs grouped in one batch), no
     collective on the data path."""
+    import torch
     import torch.distributed as dist
     if send_up.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal transport (several ranks sharing ONE GPU, where RCCL refuses duplicate
@@ -90,4 +91,5 @@ class DeviceBuffer:
                                          "data": (int(ptr), False), "version": 2}
 
     def tensor(self, device):
+        import torch
         return torch.as_tensor(self, device=device)

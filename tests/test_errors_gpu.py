@@ -83,3 +83,34 @@ def test_rk3d_protocol_misuse_is_reported():
     assert _lib.lib().lbmpm_rk3d_buffer(top._h, 99, C.byref(ptr), C.byref(n)) < 0
     assert b"unknown buffer" in _lib.lib().lbmpm_last_error()
     top.close()
+
+
+def test_empty_inputs():
+    """zero steps are a no-op; lattices without a fluid node or below the minimum size are refused
+    with a message instead of launching empty grids"""
+    from openlbmpm_amd._lib import LbmpmError
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.sc2d import SC2DSolver
+    from openlbmpm_amd.rk3d import RK3DSlab
+    from openlbmpm_amd.geometry import simple_geometry
+    dom = simple_geometry(20, 40)
+    rR = np.where(dom == 1, 1.0, 0.0)
+    s = RK2DSolver(dom, None)
+    s.set_macro(rR, np.zeros(dom.shape))
+    before = s.get("fR")
+    s.step(0)
+    assert s.steps_done == 0 and np.array_equal(s.get("fR"), before)
+    with pytest.raises(LbmpmError):
+        s.step(-3)
+    s.close()
+    for make in (lambda d: RK2DSolver(d, None), lambda d: SC2DSolver(d, dict(inter="EFS"))):
+        with pytest.raises(LbmpmError) as e:
+            make(np.zeros((40, 20), dtype=np.uint8))                 # no fluid node at all
+        assert "fluid" in str(e.value)
+        with pytest.raises(LbmpmError):
+            make(np.ones((4, 3), dtype=np.uint8))                    # smaller than the boundary rows need
+    with pytest.raises(LbmpmError) as e:
+        RK3DSlab(np.zeros((12, 8, 8), dtype=np.uint8), 0, 12)
+    assert "fluid" in str(e.value)
+    with pytest.raises(LbmpmError):
+        RK3DSlab(np.ones((4, 4, 4), dtype=np.uint8), 0, 4)               # fewer than 8 planes
