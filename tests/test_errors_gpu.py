@@ -114,3 +114,15 @@ def test_empty_inputs():
     assert "fluid" in str(e.value)
     with pytest.raises(LbmpmError):
         RK3DSlab(np.ones((4, 4, 4), dtype=np.uint8), 0, 4)               # fewer than 8 planes
+
+
+def test_stream_test_reports_plausible_rates():
+    """lbmpm_hbm_stream_test (the measured ceiling quoted by bench.py): sane ordering and magnitude on an
+    MI355X (spec 8 TB/s), bad arguments refused"""
+    from openlbmpm_amd import _lib
+    L = _lib.lib()
+    a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+    assert L.lbmpm_hbm_stream_test(0, 1 << 30, 3, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert 2000.0 < a.value < 8000.0 and 2000.0 < b.value < 8000.0 and 2000.0 < c.value < 8000.0
+    assert L.lbmpm_hbm_stream_test(0, 16, 3, C.byref(a), C.byref(b), C.byref(c)) < 0
+    assert L.lbmpm_hbm_stream_test(0, 1 << 30, 0, C.byref(a), C.byref(b), C.byref(c)) < 0
