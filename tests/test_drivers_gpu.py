@@ -177,3 +177,40 @@ def test_cli_runs(tmp_path):
     from ini_fixtures import write_rk3d
     write_rk3d(str(tmp_path), nx=16, ny=12, nz=24, steps=10)
     assert main(["rk3d", str(tmp_path), "--out", str(tmp_path / "o3")]) == 0
+
+
+def test_rk3d_driver_under_two_processes_writes_the_same_records(tmp_path):
+    """RKColorGradient3D under torchrun (two ranks sharing this GPU, gloo transport): every rank writes the
+    planes it owns; stacked, the records equal those of the single-process driver bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from ini_fixtures import write_rk3d
+    from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D
+    from openlbmpm_amd.results import load_results
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    write_rk3d(str(tmp_path), nx=20, ny=14, nz=40, steps=20, relax="MRT")
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+sim = RKColorGradient3D(%r, output_dir=%r, record_every=8, device=0)
+sim.runRKColorGradient3D()
+dist.destroy_process_group()
+''' % (root, str(tmp_path), str(tmp_path / "out2")))
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)], env=dict(os.environ), timeout=300)
+    single = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out1"), record_every=8)
+    ref = load_results(single.runRKColorGradient3D())
+    parts = []
+    for r in range(2):
+        files = [f for f in os.listdir(tmp_path / "out2") if f.startswith("SimulationResultsRK3D_rank%d." % r)]
+        assert len(files) == 1
+        parts.append(load_results(str(tmp_path / "out2" / files[0])))
+    assert set(parts[0]) == set(ref) and len(ref) == 5 * single.records
+    for key in ref:
+        assert np.array_equal(np.concatenate([parts[0][key], parts[1][key]], axis=0), ref[key]), key
