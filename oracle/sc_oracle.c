@@ -62,6 +62,23 @@ void sc_rho(i64 N, double *rho, const double *f)
     }
 }
 
+/* O:334-357 calMacroWholeVelocity: common velocity sum_k (momentum_k / tau_k) / sum_k (rho_k / tau_k).  The
+ * original Shan-Chen loop launches it every step (D:1574); interactionCollisionProcess recomputes the same
+ * quantity itself, so the output arrays feed nothing further. */
+void sc_macro_whole_velocity(i64 N, const double *tau, const double *rho, const double *f, double *pvx, double *pvy)
+{
+    PARFOR
+    for (i64 n = 0; n < N; ++n) {
+        double vxt = 0., vyt = 0., rt = 0.;
+        for (int k = 0; k < NF; ++k) {
+            vxt += (F(f, k, n, 1) - F(f, k, n, 3) + F(f, k, n, 5) - F(f, k, n, 6) - F(f, k, n, 7) + F(f, k, n, 8)) / tau[k];
+            vyt += (F(f, k, n, 2) - F(f, k, n, 4) + F(f, k, n, 5) + F(f, k, n, 6) - F(f, k, n, 7) - F(f, k, n, 8)) / tau[k];
+            rt += R(rho, k, n) / tau[k];
+        }
+        pvx[n] = vxt / rt; pvy[n] = vyt / rt;
+    }
+}
+
 /* O:156-180 calPhysicalVelocity */
 void sc_physical_velocity(i64 N, const double *f, const double *rho, const double *Fx,
                           const double *Fy, double *vx, double *vy)

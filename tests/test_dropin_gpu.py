@@ -31,13 +31,18 @@ def dropin():
         sys.modules.pop(m, None)
 
 
-def test_colour_gradient_loop_with_reference_launch_statements(dropin):
+@pytest.mark.parametrize("scenario", ["csf_mrt_capillary", "csf_mrt_convective", "csf_mrt_pinlet", "csf_mrt_wetting1",
+                                      "csf_srt_capillary"])
+def test_colour_gradient_loop_with_reference_launch_statements(dropin, scenario):
+    """RKD2Q9.py:1295-1490 with its branches: velocity / pressure inlet, pressure / convective outlet, wetting
+    type 1 / 2, SRT / MRT (one captured run of the real driver per branch)"""
     cuda, RKGPU2D, _, _, _ = dropin
     from oracle.rk import RKOracle, simple_geometry, mrt_matrices
-    d = np.load(os.path.join(GOLDEN, "rk_csf_mrt_capillary.npz"))
+    d = np.load(os.path.join(GOLDEN, "rk_%s.npz" % scenario))
     par = load_params(d)
     xDomain, yDomain = par["nx"], par["ny"]
-    o = RKOracle(simple_geometry(xDomain, yDomain), par)       # host set-up only (tables, initial fields)
+    o = RKOracle(d["isDomain"], par)                           # host set-up only (tables, initial fields)
+    assert np.array_equal(o.fluidNodes, d["fluidNodes"])
     assert cuda.is_available()
     totalNodes = o.N
     xDimension, threadNum = 128, 32
@@ -78,17 +83,31 @@ def test_colour_gradient_loop_with_reference_launch_statements(dropin):
 
     snaps = [int(k) for k in d["snaps"] if int(k) <= 50]
     for iStep in range(1, max(snaps) + 1):
-        RKGPU2D.constantTotalVelocityInlet[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension, specificVY,
-                deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR,
-                deviceFluidPDFB, deviceFluidPDFTotal, devicePhysicalVY)
-        RKGPU2D.ghostPointsConstantVelocityRK[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension,
-                deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR,
-                deviceFluidPDFB, deviceForceX, deviceForceY)
-        RKGPU2D.calConstPressureLowerGPUTotal[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, totalPressure,
-                deviceFluidNodes, deviceFluidPDFTotal, devicePhysicalVY, deviceFluidRhoR, deviceFluidRhoB,
-                deviceFluidPDFR, deviceFluidPDFB)
-        RKGPU2D.ghostPointsConstPressureLowerRK[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
-                deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR, deviceFluidPDFB)
+        if par["inlet"] == "Neumann":
+            RKGPU2D.constantTotalVelocityInlet[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension, specificVY,
+                    deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR,
+                    deviceFluidPDFB, deviceFluidPDFTotal, devicePhysicalVY)
+            RKGPU2D.ghostPointsConstantVelocityRK[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension,
+                    deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR,
+                    deviceFluidPDFB, deviceForceX, deviceForceY)
+        if par["inlet"] == "Dirichlet":
+            RKGPU2D.calConstPressureInletGPU[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension, par["rhoBH"],
+                    par["rhoRH"], deviceFluidNodes, deviceFluidRhoB, deviceFluidRhoR, deviceFluidPDFB, deviceFluidPDFR)
+            RKGPU2D.ghostPointsConstPressureInletRK[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension,
+                    deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR, deviceFluidPDFB)
+        if par["outlet"] == "Convective":
+            RKGPU2D.convectiveOutletGPU[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
+                    deviceNeighboringNodes, deviceFluidPDFR, deviceFluidPDFB, deviceFluidRhoR, deviceFluidRhoB)
+            RKGPU2D.convectiveOutletGhost2GPU[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
+                    deviceNeighboringNodes, deviceFluidPDFR, deviceFluidPDFB, deviceFluidRhoR, deviceFluidRhoB)
+            RKGPU2D.convectiveOutletGhost3GPU[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
+                    deviceNeighboringNodes, deviceFluidPDFR, deviceFluidPDFB, deviceFluidRhoR, deviceFluidRhoB)
+        elif par["outlet"] == "Dirichlet":
+            RKGPU2D.calConstPressureLowerGPUTotal[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, totalPressure,
+                    deviceFluidNodes, deviceFluidPDFTotal, devicePhysicalVY, deviceFluidRhoR, deviceFluidRhoB,
+                    deviceFluidPDFR, deviceFluidPDFB)
+            RKGPU2D.ghostPointsConstPressureLowerRK[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
+                    deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR, deviceFluidPDFB)
         RKGPU2D.calTotalFluidPDF[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFR, deviceFluidPDFB,
                 deviceFluidPDFTotal)
         RKGPU2D.calPhysicalVelocityRKGPU2DNew1[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFTotal,
@@ -100,19 +119,30 @@ def test_colour_gradient_loop_with_reference_launch_statements(dropin):
         RKGPU2D.calRKInitialGradient[grid1D, threadPerBlock1D](totalNodes, xDimension, numColorSolid, deviceFluidNodes,
                 deviceNeighboringNodes, deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, deviceColorValue, deviceSolidColor,
                 deviceGradientX, deviceGradientY)
-        RKGPU2D.updateColorGradientOnWettingNew[grid1D, threadPerBlock1D](numWettingFluid, xDimension, cosTheta, sinTheta,
-                deviceFluidNodesWithSolid, deviceUnitNsx, deviceUnitNsy, deviceGradientX, deviceGradientY)
-        RKGPU2D.calForceTermInColorGradientNew2D[grid1D, threadPerBlock1D](totalNodes, xDimension, par["sigma"],
+        wet = RKGPU2D.updateColorGradientOnWetting if par["wetting"] == 1 else RKGPU2D.updateColorGradientOnWettingNew
+        if numWettingFluid > 0:
+            wet[grid1D, threadPerBlock1D](numWettingFluid, xDimension, cosTheta, sinTheta,
+                    deviceFluidNodesWithSolid, deviceUnitNsx, deviceUnitNsy, deviceGradientX, deviceGradientY)
+        force = RKGPU2D.calForceTermInColorGradient2D if par["wetting"] == 1 else RKGPU2D.calForceTermInColorGradientNew2D
+        force[grid1D, threadPerBlock1D](totalNodes, xDimension, par["sigma"],
                 deviceNeighboringNodes, deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, deviceGradientX, deviceGradientY,
                 deviceForceX, deviceForceY, deviceKValue)
-        RKGPU2D.calRKCollision1TotalGPU2DMRTM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
-                par["tauB"], par["delta"], deviceUnitEX, deviceUnitEY, deviceWeightsCoeff, devicePhysicalVX, devicePhysicalVY,
-                deviceFluidRhoR, deviceFluidRhoB, deviceColorValue, deviceFluidPDFTotal, deviceTransformationM,
-                deviceTransformationIM, deviceCollisionM)
-        RKGPU2D.calPerturbationFromForce2DMRT[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
-                par["tauB"], par["delta"], deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, devicePhysicalVX, devicePhysicalVY,
-                deviceForceX, deviceForceY, deviceColorValue, deviceFluidPDFTotal, deviceTransformationM,
-                deviceTransformationIM, deviceCollisionM, deviceFluidRhoR, deviceFluidRhoB)
+        if par["relax"] == "SRT":
+            RKGPU2D.calRKCollision1TotalGPU2DSRTM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
+                    par["tauB"], par["delta"], deviceUnitEX, deviceUnitEY, deviceWeightsCoeff, devicePhysicalVX, devicePhysicalVY,
+                    deviceFluidRhoR, deviceFluidRhoB, deviceColorValue, deviceFluidPDFTotal)
+            RKGPU2D.calPerturbationFromForce2D[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
+                    par["tauB"], par["delta"], deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, devicePhysicalVX, devicePhysicalVY,
+                    deviceForceX, deviceForceY, deviceColorValue, deviceFluidPDFTotal, deviceFluidRhoR, deviceFluidRhoB)
+        else:
+            RKGPU2D.calRKCollision1TotalGPU2DMRTM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
+                    par["tauB"], par["delta"], deviceUnitEX, deviceUnitEY, deviceWeightsCoeff, devicePhysicalVX, devicePhysicalVY,
+                    deviceFluidRhoR, deviceFluidRhoB, deviceColorValue, deviceFluidPDFTotal, deviceTransformationM,
+                    deviceTransformationIM, deviceCollisionM)
+            RKGPU2D.calPerturbationFromForce2DMRT[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
+                    par["tauB"], par["delta"], deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, devicePhysicalVX, devicePhysicalVY,
+                    deviceForceX, deviceForceY, deviceColorValue, deviceFluidPDFTotal, deviceTransformationM,
+                    deviceTransformationIM, deviceCollisionM, deviceFluidRhoR, deviceFluidRhoB)
         RKGPU2D.calRecoloringProcessM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["beta"], deviceWeightsCoeff,
                 deviceFluidRhoR, deviceFluidRhoB, deviceUnitEX, deviceUnitEY, deviceGradientX, deviceGradientY,
                 deviceFluidPDFR, deviceFluidPDFB, deviceFluidPDFTotal)
@@ -297,3 +327,68 @@ def test_tracer_kernels_against_reference_vectors(dropin):
     dG3 = dev(d["rea_in_g"])                    # reaction between three tracers
     TR.calReactionTracersGPU[cfg](N, 3, xDim, dev(d["rea_rate"]), dev(d["rea_J"]), dev(d["rea_conc"]), dG3)
     assert rel_err(dG3.copy_to_host(), d["rea_out_g"]) < 1e-13
+
+
+@pytest.mark.parametrize("scenario", ["sc_srt_convective"])
+def test_original_shan_chen_loop_with_reference_launch_statements(dropin, scenario):
+    """runOptimizedLBM, ShanChenD2Q9.py:1492-1629 (Neumann / Zou-He inlet, convective outlet): the fused
+    interaction + collision kernel, the three outlet-row kernels and the (result-less) whole-fluid velocity"""
+    cuda, _, OPT, _, _ = dropin
+    from oracle.sc import simple_geometry, initial_densities
+    g = np.load(os.path.join(GOLDEN, "sc_%s.npz" % scenario))
+    par = load_params(g)
+    nx, ny = par["nx"], par["ny"]
+    dom = simple_geometry(nx, ny)
+    fluidNodes = np.flatnonzero(dom.reshape(-1) == 1).astype(np.int64)
+    assert np.array_equal(fluidNodes, g["fluidNodes"])
+    N = fluidNodes.size
+    newIndex = -np.ones(nx * ny, dtype=np.int64); newIndex[fluidNodes] = np.arange(N)
+    typesFluids = 2
+    rho0 = initial_densities(dom, False, par).reshape(2, -1)[:, fluidNodes]
+    w9 = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+    optFluidPDF = np.ascontiguousarray(w9[None, None, :] * rho0[:, :, None])
+    assert rel_err(optFluidPDF, g["init_f"]) < 1e-15
+    xDimension, threadNum = 256, 32
+    grid1D = (int(xDimension / threadNum), math.ceil(N / xDimension)); tpb = (threadNum, 1)
+    dFluidIndices = cuda.to_device(fluidNodes); dIdx = cuda.to_device(newIndex)
+    dNbr = cuda.to_device(np.zeros(8 * N, dtype=np.int64))
+    OPT.fillNeighboringNodes[grid1D, tpb](N, nx, ny, xDimension, dFluidIndices, dIdx, dNbr)
+    dPDF = cuda.to_device(optFluidPDF); dPDFold = cuda.to_device(optFluidPDF); dPDFNew = cuda.to_device(optFluidPDF)
+    dRho = cuda.to_device(np.ascontiguousarray(rho0)); dPot = cuda.to_device(np.zeros((2, N)))
+    dFx = cuda.to_device(np.zeros((2, N))); dFy = cuda.to_device(np.zeros((2, N)))
+    dVX = cuda.to_device(np.zeros(N)); dVY = cuda.to_device(np.zeros(N))
+    dPrimeVX = cuda.to_device(np.zeros(N)); dPrimeVY = cuda.to_device(np.zeros(N))
+    tau = np.array([par["tau0"], par["tau1"]])
+    dTau = cuda.to_device(tau)
+    dG = cuda.to_device(np.array([[0., par["G"]], [par["G"], 0.]])); dGs = cuda.to_device(np.array([par["Gs0"], par["Gs1"]]))
+    dWI = cuda.to_device(np.array([1. / 9.] * 4 + [1. / 36.] * 4)); dW = cuda.to_device(w9)       # ShanChenD2Q9.py:1478
+    dVelY = cuda.to_device(np.array([par["vy0"], par["vy1"]]))
+    snaps = [int(k) for k in g["snaps"]]
+    for tmpStep in range(1, max(snaps) + 1):
+        OPT.constantVelocityZouHeBoundaryHigher[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dVelY, dFluidIndices, dRho, dPDF)
+        OPT.ghostPointsConstantVelocityInlet[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
+        OPT.savePDFLastStep[grid1D, tpb](N, typesFluids, xDimension, dPDF, dPDFold)
+        OPT.calMacroWholeVelocity[grid1D, tpb](N, typesFluids, xDimension, dTau, dRho, dPDF, dPrimeVX, dPrimeVY)
+        if tmpStep == 3:          # the kernel's own formula (O:345-356); nothing downstream reads these arrays
+            f, r = dPDF.copy_to_host(), dRho.copy_to_host()
+            mx = sum((f[k, :, 1] - f[k, :, 3] + f[k, :, 5] - f[k, :, 6] - f[k, :, 7] + f[k, :, 8]) / tau[k] for k in range(2))
+            my = sum((f[k, :, 2] - f[k, :, 4] + f[k, :, 5] + f[k, :, 6] - f[k, :, 7] - f[k, :, 8]) / tau[k] for k in range(2))
+            rt = sum(r[k] / tau[k] for k in range(2))
+            assert rel_err(dPrimeVX.copy_to_host(), mx / rt) < 1e-12 and rel_err(dPrimeVY.copy_to_host(), my / rt) < 1e-12
+        OPT.calFluidRhoGPU[grid1D, tpb](N, typesFluids, xDimension, dRho, dPDF)
+        OPT.calFluidPotentialGPUEql[grid1D, tpb](N, typesFluids, xDimension, dRho, dPot)
+        OPT.interactionCollisionProcess[grid1D, tpb](N, typesFluids, xDimension, dWI, dTau, dG, dGs, dW, dRho, dPot, dPDF,
+                                                     dPDFNew, dFluidIndices, dNbr, dFx, dFy)
+        OPT.calStreaming1GPU[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbr, dPDF, dPDFNew)
+        OPT.calStreaming2GPU[grid1D, tpb](N, typesFluids, xDimension, dPDFNew, dPDF)
+        if par["outlet"] == "Convective":
+            OPT.convectiveOutletGPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dRho)
+            OPT.convectiveOutletGhost2GPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dRho)
+            OPT.convectiveOutletGhost3GPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dRho)
+        OPT.calFluidRhoGPU[grid1D, tpb](N, typesFluids, xDimension, dRho, dPDF)
+        OPT.calPhysicalVelocity[grid1D, tpb](N, typesFluids, xDimension, dPDF, dRho, dFx, dFy, dVX, dVY)
+        if tmpStep in snaps:
+            got = dict(f=dPDF, rho=dRho, Fx=dFx, Fy=dFy, vx=dVX, vy=dVY)
+            for name, arr in got.items():
+                e = rel_err(arr.copy_to_host(), g["s%d_%s" % (tmpStep, name)])
+                assert e < 1e-11, "step %d %s rel err %.3e" % (tmpStep, name, e)

@@ -74,6 +74,8 @@ SPEC = [
   "launch_rk_fill_neighbors(st, totalNodes, nx, ny, fluidNodes, domainNewIndex, neighboringNodes)"),
  ("sc", "savePDFLastStep", O + ":70", "totalNodes:i numFluids:i xDim:i fluidPDF:D fluidPDFOld:D",
   "sc_check_nf(numFluids); LBMPM_HIP_TRY(hipMemcpyAsync(fluidPDFOld, fluidPDF, sizeof(double) * 2 * 9 * (size_t)totalNodes, hipMemcpyDeviceToDevice, st))"),
+ ("sc", "calMacroWholeVelocity", O + ":336", "totalNodes:i numFluids:i xDim:i tau:D fluidRho:D fluidPDF:D primeVX:D primeVY:D",
+  "sc_check_nf(numFluids); launch_sc_macro_whole_velocity(st, totalNodes, tau, fluidRho, fluidPDF, primeVX, primeVY)"),
  ("sc", "calFluidRhoGPU", O + ":84", "totalNodes:i numFluids:i xDim:i fluidRho:D fluidPDF:D",
   "sc_check_nf(numFluids); launch_sc_rho(st, totalNodes, fluidRho, fluidPDF)"),
  ("sc", "calFluidPotentialGPUEql", O + ":99", "totalNodes:i numFluids:i xDim:i fluidRho:D fluidPotential:D",
