@@ -124,6 +124,11 @@ class RK3DSlab:
         return int(self._L.lbmpm_rk3d_num_fluid_nodes(self._h))
 
     @property
+    def device_bytes(self):
+        """device memory held by this context"""
+        return int(self._L.lbmpm_rk3d_device_bytes(self._h))
+
+    @property
     def steps_done(self):
         return int(self._L.lbmpm_rk3d_steps_done(self._h))
 

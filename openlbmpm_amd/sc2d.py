@@ -114,6 +114,11 @@ class SC2DSolver:
         return int(self._L.lbmpm_sc2d_num_fluid_nodes(self._h))
 
     @property
+    def device_bytes(self):
+        """device memory held by this context"""
+        return int(self._L.lbmpm_sc2d_device_bytes(self._h))
+
+    @property
     def steps_done(self):
         return int(self._L.lbmpm_sc2d_steps_done(self._h))
 

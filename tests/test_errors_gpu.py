@@ -1,6 +1,7 @@
 """Error behaviour of the C ABI on a GPU box: every misuse returns a negative
 status with a message in lbmpm_last_error(); nothing aborts, nothing falls back to a CPU path."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -126,3 +127,26 @@ def test_stream_test_reports_plausible_rates():
     assert 2000.0 < a.value < 8000.0 and 2000.0 < b.value < 8000.0 and 2000.0 < c.value < 8000.0
     assert L.lbmpm_hbm_stream_test(0, 16, 3, C.byref(a), C.byref(b), C.byref(c)) < 0
     assert L.lbmpm_hbm_stream_test(0, 1 << 30, 0, C.byref(a), C.byref(b), C.byref(c)) < 0
+
+
+def test_device_memory_accounting():
+    """lbmpm_*_device_bytes: two copies of the populations dominate; the compact 3-D storage holds less than
+    the dense one on a porous sample"""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.sc2d import SC2DSolver
+    from openlbmpm_amd.rk3d import RK3DSlab
+    from openlbmpm_amd.geometry import simple_geometry, porous_spheres
+    dom = simple_geometry(64, 96)
+    for s in (RK2DSolver(dom, None), SC2DSolver(dom, dict(inter="EFS"))):
+        assert 2 * 18 * 8 * dom.size <= s.device_bytes < 8 * 18 * 8 * dom.size
+        s.close()
+    vox = porous_spheres(64, 32, 40, porosity=0.6, rmin=3.0, rmax=6.0, seed=1, nbuf=4)
+    compact = RK3DSlab(vox, 0, 40)
+    assert compact.dominant_kernel == "rk3dc_fused"
+    os.environ["LBMPM_RK3D_LAYOUT"] = "dense"
+    try:
+        dense = RK3DSlab(vox, 0, 40)
+    finally:
+        del os.environ["LBMPM_RK3D_LAYOUT"]
+    assert 2 * 38 * 8 * compact.num_fluid_nodes <= compact.device_bytes < dense.device_bytes
+    compact.close(); dense.close()
