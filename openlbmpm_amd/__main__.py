@@ -34,10 +34,13 @@ def main(argv=None):
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:          # launched by torchrun: one rank per GPU
             import torch
             import torch.distributed as dist
-            device = int(os.environ.get("LOCAL_RANK", "0"))
+            device = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
             torch.cuda.set_device(device)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+            if os.environ.get("LBMPM_DIST_BACKEND", "nccl") == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+            else:                                                # "gloo": several ranks rehearsing on one GPU
+                dist.init_process_group(backend=os.environ["LBMPM_DIST_BACKEND"])
         sim = RKColorGradient3D(a.ini_dir, output_dir=a.out, device=device)
         if a.steps is not None:
             sim.timeSteps = a.steps
