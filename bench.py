@@ -323,6 +323,18 @@ def main():
                                 "ms_per_step": round(w * 1e3 / k, 5), "fluid_nodes": nf, "kernel": s.dominant_kernel,
                                 "roofline_frac": round(B_ALG[name] * nf / (md / k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
                     s.close()
+                # the other relaxation of the same 3-D workload (the shipped ini says 'SRT', BASELINE.json names MRT)
+                other = "SRT" if args.relax == "MRT" else "MRT"
+                rR2, rB2 = c5_densities(dom, 0, nz)
+                s3 = RK3DSlab(dom, 0, nz, dict(relax=other), device=local_rank)
+                s3.set_density(rR2, rB2)
+                del rR2, rB2
+                s3.step_single(5); s3.sync()
+                t1 = time.perf_counter(); mt3, md3 = s3.step_timed(30); s3.sync(); w3 = time.perf_counter() - t1
+                sec.append({"workload": "c5 with %s relaxation" % other, "value": round(s3.num_fluid_nodes * 30 / w3 / 1e6, 2), "unit": "MLUPS",
+                            "ms_per_step": round(w3 * 1e3 / 30, 5), "fluid_nodes": s3.num_fluid_nodes, "kernel": s3.dominant_kernel,
+                            "roofline_frac": round(B_ALG["c5"] * s3.num_fluid_nodes / (md3 / 30 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                s3.close()
                 out["secondary"] = sec
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_c5(args.relax)
