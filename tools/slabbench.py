@@ -16,7 +16,7 @@ dom = bench.c5_domain((n, n, n))
 rR, rB = bench.c5_densities(dom, 0, n)
 nf = int(dom.sum())
 for k in ks:
-    c = RK3DCluster(dom, k)
+    c = RK3DCluster(dom, k, dict(relax=os.environ.get("LBMPM_K3_RELAX", "MRT")))
     c.set_density(rR, rB)
     c.step(3)
     torch.cuda.synchronize()
