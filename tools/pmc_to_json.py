@@ -42,6 +42,16 @@ def main():
         if k == "rk2d_fused":             # c2 (no tracer) and c4 (tracer) are different template instances
             rec["workload"] = "c4 2048x2048" if re.search(r"rk2d_fused<(true|false), true", name) else "c2 1024x1024"
             k = "rk2d_fused" if rec["workload"].startswith("c2") else "rk2d_fused[tracer]"
+        if k == "sc2d_fused" and "sc2d_fused<false>" in name:      # SRT instance = the 128 x 128 droplet of configs[0]
+            rec["workload"] = "c1 128x128"
+            k = "sc2d_fused[c1]"
+        m3 = re.search(r"rk3dc?_fused<([^>]*)>", name)
+        if m3:                            # <.., FIRST, MRT>: first-step instances carry one launch; SRT is the secondary entry
+            targs = [t.strip() for t in m3.group(1).split(",")]
+            if targs[-2] == "true":
+                continue
+            if targs[-1] == "false":
+                k += "[SRT]"
         if k in kernels and kernels[k]["launches_profiled"] >= n:
             continue                      # e.g. the first-step instantiation of the 3-D kernel: one launch only
         kernels[k] = rec
