@@ -303,7 +303,7 @@ def main():
                            "parity": "unpinned (no 3-D code in the reference); checked against oracle/rk3d_oracle.c"},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
-                             "traffic": pmc_traffic(dom_kernel, "c5 %dx%dx%d" % size) if world == 1 else None,
+                             "traffic": pmc_traffic(dom_kernel + ("[SRT]" if args.relax == "SRT" else ""), "c5 %dx%dx%d" % size) if world == 1 else None,
                              "kernel": dom_kernel,
                              "measured_stream_ceiling": measured_hbm(local_rank) if world == 1 else None,
                              "note": None if world == 1 else "N>1: the kernel runs as interior + boundary launches on two "
