@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import refenv  # noqa: E402
 
-OUT = os.path.dirname(HERE)
+OUT = os.environ.get("LBMPM_GOLDEN_OUT") or os.path.dirname(HERE)      # (redirected by tests/test_golden_provenance.py)
 
 INI_TEMPLATE = """[ImageSetup]
 Existance = '{image}'
