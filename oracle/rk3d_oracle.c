@@ -157,14 +157,24 @@ static void mrt_basis(double M[Q][Q])
     }
 }
 
+/* |row k|^2 of the basis (small integers, exact in floating point) */
+static void mrt_norms(const double M[Q][Q], double nrm[Q])
+{
+    for (int k = 0; k < Q; ++k) {
+        double a = 0.;
+        for (int i = 0; i < Q; ++i) a += M[k][i] * M[k][i];
+        nrm[k] = a;
+    }
+}
+
 /* d <- M^-1 S M d; the rows of M are mutually orthogonal, so M^-1 = M^T diag(1/|row|^2) */
-static void mrt_relax_with(const double M[Q][Q], const double S[Q], double d[Q])
+static void mrt_relax_with(const double M[Q][Q], const double nrm[Q], const double S[Q], double d[Q])
 {
     double m[Q], out[Q];
     for (int k = 0; k < Q; ++k) {
-        double acc = 0., nrm = 0.;
-        for (int i = 0; i < Q; ++i) { acc += M[k][i] * d[i]; nrm += M[k][i] * M[k][i]; }   /* |row|^2: small integers, exact */
-        m[k] = S[k] * acc / nrm;
+        double acc = 0.;
+        for (int i = 0; i < Q; ++i) acc += M[k][i] * d[i];
+        m[k] = S[k] * acc / nrm[k];
     }
     for (int i = 0; i < Q; ++i) {
         double acc = 0.;
@@ -179,27 +189,29 @@ static void mrt_relax_with(const double M[Q][Q], const double S[Q], double d[Q])
  * families therefore share 1.2. */
 static double RATES[5] = {1.19, 1.4, 1.2, 1.4, 1.2};
 void rk3d_set_mrt_rates_public(const double *r) { for (int i = 0; i < 5; ++i) RATES[i] = r[i]; }
-static void mrt_relax(const double M[Q][Q], double inv_tau, double d[Q])
+static void mrt_relax(const double M[Q][Q], const double nrm[Q], double inv_tau, double d[Q])
 {
     const double S[Q] = {0., RATES[0], RATES[1], 0., RATES[2], 0., RATES[2], 0., RATES[2], inv_tau, RATES[3], inv_tau, RATES[3],
                          inv_tau, inv_tau, inv_tau, RATES[4], RATES[4], RATES[4]};
-    mrt_relax_with(M, S, d);
+    mrt_relax_with(M, nrm, S, d);
 }
 
 /* test hooks: the basis itself, and d <- M^-1 diag(S) M d for any S */
 void rk3d_mrt_basis_public(double *M19x19) { mrt_basis((double (*)[Q])M19x19); }
 void rk3d_mrt_relax_public(const double *S, double *d)
 {
-    double M[Q][Q];
+    double M[Q][Q], nrm[Q];
     mrt_basis(M);
-    mrt_relax_with(M, S, d);
+    mrt_norms(M, nrm);
+    mrt_relax_with(M, nrm, S, d);
 }
 
 static void rk3d_collide_stream(rk3d_sim *s)
 {
     i64 nx = s->nx, ny = s->ny, nz = s->nz, pl = nx * ny;
-    double M[Q][Q];
+    double M[Q][Q], nrm[Q];
     mrt_basis(M);
+    mrt_norms(M, nrm);
     PARFOR
     for (i64 z = 0; z < nz; ++z)
         for (i64 y = 0; y < ny; ++y)
@@ -230,7 +242,7 @@ static void rk3d_collide_stream(rk3d_sim *s)
                         double eu = CX[i] * ux + CY[i] * uy + CZ[i] * uz;
                         dm[i] = (r[i] + b[i]) - rho * WT(i) * (1. + 3. * eu + 4.5 * eu * eu - 1.5 * usq);
                     }
-                    mrt_relax(M, 1. / tau, dm);
+                    mrt_relax(M, nrm, 1. / tau, dm);
                 }
                 for (int i = 0; i < Q; ++i) {
                     double eu = CX[i] * ux + CY[i] * uy + CZ[i] * uz;
