@@ -300,7 +300,7 @@ def main():
                            "kernel_schedule": "one fused z-marching kernel per step (pull, phase field in an LDS ring, collide, store), "
                                               + ("compact storage: fluid cells only" if dom_kernel == "rk3dc_fused" else "dense storage")
                                               if "fused" in dom_kernel else "phase_field + collide (split-2)",
-                           "parity": "unpinned (no 3-D code in the reference); checked against oracle/rk3d_oracle.c"},
+                           "parity": "pinned by reduction: y-uniform lattice through this kernel == captures of the reference's real D2Q9 perturbation driver (RKD2Q9.py:978-1223) to 3e-13, SRT (tests/test_rk3d_reduction.py); full 3-D and MRT vs oracle/rk3d_oracle.c 1e-10"},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
                              "traffic": pmc_traffic(dom_kernel + ("[SRT]" if args.relax == "SRT" else ""), "c5 %dx%dx%d" % size) if world == 1 else None,

@@ -265,7 +265,8 @@ int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
  * module that is not in the tree), so there is no reference interface to mirror: the model
  * is the D3Q19 extension of the 2-D kernels AcceleratedRKGPU2D.py:1125 (BGK), :1169
  * (gradient + perturbation + recolouring), :657/:1008 (Zou-He per colour), :607/:1045 (ghost
- * planes), :340/:409 (streaming).  PARITY UNPINNED.
+ * planes), :340/:409 (streaming).  Pinned by reduction to that 2-D loop
+ * (tests/test_rk3d_reduction.py).
  * A context owns the planes [z_offset, z_offset + nz_local) of a global lattice of
  * nz_global planes plus one halo plane on each side.  One time step of a slab is
  *     pack_halo -> [caller moves F_SEND_* to the neighbours' F_RECV_*] -> unpack_halo
@@ -288,6 +289,12 @@ typedef struct lbmpm_rk3d_config {
     int32_t relaxation;         /* [RelaxationType] Type: 0 'SRT', 1 'MRT' (RKtwophasesetup3D.ini:53-55;
                                  * D3Q19 moment basis of d'Humieres et al. 2002: s_e 1.19, s_eps = s_pi 1.4,
                                  * s_q = s_m 1.2, stress moments at 1/tau) */
+    int32_t reserved;
+    double recolor_axis, recolor_diag;  /* weights w_i / |e_i| of the recolouring term beta rhoR rhoB / rho^2 w_i cos(theta_i)
+                                 * (AcceleratedRKGPU2D.py:1241-1267) for the directions with |e_i| = 1 and sqrt 2.
+                                 * 0 = the model's own, 1/18 and 1/(36 sqrt 2).  Other values exist for the parity pin:
+                                 * recolor_axis = 1/9 - 2/(36 sqrt 2) makes a y-uniform lattice project exactly onto the
+                                 * reference's D2Q9 perturbation loop (tests/test_rk3d_reduction.py) */
 } lbmpm_rk3d_config;
 
 typedef struct lbmpm_rk3d lbmpm_rk3d;

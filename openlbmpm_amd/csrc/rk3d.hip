@@ -4,8 +4,9 @@
 // The reference ships only an ini for this model (IniFiles/RKtwophasesetup3D.ini; the module
 // RKColorGradientD3Q19 imported by main.py:22 is absent), so the model is the D3Q19 extension
 // of the reference's 2-D kernels, operator by operator (list + citations in
-// oracle/rk3d_oracle.c and DESIGN.md).  PARITY UNPINNED against the reference; pinned
-// against the independent CPU statement oracle/rk3d_oracle.c.
+// oracle/rk3d_oracle.c and DESIGN.md).  Pinned to the reference by reduction: a y-uniform lattice through
+// these kernels reproduces the captures of the reference's real D2Q9 perturbation driver (RKD2Q9.py:978-1223)
+// to 3e-13 (tests/test_rk3d_reduction.py), and pinned in full 3-D against oracle/rk3d_oracle.c.
 //
 // Two storage layouts per rank (zl = 0..nzl+1: owned planes 1..nzl + one halo plane on each side that
 // holds the neighbour rank's outermost plane; only the five populations that cross the cut are
@@ -54,6 +55,7 @@ struct RK3Dev {
     double *phi;                 // [vol]; non-fluid cells hold solidPhi
     double *diag;                // [5][vol] rhoR, rhoB, vx, vy, vz or nullptr
     double ak, beta, cR, cB, solidPhi, vzR, vzB, rhoOutR, rhoOutB;   // cX = 1 / (2 (tauX - 1/2))
+    double rcA, rcD;             // beta w_i / |e_i| of the recolouring term for |e_i| = 1 and sqrt 2 (lbmpm_rk3d_config::recolor_*)
     int first, fill;
     int mrt;                     // 0: BGK, 1: MRT (d'Humieres D3Q19 basis) on the colour-blind populations
     // compact storage (layout 1): only fluid cells are stored, see "compact storage" below
@@ -417,7 +419,8 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     const double omega = 1. / (0.5 + 1. / ((1. + phi) * p.cR + (1. - phi) * p.cB));
     const double g2 = gx * gx + gy * gy + gz * gz, gn = sqrt(g2);
     const double ig2 = g2 != 0. ? 1. / g2 : 0., ign = gn * ig2;
-    const double kR = rR * irho, kB = rB * irho, arc = p.beta * rR * rB * irho * irho, akgn = p.ak * gn;
+    const double kR = rR * irho, kB = rB * irho, arc = rR * rB * irho * irho, akgn = p.ak * gn;
+    const double arcA = (arc * p.rcA) * ign, arcD = (arc * p.rcD) * ign;
     const double c0 = 1. - 1.5 * usq;
     // MRT ([RelaxationType] Type = 'MRT'): f -= M^-1 S M (f - feq) in the D3Q19 basis of d'Humieres et al. 2002
     // with s_e = 1.19, s_eps = s_pi = 1.4, the third-order moments q and m at 1.2 and the stress
@@ -458,12 +461,12 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     put(0, ((ft_in[0] - (ft_in[0] - (rho * wq(0)) * c0) * omega) - (MRT ? -30. * kev[0] + 12. * kev[1] : 0.)) - akgn * bq(0), 0.);
 #pragma unroll
     for (int i = 1; i < Q; i += 2) {             // i and i + 1 are opposite
-        const double w = wq(i), ien = i < 7 ? 1. : 0.70710678118654752440;
+        const double w = wq(i);
         const double eu = (double)CX[i] * ux + (double)CY[i] * uy + (double)CZ[i] * uz;
         const double eg = (double)CX[i] * gx + (double)CY[i] * gy + (double)CZ[i] * gz;
         const double sym = (rho * w) * (c0 + 4.5 * eu * eu), odd = (3. * rho * w) * eu;
         const double pert = (akgn * w * ig2) * (eg * eg) - akgn * bq(i);
-        const double a = (arc * w * ien * ign) * eg;
+        const double a = (i < 7 ? arcA : arcD) * eg;
         double ev = 0., od = 0.;
         if (MRT) {
             ev = mrt_e(i) * kev[0] + mrt_eps(i) * kev[1] + mrt_pixx(i) * kev[2] + mrt_piww(i) * kev[3];
@@ -1017,6 +1020,8 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     p.ak = (c->cfg.ak_r + c->cfg.ak_b) * 0.5; p.beta = c->cfg.beta; p.cR = 1. / (2. * (c->cfg.tau_r - 0.5)); p.cB = 1. / (2. * (c->cfg.tau_b - 0.5));
     p.solidPhi = c->cfg.solid_phi; p.vzR = c->cfg.inlet_vz_r; p.vzB = c->cfg.inlet_vz_b;
     p.rhoOutR = c->cfg.outlet_rho_r; p.rhoOutB = c->cfg.outlet_rho_b;
+    p.rcA = c->cfg.beta * (c->cfg.recolor_axis > 0. ? c->cfg.recolor_axis : 1. / 18.);
+    p.rcD = c->cfg.beta * (c->cfg.recolor_diag > 0. ? c->cfg.recolor_diag : (1. / 36.) * 0.70710678118654752440);
     p.first = c->streamed ? 0 : 1;
     p.fill = c->fill;
     p.mrt = c->cfg.relaxation;
@@ -1059,6 +1064,8 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_FILL")) fill = atoi(e);
     LBMPM_REQUIRE(variant == 0 || variant == 1, "lbmpm_rk3d_create: variant must be 0 (fused) or 1 (split)");
     LBMPM_REQUIRE(cfg->relaxation == 0 || cfg->relaxation == 1, "lbmpm_rk3d_create: relaxation must be 0 (SRT) or 1 (MRT)");
+    LBMPM_REQUIRE(cfg->recolor_axis >= 0. && cfg->recolor_diag >= 0. && cfg->recolor_axis < 1. && cfg->recolor_diag < 1.,
+                  "lbmpm_rk3d_create: recolor_axis / recolor_diag must be 0 (the model's weights) or a weight in (0, 1)");
     LBMPM_REQUIRE(fill == 0 || fill == 4 || fill == 8 || fill == 16 || fill == 32 || fill == 64,
                   "LBMPM_RK3D_FILL must be 0 or a power of two <= 64");
     LBMPM_HIP_TRY(hipSetDevice(cfg->device));

@@ -186,3 +186,74 @@ class RKOracle:
         out = np.zeros((self.ny * self.nx,) + a.shape[1:])
         out[self.fluidNodes] = a
         return out.reshape((self.ny, self.nx) + a.shape[1:])
+
+
+# ---------------------------------------------------------------- perturbation path (oracle/rk_pert_oracle.c)
+class _PertSim(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("N", "nx", "ny")] + \
+               [(n, I64P) for n in ("fluidNodes", "nbr")] + \
+               [(n, C.c_double) for n in ("beta", "AkR", "AkB", "solidPhi", "tauR", "tauB", "vyR", "vyB", "pLB", "pLR")] + \
+               [("mrt", C.c_int)] + \
+               [(n, F64P) for n in ("Bc", "rw", "M", "Minv", "S")] + \
+               [(n, F64P) for n in ("fR", "fB", "fRn", "fBn", "fT", "rhoR", "rhoB", "vx", "vy", "phi", "Gx", "Gy")]
+
+
+PERT_DEFAULTS = dict(beta=1.0, AkR=7.0e-3, AkB=7.0e-3, solidPhi=1.0, tauR=1.0, tauB=1.0, relax="SRT",
+                     vyR=0.0, vyB=-1.0e-4, rhoBL=1.0, rhoRL=1.0e-8)
+PERT_B = np.array([-2. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)      # constantBNew, RKD2Q9.py:131-133
+
+
+class RKPertOracle:
+    """The reference's perturbation colour-gradient loop (RKD2Q9.py:978-1223; velocity inlet A:657 + pressure
+    outlet A:1008) with the repairs listed in tests/golden/gen/make_golden_rk_pert.py.  `recolor_weights`
+    replaces the w_i of the recolouring term (A:1262-1267) -- None = the reference's."""
+
+    def __init__(self, dom, params=None, fR0=None, fB0=None, rhoR0=None, rhoB0=None, recolor_weights=None):
+        L = lib()
+        p = dict(PERT_DEFAULTS); p.update(params or {})
+        self.p = p
+        dom = np.ascontiguousarray(dom, dtype=np.uint8)
+        ny, nx = dom.shape
+        self.nx, self.ny, self.dom = nx, ny, dom
+        self.fluidNodes = np.flatnonzero(dom.reshape(-1) == 1).astype(np.int64)
+        N = self.N = int(self.fluidNodes.size)
+        newidx = -np.ones(nx * ny, dtype=np.int64); newidx[self.fluidNodes] = np.arange(N)
+        self.nbr = np.empty(8 * N, np.int64)
+        L.rk_fill_neighbors(C.c_int64(N), C.c_int64(nx), C.c_int64(ny), _p(self.fluidNodes, I64P), _p(newidx, I64P),
+                            _p(self.nbr, I64P))
+        self.nbr[self.nbr < -1] = -1         # optimizeFluidArray (RKD2Q9.py:603-655) knows fluid / not fluid only
+        w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+        if fR0 is None:
+            sel = dom.reshape(-1) == 1
+            fR0 = np.asarray(rhoR0, dtype=np.float64).reshape(-1)[sel][:, None] * w[None, :]
+            fB0 = np.asarray(rhoB0, dtype=np.float64).reshape(-1)[sel][:, None] * w[None, :]
+        self.fR = np.ascontiguousarray(fR0, dtype=np.float64).copy(); self.fB = np.ascontiguousarray(fB0, dtype=np.float64).copy()
+        z = lambda *s: np.zeros(s)
+        self.fRn, self.fBn, self.fT = z(N, 9), z(N, 9), self.fR + self.fB
+        self.rhoR, self.rhoB = self.fR.sum(axis=1), self.fB.sum(axis=1)
+        self.vx, self.vy, self.phi, self.Gx, self.Gy = z(N), z(N), z(N), z(N), z(N)
+        self.Bc = PERT_B.copy()
+        self.rw = None if recolor_weights is None else np.ascontiguousarray(recolor_weights, dtype=np.float64)
+        self.M, self.Minv, self.S = mrt_matrices()
+        s = _PertSim()
+        s.N, s.nx, s.ny = N, nx, ny
+        s.fluidNodes, s.nbr = _p(self.fluidNodes, I64P), _p(self.nbr, I64P)
+        s.beta, s.AkR, s.AkB, s.solidPhi, s.tauR, s.tauB = p["beta"], p["AkR"], p["AkB"], p["solidPhi"], p["tauR"], p["tauB"]
+        s.vyR, s.vyB, s.pLB, s.pLR = p["vyR"], p["vyB"], p["rhoBL"], p["rhoRL"]
+        s.mrt = 1 if p["relax"] == "MRT" else 0
+        s.Bc = _p(self.Bc, F64P)
+        s.rw = _p(self.rw, F64P) if self.rw is not None else C.cast(None, F64P)
+        s.M, s.Minv, s.S = _p(self.M, F64P), _p(self.Minv, F64P), _p(self.S, F64P)
+        for name in ("fR", "fB", "fRn", "fBn", "fT", "rhoR", "rhoB", "vx", "vy", "phi", "Gx", "Gy"):
+            setattr(s, name, _p(getattr(self, name), F64P))
+        self._s, self._L = s, L
+
+    def run(self, nsteps):
+        self._L.rk_pert_run(C.byref(self._s), C.c_int64(int(nsteps)))
+        return self
+
+    def dense(self, name):
+        a = getattr(self, name)
+        out = np.zeros((self.ny * self.nx,) + a.shape[1:])
+        out[self.fluidNodes] = a
+        return out.reshape((self.ny, self.nx) + a.shape[1:])

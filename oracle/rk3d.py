@@ -1,4 +1,4 @@
-"""ctypes front-end of oracle/rk3d_oracle.c (D3Q19 colour gradient; PARITY UNPINNED).
+"""ctypes front-end of oracle/rk3d_oracle.c (D3Q19 colour gradient; pinned by reduction to the reference's D2Q9 perturbation loop, tests/test_rk3d_reduction.py).
 TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py."""
 import ctypes as C
 
@@ -15,7 +15,8 @@ class _Sim(C.Structure):
                [(n, C.c_double) for n in ("akR", "akB", "beta", "tauR", "tauB", "solidPhi", "vzR", "vzB",
                                           "rhoOutR", "rhoOutB")] + \
                [("mrt", C.c_int)] + \
-               [(n, F64P) for n in ("fR", "fB", "gR", "gB", "rhoR", "rhoB", "phi", "vx", "vy", "vz", "Gx", "Gy", "Gz")]
+               [(n, F64P) for n in ("fR", "fB", "gR", "gB", "rhoR", "rhoB", "phi", "vx", "vy", "vz", "Gx", "Gy", "Gz")] + \
+               [("rcA", C.c_double), ("rcD", C.c_double)]
 
 
 DEFAULT_PARAMS = dict(AkR=7.0e-3, AkB=7.0e-3, beta=1.0, tauR=1.0, tauB=1.0, SolidRhoR=0.7, SolidRhoB=0.0,
@@ -41,6 +42,7 @@ class RK3DOracle:
         s.solidPhi = (p["SolidRhoR"] - p["SolidRhoB"]) / (p["SolidRhoR"] + p["SolidRhoB"])
         s.vzR, s.vzB, s.rhoOutR, s.rhoOutB = p["velocityZR"], p["velocityZB"], p["densityRL"], p["densityBL"]
         s.mrt = 1 if p["relax"] == "MRT" else 0
+        s.rcA, s.rcD = float(p.get("recolor_axis", 0.0)), float(p.get("recolor_diag", 0.0))
         self._names = ("fR", "fB", "gR", "gB", "rhoR", "rhoB", "phi", "vx", "vy", "vz", "Gx", "Gy", "Gz")
         for name in self._names:
             setattr(s, name, getattr(self, "_" + name).ctypes.data_as(F64P))

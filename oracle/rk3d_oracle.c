@@ -5,8 +5,18 @@
  *
  * TEST INFRASTRUCTURE ONLY (rules in oracle/rk_oracle.c).
  *
- * PARITY UNPINNED: there is no reference code or golden vector for this path.  The model is
- * the D3Q19 extension of the reference's 2-D kernels, operator by operator:
+ * Parity status: PINNED BY REDUCTION.  There is no 3-D reference code, but there is the 2-D loop this model
+ * extends (runRKColorGradient2DPerturbation, RKD2Q9.py:978-1223).  A y-uniform D3Q19 lattice projects onto
+ * D2Q9 term by term -- weights, the B_i below onto the reference's constantBNew (RKD2Q9.py:131-133), gradient,
+ * BGK, perturbation, both Zou-He closures, bounce-back -- except for the |e_i| inside cos(theta_i) of the
+ * recolouring; with that one pair of weights set to its projection-exact value (rcA below) this file
+ * reproduces the captures of the REAL 2-D driver (tests/golden/rk_pert_srt_*.npz) to 1e-10 on rhoR, rhoB,
+ * phi, u over 50-80 steps, inlet/outlet/ghost planes and solid-phi walls included, and with its own weights
+ * the pinned D2Q9 oracle run with the projected ones (tests/test_rk3d_reduction.py).  What the reduction cannot
+ * see: anything that vanishes on y-uniform fields (the y-components of gradient and closures; covered by the
+ * x<->y symmetry tests of tests/test_oracle_rk3d.py) and the MRT option (the D2Q9 and D3Q19 moment bases do
+ * not project onto each other; held to the BGK limit, basis orthogonality and physics tests).
+ * The model is the D3Q19 extension of the reference's 2-D kernels, operator by operator:
  *   colour gradient   G = 3 sum_i w_i e_i phi(x+e_i), solid neighbours carry the constant
  *                     phi_s = (SolidRhoR-SolidRhoB)/(SolidRhoR+SolidRhoB)
  *                     (AcceleratedRKGPU2D.py:1199-1219)
@@ -22,7 +32,7 @@
  *   inlet  (z=nz-2)   Zou-He velocity per colour (A:657-695 -> Hecht & Harting 2010 D3Q19),
  *                     ghost plane nz-1 = copy with rho re-summed (A:607-650)
  *   outlet (z=1)      Zou-He pressure per colour (A:1008-1039), ghost plane 0 = copy (A:1045-1081)
- * Validated by physics/self-consistency tests only (tests/test_oracle_rk3d.py).
+ * Further self-consistency / physics tests: tests/test_oracle_rk3d.py.
  *
  * Layout here: dense AoS f[c][z][y][x][19] for clarity; x,y periodic, no wrap in z.
  */
@@ -54,6 +64,11 @@ typedef struct {
     int mrt;
     double *fR, *fB, *gR, *gB;   /* [nz*ny*nx][19] current / scratch */
     double *rhoR, *rhoB, *phi, *vx, *vy, *vz, *Gx, *Gy, *Gz;
+    double rcA, rcD;             /* weights w_i / |e_i| of the recolouring term for |e_i| = 1 and sqrt 2; 0 = the model's
+                                    own (1/18, 1/(36 sqrt 2)).  Other values exist for ONE purpose: rcA = 1/9 - 2/(36 sqrt 2)
+                                    makes a y-uniform lattice project exactly onto the reference's D2Q9 loop
+                                    (tests/test_rk3d_reduction.py; the D3Q19 w_i, B_i, gradient and Zou-He closures project
+                                    onto their D2Q9 counterparts by themselves, the |e_i| of cos(theta_i) does not) */
 } rk3d_sim;
 
 static i64 wrap(i64 v, i64 n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
@@ -254,6 +269,10 @@ static void rk3d_collide_stream(rk3d_sim *s)
                     double en = sqrt((double)(CX[i] * CX[i] + CY[i] * CY[i] + CZ[i] * CZ[i]));
                     double c = (en == 0. || gn == 0.) ? 0. : eg / (en * gn);
                     double a = (s->beta * rR * rB / (rho * rho)) * WT(i) * c;
+                    if (s->rcA > 0. || s->rcD > 0.) {
+                        double wa = s->rcA > 0. ? s->rcA : 1. / 18., wd = s->rcD > 0. ? s->rcD : 1. / 36. / sqrt(2.);
+                        a = (s->beta * rR * rB / (rho * rho)) * (i == 0 ? 0. : (i < 7 ? wa : wd)) * (gn == 0. ? 0. : eg / gn);
+                    }
                     double pr = rR / rho * ft + a, pb = rB / rho * ft - a;
                     /* push with half-way bounce-back */
                     if (i == 0) { s->gR[Q * n] = pr; s->gB[Q * n] = pb; }

@@ -1,5 +1,6 @@
 """Self-consistency of the D3Q19 colour-gradient oracle (oracle/rk3d_oracle.c).  There is no
-reference code for this model (PARITY UNPINNED), so the oracle itself is held to physics:
+reference code for this model; its pin is the reduction to the reference's 2-D loop in
+tests/test_rk3d_reduction.py.  Here the oracle is additionally held to physics:
 lattice symmetry, colour/mass bookkeeping, and a flat interface at rest staying at rest."""
 import numpy as np
 

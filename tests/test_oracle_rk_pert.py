@@ -1,0 +1,95 @@
+"""Pins the perturbation colour-gradient oracle (oracle/rk_pert_oracle.c) -- the 2-D path the D3Q19 model
+extends -- to the reference: kernel by kernel against tests/golden/rk_pert_kernels.npz (real kernel bodies of
+AcceleratedRKGPU2D.py:103-1424 on seeded inputs) and as a loop against the captures of the real driver
+runRKColorGradient2DPerturbation (RKD2Q9.py:978-1223, with the repairs listed in the generator)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_params, rel_err
+from oracle import lib
+from oracle.rk import RKPertOracle, mrt_matrices
+
+F64P = C.POINTER(C.c_double); I64P = C.POINTER(C.c_int64)
+P = lambda a, t=F64P: a.ctypes.data_as(t)
+c = lambda a: np.ascontiguousarray(a).copy()
+TOL = 1e-13
+
+
+def test_each_kernel():
+    d = np.load(os.path.join(GOLDEN, "rk_pert_kernels.npz"))
+    L = lib()
+    ny, nx = d["isDomain"].shape
+    N = int(d["fluidNodes"].size)
+    fl, nbr = c(d["fluidNodes"]), c(d["nbr"])
+    fR, fB, rhoR, rhoB = c(d["fR"]), c(d["fB"]), c(d["rhoR"]), c(d["rhoB"])
+    r, b = np.zeros(N), np.zeros(N)
+    L.rk_macro_density(C.c_int64(N), P(fR), P(fB), P(r), P(b))                           # A:103
+    assert np.array_equal(r, rhoR) and np.array_equal(b, rhoB)
+    fT = np.zeros((N, 9))
+    L.rk_total_pdf(C.c_int64(N), P(fR), P(fB), P(fT))                                    # A:1414
+    assert np.array_equal(fT, d["fT"])
+    vx, vy = np.zeros(N), np.zeros(N)
+    L.rk_pert_velocity(C.c_int64(N), P(fR), P(fB), P(rhoR), P(rhoB), P(vx), P(vy))       # A:125
+    assert np.array_equal(vx, d["vx"]) and np.array_equal(vy, d["vy"])
+    phi = np.zeros(N)
+    L.rk_phase_field(C.c_int64(N), P(rhoR), P(rhoB), P(phi))                             # A:1348
+    assert np.array_equal(phi, d["phi"])
+    tauR, tauB = float(d["tauR"]), float(d["tauB"])
+    a, e = c(fR), c(fB)
+    L.rk_pert_collide1_srt(C.c_int64(N), C.c_double(tauR), C.c_double(tauB), P(vx), P(vy), P(rhoR), P(rhoB), P(phi), P(a), P(e))   # A:1125
+    assert rel_err(a, d["col1_fR"]) < TOL and rel_err(e, d["col1_fB"]) < TOL
+    M, Minv, S = mrt_matrices()
+    assert np.array_equal(M, d["M"]) and np.array_equal(S, d["S"]) and rel_err(Minv, d["Minv"]) < 1e-15
+    for key, bf in (("mrt1_fT", (0., 0.)), ("mrt1_fT_force", tuple(d["bodyF"]))):
+        t = c(fT)
+        L.rk_pert_collide1_mrt(C.c_int64(N), C.c_double(tauR), C.c_double(tauB), C.c_double(bf[0]), C.c_double(bf[1]), P(vx), P(vy),
+                               P(rhoR), P(rhoB), P(phi), P(t), P(c(d["M"])), P(c(d["Minv"])), P(c(d["S"])))                      # A:1272
+        assert rel_err(t, d[key]) < TOL
+    a, e, t = c(d["col1_fR"]), c(d["col1_fB"]), c(d["c23_in_fT"])
+    Bc = c(d["constantB"])
+    L.rk_pert_collide23(C.c_int64(N), C.c_double(float(d["beta"])), C.c_double(float(d["AkR"])), C.c_double(float(d["AkB"])),
+                        C.c_double(float(d["solidPhi"])), P(nbr, I64P), P(Bc), P(rhoR), P(rhoB), P(a), P(e), P(t), None, None, None)   # A:1169
+    assert rel_err(t, d["c23_fT"]) < TOL and rel_err(a, d["c23_fR"]) < TOL and rel_err(e, d["c23_fB"]) < TOL
+    rU, bU = np.full(N, 0.7), np.full(N, 0.3)            # zero-gradient branches
+    a, e, t = np.zeros((N, 9)), np.zeros((N, 9)), c(fT)
+    L.rk_pert_collide23(C.c_int64(N), C.c_double(float(d["beta"])), C.c_double(float(d["AkR"])), C.c_double(float(d["AkB"])),
+                        C.c_double(0.4), P(nbr, I64P), P(Bc), P(rU), P(bU), P(a), P(e), P(t), None, None, None)
+    assert np.array_equal(t, d["c23u_fT"]) and rel_err(a, d["c23u_fR"]) < TOL and rel_err(e, d["c23u_fB"]) < TOL
+    a, e, r, b = c(fR), c(fB), c(rhoR), c(rhoB)
+    L.rk_pert_inlet_velocity(C.c_int64(N), C.c_int64(nx), C.c_int64(ny), C.c_double(float(d["vyR"])), C.c_double(float(d["vyB"])),
+                             P(fl, I64P), P(r), P(b), P(a), P(e))                                                                # A:657
+    for got, key in ((a, "zh_fR"), (e, "zh_fB"), (r, "zh_rhoR"), (b, "zh_rhoB")):
+        assert rel_err(got, d[key]) < TOL, key
+    L.rk_ghost_inlet_velocity(C.c_int64(N), C.c_int64(nx), C.c_int64(ny), P(fl, I64P), P(nbr, I64P), P(r), P(b), P(a), P(e))    # A:607
+    for got, key in ((a, "zhg_fR"), (e, "zhg_fB"), (r, "zhg_rhoR"), (b, "zhg_rhoB")):
+        assert rel_err(got, d[key]) < TOL, key
+    a, e, r, b = c(fR), c(fB), c(rhoR), c(rhoB)
+    L.rk_pert_outlet_pressure(C.c_int64(N), C.c_int64(nx), C.c_double(float(d["pLB"])), C.c_double(float(d["pLR"])), P(b), P(r), P(e), P(a))   # A:1008
+    for got, key in ((a, "pl_fR"), (e, "pl_fB"), (r, "pl_rhoR"), (b, "pl_rhoB")):
+        assert rel_err(got, d[key]) < TOL, key
+    L.rk_ghost_outlet_pressure(C.c_int64(N), C.c_int64(nx), P(nbr, I64P), P(r), P(b), P(a), P(e))                               # A:1045
+    for got, key in ((a, "plg_fR"), (e, "plg_fB"), (r, "plg_rhoR"), (b, "plg_rhoB")):
+        assert rel_err(got, d[key]) < TOL, key
+
+
+def pert_params(d):
+    p = load_params(d)
+    return dict(beta=p["beta"], AkR=float(d["AkR"]), AkB=float(d["AkB"]), solidPhi=float(d["solidPhi"]), tauR=p["tauR"], tauB=p["tauB"],
+                relax=p["relax"], vyR=p["vyR"], vyB=p["vyB"], rhoBL=p["rhoBL"], rhoRL=p["rhoRL"])
+
+
+@pytest.mark.parametrize("name", ["srt_capillary", "srt_porous", "mrt_capillary"])
+def test_loop_against_the_real_driver(name):
+    d = np.load(os.path.join(GOLDEN, "rk_pert_%s.npz" % name))
+    assert len(d["repairs"]) == 4
+    o = RKPertOracle(d["isDomain"], pert_params(d), fR0=d["init_fR"], fB0=d["init_fB"])
+    assert np.array_equal(o.fluidNodes, d["fluidNodes"]) and np.array_equal(o.nbr, d["neighboringNodes"])
+    assert np.array_equal(o.Bc, d["constantB"])
+    done = 0
+    for k in d["snaps"]:
+        o.run(int(k) - done); done = int(k)
+        for f in ("fR", "fB", "fT", "rhoR", "rhoB", "phi", "vx", "vy"):
+            assert rel_err(getattr(o, f), d["s%d_%s" % (k, "fTot" if f == "fT" else f)]) < 1e-12, (name, k, f)

@@ -1,5 +1,5 @@
 """GPU tests of the D3Q19 colour-gradient solver (C ABI): against the independent CPU statement
-oracle/rk3d_oracle.c (PARITY UNPINNED vs the reference, which has no 3-D code), and the
+oracle/rk3d_oracle.c (pinned to the reference by reduction, tests/test_rk3d_reduction.py), and the
 slab-decomposed run (k virtual ranks, halo buffers moved exactly as the RCCL path moves them)
 against the single-domain run, bit for bit."""
 import numpy as np
