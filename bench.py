@@ -146,18 +146,27 @@ def time_solver_2d(solver, steps, warmup):
 
 
 # ----------------------------------------------------------------------------- CPU baselines
+def cpu_team():
+    """every core this process may use runs the timed CPU leg; what the box has and what was used goes in the line"""
+    import oracle
+    n = oracle.usable_cores()
+    L = oracle.lib(threads=n)
+    return dict(cores=int(L.rk_oracle_threads()), cores_box=os.cpu_count(), cores_usable=n, cpu_model=oracle.cpu_model())
+
+
 def cpu_baseline_c2(nx, ny, target_seconds=10.0):
     from oracle.rk import RKOracle
     from openlbmpm_amd.geometry import simple_geometry, initial_densities_rk
     dom = simple_geometry(nx, ny)
     rR, rB = initial_densities_rk(dom, False, 10, mode="intrusion")
+    team = cpu_team()
     o = RKOracle(dom, dict(relax="MRT"), rR, rB)
     o.run(1)
     t0 = time.perf_counter(); o.run(2); dt = (time.perf_counter() - t0) / 2
     n = max(2, min(200, int(target_seconds / max(dt, 1e-6))))
     t0 = time.perf_counter(); o.run(n); el = time.perf_counter() - t0
-    return dict(value=round(o.N * n / el / 1e6, 3), unit="MLUPS", cores=o.threads(), kind="port",
-                sample="c2 %dx%d capillary, %d steps of oracle/rk_oracle.c (OpenMP), %.1f s" % (nx, ny, n, el))
+    return dict(value=round(o.N * n / el / 1e6, 3), unit="MLUPS", kind="port",
+                sample="c2 %dx%d capillary, %d steps of oracle/rk_oracle.c (OpenMP, %d threads), %.1f s" % (nx, ny, n, team["cores"], el), **team)
 
 
 def cpu_baseline_c5(relax, edge=128, target_seconds=12.0):
@@ -166,15 +175,18 @@ def cpu_baseline_c5(relax, edge=128, target_seconds=12.0):
     from openlbmpm_amd.geometry import porous_spheres
     dom = porous_spheres(edge, edge, edge, porosity=0.65, rmin=6.0, rmax=20.0, seed=SEED, nbuf=10)
     rR, rB = c5_densities(dom, 0, edge)
+    team = cpu_team()
     o = RK3DOracle(dom, rR, rB, dict(relax=relax))
     nfl = int(dom.sum())
     o.run(1)
     t0 = time.perf_counter(); o.run(1); dt = time.perf_counter() - t0
     n = max(1, min(2000, int(target_seconds / max(dt, 1e-6))))       # about 12 s of CPU work
     t0 = time.perf_counter(); o.run(n); el = time.perf_counter() - t0
-    return dict(value=round(nfl * n / el / 1e6, 3), unit="MLUPS", cores=int(lib().rk_oracle_threads()), kind="port",
-                sample="c5 model (%s) on a %d^3 porous sample (same generator/parameters), %d steps of "
-                       "oracle/rk3d_oracle.c (OpenMP), %.1f s" % (relax, edge, n, el))
+    return dict(value=round(nfl * n / el / 1e6, 3), unit="MLUPS", kind="port",
+                sample="c5 model (%s%s) on a %d^3 porous sample (same generator/parameters), %d steps of "
+                       "oracle/rk3d_oracle.c (OpenMP, %d threads = every usable core), %.1f s"
+                       % (relax, ": relaxation by four moment projections + odd/even split, not 19x19 products" if relax == "MRT" else "",
+                          edge, n, team["cores"], el), **team)
 
 
 def cpu_baseline_simple_d2q9(target_seconds=6.0):
@@ -188,7 +200,8 @@ def cpu_baseline_simple_d2q9(target_seconds=6.0):
     n = max(5, min(400, int(target_seconds / max(dt, 1e-6))))
     t0 = time.perf_counter(); s.run(n); el = time.perf_counter() - t0
     assert np.isfinite(s.rho[0]).all()
-    return dict(value=round(128 * 128 * n / el / 1e6, 3), unit="MLUPS", cores=1, kind="port",
+    import oracle
+    return dict(value=round(128 * 128 * n / el / 1e6, 3), unit="MLUPS", cores=1, cores_box=os.cpu_count(), cpu_model=oracle.cpu_model(), kind="port",
                 sample="configs[0] (original Shan-Chen, 128x128 periodic static droplet), %d steps of oracle/simple_d2q9.py "
                        "(NumPy, SimpleD2Q9-shaped; the reference's own CPU loop does not run), %.1f s" % (n, el))
 

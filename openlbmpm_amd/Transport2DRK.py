@@ -46,6 +46,11 @@ class Transport2DRK(RKColorGradientLBM):
         p, t = self.par, self.tr
         if p["tension_type"] != "CSF":
             raise config.ConfigError("the coupled loop uses the CSF colour-gradient flow (Transport2DRK.py:1434-1485)")
+        if p.get("cycle"):
+            # the reference restarts the tracers from TransportResults.h5 TracerConcType%din%d then (Transport2DRK.py:431-452);
+            # restarting only the flow would silently pair a developed flow with fresh tracers
+            raise config.ConfigError("[CyclesSetup] IsCycle = 'yes' is not supported by the coupled transport driver: "
+                                     "the tracer restart of Transport2DRK.py:431-452 is not implemented")
         self.initializeDomainBorder()
         self.initializeDomainCondition()
         self.initializeTransportDomain()

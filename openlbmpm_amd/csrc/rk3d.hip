@@ -1004,6 +1004,7 @@ struct lbmpm_rk3d {
     hipEvent_t ev_dep = nullptr, ev_done = nullptr;
     bool interior_pending = false;
     int64_t steps = 0, bytes = 0;
+    int64_t observed_at = -1;        // value of `steps` when lbmpm_rk3d_phase_field(ctx, 1) last filled phi / diag for all owned planes
     lbmpm::EventPool pool;
 };
 
@@ -1232,6 +1233,7 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     c->streamed = false;
     c->steps = 0;
+    c->observed_at = -1;
     return LBMPM_OK;
 }
 
@@ -1270,6 +1272,7 @@ extern "C" int lbmpm_rk3d_phase_field(lbmpm_rk3d *c, int with_diagnostics)
         if (c->compact) rk3dc_phase_field<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3, planes), dim3(BX3, BY3), 0, c->stream>>>(p, zl0);
         else rk3d_phase_field<<<grid3(c, planes), dim3(BX3, BY3), 0, c->stream>>>(p, zl0);
     };
+    if (with_diagnostics) c->observed_at = c->steps;
     if (c->variant == 1 || with_diagnostics) k1(c->nzl, 1);
     else {
         // fused variant: the marching kernel computes the phase field itself; only the planes a
@@ -1480,6 +1483,13 @@ extern "C" int lbmpm_rk3d_get_field(lbmpm_rk3d *c, int field, double *out)
     LBMPM_REQUIRE(c && out, "lbmpm_rk3d_get_field: null argument");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     const double *src = nullptr;
+    // the fused kernels keep phi in LDS and write no diagnostics: every field is that of the last
+    // lbmpm_rk3d_phase_field(ctx, 1); refuse to hand out one that a later step has outdated
+    if (c->observed_at != c->steps && field >= LBMPM_RK3D_PHI && field <= LBMPM_RK3D_VZ) {
+        set_error("field %d is stale: call lbmpm_rk3d_phase_field(ctx, 1) after the last step (fields are those of the streamed, "
+                  "boundary-corrected lattice at that call; observed at step %lld, now %lld)", field, (long long)c->observed_at, (long long)c->steps);
+        return LBMPM_ERR_STATE;
+    }
     switch (field) {
         case LBMPM_RK3D_PHI: src = c->phi; break;
         case LBMPM_RK3D_RHO_R: case LBMPM_RK3D_RHO_B: case LBMPM_RK3D_VX: case LBMPM_RK3D_VY: case LBMPM_RK3D_VZ:

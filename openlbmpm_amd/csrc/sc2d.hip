@@ -790,7 +790,7 @@ extern "C" void lbmpm_sc2d_destroy(lbmpm_sc2d *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *ptr : {(void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->F,
-                      (void *)c->foldA, (void *)c->foldB, (void *)c->diag, (void *)c->obs})
+                      (void *)c->foldA, (void *)c->foldB, (void *)c->diag, (void *)c->obs, (void *)c->psi})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
     if (c->stream) (void)hipStreamDestroy(c->stream);

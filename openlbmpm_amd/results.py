@@ -39,6 +39,11 @@ class ResultFile:
         self.groups = list(groups)
         self.path = os.path.join(directory, name + (".h5" if self.backend != "npz" else ".npz"))
         self._npz = {}
+        if self.backend == "npz":
+            import warnings
+            import zipfile
+            warnings.warn("no HDF5 library found (PyTables, h5py, libhdf5): results go to %s" % self.path)
+            zipfile.ZipFile(self.path, "w").close()
         if self.backend == "tables":
             import tables as tb
             f = tb.open_file(self.path, "w")
@@ -69,8 +74,18 @@ class ResultFile:
             from . import _hdf5
             _hdf5.write(self.path, "/%s/%s" % (group, name), array)
         else:
-            self._npz["/%s/%s" % (group, name)] = np.array(array, copy=True)
-            np.savez_compressed(self.path, **self._npz)
+            # no HDF5 anywhere: a zip archive of .npy members (what np.load reads as .npz), one member appended
+            # per record -- never the whole history rewritten
+            import io
+            import zipfile
+            key = "/%s/%s" % (group, name)
+            if key in self._npz:
+                raise ValueError("record %s written twice" % key)
+            self._npz[key] = True
+            buf = io.BytesIO()
+            np.save(buf, array)
+            with zipfile.ZipFile(self.path, "a", zipfile.ZIP_DEFLATED) as z:
+                z.writestr(key + ".npy", buf.getvalue())
 
 
 def load_results(path):

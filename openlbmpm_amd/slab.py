@@ -39,7 +39,16 @@ def partition_z_balanced(fluid_per_plane, world, min_planes=2):
             z += 1
         cuts.append(z)
     cuts.append(nz)
-    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+    parts = [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+    # a slab without a fluid cell cannot be created (lbmpm_rk3d_create refuses it), and ONE rank raising while the
+    # others enter the first halo exchange would hang the job: fail here, on every rank alike (same mask, same cuts)
+    empty = [r for r, (z0, n) in enumerate(parts) if sum(w[z0:z0 + n]) == 0]
+    if empty:
+        even = partition_z(nz, world)
+        if all(sum(w[z0:z0 + n]) > 0 for z0, n in even):
+            return even
+        raise ValueError("slabs %s of %d would hold no fluid cell; use fewer ranks" % (empty, world))
+    return parts
 
 
 def neighbour_exchange(send_up, send_down, recv_from_below, recv_from_above, rank, world, group=None):

@@ -48,13 +48,28 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    """CPU model string of this box (for the bench line)"""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def lib(threads=None):
-    """Load the oracle; OpenMP team = min(usable cores, LBMPM_ORACLE_THREADS or 16)."""
+    """Load the oracle.  OpenMP team: LBMPM_ORACLE_THREADS if set, else every usable core (affinity mask and
+    cgroup quota, usable_cores()).  `threads` overrides for this and later calls (the checker of the small
+    test problems asks for a small team: waking 100+ threads per loop costs more than the loops)."""
     global _LIB
     if _LIB is None:
         _LIB = ctypes.CDLL(build())
-        cap = int(os.environ.get("LBMPM_ORACLE_THREADS", "16"))
-        _LIB.rk_oracle_set_threads(ctypes.c_int(min(usable_cores(), cap)))
+        env = os.environ.get("LBMPM_ORACLE_THREADS")
+        _LIB.rk_oracle_set_threads(ctypes.c_int(int(env) if env else usable_cores()))
     if threads is not None:
         _LIB.rk_oracle_set_threads(ctypes.c_int(int(threads)))
     return _LIB

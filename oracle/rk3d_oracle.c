@@ -10,7 +10,7 @@
  * D2Q9 term by term -- weights, the B_i below onto the reference's constantBNew (RKD2Q9.py:131-133), gradient,
  * BGK, perturbation, both Zou-He closures, bounce-back -- except for the |e_i| inside cos(theta_i) of the
  * recolouring; with that one pair of weights set to its projection-exact value (rcA below) this file
- * reproduces the captures of the REAL 2-D driver (tests/golden/rk_pert_srt_*.npz) to 1e-10 on rhoR, rhoB,
+ * reproduces the captures of the REAL 2-D driver (tests/golden/rkpert_srt_*.npz) to 1e-10 on rhoR, rhoB,
  * phi, u over 50-80 steps, inlet/outlet/ghost planes and solid-phi walls included, and with its own weights
  * the pinned D2Q9 oracle run with the projected ones (tests/test_rk3d_reduction.py).  What the reduction cannot
  * see: anything that vanishes on y-uniform fields (the y-components of gradient and closures; covered by the
@@ -204,11 +204,52 @@ static void mrt_relax_with(const double M[Q][Q], const double nrm[Q], const doub
  * families therefore share 1.2. */
 static double RATES[5] = {1.19, 1.4, 1.2, 1.4, 1.2};
 void rk3d_set_mrt_rates_public(const double *r) { for (int i = 0; i < 5; ++i) RATES[i] = r[i]; }
-static void mrt_relax(const double M[Q][Q], const double nrm[Q], double inv_tau, double d[Q])
+static void mrt_relax_matrix(const double M[Q][Q], const double nrm[Q], double inv_tau, double d[Q])
 {
     const double S[Q] = {0., RATES[0], RATES[1], 0., RATES[2], 0., RATES[2], 0., RATES[2], inv_tau, RATES[3], inv_tau, RATES[3],
                          inv_tau, inv_tau, inv_tau, RATES[4], RATES[4], RATES[4]};
     mrt_relax_with(M, nrm, S, d);
+}
+
+/* The same operator without the two 19 x 19 products, for d = f - feq (no mass, no momentum) and s_q = s_m:
+ * the odd part of d (differences of opposite pairs) then holds only q and m moments and relaxes at s_q as a
+ * whole; of the even part the stress moments relax at 1/tau, so
+ *   Delta = s_q odd(d) + (1/tau) even(d) + sum_{k in e, eps, pi_xx, pi_ww} (s_k - 1/tau) M_k (M_k . d) / |M_k|^2.
+ * (What the timed CPU baseline runs; tests/test_oracle_rk3d.py holds it to the matrix form.) */
+static void mrt_relax_fast(const double M[Q][Q], const double nrm[Q], double inv_tau, double d[Q])
+{
+    static const int ROWS[4] = {1, 2, 10, 12};
+    const double rate[4] = {RATES[0], RATES[1], RATES[3], RATES[3]};
+    double c[4];
+    for (int a = 0; a < 4; ++a) {
+        const double *m = M[ROWS[a]];
+        double acc = 0.;
+        for (int i = 0; i < Q; ++i) acc += m[i] * d[i];
+        c[a] = (rate[a] - inv_tau) * acc / nrm[ROWS[a]];
+    }
+    double out[Q];
+    for (int i = 0; i < Q; ++i) {
+        double ev = 0.5 * (d[i] + d[OPP[i]]), od = 0.5 * (d[i] - d[OPP[i]]);
+        double corr = 0.;
+        for (int a = 0; a < 4; ++a) corr += M[ROWS[a]][i] * c[a];
+        out[i] = RATES[2] * od + inv_tau * ev + corr;
+    }
+    for (int i = 0; i < Q; ++i) d[i] = out[i];
+}
+
+static void mrt_relax(const double M[Q][Q], const double nrm[Q], double inv_tau, double d[Q])
+{
+    if (RATES[2] == RATES[4]) mrt_relax_fast(M, nrm, inv_tau, d);
+    else mrt_relax_matrix(M, nrm, inv_tau, d);
+}
+void rk3d_mrt_relax_both_public(double inv_tau, const double *d_in, double *d_matrix, double *d_fast)
+{
+    double M[Q][Q], nrm[Q];
+    mrt_basis(M);
+    mrt_norms(M, nrm);
+    memcpy(d_matrix, d_in, sizeof(double) * Q); memcpy(d_fast, d_in, sizeof(double) * Q);
+    mrt_relax_matrix(M, nrm, inv_tau, d_matrix);
+    mrt_relax_fast(M, nrm, inv_tau, d_fast);
 }
 
 /* test hooks: the basis itself, and d <- M^-1 diag(S) M d for any S */

@@ -7,8 +7,8 @@
  *
  * TEST INFRASTRUCTURE ONLY (rules in oracle/rk_oracle.c).
  *
- * Parity status: PINNED.  Kernel by kernel against tests/golden/rk_pert_kernels.npz and loop against
- * tests/golden/rk_pert_{srt_capillary,srt_porous,mrt_capillary}.npz, all produced by the real reference
+ * Parity status: PINNED.  Kernel by kernel against tests/golden/rkpert_kernels.npz and loop against
+ * tests/golden/rkpert_{srt_capillary,srt_porous,mrt_capillary}.npz, all produced by the real reference
  * kernels / the real driver under the numba stand-in (tests/golden/gen/make_golden_rk_pert.py, which lists
  * the four in-memory repairs the dead driver needs; R3 fixes where fluidPDFTotal is summed).
  *

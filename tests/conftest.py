@@ -8,6 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the checker's problems are small: a team of a few threads beats one of every core of a large box
+os.environ.setdefault("LBMPM_ORACLE_THREADS", str(min(8, os.cpu_count() or 1)))
 
 
 def pytest_configure(config):

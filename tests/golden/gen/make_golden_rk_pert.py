@@ -6,7 +6,7 @@ Container-only (needs /root/reference).  Usage:
 
 Two kinds of fixture:
 
-1. ``rk_pert_kernels.npz`` -- the kernels of AcceleratedRKGPU2D.py that only the perturbation loop uses,
+1. ``rkpert_kernels.npz`` -- the kernels of AcceleratedRKGPU2D.py that only the perturbation loop uses,
    ONE BY ONE on seeded random inputs over a small porous domain (real kernel bodies under the numba
    stand-in): calRKCollision1GPU2DSRTNew (A:1125), calRKCollision1GPU2DMRTNew (A:1272),
    calRKCollision23GPUNew (A:1169), constantVelocityZHBoundaryHigherRK (A:657),
@@ -14,7 +14,7 @@ Two kinds of fixture:
    ghostPointsConstPressureLowerRK (A:1045), calPhysicalVelocityRKGPU2D (A:125), calPhaseFieldPhi (A:1348),
    calTotalFluidPDF (A:1414), calMacroDensityRKGPU2D (A:103).
 
-2. ``rk_pert_<scenario>.npz`` -- the REAL driver RKColorGradientLBM.runRKColorGradient2DPerturbation
+2. ``rkpert_<scenario>.npz`` -- the REAL driver RKColorGradientLBM.runRKColorGradient2DPerturbation
    (RKD2Q9.py:978-1223) run to completion.  As shipped it dies at its first time step (SURVEY.md
    Appendix B-7); it runs with these in-memory repairs, none of which touches a kernel body and all of
    which are recorded in the fixture (key ``repairs``):
@@ -216,7 +216,7 @@ def run_loop(name):
         out["image"] = img
     for key, val in par.items():
         out["par_" + key] = np.array(val)
-    np.savez_compressed(os.path.join(OUT, "rk_pert_%s.npz" % name), **out)
+    np.savez_compressed(os.path.join(OUT, "rkpert_%s.npz" % name), **out)
 
 
 def run_kernels():
@@ -313,7 +313,7 @@ def run_kernels():
     out.update(pLB=np.float64(pLB), pLR=np.float64(pLR), pl_fR=pR.copy(), pl_fB=pB.copy(), pl_rhoR=prR.copy(), pl_rhoB=prB.copy())
     A.ghostPointsConstPressureLowerRK[grid, block](N, nx, xDim, fluidNodes, nbr, prR, prB, pR, pB)
     out.update(plg_fR=pR.copy(), plg_fB=pB.copy(), plg_rhoR=prR.copy(), plg_rhoB=prB.copy())
-    np.savez_compressed(os.path.join(OUT, "rk_pert_kernels.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "rkpert_kernels.npz"), **out)
     refenv.say("rk_pert_kernels: N=%d" % N)
 
 

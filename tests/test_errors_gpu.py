@@ -150,3 +150,47 @@ def test_device_memory_accounting():
         del os.environ["LBMPM_RK3D_LAYOUT"]
     assert 2 * 38 * 8 * compact.num_fluid_nodes <= compact.device_bytes < dense.device_bytes
     compact.close(); dense.close()
+
+
+def test_create_destroy_does_not_leak_device_memory():
+    """EFS with an iso-8 force keeps a psi array (16 B per cell) that destroy once forgot"""
+    import torch
+    from openlbmpm_amd.sc2d import SC2DSolver
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.rk3d import RK3DSlab
+    from openlbmpm_amd.geometry import simple_geometry
+    dom = simple_geometry(512, 512)
+    dom3 = np.ones((12, 16, 64), dtype=np.uint8)
+
+    def cycle():
+        s = SC2DSolver(dom, dict(inter="EFS", scheme=8)); s.close()
+        s = RK2DSolver(dom, None, diagnostics=True); s.close()
+        s = RK3DSlab(dom3, 0, 12); s.close()
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(10):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 4 << 20, "device memory shrank by %d bytes over 10 create/destroy cycles" % (free0 - free1)
+
+
+def test_rk3d_fields_are_refused_when_stale():
+    from openlbmpm_amd._lib import LbmpmError
+    from openlbmpm_amd.rk3d import RK3DSlab
+    dom = np.ones((12, 8, 64), dtype=np.uint8)
+    s = RK3DSlab(dom, 0, 12)
+    s.set_density(np.ones(dom.shape), np.zeros(dom.shape))
+    with pytest.raises(LbmpmError):
+        s.get("phi")                                          # nothing observed yet
+    s.step_single(2)
+    with pytest.raises(LbmpmError) as e:
+        s.get("phi")                                          # the fused kernel keeps phi in LDS
+    assert "stale" in str(e.value)
+    s.phase_field(diagnostics=True)
+    assert np.allclose(s.get("phi")[4:8], 1.0) and np.allclose(s.get("rhoR")[4:8], 1.0)     # away from the open planes
+    s.step_single(1)
+    with pytest.raises(LbmpmError):
+        s.get("rhoR")
+    s.close()

@@ -19,8 +19,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="th
     ("make_golden_rk.py", ["csf_mrt_convective"], "rk_csf_mrt_convective.npz"),
     ("make_golden_sc.py", ["efs_srt_convective"], "sc_efs_srt_convective.npz"),
     ("make_golden_tr.py", [], "tr_kernels.npz"),
-    ("make_golden_rk_pert.py", ["kernels"], "rk_pert_kernels.npz"),
-    ("make_golden_rk_pert.py", ["srt_porous"], "rk_pert_srt_porous.npz"),
+    ("make_golden_rk_pert.py", ["kernels"], "rkpert_kernels.npz"),
+    ("make_golden_rk_pert.py", ["srt_porous"], "rkpert_srt_porous.npz"),
 ])
 def test_fixture_is_reproduced_from_the_reference(tmp_path, script, args, fixture):
     env = dict(os.environ, LBMPM_GOLDEN_OUT=str(tmp_path))

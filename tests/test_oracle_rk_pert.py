@@ -1,5 +1,5 @@
 """Pins the perturbation colour-gradient oracle (oracle/rk_pert_oracle.c) -- the 2-D path the D3Q19 model
-extends -- to the reference: kernel by kernel against tests/golden/rk_pert_kernels.npz (real kernel bodies of
+extends -- to the reference: kernel by kernel against tests/golden/rkpert_kernels.npz (real kernel bodies of
 AcceleratedRKGPU2D.py:103-1424 on seeded inputs) and as a loop against the captures of the real driver
 runRKColorGradient2DPerturbation (RKD2Q9.py:978-1223, with the repairs listed in the generator)."""
 import ctypes as C
@@ -19,7 +19,7 @@ TOL = 1e-13
 
 
 def test_each_kernel():
-    d = np.load(os.path.join(GOLDEN, "rk_pert_kernels.npz"))
+    d = np.load(os.path.join(GOLDEN, "rkpert_kernels.npz"))
     L = lib()
     ny, nx = d["isDomain"].shape
     N = int(d["fluidNodes"].size)
@@ -83,7 +83,7 @@ def pert_params(d):
 
 @pytest.mark.parametrize("name", ["srt_capillary", "srt_porous", "mrt_capillary"])
 def test_loop_against_the_real_driver(name):
-    d = np.load(os.path.join(GOLDEN, "rk_pert_%s.npz" % name))
+    d = np.load(os.path.join(GOLDEN, "rkpert_%s.npz" % name))
     assert len(d["repairs"]) == 4
     o = RKPertOracle(d["isDomain"], pert_params(d), fR0=d["init_fR"], fB0=d["init_fB"])
     assert np.array_equal(o.fluidNodes, d["fluidNodes"]) and np.array_equal(o.nbr, d["neighboringNodes"])

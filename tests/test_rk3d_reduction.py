@@ -11,7 +11,7 @@ neighbours (+-1, +-1, 0) of D3Q19 fold onto the D2Q9 axes with weight 1/(36 sqrt
 
 * with the recolouring weights overridden by their projection-exact values (recolor_axis = 1/9 - 2/(36 sqrt 2);
   the only use of that switch), the 3-D code must reproduce the captures of the REAL 2-D driver
-  (tests/golden/rk_pert_srt_*.npz) on rhoR, rhoB, phi, u at every snapshot -- inlet/outlet planes, ghost planes
+  (tests/golden/rkpert_srt_*.npz) on rhoR, rhoB, phi, u at every snapshot -- inlet/outlet planes, ghost planes
   and solid-phi walls included;
 * with the model's own weights it must equal the pinned D2Q9 oracle (oracle/rk_pert_oracle.c, pinned by
   tests/test_oracle_rk_pert.py) run with the correspondingly projected recolouring weights.
@@ -35,7 +35,7 @@ TOL = 1e-10
 
 
 def scenario(name):
-    d = np.load(os.path.join(GOLDEN, "rk_pert_%s.npz" % name))
+    d = np.load(os.path.join(GOLDEN, "rkpert_%s.npz" % name))
     p = load_params(d)
     dom2 = d["isDomain"]
     sp = float(d["solidPhi"])

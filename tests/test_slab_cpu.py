@@ -94,8 +94,16 @@ def test_balanced_partition_equalises_fluid_cells():
         assert all(n >= 2 for _, n in parts)
         loads = [int(w[z0:z0 + n].sum()) for z0, n in parts]
         assert max(loads) <= 1.01 * (w.sum() / world) + w.max()
-    # degenerate: all fluid in one plane still leaves every rank its two planes
+    # a slab without a fluid cell cannot be created, and one rank failing alone would hang the others in the first
+    # exchange: the cut itself refuses, identically on every rank; where an even cut avoids the empty slab it is used
     w = np.zeros(16, dtype=int); w[5] = 100
-    assert all(n >= 2 for _, n in partition_z_balanced(w, 8))
+    with pytest.raises(ValueError):
+        partition_z_balanced(w, 8)
+    w = np.array([0] * 20 + [5] * 4)
+    with pytest.raises(ValueError):
+        partition_z_balanced(w, 4)
+    w = np.array([1] * 4 + [50] * 4 + [1] * 4)
+    parts = partition_z_balanced(w, 3)
+    assert all(w[z0:z0 + n].sum() > 0 for z0, n in parts)
     with pytest.raises(ValueError):
         partition_z_balanced(np.ones(7), 4)
