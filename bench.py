@@ -278,13 +278,17 @@ def main():
             del rR, rB
             d.step(warmup)
             d.sync(); barrier()
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
             t0 = time.perf_counter()
-            d.step(steps, events=ev)
+            d.step(steps, timed=True)      # one call into the library; per-phase HIP events on the slab's streams
             d.sync(); barrier()
             wall = time.perf_counter() - t0
-            ms_dom = sum(a.elapsed_time(b) for a, b in ev)
+            tm = d.timing()
+            ms_dom = tm["step_ms"] * steps
             ms_total = wall * 1e3
+            mine = dict(rank=rank, planes=[int(z0), int(z0 + nzl)], fluid_nodes=int(d.slab.num_fluid_nodes),
+                        **{k: (round(v, 5) if isinstance(v, float) else v) for k, v in tm.items()})
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
             d.observe()
             rho = d.slab.get("rhoR") + d.slab.get("rhoB")
             nfl_local, dom_kernel = d.slab.num_fluid_nodes, d.slab.dominant_kernel
@@ -324,6 +328,14 @@ def main():
                              "avg_launch_ms": round(per_launch_ms, 5),
                              "algorithmic_bytes_per_launch": B_ALG["c5"] * nfl_local},
             }
+            if world > 1:
+                # what the transport really was, and where a step's time went on every rank (HIP events inside
+                # lbmpm_rk3d_step_slab): exchange_exposed_ms = step - max(interior, boundary)
+                out["multi_gpu"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                    "transport": "torch.distributed batch_isend_irecv (ncclSend/ncclRecv pairs, RCCL) per face; "
+                                                 "no collective on the data path",
+                                    "boundary_depth_planes": int(os.environ.get("LBMPM_RK3D_BOUNDARY", "2")),
+                                    "per_rank": per_rank}
             if world == 1 and not args.no_secondary:
                 sec = []
                 for name, build, size2 in (("c1", build_c1, (128, 128)), ("c2", build_c2, (1024, 1024)),

@@ -325,6 +325,17 @@ int lbmpm_rk3d_collide(lbmpm_rk3d *ctx);
  * step).  collide_boundary without a preceding collide_interior equals lbmpm_rk3d_collide. */
 int lbmpm_rk3d_collide_interior(lbmpm_rk3d *ctx);
 int lbmpm_rk3d_collide_boundary(lbmpm_rk3d *ctx);
+/* One call = n whole time steps of a slab with the schedule above, the transfers left to the caller's transport:
+ * exchange(user, what) -- what 0: populations (F_SEND_* -> the neighbours' F_RECV_*), 1: phase field (PHI_*) --
+ * must ENQUEUE the transfers on the context's stream (lbmpm_rk3d_set_stream) and return 0; it is called twice per
+ * step from the calling thread (not at all on a slab without neighbours; the first step moves no populations).
+ * timed != 0: HIP events around the step, the interior launch, the exchange chain and the boundary launches of
+ * (up to 256) steps; read the averages with lbmpm_rk3d_slab_timing (out[5]: step, interior, pack..phi exchange,
+ * boundary [ms], steps averaged). */
+typedef int (*lbmpm_rk3d_exchange_fn)(void *user, int what);
+int lbmpm_rk3d_step_slab(lbmpm_rk3d *ctx, int64_t nsteps, int has_below, int has_above, lbmpm_rk3d_exchange_fn exchange,
+                         void *user, int timed);
+int lbmpm_rk3d_slab_timing(lbmpm_rk3d *ctx, double *out);
 int lbmpm_rk3d_step(lbmpm_rk3d *ctx, int64_t nsteps);
 int lbmpm_rk3d_step_timed(lbmpm_rk3d *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
 int lbmpm_rk3d_sync(lbmpm_rk3d *ctx);

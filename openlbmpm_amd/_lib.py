@@ -58,6 +58,8 @@ class RK3DConfig(C.Structure):
                 ("recolor_axis", C.c_double), ("recolor_diag", C.c_double)]
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # lbmpm_rk3d_exchange_fn
+
 _lib = None
 
 # every symbol include/lbmpm.h declares (checked by tests/test_abi.py)
@@ -106,6 +108,8 @@ _SIGNATURES = {
     "lbmpm_rk3d_collide_interior": (C.c_int, [C.c_void_p]),
     "lbmpm_hbm_stream_test": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lbmpm_rk3d_collide_boundary": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3d_step_slab": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "lbmpm_rk3d_slab_timing": (C.c_int, [C.c_void_p, F64P]),
     "lbmpm_rk3d_step": (C.c_int, [C.c_void_p, C.c_int64]),
     "lbmpm_rk3d_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),
     "lbmpm_rk3d_sync": (C.c_int, [C.c_void_p]),

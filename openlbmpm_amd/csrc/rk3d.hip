@@ -999,11 +999,17 @@ struct lbmpm_rk3d {
     uint32_t *seg = nullptr, *seg2 = nullptr;        // 4 words per record
     std::vector<unsigned long long> h_pstart;
     bool streamed = false;
-    int variant = 0, tile = 0, chunk_len = 32, fill = 16, boundary = 8;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL / _BOUNDARY
+    int variant = 0, tile = 0, chunk_len = 32, fill = 16;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL
+    // planes next to each face that wait for the halo exchange (LBMPM_RK3D_BOUNDARY): plane 1 needs the neighbour's populations
+    // and phase field, plane 2 the phase field of plane 1; from plane 3 on nothing of the neighbour is read.  Measured with k = 8
+    // virtual ranks on one GPU (tools/slabbench.py, 512^3): depth 2 / 3 / 4 / 8 -> +4.5 / +5.9 / +6.6 / +8.1 % over the single slab
+    int boundary = 2;
     hipStream_t aux = nullptr;       // second stream for the interior planes (lbmpm_rk3d_collide_interior)
     hipEvent_t ev_dep = nullptr, ev_done = nullptr;
     bool interior_pending = false;
     int64_t steps = 0, bytes = 0;
+    lbmpm::EventPool slab_pool;      // lbmpm_rk3d_step_slab(timed): 4 event pairs per step {step, interior, exchange chain, boundary}
+    int64_t slab_timed_steps = 0;
     int64_t observed_at = -1;        // value of `steps` when lbmpm_rk3d_phase_field(ctx, 1) last filled phi / diag for all owned planes
     lbmpm::EventPool pool;
 };
@@ -1190,6 +1196,7 @@ extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
+    c->slab_pool.destroy();
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); (void)hipEventDestroy(c->ev_dep); (void)hipEventDestroy(c->ev_done); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1359,7 +1366,12 @@ extern "C" int lbmpm_rk3d_collide(lbmpm_rk3d *c)
 // their phase field, so they are collided on a second stream while the caller packs, exchanges
 // and unpacks on the context's stream; lbmpm_rk3d_collide_boundary then does the planes next to
 // the faces and joins the two streams.
-extern "C" int lbmpm_rk3d_collide_interior(lbmpm_rk3d *c)
+static int collide_interior_ev(lbmpm_rk3d *c, hipEvent_t e0, hipEvent_t e1);
+static int collide_boundary_ev(lbmpm_rk3d *c, hipEvent_t e0, hipEvent_t e1);
+extern "C" int lbmpm_rk3d_collide_interior(lbmpm_rk3d *c) { return collide_interior_ev(c, nullptr, nullptr); }
+extern "C" int lbmpm_rk3d_collide_boundary(lbmpm_rk3d *c) { return collide_boundary_ev(c, nullptr, nullptr); }
+
+static int collide_interior_ev(lbmpm_rk3d *c, hipEvent_t e0, hipEvent_t e1)
 {
     LBMPM_REQUIRE(c, "null context");
     LBMPM_REQUIRE(!c->interior_pending, "lbmpm_rk3d_collide_interior called twice in one step");
@@ -1374,25 +1386,105 @@ extern "C" int lbmpm_rk3d_collide_interior(lbmpm_rk3d *c)
     LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));                // everything issued so far (previous step) first
     LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));
     RK3Dev p = make_dev(c);
+    if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->aux));
     launch_step_range(c, p, c->aux, cb + 1, c->nzl - cb);
     LBMPM_HIP_TRY(hipGetLastError());
+    if (e1) LBMPM_HIP_TRY(hipEventRecord(e1, c->aux));
     LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));
     c->interior_pending = true;
     return LBMPM_OK;
 }
 
-extern "C" int lbmpm_rk3d_collide_boundary(lbmpm_rk3d *c)
+static int collide_boundary_ev(lbmpm_rk3d *c, hipEvent_t e0, hipEvent_t e1)
 {
     LBMPM_REQUIRE(c, "null context");
-    if (!c->interior_pending) return lbmpm_rk3d_collide(c);
+    if (!c->interior_pending) {
+        if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+        const int rc = lbmpm_rk3d_collide(c);
+        if (rc == LBMPM_OK && e1) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
+        return rc;
+    }
     const int cb = c->boundary;
     RK3Dev p = make_dev(c);
+    if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
     launch_step_range(c, p, c->stream, 1, cb);
     launch_step_range(c, p, c->stream, c->nzl - cb + 1, c->nzl);
     LBMPM_HIP_TRY(hipGetLastError());
+    if (e1) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
     c->interior_pending = false;
     finish_step(c);
+    return LBMPM_OK;
+}
+
+// The whole time step of a slab behind ONE call: interior planes on the second stream, then on the context's
+// stream pack -> exchange(populations) -> unpack -> phase field of the face planes -> exchange(phase field) ->
+// boundary planes -> join.  `exchange(user, what)` (what = 0 populations, 1 phase field) is the caller's transport:
+// it must enqueue the transfer of the LBMPM_RK3D_BUF_* send buffers into the neighbours' receive buffers on the
+// context's stream (torch.distributed P2P under torch.cuda.stream(...) does exactly that; so would ncclSend /
+// ncclRecv) and return 0.  The library never blocks the host here.
+extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below, int has_above, lbmpm_rk3d_exchange_fn exchange,
+                                    void *user, int timed)
+{
+    LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_rk3d_step_slab: bad argument");
+    const bool nb = has_below || has_above;
+    LBMPM_REQUIRE(!nb || exchange, "lbmpm_rk3d_step_slab: a slab with neighbours needs an exchange callback");
+    LBMPM_REQUIRE((has_below != 0) == (c->cfg.z_offset > 0) && (has_above != 0) == (c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global),
+                  "lbmpm_rk3d_step_slab: has_below / has_above contradict the slab's position in the lattice");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    const int64_t tsteps = timed ? (nsteps < 256 ? nsteps : 256) : 0;
+    if (timed) {
+        if (c->slab_pool.reserve((size_t)(4 * tsteps)) != LBMPM_OK) { set_error("hipEventCreate failed"); return LBMPM_ERR_HIP; }
+        c->slab_pool.reset();
+        c->slab_timed_steps = tsteps;
+    }
+    for (int64_t k = 0; k < nsteps; ++k) {
+        hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (k < tsteps) for (int i = 0; i < 4; ++i) c->slab_pool.take(&ev[2 * i], &ev[2 * i + 1]);
+        if (ev[0]) LBMPM_HIP_TRY(hipEventRecord(ev[0], c->stream));
+        int rc = LBMPM_OK;
+        if (nb) rc = collide_interior_ev(c, ev[2], ev[3]);
+        if (rc != LBMPM_OK) return rc;
+        if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
+        if (nb && c->steps > 0) {
+            rc = lbmpm_rk3d_pack_halo(c);
+            if (rc == LBMPM_OK && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (populations)"); rc = LBMPM_ERR_STATE; }
+            if (rc == LBMPM_OK) rc = lbmpm_rk3d_unpack_halo(c, has_below, has_above);
+            if (rc != LBMPM_OK) return rc;
+        }
+        rc = lbmpm_rk3d_phase_field(c, 0);
+        if (rc != LBMPM_OK) return rc;
+        if (nb && exchange(user, 1) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (phase field)"); return LBMPM_ERR_STATE; }
+        if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
+        rc = collide_boundary_ev(c, ev[6], ev[7]);
+        if (rc != LBMPM_OK) return rc;
+        if (ev[1]) LBMPM_HIP_TRY(hipEventRecord(ev[1], c->stream));
+    }
+    return LBMPM_OK;
+}
+
+// averages [ms] over the timed steps of the last lbmpm_rk3d_step_slab(..., timed = 1): out[0] whole step,
+// out[1] interior planes (second stream), out[2] pack .. phase-field exchange on the context's stream (transfers
+// included), out[3] boundary planes; out[4] = number of steps averaged.  Synchronises the context's streams.
+extern "C" int lbmpm_rk3d_slab_timing(lbmpm_rk3d *c, double *out)
+{
+    LBMPM_REQUIRE(c && out, "lbmpm_rk3d_slab_timing: null argument");
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->aux) LBMPM_HIP_TRY(hipStreamSynchronize(c->aux));
+    for (int i = 0; i < 5; ++i) out[i] = 0.;
+    const int64_t n = c->slab_timed_steps;
+    if (n <= 0) return LBMPM_OK;
+    const bool has_interior = c->aux && !(c->variant == 1 || c->nzl < 2 * c->boundary + 1) &&
+                              (c->cfg.z_offset > 0 || c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global);
+    for (int64_t k = 0; k < n; ++k)
+        for (int i = 0; i < 4; ++i) {
+            if (i == 1 && !has_interior) continue;
+            float ms = 0.f;
+            LBMPM_HIP_TRY(hipEventElapsedTime(&ms, c->slab_pool.ev[(size_t)(8 * k + 2 * i)], c->slab_pool.ev[(size_t)(8 * k + 2 * i + 1)]));
+            out[i] += ms;
+        }
+    for (int i = 0; i < 4; ++i) out[i] /= (double)n;
+    out[4] = (double)n;
     return LBMPM_OK;
 }
 

@@ -105,6 +105,32 @@ class RK3DSlab:
     def collide_boundary(self):
         check(self._L.lbmpm_rk3d_collide_boundary(self._h), "collide_boundary")
 
+    def step_slab(self, n, has_below, has_above, exchange=None, timed=False):
+        """n whole time steps behind one C call (lbmpm_rk3d_step_slab); `exchange(what)` enqueues the transfer of the
+        population (0) / phase-field (1) halo buffers on the slab's stream"""
+        from ._lib import EXCHANGE_FN
+        err = []
+
+        def _cb(_user, what):
+            try:
+                exchange(int(what))
+                return 0
+            except BaseException as e:          # an exception must not unwind through the C frames
+                err.append(e)
+                return 1
+        cb = EXCHANGE_FN(_cb) if exchange is not None else None
+        rc = self._L.lbmpm_rk3d_step_slab(self._h, int(n), int(bool(has_below)), int(bool(has_above)),
+                                          C.cast(cb, C.c_void_p) if cb is not None else None, None, int(bool(timed)))
+        if err:
+            raise err[0]
+        check(rc, "lbmpm_rk3d_step_slab")
+
+    def slab_timing(self):
+        """dict of average ms over the timed steps of the last step_slab(..., timed=True)"""
+        out = (C.c_double * 5)()
+        check(self._L.lbmpm_rk3d_slab_timing(self._h, out), "lbmpm_rk3d_slab_timing")
+        return dict(step_ms=out[0], interior_ms=out[1], exchange_chain_ms=out[2], boundary_ms=out[3], steps=int(out[4]))
+
     def step_single(self, n):
         check(self._L.lbmpm_rk3d_step(self._h, int(n)), "lbmpm_rk3d_step")
 
@@ -237,24 +263,21 @@ class RK3DDistributed:
             self._exchange("f")
             s.unpack(self.rank > 0, self.rank + 1 < self.world)
 
-    def step(self, n, events=None):
-        """events: optional list of n (start, stop) torch.cuda.Event pairs recorded around each step
-        on the slab's main stream (the interior part of the fused kernel runs on a second stream and
-        is joined before the stop event)."""
+    def step(self, n, timed=False):
+        """n time steps: ONE call into the library (lbmpm_rk3d_step_slab), which runs the interior planes on the slab's
+        second stream and calls back twice per step for the two neighbour exchanges (torch.distributed P2P = RCCL
+        over xGMI, enqueued on the slab's stream).  timed: per-phase HIP events, read with timing()."""
         s = self.slab
         with self._torch.cuda.stream(self.stream):
-            for k in range(int(n)):
-                if events is not None:
-                    events[k][0].record(self.stream)
-                if self.world > 1:
-                    s.collide_interior()       # bulk of the slab on its second stream, under the exchange
-                self._halo_f()
-                s.phase_field()
-                if self.world > 1:
-                    self._exchange("phi")
-                s.collide_boundary()           # planes next to the faces; joins the streams
-                if events is not None:
-                    events[k][1].record(self.stream)
+            s.step_slab(n, self.rank > 0, self.rank + 1 < self.world,
+                        (lambda what: self._exchange("phi" if what else "f")) if self.world > 1 else None, timed)
+
+    def timing(self):
+        t = self.slab.slab_timing()
+        t["exchange_exposed_ms"] = t["step_ms"] - max(t["interior_ms"], t["boundary_ms"])
+        f = self.slab.buffer("f_send_up"); ph = self.slab.buffer("phi_send_up")
+        t["bytes_per_face"] = int(f.numel() * f.element_size() + ph.numel() * ph.element_size())
+        return t
 
     def observe(self):
         with self._torch.cuda.stream(self.stream):

@@ -168,40 +168,84 @@ def test_single_slab_convenience_equals_phases():
     s.close(); c.close()
 
 
-def test_two_process_slab_run_equals_single_process(tmp_path):
-    """The N>1 orchestration of bench.py / RK3DDistributed with two OS processes sharing this one
-    GPU (gloo transport staged through the host, because RCCL refuses duplicate devices): the
-    gathered result must equal the single-process run bit for bit."""
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _two_rank_run(tmp_path, backend, same_gpu):
+    """two OS processes through RK3DDistributed (one lbmpm_rk3d_step_slab call for all steps, the exchanges as
+    callbacks); returns the gathered fields and the per-rank timing dicts"""
+    import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "w.py"
     script.write_text('''
-import os, sys
+import json, os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np, torch, torch.distributed as dist
 from test_rk3d_gpu import _case
 from openlbmpm_amd.rk3d import RK3DDistributed
-dist.init_process_group("gloo")
-torch.cuda.set_device(0)
+rank = int(os.environ["RANK"])
+dev = 0 if %r else rank
+torch.cuda.set_device(dev)
+if %r == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group("gloo")
 dom, rR, rB = _case(nx=33, ny=18, nz=41, seed=9)
-d = RK3DDistributed(dom, device=0)
+d = RK3DDistributed(dom, device=dev)
 d.set_density(rR, rB)
-d.step(15); d.observe()
-np.save(os.path.join(%r, "phi_%%d.npy" %% dist.get_rank()), d.slab.get("phi"))
-np.save(os.path.join(%r, "vz_%%d.npy" %% dist.get_rank()), d.slab.get("vz"))
+d.step(9); d.step(6, timed=True)
+t = d.timing()
+d.observe()
+np.save(os.path.join(%r, "phi_%%d.npy" %% rank), d.slab.get("phi"))
+np.save(os.path.join(%r, "vz_%%d.npy" %% rank), d.slab.get("vz"))
+json.dump(dict(t, backend=dist.get_backend(), world=dist.get_world_size()), open(os.path.join(%r, "t_%%d.json" %% rank), "w"))
 d.close(); dist.destroy_process_group()
-''' % (root, root, str(tmp_path), str(tmp_path)))
-    env = dict(os.environ)
+''' % (root, root, same_gpu, backend, str(tmp_path), str(tmp_path), str(tmp_path)))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)], env=env, timeout=300)
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                          env=dict(os.environ), timeout=300)
+    fields = {f: np.concatenate([np.load(tmp_path / ("%s_%d.npy" % (f, r))) for r in range(2)], axis=0) for f in ("phi", "vz")}
+    return fields, [json.load(open(tmp_path / ("t_%d.json" % r))) for r in range(2)]
+
+
+def _single_process_reference():
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=33, ny=18, nz=41, seed=9)
     c = RK3DCluster(dom, 1)
     c.set_density(rR, rB)
     c.step(15); c.observe()
-    for f in ("phi", "vz"):
-        got = np.concatenate([np.load(tmp_path / ("%s_%d.npy" % (f, r))) for r in range(2)], axis=0)
-        assert np.array_equal(got, c.get(f)), f
+    ref = {f: c.get(f) for f in ("phi", "vz")}
     c.close()
+    return ref
+
+
+def test_two_process_slab_run_equals_single_process(tmp_path):
+    """The N>1 orchestration of bench.py / RK3DDistributed with two OS processes sharing this one
+    GPU (gloo transport staged through the host, because RCCL refuses duplicate devices): the
+    gathered result must equal the single-process run bit for bit; the per-phase timing is filled in."""
+    got, timing = _two_rank_run(tmp_path, "gloo", same_gpu=True)
+    ref = _single_process_reference()
+    for f in ref:
+        assert np.array_equal(got[f], ref[f]), f
+    for t in timing:
+        assert t["world"] == 2 and t["steps"] == 6 and t["step_ms"] > 0 and t["interior_ms"] > 0 and t["boundary_ms"] > 0
+        assert t["bytes_per_face"] > 0 and t["step_ms"] >= t["boundary_ms"]
+
+
+def test_two_gpu_rccl_slab_run_equals_single_process(tmp_path):
+    """the same over the real transport: backend nccl = RCCL, one GPU per rank (needs a box with two GPUs)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL refuses two ranks on one device: needs >= 2 GPUs")
+    got, timing = _two_rank_run(tmp_path, "nccl", same_gpu=False)
+    ref = _single_process_reference()
+    for f in ref:
+        assert np.array_equal(got[f], ref[f]), f
+    assert all(t["backend"] == "nccl" and t["world"] == 2 for t in timing)
