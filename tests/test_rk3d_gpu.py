@@ -53,7 +53,7 @@ def test_slabs_equal_single_domain_bitwise(k):
         assert np.array_equal(out[0][f], out[1][f]), f
 
 
-@pytest.mark.parametrize("env", [{"LBMPM_RK3D_BOUNDARY": "2"}, {"LBMPM_RK3D_VARIANT": "1"}, {"LBMPM_RK3D_TILE": "1"},
+@pytest.mark.parametrize("env", [{"LBMPM_RK3D_BOUNDARY": "4"}, {"LBMPM_RK3D_VARIANT": "1"}, {"LBMPM_RK3D_TILE": "1"},
                                  {"LBMPM_RK3D_TILE": "2", "LBMPM_RK3D_CHUNK": "5"}, {"LBMPM_RK3D_FILL": "0"}],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()))
 def test_kernel_schedules_agree_bitwise(env, monkeypatch):
@@ -95,7 +95,7 @@ def test_compact_storage_vs_oracle(relax):
     c.close()
 
 
-@pytest.mark.parametrize("env,k", [({}, 2), ({}, 3), ({"LBMPM_RK3D_BOUNDARY": "2"}, 3), ({"LBMPM_RK3D_TILE": "1"}, 1),
+@pytest.mark.parametrize("env,k", [({}, 2), ({}, 3), ({"LBMPM_RK3D_BOUNDARY": "4"}, 3), ({"LBMPM_RK3D_TILE": "1"}, 1),
                                    ({"LBMPM_RK3D_CHUNK": "7"}, 2)],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
 def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch):
