@@ -26,7 +26,7 @@ def _L():
     global _ready
     L = _lib.lib()
     if not _ready:
-        for (mod, name), (sym, kinds) in KERNELS.items():
+        for (mod, name), (sym, kinds, _names) in KERNELS.items():
             fn = getattr(L, sym)
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p] + list(kinds)
@@ -95,7 +95,7 @@ def device_array(shape, dtype=np.float64, strides=None, order="C", stream=0):
 class Kernel:
     def __init__(self, module, name):
         self.module, self.name = module, name
-        self.sym, self.kinds = KERNELS[(module, name)]
+        self.sym, self.kinds, self.argnames = KERNELS[(module, name)]
         self.__name__ = name
 
     def __getitem__(self, launch_config):            # kernel[grid, block] / kernel[grid, block, stream]
@@ -119,6 +119,16 @@ class Kernel:
             else:
                 conv.append(C.c_double(float(a)))
         _lib.check(getattr(_L(), self.sym)(None, *conv), self.name)
+
+
+def launch_by_name(module, name, values, grid=(1, 1), block=(1, 1)):
+    """kernel[grid, block](*args) with the arguments picked BY THE REFERENCE KERNEL'S PARAMETER NAMES from the mapping
+    `values` (tests and scripted loops: a launch sequence is then a list of kernel names over one name -> array table)"""
+    k = Kernel(module, name)
+    missing = [a for a in k.argnames if a not in values]
+    if missing:
+        raise KeyError("%s: no value for %s" % (name, missing))
+    k[grid, block](*[values[a] for a in k.argnames])
 
 
 def export(module, namespace):

@@ -9,7 +9,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 A = "RKCG2D/AcceleratedRKGPU2D.py"; O = "ShanChen2D/OptimizedD2Q9GPU.py"; E = "ShanChen2D/ExplicitD2Q9GPU.py"
-T = "RKCG2D/AccelerateTransport2DRK.py"
+T = "RKCG2D/AccelerateTransport2DRK.py"; B = "RKCG2D/RKGPU2DBoundary.py"
 
 # (module tag, reference kernel, file:line, "name:kind ...", launcher call)
 SPEC = [
@@ -69,6 +69,62 @@ SPEC = [
   "launch_rk_outlet_pressure_total(st, totalNodes, nx, constPL, fluidNodes, fluidPDFTotal, physicalVY, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
  ("rk", "calPhysicalVelocityRKGPU2DNew1", A + ":2634", "totalNodes:i xDim:i fluidPDFTotal:D fluidRhoR:D fluidRhoB:D physicalVX:D physicalVY:D forceX:D forceY:D",
   "launch_rk_velocity(st, totalNodes, fluidPDFTotal, fluidRhoR, fluidRhoB, physicalVX, physicalVY, forceX, forceY)"),
+ # ---------------- the perturbation loop's kernels (RKD2Q9.py:1046-1223; the 2-D loop the D3Q19 model extends)
+ ("rk", "calPhysicalVelocityRKGPU2D", A + ":125", "totalNodes:i xDim:i fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D physicalVX:D physicalVY:D",
+  "launch_rk_pert_velocity(st, totalNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB, physicalVX, physicalVY)"),
+ ("rk", "constantVelocityZHBoundaryHigherRK", A + ":657", "totalNodes:i nx:i ny:i xDim:i specificVYR:d specificVYB:d fluidNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_pert_inlet_velocity(st, totalNodes, nx, ny, specificVYR, specificVYB, fluidNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rk", "calConstPressureLowerGPU", A + ":1008", "totalNodes:i nx:i xDim:i constPLB:d constPLR:d fluidNodes:I fluidRhoB:D fluidRhoR:D fluidPDFB:D fluidPDFR:D",
+  "launch_rk_pert_outlet_pressure(st, totalNodes, nx, constPLB, constPLR, fluidNodes, fluidRhoB, fluidRhoR, fluidPDFB, fluidPDFR, 0)"),
+ ("rk", "calRKCollision1GPU2DSRTNew", A + ":1125", "totalNodes:i xDim:i delta:d tauR:d tauB:d unitEX:D unitEY:D constantCR:D constantCB:D weightsCoeff:D physicalVX:D physicalVY:D fluidRhoR:D fluidRhoB:D phiValue:D fluidPDFR:D fluidPDFB:D collisionR1:D collisionB1:D",
+  "launch_rk_pert_collide1_srt(st, totalNodes, tauR, tauB, physicalVX, physicalVY, fluidRhoR, fluidRhoB, phiValue, fluidPDFR, fluidPDFB)"),
+ ("rk", "calRKCollision23GPUNew", A + ":1169", "totalNodes:i xDim:i betaCoeff:d AkR:d AkB:d solidPhi:d fluidNodes:I neighboringNodes:I constantB:D weightsCoeff:D unitEX:D unitEY:D schemeGradient:D fluidRhoR:D fluidRhoB:D phiValue:D constantCR:D constantCB:D fluidPDFR:D fluidPDFB:D CGX:D CGY:D fluidPDFTotal:D",
+  "launch_rk_pert_collide23(st, totalNodes, betaCoeff, AkR, AkB, solidPhi, neighboringNodes, constantB, weightsCoeff, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB, fluidPDFTotal)"),
+ ("rk", "calRKCollision1GPU2DMRTNew", A + ":1272", "totalNodes:i xDim:i delta:d tauR:d tauB:d bodyFX:d bodyFY:d unitEX:D unitEY:D constantCR:D constantCB:D weightsCoeff:D physicalVX:D physicalVY:D fluidRhoR:D fluidRhoB:D phiValue:D fluidPDFTotal:D transformationM:D inverseTM:D collisionS:D",
+  "launch_rk_pert_collide1_mrt(st, totalNodes, tauR, tauB, bodyFX, bodyFY, physicalVX, physicalVY, fluidRhoR, fluidRhoB, phiValue, fluidPDFTotal, transformationM, inverseTM, collisionS)"),
+ ("rk", "convectiveAverageBoundaryGPU", A + ":791", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I normalVelocity:D fluidPDFR:D fluidPDFB:D fluidPDFROld:D fluidPDFBOld:D",
+  "launch_rk_outlet_average_row(st, totalNodes, nx, 2, fluidNodes, neighboringNodes, normalVelocity, fluidPDFR, fluidPDFB, fluidPDFROld, fluidPDFBOld)"),
+ ("rk", "convectiveAverageBoundaryGPU2", A + ":820", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I normalVelocity:D fluidPDFR:D fluidPDFB:D fluidPDFROld:D fluidPDFBOld:D",
+  "launch_rk_outlet_average_row(st, totalNodes, nx, 1, fluidNodes, neighboringNodes, normalVelocity, fluidPDFR, fluidPDFB, fluidPDFROld, fluidPDFBOld)"),
+ ("rk", "convectiveAverageBoundaryGPU3", A + ":852", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I normalVelocity:D fluidPDFR:D fluidPDFB:D fluidPDFROld:D fluidPDFBOld:D",
+  "launch_rk_outlet_average_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, normalVelocity, fluidPDFR, fluidPDFB, fluidPDFROld, fluidPDFBOld)"),
+ ("rk", "calConstPressureHighGPU", A + ":1087", "totalNodes:i nx:i ny:i xDim:i constPHB:d constPHR:d fluidNodes:I fluidPDFB:D fluidPDFR:D",
+  "launch_rk_pressure_high(st, totalNodes, nx, ny, constPHB, constPHR, fluidNodes, fluidPDFB, fluidPDFR)"),
+ ("rk", "constantVelocityZHBoundaryHigherNewRK", A + ":2307", "totalNodes:i nx:i ny:i xDim:i specificVYR:d specificVYB:d fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_inlet_velocity_red(st, totalNodes, nx, ny, specificVYR, fluidNodes, neighboringNodes, fluidRhoR, fluidPDFR, fluidPDFB, 0)"),
+ # ---------------- RKGPU2DBoundary.py: the same-named kernels of AcceleratedRKGPU2D.py, four of them with other semantics
+ ("rkb", "constantVelocityZHBoundaryHigherRK", B + ":11", "totalNodes:i nx:i ny:i xDim:i specificVYR:d specificVYB:d fluidNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_pert_inlet_velocity(st, totalNodes, nx, ny, specificVYR, specificVYB, fluidNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rkb", "ghostPointsConstantVelocityRK", B + ":58", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_ghost_inlet_velocity(st, totalNodes, nx, ny, fluidNodes, neighboringNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rkb", "convectiveOutletGPU", B + ":112", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_outlet_convective_row(st, totalNodes, nx, 2, fluidNodes, neighboringNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB)"),
+ ("rkb", "convectiveOutletGhost2GPU", B + ":149", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_outlet_convective_row(st, totalNodes, nx, 1, fluidNodes, neighboringNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB)"),
+ ("rkb", "convectiveOutletGhost3GPU", B + ":187", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_outlet_convective_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB)"),
+ ("rkb", "convectiveAverageBoundaryGPU", B + ":222", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I normalVelocity:D fluidPDFR:D fluidPDFB:D fluidPDFROld:D fluidPDFBOld:D",
+  "launch_rk_outlet_average_row(st, totalNodes, nx, 2, fluidNodes, neighboringNodes, normalVelocity, fluidPDFR, fluidPDFB, fluidPDFROld, fluidPDFBOld)"),
+ ("rkb", "convectiveAverageBoundaryGPU2", B + ":254", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I normalVelocity:D fluidPDFR:D fluidPDFB:D fluidPDFROld:D fluidPDFBOld:D",
+  "launch_rk_outlet_average_row(st, totalNodes, nx, 1, fluidNodes, neighboringNodes, normalVelocity, fluidPDFR, fluidPDFB, fluidPDFROld, fluidPDFBOld)"),
+ ("rkb", "convectiveAverageBoundaryGPU3", B + ":289", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I normalVelocity:D fluidPDFR:D fluidPDFB:D fluidPDFROld:D fluidPDFBOld:D",
+  "launch_rk_outlet_average_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, normalVelocity, fluidPDFR, fluidPDFB, fluidPDFROld, fluidPDFBOld)"),
+ ("rkb", "calConstPressureInletGPU", B + ":325", "totalNodes:i nx:i ny:i xDim:i constPHB:d constPHR:d fluidNodes:I fluidRhoB:D fluidRhoR:D fluidPDFB:D fluidPDFR:D",
+  "launch_rk_inlet_pressure(st, totalNodes, nx, ny, constPHB, constPHR, fluidNodes, fluidRhoB, fluidRhoR, fluidPDFB, fluidPDFR)"),
+ ("rkb", "ghostPointsConstPressureInletRK", B + ":371", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_ghost_inlet_pressure(st, totalNodes, nx, ny, fluidNodes, neighboringNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rkb", "calConstPressureLowerGPU", B + ":414", "totalNodes:i nx:i xDim:i constPLB:d constPLR:d fluidNodes:I fluidRhoB:D fluidRhoR:D fluidPDFB:D fluidPDFR:D",
+  "launch_rk_pert_outlet_pressure(st, totalNodes, nx, constPLB, constPLR, fluidNodes, fluidRhoB, fluidRhoR, fluidPDFB, fluidPDFR, 1)"),
+ ("rkb", "ghostPointsConstPressureLowerRK", B + ":452", "totalNodes:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_ghost_outlet_pressure_grid(st, totalNodes, nx, fluidNodes, neighboringNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rkb", "calConstPressureHighGPU", B + ":496", "totalNodes:i nx:i ny:i xDim:i constPHB:d constPHR:d fluidNodes:I fluidPDFB:D fluidPDFR:D",
+  "launch_rk_pressure_high(st, totalNodes, nx, ny, constPHB, constPHR, fluidNodes, fluidPDFB, fluidPDFR)"),
+ ("rkb", "constantVelocityZHBoundaryHigherNewRK", B + ":535", "totalNodes:i nx:i ny:i xDim:i specificVYR:d specificVYB:d fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_inlet_velocity_red(st, totalNodes, nx, ny, specificVYR, fluidNodes, neighboringNodes, fluidRhoR, fluidPDFR, fluidPDFB, 1)"),
+ ("rkb", "calConstPressureLowerGPUTotal", B + ":581", "totalNodes:i nx:i xDim:i constPL:d fluidNodes:I fluidPDFTotal:D physicalVY:D fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_outlet_pressure_total(st, totalNodes, nx, constPL, fluidNodes, fluidPDFTotal, physicalVY, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rkb", "constantTotalVelocityInlet", B + ":623", "totalNodes:i nx:i ny:i xDim:i specificVY:d fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D fluidPDFTotal:D physicalVY:D",
+  "launch_rk_inlet_velocity_total(st, totalNodes, nx, ny, specificVY, fluidNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB, fluidPDFTotal, physicalVY)"),
  # ---------------- Shan-Chen / EFS (two fluids)
  ("sc", "fillNeighboringNodes", O + ":22", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
   "launch_rk_fill_neighbors(st, totalNodes, nx, ny, fluidNodes, domainNewIndex, neighboringNodes)"),
@@ -205,7 +261,7 @@ int lbmpm_memcpy_d2h(void *dst, const void *src, int64_t bytes);   /* synchronis
 int lbmpm_device_synchronize(void);
 ''']
     ent = ["// GENERATED by tools/gen_shim.py -- extern \"C\" kernel-level entry points\n#pragma once\n"]
-    py = ['"""GENERATED by tools/gen_shim.py: ctypes signatures of the kernel-level entry points."""\nimport ctypes as C\n\nKERNELS = {']
+    py = ['"""GENERATED by tools/gen_shim.py: ctypes signatures of the kernel-level entry points:\n(module tag, reference kernel) -> (C symbol, argument kinds, the reference kernel\'s own argument names)."""\nimport ctypes as C\n\nKERNELS = {']
     for mod, name, cite, args, call in SPEC:
         al = [a.split(":") for a in args.split()]
         cargs = ", ".join("%s%s" % (CT[k] + ("" if CT[k].endswith("*") else " "), n) for n, k in al)
@@ -214,7 +270,7 @@ int lbmpm_device_synchronize(void);
         ent.append("extern \"C\" int %s(void *stream, %s)\n{\n    hipStream_t st = static_cast<hipStream_t>(stream);\n"
                    "    (void)st;%s\n    %s;\n    LBMPM_HIP_TRY(hipGetLastError());\n    return LBMPM_OK;\n}\n"
                    % (sym, cargs, "".join(" (void)%s;" % n for n, k in al), call))
-        py.append("    (%r, %r): (%r, [%s])," % (mod, name, sym, ", ".join(PY[k] for n, k in al)))
+        py.append("    (%r, %r): (%r, [%s], %r)," % (mod, name, sym, ", ".join(PY[k] for n, k in al), tuple(n for n, k in al)))
     hdr.append("\n#ifdef __cplusplus\n}\n#endif\n#endif /* LBMPM_KERNELS_H */\n")
     py.append("}\n")
     open(os.path.join(ROOT, "include", "lbmpm_kernels.h"), "w").write("\n".join(hdr))
