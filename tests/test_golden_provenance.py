@@ -23,6 +23,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="th
     ("make_golden_rk_pert.py", ["srt_porous"], "rkpert_srt_porous.npz"),
     ("make_golden_rkb.py", [], "rkb_kernels.npz"),
     ("make_golden_dense.py", [], "dense_kernels.npz"),
+    ("make_golden_tr_coupled.py", ["capillary"], "trc_capillary.npz"),
 ])
 def test_fixture_is_reproduced_from_the_reference(tmp_path, script, args, fixture):
     env = dict(os.environ, LBMPM_GOLDEN_OUT=str(tmp_path))

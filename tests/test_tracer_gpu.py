@@ -1,6 +1,7 @@
 """GPU parity of the tracer transport fused into the colour-gradient kernel (BASELINE config 4)
 against the coupled oracle (flow oracle pinned by the reference driver; tracer kernels pinned one
-by one by the reference kernels; coupling order by reading Transport2DRK.py:1316-1418)."""
+by one by the reference kernels; coupling order pinned by captures of the real, repaired driver:
+tests/test_tr_coupled.py)."""
 import numpy as np
 import pytest
 
