@@ -606,6 +606,7 @@ struct lbmpm_sc2d {
     int scheme = 4;                  // [ForceScheme] ExplicitScheme
     double *psi = nullptr;           // [2][plane], schemes 8 / 10 only
     int64_t steps = 0, bytes = 0;
+    int64_t graph_launches = 0, timed_steps = 0;      // hipGraph replays so far; time steps covered by the event pairs of the pool
     lbmpm::EventPool pool;
 };
 
@@ -675,7 +676,7 @@ int launch_step(lbmpm_sc2d *c, bool diag, bool timed)
     const int tiles_x = (c->nx + TW - 1) / TW, tiles_y = (c->ny + TH - 1) / TH;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool ev = timed && c->pool.take(&e0, &e1);
-    if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+    if (ev) { LBMPM_HIP_TRY(hipEventRecord(e0, c->stream)); c->timed_steps += 1; }
     if (c->scheme != 4) {
         const dim3 g((c->nx + 63) / 64, (c->ny + 3) / 4), b(64, 4);
         sc2d_iso_psi<<<g, b, 0, c->stream>>>(p);
@@ -693,9 +694,47 @@ int launch_step(lbmpm_sc2d *c, bool diag, bool timed)
     return LBMPM_OK;
 }
 
+// Small lattices are launch-bound (128 x 128: 64 workgroups, 3 us of kernel behind 5 us of launch): there the time loop
+// is replayed from a hipGraph of GRAPH_STEPS captured launches (an even number: the ping-pong buffers are back where they
+// were), so the kernels follow each other at the graph's node-to-node gap instead of the host's launch rate.
+constexpr int GRAPH_STEPS = 64;
+
 int run_steps(lbmpm_sc2d *c, int64_t n, bool timed)
 {
-    for (int64_t k = 0; k < n; ++k) {
+    int64_t k = 0;
+    const bool small = c->plane <= ((size_t)1 << 18) && c->scheme == 4 && !getenv("LBMPM_NO_GRAPH");
+    if (small && n >= 3 * GRAPH_STEPS) {
+        // the first step may be special (EFS initialisation): run it directly
+        int rc = launch_step(c, false, false);
+        if (rc != LBMPM_OK) return rc;
+        ++k;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        LBMPM_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int g = 0; g < GRAPH_STEPS && rc == LBMPM_OK; ++g) rc = launch_step(c, false, false);     // recorded, not run; host state advances
+        hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (rc != LBMPM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        LBMPM_HIP_TRY(e);
+        LBMPM_HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        bool first = true;
+        while (true) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            const bool ev = timed && c->pool.take(&e0, &e1);
+            if (ev) { LBMPM_HIP_TRY(hipEventRecord(e0, c->stream)); c->timed_steps += GRAPH_STEPS; }
+            LBMPM_HIP_TRY(hipGraphLaunch(exec, c->stream));
+            if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
+            if (!first) c->steps += GRAPH_STEPS;            // (the capture pass already counted the first batch)
+            first = false;
+            k += GRAPH_STEPS;
+            c->graph_launches += 1;
+            if (n - k < GRAPH_STEPS + 1) break;             // keep at least one direct step for the diagnostics of the last one
+        }
+        LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        c->diag_valid = false;
+    }
+    for (; k < n; ++k) {
         const bool diag = (c->diag != nullptr) && (k == n - 1);
         // event pairs around every 8th launch only: a record on each side of every 0.1 ms kernel would
         // open a gap behind each of them and slow down the very loop that is being measured
@@ -841,6 +880,7 @@ extern "C" int lbmpm_sc2d_step_timed(lbmpm_sc2d *c, int64_t nsteps, double *ms_t
     const size_t pairs = (size_t)(nsteps < 4096 ? nsteps : 4096);
     if (c->pool.reserve(pairs + 1) != LBMPM_OK) { set_error("hipEventCreate failed"); return LBMPM_ERR_HIP; }
     c->pool.reset();
+    c->timed_steps = 0;
     hipEvent_t t0, t1;
     c->pool.take(&t0, &t1);
     LBMPM_HIP_TRY(hipEventRecord(t0, c->stream));
@@ -852,14 +892,13 @@ extern "C" int lbmpm_sc2d_step_timed(lbmpm_sc2d *c, int64_t nsteps, double *ms_t
     LBMPM_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
     if (ms_total) *ms_total = ms;
     if (ms_dominant) {
-        const size_t timed_launches = c->pool.used / 2 - 1;
         double s = 0.0;
         for (size_t k = 2; k + 1 < c->pool.used; k += 2) {
             float m = 0.f;
             LBMPM_HIP_TRY(hipEventElapsedTime(&m, c->pool.ev[k], c->pool.ev[k + 1]));
             s += m;
         }
-        *ms_dominant = timed_launches ? s * (double)nsteps / (double)timed_launches : 0.0;
+        *ms_dominant = c->timed_steps ? s * (double)nsteps / (double)c->timed_steps : 0.0;    // (a graph replay is timed as a whole)
     }
     return LBMPM_OK;
 }

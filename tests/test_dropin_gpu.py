@@ -1,7 +1,12 @@
-"""GPU tests of the kernel-level drop-in path (include/lbmpm_kernels.h through the numba.cuda-shaped
-shim in openlbmpm_amd/dropin).  The loops below are the reference drivers' own launch statements
-(RKD2Q9.py:1295-1490, ShanChenD2Q9.py:1714-2087 / :1492-1629) with the kernel objects resolved to the
-pre-built HIP kernels; results are compared with the golden vectors the real reference produced."""
+"""GPU tests of the kernel-level drop-in path (include/lbmpm_kernels.h through the numba.cuda-shaped shim in
+openlbmpm_amd/dropin) against the golden vectors the real reference produced.
+
+A time loop here is DATA: a list of (kernel name, {kernel parameter: table entry}) over one table of device arrays and
+scalars; the launcher picks each kernel's arguments by the reference kernel's own parameter names
+(openlbmpm_amd/_kernel_specs.py), so no driver text is re-typed.  The sequences are those of the working reference loops:
+    colour gradient CSF   RKD2Q9.py:1295-1490          explicit forcing   ShanChenD2Q9.py:1714-2087
+    original Shan-Chen    ShanChenD2Q9.py:1492-1629
+One test keeps a handful of literal `kernel[grid, block](...)` statements: that call form is the drop-in interface."""
 import math
 import os
 import sys
@@ -13,382 +18,255 @@ from helpers import GOLDEN, load_params, rel_err
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXV = np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.]); EYV = np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.])
+W9 = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
 
 
 @pytest.fixture(scope="module")
-def dropin():
+def rt():
     sys.path.insert(0, os.path.join(ROOT, "openlbmpm_amd", "dropin"))
     for m in ("numba", "numba.cuda"):
         sys.modules.pop(m, None)
-    from numba import cuda
-    import AcceleratedRKGPU2D as RKGPU2D
-    import OptimizedD2Q9GPU as OPT
-    import ExplicitD2Q9GPU as EXP
-    import AccelerateTransport2DRK as TR
-    yield cuda, RKGPU2D, OPT, EXP, TR
+    import _runtime
+    yield _runtime
     sys.path.remove(os.path.join(ROOT, "openlbmpm_amd", "dropin"))
     for m in ("numba", "numba.cuda"):
         sys.modules.pop(m, None)
 
 
-@pytest.mark.parametrize("scenario", ["csf_mrt_capillary", "csf_mrt_convective", "csf_mrt_pinlet", "csf_mrt_wetting1",
-                                      "csf_srt_capillary"])
-def test_colour_gradient_loop_with_reference_launch_statements(dropin, scenario):
-    """RKD2Q9.py:1295-1490 with its branches: velocity / pressure inlet, pressure / convective outlet, wetting
-    type 1 / 2, SRT / MRT (one captured run of the real driver per branch)"""
-    cuda, RKGPU2D, _, _, _ = dropin
-    from oracle.rk import RKOracle, simple_geometry, mrt_matrices
+class Table(dict):
+    def __init__(self, rt, **kw):
+        dict.__init__(self)
+        self.rt = rt
+        self.put(**kw)
+
+    def put(self, **kw):
+        for k, v in kw.items():
+            self[k] = self.rt.to_device(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+        return self
+
+    def host(self, name):
+        return self[name].copy_to_host()
+
+
+def run(rt, module, table, sequence):
+    from openlbmpm_amd._kernel_specs import KERNELS
+    for kern, rename in sequence:
+        rt.launch_by_name(module, kern, {a: table[rename.get(a, a)] for a in KERNELS[(module, kern)][2]})
+
+
+def check(table, golden, prefix, fields, tol, what):
+    for key, entry in fields.items():
+        e = rel_err(table.host(entry), golden[prefix + key])
+        assert e < tol, "%s %s%s rel err %.3e" % (what, prefix, key, e)
+
+
+def test_numba_call_form_and_signature_checks(rt):
+    """`kernel[grid, block](*args)` with to_device / copy_to_host is the interface a reference driver uses"""
+    from numba import cuda
+    import AcceleratedRKGPU2D as RKGPU2D
+    assert cuda.is_available()
+    grid1D, threadPerBlock1D = (4, 1), (32, 1)
+    rhoR = np.linspace(0.2, 1.0, 100); rhoB = np.linspace(0.9, 0.1, 100)
+    deviceFluidRhoR = cuda.to_device(rhoR); deviceFluidRhoB = cuda.to_device(rhoB)
+    deviceColorValue = cuda.device_array_like(rhoR)
+    RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](100, 128, deviceFluidRhoR, deviceFluidRhoB, deviceColorValue)
+    assert np.array_equal(deviceColorValue.copy_to_host(), (rhoR - rhoB) / (rhoR + rhoB))
+    with pytest.raises(TypeError):       # wrong argument count, like Numba's explicit signatures
+        RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](100, 128, deviceFluidRhoR, deviceFluidRhoB)
+    with pytest.raises(TypeError):       # host array where a device array is expected
+        RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](100, 128, rhoR, deviceFluidRhoB, deviceColorValue)
+
+
+# ------------------------------------------------------------------------------------------------ colour gradient, CSF
+def csf_sequence(par, has_wetting):
+    R = dict(fluidPDF="fluidPDFR", fluidPDFNew="fluidPDFRNew"); Bq = dict(fluidPDF="fluidPDFB", fluidPDFNew="fluidPDFBNew")
+    grad = dict(colorValueFluid="ColorValue", colorValueSolid="colorValueSolid")
+    coll = dict(colorValue="ColorValue", fluidTotalPDF="fluidPDFTotal")
+    seq = []
+    if par["inlet"] == "Neumann":
+        seq += [("constantTotalVelocityInlet", {}), ("ghostPointsConstantVelocityRK", {})]
+    else:
+        seq += [("calConstPressureInletGPU", {}), ("ghostPointsConstPressureInletRK", {})]
+    if par["outlet"] == "Convective":
+        seq += [("convectiveOutletGPU", {}), ("convectiveOutletGhost2GPU", {}), ("convectiveOutletGhost3GPU", {})]
+    else:
+        seq += [("calConstPressureLowerGPUTotal", {}), ("ghostPointsConstPressureLowerRK", {})]
+    seq += [("calTotalFluidPDF", {}), ("calPhysicalVelocityRKGPU2DNew1", {}), ("calPhaseFieldPhi", dict(phiValue="ColorValue")),
+            ("calColorValueOnSolid", dict(grad, xDim="xDim")), ("calRKInitialGradient", grad)]
+    if has_wetting:
+        seq += [("updateColorGradientOnWetting" if par["wetting"] == 1 else "updateColorGradientOnWettingNew", {})]
+    seq += [("calForceTermInColorGradient2D" if par["wetting"] == 1 else "calForceTermInColorGradientNew2D", {})]
+    if par["relax"] == "SRT":
+        seq += [("calRKCollision1TotalGPU2DSRTM", {}), ("calPerturbationFromForce2D", coll)]
+    else:
+        seq += [("calRKCollision1TotalGPU2DMRTM", {}), ("calPerturbationFromForce2DMRT", coll)]
+    seq += [("calRecoloringProcessM", {}), ("calStreaming1GPU", R), ("calStreaming1GPU", Bq), ("calStreaming2GPU", R), ("calStreaming2GPU", Bq),
+            ("calTotalFluidPDF", {}), ("calMacroDensityRKGPU2D", {})]
+    return seq
+
+
+@pytest.mark.parametrize("scenario", ["csf_mrt_capillary", "csf_mrt_convective", "csf_mrt_pinlet", "csf_mrt_wetting1", "csf_srt_capillary"])
+def test_colour_gradient_loop(rt, scenario):
+    """velocity / pressure inlet, pressure / convective outlet, wetting type 1 / 2, SRT / MRT: one capture of the real driver each"""
+    from oracle.rk import RKOracle, mrt_matrices
     d = np.load(os.path.join(GOLDEN, "rk_%s.npz" % scenario))
     par = load_params(d)
-    xDomain, yDomain = par["nx"], par["ny"]
-    o = RKOracle(d["isDomain"], par)                           # host set-up only (tables, initial fields)
+    o = RKOracle(d["isDomain"], par)                           # host set-up only (compaction tables, normals, initial fields)
     assert np.array_equal(o.fluidNodes, d["fluidNodes"])
-    assert cuda.is_available()
-    totalNodes = o.N
-    xDimension, threadNum = 128, 32
-    grid1D = (int(xDimension / threadNum), math.ceil(totalNodes / xDimension)); threadPerBlock1D = (threadNum, 1)
-    # neighbour tables by the drop-in kernels themselves (RKD2Q9.py:709-716)
-    deviceFluidNodes = cuda.to_device(o.fluidNodes); deviceIdx = cuda.to_device(o.newIndex)
-    deviceNeighboringNodes = cuda.to_device(np.zeros(8 * totalNodes, dtype=np.int64))
-    RKGPU2D.fillNeighboringNodes[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension, deviceFluidNodes,
-                                                          deviceIdx, deviceNeighboringNodes)
-    assert np.array_equal(deviceNeighboringNodes.copy_to_host(), d["neighboringNodes"])
-    deviceWet = cuda.to_device(o.wettingSolidNodes)
-    deviceNeighboringWettingSolid = cuda.to_device(np.zeros(8 * o.W, dtype=np.int64))
-    RKGPU2D.fillNeighboringWettingNodes[grid1D, threadPerBlock1D](o.W, xDomain, yDomain, xDimension, deviceWet, deviceIdx,
-                                                                 deviceNeighboringWettingSolid)
-    assert np.array_equal(deviceNeighboringWettingSolid.copy_to_host(), d["neighboringWettingSolidNodes"])
-    # device arrays as in RKD2Q9.py:1243-1287
-    deviceFluidRhoR = cuda.to_device(o.rhoR); deviceFluidRhoB = cuda.to_device(o.rhoB)
-    deviceFluidPDFR = cuda.to_device(o.fR); deviceFluidPDFB = cuda.to_device(o.fB)
-    deviceFluidPDFRNew = cuda.to_device(np.zeros_like(o.fR)); deviceFluidPDFBNew = cuda.to_device(np.zeros_like(o.fB))
-    devicePhysicalVX = cuda.to_device(np.zeros(totalNodes)); devicePhysicalVY = cuda.to_device(np.zeros(totalNodes))
-    deviceColorValue = cuda.to_device(np.zeros(totalNodes))
-    deviceFluidPDFTotal = cuda.to_device(o.fR + o.fB)
-    deviceForceX = cuda.to_device(np.zeros(totalNodes)); deviceForceY = cuda.to_device(np.zeros(totalNodes))
-    deviceGradientX = cuda.to_device(np.zeros(totalNodes)); deviceGradientY = cuda.to_device(np.zeros(totalNodes))
-    deviceSolidColor = cuda.to_device(np.zeros(o.W)); deviceKValue = cuda.to_device(o.rhoB)
-    deviceFluidNodesWithSolid = cuda.to_device(o.fluidWet)
-    deviceUnitNsx = cuda.to_device(o.nsx); deviceUnitNsy = cuda.to_device(o.nsy)
-    w = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
-    deviceWeightsCoeff = cuda.to_device(w)
-    deviceUnitEX = cuda.to_device(np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.]))
-    deviceUnitEY = cuda.to_device(np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.]))
+    N = o.N
     M, Minv, S = mrt_matrices()
-    deviceTransformationM = cuda.to_device(M); deviceTransformationIM = cuda.to_device(Minv); deviceCollisionM = cuda.to_device(S)
     th = par["theta"] / 180. * np.pi
-    cosTheta, sinTheta = float(np.cos(th)), float(np.sin(th))
-    specificVY = par["vyB"] + par["vyR"]; totalPressure = par["rhoBL"] + par["rhoRL"]
-    numColorSolid, numWettingFluid = o.W, o.Wf
-
+    z = lambda *s: np.zeros(s)
+    t = Table(rt, totalNodes=N, totalNum=N, totalSolidWetting=o.W, totalWettingNodes=o.W, numColorSolid=o.W, totalFluidWettingNodes=o.Wf,
+              nx=par["nx"], ny=par["ny"], xDim=128, fluidNodes=o.fluidNodes, domainNewIndex=o.newIndex, wettingNodes=o.wettingSolidNodes,
+              neighboringNodes=np.zeros(8 * N, dtype=np.int64), neighboringWettingNodes=np.zeros(8 * max(o.W, 1), dtype=np.int64),
+              fluidRhoR=o.rhoR, fluidRhoB=o.rhoB, fluidPDFR=o.fR, fluidPDFB=o.fB, fluidPDFRNew=z(N, 9), fluidPDFBNew=z(N, 9),
+              fluidPDFTotal=o.fR + o.fB, physicalVX=z(N), physicalVY=z(N), ColorValue=z(N), colorValueSolid=z(max(o.W, 1)),
+              forceX=z(N), forceY=z(N), gradientX=z(N), gradientY=z(N), KValue=o.rhoB, fluidNodesWetting=o.fluidWet,
+              unitVectorNsx=o.nsx, unitVectorNsy=o.nsy, weightsCoeff=W9, unitEX=EXV, unitEY=EYV, transformationM=M, inverseTM=Minv, collisionS=S,
+              cosTheta=float(np.cos(th)), sinTheta=float(np.sin(th)), specificVY=par["vyB"] + par["vyR"], constPL=par["rhoBL"] + par["rhoRL"],
+              constPHB=par["rhoBH"], constPHR=par["rhoRH"], surfaceTension=par["sigma"], optionF=par["tautype"], tauR=par["tauR"],
+              tauB=par["tauB"], deltaValue=par["delta"], betaValue=par["beta"])
+    run(rt, "rk", t, [("fillNeighboringNodes", {})])                       # RKD2Q9.py:709-716
+    assert np.array_equal(t.host("neighboringNodes"), d["neighboringNodes"])
+    if o.W:
+        run(rt, "rk", t, [("fillNeighboringWettingNodes", {})])
+        assert np.array_equal(t.host("neighboringWettingNodes"), d["neighboringWettingSolidNodes"])
+    t["neighboringWettingSolid"] = t["neighboringWettingNodes"]
+    seq = csf_sequence(par, o.Wf > 0)
+    fields = dict(fR="fluidPDFR", fB="fluidPDFB", rhoR="fluidRhoR", rhoB="fluidRhoB", vx="physicalVX", vy="physicalVY", phi="ColorValue",
+                  Gx="gradientX", Gy="gradientY", Fx="forceX", Fy="forceY", K="KValue")
     snaps = [int(k) for k in d["snaps"] if int(k) <= 50]
-    for iStep in range(1, max(snaps) + 1):
-        if par["inlet"] == "Neumann":
-            RKGPU2D.constantTotalVelocityInlet[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension, specificVY,
-                    deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR,
-                    deviceFluidPDFB, deviceFluidPDFTotal, devicePhysicalVY)
-            RKGPU2D.ghostPointsConstantVelocityRK[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension,
-                    deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR,
-                    deviceFluidPDFB, deviceForceX, deviceForceY)
-        if par["inlet"] == "Dirichlet":
-            RKGPU2D.calConstPressureInletGPU[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension, par["rhoBH"],
-                    par["rhoRH"], deviceFluidNodes, deviceFluidRhoB, deviceFluidRhoR, deviceFluidPDFB, deviceFluidPDFR)
-            RKGPU2D.ghostPointsConstPressureInletRK[grid1D, threadPerBlock1D](totalNodes, xDomain, yDomain, xDimension,
-                    deviceFluidNodes, deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR, deviceFluidPDFB)
-        if par["outlet"] == "Convective":
-            RKGPU2D.convectiveOutletGPU[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
-                    deviceNeighboringNodes, deviceFluidPDFR, deviceFluidPDFB, deviceFluidRhoR, deviceFluidRhoB)
-            RKGPU2D.convectiveOutletGhost2GPU[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
-                    deviceNeighboringNodes, deviceFluidPDFR, deviceFluidPDFB, deviceFluidRhoR, deviceFluidRhoB)
-            RKGPU2D.convectiveOutletGhost3GPU[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
-                    deviceNeighboringNodes, deviceFluidPDFR, deviceFluidPDFB, deviceFluidRhoR, deviceFluidRhoB)
-        elif par["outlet"] == "Dirichlet":
-            RKGPU2D.calConstPressureLowerGPUTotal[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, totalPressure,
-                    deviceFluidNodes, deviceFluidPDFTotal, devicePhysicalVY, deviceFluidRhoR, deviceFluidRhoB,
-                    deviceFluidPDFR, deviceFluidPDFB)
-            RKGPU2D.ghostPointsConstPressureLowerRK[grid1D, threadPerBlock1D](totalNodes, xDomain, xDimension, deviceFluidNodes,
-                    deviceNeighboringNodes, deviceFluidRhoR, deviceFluidRhoB, deviceFluidPDFR, deviceFluidPDFB)
-        RKGPU2D.calTotalFluidPDF[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFR, deviceFluidPDFB,
-                deviceFluidPDFTotal)
-        RKGPU2D.calPhysicalVelocityRKGPU2DNew1[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFTotal,
-                deviceFluidRhoR, deviceFluidRhoB, devicePhysicalVX, devicePhysicalVY, deviceForceX, deviceForceY)
-        RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidRhoR, deviceFluidRhoB,
-                deviceColorValue)
-        RKGPU2D.calColorValueOnSolid[grid1D, threadPerBlock1D](numColorSolid, xDimension, deviceNeighboringWettingSolid,
-                deviceWeightsCoeff, deviceColorValue, deviceSolidColor)
-        RKGPU2D.calRKInitialGradient[grid1D, threadPerBlock1D](totalNodes, xDimension, numColorSolid, deviceFluidNodes,
-                deviceNeighboringNodes, deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, deviceColorValue, deviceSolidColor,
-                deviceGradientX, deviceGradientY)
-        wet = RKGPU2D.updateColorGradientOnWetting if par["wetting"] == 1 else RKGPU2D.updateColorGradientOnWettingNew
-        if numWettingFluid > 0:
-            wet[grid1D, threadPerBlock1D](numWettingFluid, xDimension, cosTheta, sinTheta,
-                    deviceFluidNodesWithSolid, deviceUnitNsx, deviceUnitNsy, deviceGradientX, deviceGradientY)
-        force = RKGPU2D.calForceTermInColorGradient2D if par["wetting"] == 1 else RKGPU2D.calForceTermInColorGradientNew2D
-        force[grid1D, threadPerBlock1D](totalNodes, xDimension, par["sigma"],
-                deviceNeighboringNodes, deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, deviceGradientX, deviceGradientY,
-                deviceForceX, deviceForceY, deviceKValue)
-        if par["relax"] == "SRT":
-            RKGPU2D.calRKCollision1TotalGPU2DSRTM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
-                    par["tauB"], par["delta"], deviceUnitEX, deviceUnitEY, deviceWeightsCoeff, devicePhysicalVX, devicePhysicalVY,
-                    deviceFluidRhoR, deviceFluidRhoB, deviceColorValue, deviceFluidPDFTotal)
-            RKGPU2D.calPerturbationFromForce2D[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
-                    par["tauB"], par["delta"], deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, devicePhysicalVX, devicePhysicalVY,
-                    deviceForceX, deviceForceY, deviceColorValue, deviceFluidPDFTotal, deviceFluidRhoR, deviceFluidRhoB)
-        else:
-            RKGPU2D.calRKCollision1TotalGPU2DMRTM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
-                    par["tauB"], par["delta"], deviceUnitEX, deviceUnitEY, deviceWeightsCoeff, devicePhysicalVX, devicePhysicalVY,
-                    deviceFluidRhoR, deviceFluidRhoB, deviceColorValue, deviceFluidPDFTotal, deviceTransformationM,
-                    deviceTransformationIM, deviceCollisionM)
-            RKGPU2D.calPerturbationFromForce2DMRT[grid1D, threadPerBlock1D](totalNodes, xDimension, par["tautype"], par["tauR"],
-                    par["tauB"], par["delta"], deviceWeightsCoeff, deviceUnitEX, deviceUnitEY, devicePhysicalVX, devicePhysicalVY,
-                    deviceForceX, deviceForceY, deviceColorValue, deviceFluidPDFTotal, deviceTransformationM,
-                    deviceTransformationIM, deviceCollisionM, deviceFluidRhoR, deviceFluidRhoB)
-        RKGPU2D.calRecoloringProcessM[grid1D, threadPerBlock1D](totalNodes, xDimension, par["beta"], deviceWeightsCoeff,
-                deviceFluidRhoR, deviceFluidRhoB, deviceUnitEX, deviceUnitEY, deviceGradientX, deviceGradientY,
-                deviceFluidPDFR, deviceFluidPDFB, deviceFluidPDFTotal)
-        RKGPU2D.calStreaming1GPU[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidNodes, deviceNeighboringNodes,
-                deviceFluidPDFR, deviceFluidPDFRNew)
-        RKGPU2D.calStreaming1GPU[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidNodes, deviceNeighboringNodes,
-                deviceFluidPDFB, deviceFluidPDFBNew)
-        RKGPU2D.calStreaming2GPU[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFRNew, deviceFluidPDFR)
-        RKGPU2D.calStreaming2GPU[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFBNew, deviceFluidPDFB)
-        RKGPU2D.calTotalFluidPDF[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFR, deviceFluidPDFB,
-                deviceFluidPDFTotal)
-        RKGPU2D.calMacroDensityRKGPU2D[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidPDFR, deviceFluidPDFB,
-                deviceFluidRhoR, deviceFluidRhoB)
-        if iStep in snaps:
-            got = dict(fR=deviceFluidPDFR, fB=deviceFluidPDFB, rhoR=deviceFluidRhoR, rhoB=deviceFluidRhoB,
-                       vx=devicePhysicalVX, vy=devicePhysicalVY, phi=deviceColorValue, Gx=deviceGradientX,
-                       Gy=deviceGradientY, Fx=deviceForceX, Fy=deviceForceY, K=deviceKValue)
-            for name, arr in got.items():
-                e = rel_err(arr.copy_to_host(), d["s%d_%s" % (iStep, name)])
-                assert e < 1e-11, "step %d %s rel err %.3e" % (iStep, name, e)
-    with pytest.raises(TypeError):       # wrong argument count, like Numba's explicit signatures
-        RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](totalNodes, xDimension, deviceFluidRhoR, deviceFluidRhoB)
-    with pytest.raises(TypeError):       # host array where a device array is expected
-        RKGPU2D.calPhaseFieldPhi[grid1D, threadPerBlock1D](totalNodes, xDimension, o.rhoR, deviceFluidRhoB, deviceColorValue)
+    for step in range(1, max(snaps) + 1):
+        run(rt, "rk", t, seq)
+        if step in snaps:
+            check(t, d, "s%d_" % step, fields, 1e-11, "%s step %d" % (scenario, step))
 
 
-@pytest.mark.parametrize("scenario", ["efs_srt_dirichlet", "efs_mrt_dirichlet", "efs_srt_convective", "efs_srt_iso8", "efs_srt_iso10"])
-def test_explicit_forcing_loop_with_reference_launch_statements(dropin, scenario):
-    cuda, _, OPT, EXP, _ = dropin
-    from oracle.sc import SCOracle, simple_geometry, collision_matrices
-    g = np.load(os.path.join(GOLDEN, "sc_%s.npz" % scenario))
-    par = load_params(g)
-    nx, ny = par["nx"], par["ny"]
-    keys = ("inter", "relax", "rho0", "rho1", "bg0", "bg1", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "vy0", "vy1")
-    o = SCOracle.__new__(SCOracle)          # host set-up only: tables + initial densities
-    from oracle.sc import initial_densities
-    from oracle import lib as olib
-    dom = simple_geometry(nx, ny)
-    fluidNodes = np.flatnonzero(dom.reshape(-1) == 1).astype(np.int64)
-    N = fluidNodes.size
-    newIndex = -np.ones(nx * ny, dtype=np.int64); newIndex[fluidNodes] = np.arange(N)
-    typesFluids = 2
-    rho0 = initial_densities(dom, False, par).reshape(2, -1)[:, fluidNodes]
-    w9 = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
-    optFluidPDF = np.ascontiguousarray(w9[None, None, :] * rho0[:, :, None])
-    xDimension, threadNum = 256, 32
-    grid1D = (int(xDimension / threadNum), math.ceil(N / xDimension)); tpb = (threadNum, 1)
-    dFluidIndices = cuda.to_device(fluidNodes); dIdx = cuda.to_device(newIndex)
-    dNbr = cuda.to_device(np.zeros(8 * N, dtype=np.int64))
-    OPT.fillNeighboringNodes[grid1D, tpb](N, nx, ny, xDimension, dFluidIndices, dIdx, dNbr)
-    assert np.array_equal(dNbr.copy_to_host(), g["neighboringNodes"])
-    dPDF = cuda.to_device(optFluidPDF); dPDFold = cuda.to_device(optFluidPDF); dPDFNew = cuda.to_device(optFluidPDF)
-    dRho = cuda.to_device(np.ascontiguousarray(rho0)); dPot = cuda.to_device(np.zeros((2, N)))
-    dEqVX = cuda.to_device(np.zeros(N)); dEqVY = cuda.to_device(np.zeros(N))
-    dFx = cuda.to_device(np.zeros((2, N))); dFy = cuda.to_device(np.zeros((2, N)))
-    dFeq = cuda.to_device(optFluidPDF); dFF = cuda.to_device(np.zeros_like(optFluidPDF))
-    dVX = cuda.to_device(np.zeros(N)); dVY = cuda.to_device(np.zeros(N))
-    tau = np.array([par["tau0"], par["tau1"]])
-    dTau = cuda.to_device(tau)
-    dG = cuda.to_device(np.array([[0., par["G"]], [par["G"], 0.]])); dGs = cuda.to_device(np.array([par["Gs0"], par["Gs1"]]))
-    dEX = cuda.to_device(np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.])); dEY = cuda.to_device(np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.]))
-    scheme = int(par.get("scheme", 4))
-    weights = {4: [1. / 3.] * 4 + [1. / 12.] * 4,
-               8: [4. / 21.] * 4 + [4. / 45.] * 4 + [1. / 60.] * 4 + [1. / 5040.] * 4 + [2. / 315.] * 8,
-               10: [262. / 1785.] * 4 + [93. / 1190.] * 4 + [7. / 340.] * 4 + [9. / 9520.] * 4 + [6. / 595.] * 8 +
-                   [2. / 5355.] * 4 + [1. / 7140.] * 8}[scheme]          # ShanChenD2Q9.py:1675-1689
-    dWI = cuda.to_device(np.array(weights)); dW = cuda.to_device(w9)
-    if scheme == 8:
-        dNbrX = cuda.to_device(np.zeros(24 * N, dtype=np.int64))
-        EXP.fillNeighboringNodesISO8[grid1D, tpb](N, nx, ny, xDimension, dFluidIndices, dIdx, dNbrX)
-    elif scheme == 10:
-        dNbrX = cuda.to_device(np.zeros(36 * N, dtype=np.int64))
-        EXP.fillNeighboringNodesISO10[grid1D, tpb](N, nx, ny, xDimension, dFluidIndices, dIdx, dNbrX)
-    dVelY = cuda.to_device(np.array([par["vy0"], par["vy1"]]))
-    mrt = par["relax"] == "MRT"
-    if mrt:
-        dLam = cuda.to_device(collision_matrices(tau)); dConserveS = cuda.to_device(np.ones(2))
-        dFFM = cuda.to_device(np.zeros_like(optFluidPDF)); dPDFM = cuda.to_device(optFluidPDF)
-
-    def chain():
-        OPT.calFluidPotentialGPUEql[grid1D, tpb](N, typesFluids, xDimension, dRho, dPot)
-        if scheme == 4:
-            EXP.calExplicit4thOrderScheme[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbr, dWI, dG, dGs, dPot, dFx, dFy)
-        elif scheme == 8:
-            EXP.calExplicit8thOrderScheme[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbrX, dWI, dG, dGs, dPot, dFx, dFy)
-        else:
-            EXP.calExplicit10thOrderScheme[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbrX, dWI, dG, dGs, dPot, dFx, dFy)
-        if mrt:
-            EXP.transformEquilibriumVelocity[grid1D, tpb](N, typesFluids, xDimension, dEX, dEY, dRho, dFx, dFy, dPDF,
-                                                          dConserveS, dEqVX, dEqVY)
-        else:
-            EXP.calEquilibriumVEFGPU[grid1D, tpb](N, typesFluids, xDimension, dTau, dEX, dEY, dRho, dFx, dFy, dPDF, dEqVX, dEqVY)
-        EXP.calEquilibriumFuncEFGPU[grid1D, tpb](N, typesFluids, xDimension, dW, dEX, dEY, dRho, dEqVX, dEqVY, dFeq)
-        EXP.calForceDistrGPU[grid1D, tpb](N, typesFluids, xDimension, dEX, dEY, dEqVX, dEqVY, dRho, dFx, dFy, dFeq, dFF)
-
-    def inlet():                      # ShanChenD2Q9.py:1794-1825, :1989-2020
-        if scheme == 4:
-            OPT.constantVelocityZouHeBoundaryHigher[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dVelY, dFluidIndices, dRho, dPDF)
-            OPT.ghostPointsConstantVelocityInlet[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
-        if scheme == 8:
-            OPT.constantVelocityZouHeBoundaryHigher8[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dVelY, dFluidIndices, dRho, dPDF)
-            OPT.ghostPointsConstantVelocity8[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
-            OPT.ghostPointsConstantVelocity82[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
-
-    def outlet_dirichlet():           # :1826-1849, :1931-1953
-        if scheme == 4:
-            OPT.constantPressureZouHeBoundaryLower[grid1D, tpb](N, typesFluids, nx, xDimension, 1.002, dFluidIndices, dRho, dPDF)
-            OPT.ghostPointsConstantPressureOutlet[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dRho, dPDF)
-        elif scheme == 8:
-            OPT.constantPressureZouHeBoundaryLower8[grid1D, tpb](N, typesFluids, nx, xDimension, 1.002, dFluidIndices, dRho, dPDF)
-            OPT.ghostPointsConstantPressureOutlet8[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dRho, dPDF)
-            OPT.ghostPointsConstantPressureOutlet82[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dRho, dPDF)
-
-    # pre-loop, ShanChenD2Q9.py:1714-1849
-    chain()
-    EXP.transformPDFGPU[grid1D, tpb](N, typesFluids, xDimension, dPDF, dFF)
-    inlet()
-    if par["outlet"] == "Dirichlet":
-        outlet_dirichlet()
-    snaps = [int(k) for k in g["snaps"] if int(k) <= 10]
-    for i in range(max(snaps) + 1):          # ShanChenD2Q9.py:1852-2087
-        OPT.savePDFLastStep[grid1D, tpb](N, typesFluids, xDimension, dPDF, dPDFold)
-        if mrt:
-            EXP.transfromForceTerm[grid1D, tpb](N, typesFluids, xDimension, dFF, dLam, dFFM)
-            EXP.transformPDFandEquil[grid1D, tpb](N, typesFluids, xDimension, dPDF, dFeq, dLam, dPDFM)
-            EXP.calAfterCollisionMRT[grid1D, tpb](N, typesFluids, xDimension, dPDF, dFF, dFeq, dPDFM, dFFM)
-        else:
-            EXP.calCollisionEXGPU[grid1D, tpb](N, typesFluids, xDimension, dTau, dPDF, dFeq, dFF)
-        OPT.calStreaming1GPU[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbr, dPDF, dPDFNew)
-        OPT.calStreaming2GPU[grid1D, tpb](N, typesFluids, xDimension, dPDFNew, dPDF)
-        OPT.calFluidRhoGPU[grid1D, tpb](N, typesFluids, xDimension, dRho, dPDF)
-        OPT.calPhysicalVelocity[grid1D, tpb](N, typesFluids, xDimension, dPDF, dRho, dFx, dFy, dVX, dVY)
-        if par["outlet"] == "Convective":
-            OPT.convectiveOutletEachGPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dPDFold, dRho, dVY)
-            OPT.convectiveOutletEach2GPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dPDFold, dRho, dVY)
-            OPT.convectiveOutletEach3GPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dPDFold, dRho, dVY)
-        else:
-            outlet_dirichlet()
-        inlet()
-        OPT.calFluidRhoGPU[grid1D, tpb](N, typesFluids, xDimension, dRho, dPDF)
-        OPT.calPhysicalVelocity[grid1D, tpb](N, typesFluids, xDimension, dPDF, dRho, dFx, dFy, dVX, dVY)
-        chain()
-        if i in snaps:
-            for name, arr in dict(f=dPDF, rho=dRho, Fx=dFx, Fy=dFy, vx=dVX, vy=dVY, ueqx=dEqVX, ueqy=dEqVY, feq=dFeq,
-                                  fforce=dFF).items():
-                e = rel_err(arr.copy_to_host(), g["s%d_%s" % (i, name)])
-                assert e < 1e-11, "%s pass %d %s rel err %.3e" % (scenario, i, name, e)
-
-
-def test_tracer_kernels_against_reference_vectors(dropin):
-    cuda, _, _, _, TR = dropin
-    d = np.load(os.path.join(GOLDEN, "tr_kernels.npz"))
-    N = int(d["fluidNodes"].size); ny, nx = d["isDomain"].shape; nT = 2
-    cfg = ((4, math.ceil(N / 128)), (32, 1)); xDim = 128
-    dev = lambda a: cuda.to_device(np.ascontiguousarray(a))
-    newidx = -np.ones((ny, nx), dtype=np.int64); newidx.reshape(-1)[d["fluidNodes"]] = np.arange(N)
-    dFl = dev(d["fluidNodes"]); dNbr = dev(np.zeros(4 * N, dtype=np.int64))
-    TR.fillNeighboringNodesTransport[cfg](N, nx, ny, xDim, dFl, dev(newidx), dNbr)
-    assert np.array_equal(dNbr.copy_to_host(), d["nbr"])
-    dC = dev(np.zeros((nT, N))); dG = dev(d["conc_in_g"])
-    TR.calConcentrationGPU[cfg](N, nT, xDim, 5, dC, dG)
-    assert rel_err(dC.copy_to_host(), d["conc_out"]) < 1e-13
-    uvx = dev(np.array([0., 1., -1, 0., 0.])); uvy = dev(np.array([0., 0., 0., 1., -1.]))
-    w = dev(d["w"])
-    TR.calCollisionTransportLinearEqlMRTGPU[cfg](N, xDim, nT, uvx, uvy, dev(d["col_vx"]), dev(d["col_vy"]), dC, dG, dev(d["M"]),
-                                                 dev(d["A"]), w)
-    assert rel_err(dG.copy_to_host(), d["col_out_g"]) < 1e-13
-    dInd = dev(np.zeros(N))
-    TR.calValueTransportDomain[cfg](N, xDim, 0.5, dInd, dev(d["ind_rhoR"]))
-    assert np.array_equal(dInd.copy_to_host(), d["ind_out"])
-    ex9 = dev(np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.])); ey9 = dev(np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.]))
-    TR.calTransportWithInterfaceD2Q5[cfg](N, xDim, nT, dev(d["itf_beta"]), dInd, ex9, ey9, dev(d["itf_Gx"]), dev(d["itf_Gy"]), w, dC, dG)
-    assert rel_err(dG.copy_to_host(), d["itf_out_g"]) < 1e-13
-    TR.calFreeConcBoundary3[cfg](N, nT, nx, xDim, dFl, dNbr, dC, dG)
-    assert np.array_equal(dG.copy_to_host(), d["free_out_g"])
-    dGN = dev(np.zeros((nT, N, 5)))
-    TR.calStreamingTransportGPU[cfg](N, xDim, nT, dNbr, dG, dGN)
-    TR.calStreamingTransport2GPU[cfg](N, nT, xDim, dGN, dG)
-    assert np.array_equal(dG.copy_to_host(), d["str_out_g"])
-    TR.calInamuroConstConcBoundary[cfg](N, xDim, nT, ny, nx, dFl, dNbr, dev(d["ina_cb"]), w, dG)
-    assert rel_err(dG.copy_to_host(), d["ina_out_g"]) < 1e-13
-    dG3 = dev(d["rea_in_g"])                    # reaction between three tracers
-    TR.calReactionTracersGPU[cfg](N, 3, xDim, dev(d["rea_rate"]), dev(d["rea_J"]), dev(d["rea_conc"]), dG3)
-    assert rel_err(dG3.copy_to_host(), d["rea_out_g"]) < 1e-13
-
-
-@pytest.mark.parametrize("scenario", ["sc_srt_convective"])
-def test_original_shan_chen_loop_with_reference_launch_statements(dropin, scenario):
-    """runOptimizedLBM, ShanChenD2Q9.py:1492-1629 (Neumann / Zou-He inlet, convective outlet): the fused
-    interaction + collision kernel, the three outlet-row kernels and the (result-less) whole-fluid velocity"""
-    cuda, _, OPT, _, _ = dropin
+# ------------------------------------------------------------------------------------------------ Shan-Chen family
+def sc_table(rt, g, par, with_iso):
     from oracle.sc import simple_geometry, initial_densities
-    g = np.load(os.path.join(GOLDEN, "sc_%s.npz" % scenario))
-    par = load_params(g)
     nx, ny = par["nx"], par["ny"]
     dom = simple_geometry(nx, ny)
     fluidNodes = np.flatnonzero(dom.reshape(-1) == 1).astype(np.int64)
     assert np.array_equal(fluidNodes, g["fluidNodes"])
     N = fluidNodes.size
     newIndex = -np.ones(nx * ny, dtype=np.int64); newIndex[fluidNodes] = np.arange(N)
-    typesFluids = 2
-    rho0 = initial_densities(dom, False, par).reshape(2, -1)[:, fluidNodes]
-    w9 = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
-    optFluidPDF = np.ascontiguousarray(w9[None, None, :] * rho0[:, :, None])
-    assert rel_err(optFluidPDF, g["init_f"]) < 1e-15
-    xDimension, threadNum = 256, 32
-    grid1D = (int(xDimension / threadNum), math.ceil(N / xDimension)); tpb = (threadNum, 1)
-    dFluidIndices = cuda.to_device(fluidNodes); dIdx = cuda.to_device(newIndex)
-    dNbr = cuda.to_device(np.zeros(8 * N, dtype=np.int64))
-    OPT.fillNeighboringNodes[grid1D, tpb](N, nx, ny, xDimension, dFluidIndices, dIdx, dNbr)
-    dPDF = cuda.to_device(optFluidPDF); dPDFold = cuda.to_device(optFluidPDF); dPDFNew = cuda.to_device(optFluidPDF)
-    dRho = cuda.to_device(np.ascontiguousarray(rho0)); dPot = cuda.to_device(np.zeros((2, N)))
-    dFx = cuda.to_device(np.zeros((2, N))); dFy = cuda.to_device(np.zeros((2, N)))
-    dVX = cuda.to_device(np.zeros(N)); dVY = cuda.to_device(np.zeros(N))
-    dPrimeVX = cuda.to_device(np.zeros(N)); dPrimeVY = cuda.to_device(np.zeros(N))
+    rho0 = np.ascontiguousarray(initial_densities(dom, False, par).reshape(2, -1)[:, fluidNodes])
+    f0 = np.ascontiguousarray(W9[None, None, :] * rho0[:, :, None])
+    scheme = int(par.get("scheme", 4))
+    weights = {4: [1. / 3.] * 4 + [1. / 12.] * 4,
+               8: [4. / 21.] * 4 + [4. / 45.] * 4 + [1. / 60.] * 4 + [1. / 5040.] * 4 + [2. / 315.] * 8,
+               10: [262. / 1785.] * 4 + [93. / 1190.] * 4 + [7. / 340.] * 4 + [9. / 9520.] * 4 + [6. / 595.] * 8 +
+                   [2. / 5355.] * 4 + [1. / 7140.] * 8}[scheme]          # ShanChenD2Q9.py:1675-1689
     tau = np.array([par["tau0"], par["tau1"]])
-    dTau = cuda.to_device(tau)
-    dG = cuda.to_device(np.array([[0., par["G"]], [par["G"], 0.]])); dGs = cuda.to_device(np.array([par["Gs0"], par["Gs1"]]))
-    dWI = cuda.to_device(np.array([1. / 9.] * 4 + [1. / 36.] * 4)); dW = cuda.to_device(w9)       # ShanChenD2Q9.py:1478
-    dVelY = cuda.to_device(np.array([par["vy0"], par["vy1"]]))
+    z = lambda *s: np.zeros(s)
+    t = Table(rt, totalNodes=N, totalNum=N, numFluids=2, nx=nx, ny=ny, xDim=256, fluidNodes=fluidNodes, domainNewIndex=newIndex,
+              neighboringNodes=np.zeros(8 * N, dtype=np.int64), fluidPDF=f0, fluidPDFOld=f0, fluidPDFNew=f0, fluidRho=rho0,
+              fluidPotential=z(2, N), forceX=z(2, N), forceY=z(2, N), velocityPX=z(N), velocityPY=z(N), eqVX=z(N), eqVY=z(N),
+              fEq=f0, fForce=z(2, N, 9), tau=tau, interactionCoeff=np.array([[0., par["G"]], [par["G"], 0.]]),
+              interactionSolid=np.array([par["Gs0"], par["Gs1"]]), interCoeff=np.array([[0., par["G"]], [par["G"], 0.]]),
+              interSolid=np.array([par["Gs0"], par["Gs1"]]), EX=EXV, EY=EYV, weightCoeff=W9, weightsCoeff=W9, weightInter=np.array(weights),
+              specificVY=np.array([par["vy0"], par["vy1"]]), densityL=1.002, conserveS=np.ones(2), primeVX=z(N), primeVY=z(N))
+    t["physicalVY"] = t["velocityPY"]; t["equilibriumVX"] = t["eqVX"]; t["equilibriumVY"] = t["eqVY"]
+    run(rt, "sc", t, [("fillNeighboringNodes", {})])
+    assert np.array_equal(t.host("neighboringNodes"), g["neighboringNodes"])
+    if with_iso and scheme in (8, 10):
+        t.put(isoNodes=np.zeros((24 if scheme == 8 else 36) * N, dtype=np.int64))
+        run(rt, "sc", t, [("fillNeighboringNodesISO8" if scheme == 8 else "fillNeighboringNodesISO10", dict(neighboringNodes="isoNodes"))])
+    return t, N, f0, tau, scheme
+
+
+@pytest.mark.parametrize("scenario", ["efs_srt_dirichlet", "efs_mrt_dirichlet", "efs_srt_convective", "efs_srt_iso8", "efs_srt_iso10"])
+def test_explicit_forcing_loop(rt, scenario):
+    from oracle.sc import collision_matrices
+    g = np.load(os.path.join(GOLDEN, "sc_%s.npz" % scenario))
+    par = load_params(g)
+    t, N, f0, tau, scheme = sc_table(rt, g, par, True)
+    mrt = par["relax"] == "MRT"
+    if mrt:
+        t.put(collisionMatrix=collision_matrices(tau), fForceM=np.zeros_like(f0), fluidPDFM=f0)
+    iso = dict(neighboringNodes="isoNodes")
+    force = {4: ("calExplicit4thOrderScheme", {}), 8: ("calExplicit8thOrderScheme", iso), 10: ("calExplicit10thOrderScheme", iso)}[scheme]
+    chain = [("calFluidPotentialGPUEql", {}), force,
+             ("transformEquilibriumVelocity", {}) if mrt else ("calEquilibriumVEFGPU", {}),
+             ("calEquilibriumFuncEFGPU", {}), ("calForceDistrGPU", {})]
+    inlet = {4: [("constantVelocityZouHeBoundaryHigher", {}), ("ghostPointsConstantVelocityInlet", {})],            # S:1794-1825, :1989-2020
+             8: [("constantVelocityZouHeBoundaryHigher8", {}), ("ghostPointsConstantVelocity8", {}), ("ghostPointsConstantVelocity82", {})],
+             10: []}[scheme]
+    outlet_p = {4: [("constantPressureZouHeBoundaryLower", {}), ("ghostPointsConstantPressureOutlet", {})],         # S:1826-1849, :1931-1953
+                8: [("constantPressureZouHeBoundaryLower8", {}), ("ghostPointsConstantPressureOutlet8", {}), ("ghostPointsConstantPressureOutlet82", {})],
+                10: []}[scheme]
+    onto = dict(fluidPDFNew="fluidPDF")          # (the outlet kernels call their target array fluidPDFNew; the loops pass the main one)
+    outlet = ([("convectiveOutletEachGPU", onto), ("convectiveOutletEach2GPU", onto), ("convectiveOutletEach3GPU", onto)]
+              if par["outlet"] == "Convective" else outlet_p)
+    collide = ([("transfromForceTerm", {}), ("transformPDFandEquil", {}), ("calAfterCollisionMRT", {})] if mrt else [("calCollisionEXGPU", {})])
+    macro = [("calFluidRhoGPU", {}), ("calPhysicalVelocity", {})]
+    # before the loop, ShanChenD2Q9.py:1714-1849
+    run(rt, "sc", t, chain + [("transformPDFGPU", {})] + inlet + (outlet_p if par["outlet"] == "Dirichlet" else []))
+    loop = [("savePDFLastStep", {})] + collide + [("calStreaming1GPU", {}), ("calStreaming2GPU", {})] + macro + outlet + inlet + macro + chain   # S:1852-2087
+    fields = dict(f="fluidPDF", rho="fluidRho", Fx="forceX", Fy="forceY", vx="velocityPX", vy="velocityPY", ueqx="eqVX", ueqy="eqVY", feq="fEq",
+                  fforce="fForce")
+    snaps = [int(k) for k in g["snaps"] if int(k) <= 10]
+    for i in range(max(snaps) + 1):
+        run(rt, "sc", t, loop)
+        if i in snaps:
+            check(t, g, "s%d_" % i, fields, 1e-11, "%s pass %d" % (scenario, i))
+
+
+@pytest.mark.parametrize("scenario", ["sc_srt_convective"])
+def test_original_shan_chen_loop(rt, scenario):
+    """runOptimizedLBM (Neumann / Zou-He inlet, convective outlet): the fused interaction + collision kernel, the three
+    outlet-row kernels and the (result-less) whole-fluid velocity"""
+    g = np.load(os.path.join(GOLDEN, "sc_%s.npz" % scenario))
+    par = load_params(g)
+    t, N, f0, tau, _ = sc_table(rt, g, par, False)
+    assert rel_err(f0, g["init_f"]) < 1e-15
+    t.put(weightInter=np.array([1. / 9.] * 4 + [1. / 36.] * 4))                 # ShanChenD2Q9.py:1478
+    head = [("constantVelocityZouHeBoundaryHigher", {}), ("ghostPointsConstantVelocityInlet", {}), ("savePDFLastStep", {}),
+            ("calMacroWholeVelocity", {})]
+    tail = [("calFluidRhoGPU", {}), ("calFluidPotentialGPUEql", {}), ("interactionCollisionProcess", {}), ("calStreaming1GPU", {}),
+            ("calStreaming2GPU", {}), ("convectiveOutletGPU", dict(fluidPDFNew="fluidPDF")), ("convectiveOutletGhost2GPU", dict(fluidPDFNew="fluidPDF")),
+            ("convectiveOutletGhost3GPU", dict(fluidPDFNew="fluidPDF")),
+            ("calFluidRhoGPU", {}), ("calPhysicalVelocity", {})]
+    fields = dict(f="fluidPDF", rho="fluidRho", Fx="forceX", Fy="forceY", vx="velocityPX", vy="velocityPY")
     snaps = [int(k) for k in g["snaps"]]
-    for tmpStep in range(1, max(snaps) + 1):
-        OPT.constantVelocityZouHeBoundaryHigher[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dVelY, dFluidIndices, dRho, dPDF)
-        OPT.ghostPointsConstantVelocityInlet[grid1D, tpb](N, typesFluids, nx, ny, xDimension, dFluidIndices, dNbr, dRho, dPDF)
-        OPT.savePDFLastStep[grid1D, tpb](N, typesFluids, xDimension, dPDF, dPDFold)
-        OPT.calMacroWholeVelocity[grid1D, tpb](N, typesFluids, xDimension, dTau, dRho, dPDF, dPrimeVX, dPrimeVY)
-        if tmpStep == 3:          # the kernel's own formula (O:345-356); nothing downstream reads these arrays
-            f, r = dPDF.copy_to_host(), dRho.copy_to_host()
+    for step in range(1, max(snaps) + 1):
+        run(rt, "sc", t, head)
+        if step == 3:             # the kernel's own formula (O:345-356); nothing downstream reads these arrays
+            f, r = t.host("fluidPDF"), t.host("fluidRho")
             mx = sum((f[k, :, 1] - f[k, :, 3] + f[k, :, 5] - f[k, :, 6] - f[k, :, 7] + f[k, :, 8]) / tau[k] for k in range(2))
             my = sum((f[k, :, 2] - f[k, :, 4] + f[k, :, 5] + f[k, :, 6] - f[k, :, 7] - f[k, :, 8]) / tau[k] for k in range(2))
-            rt = sum(r[k] / tau[k] for k in range(2))
-            assert rel_err(dPrimeVX.copy_to_host(), mx / rt) < 1e-12 and rel_err(dPrimeVY.copy_to_host(), my / rt) < 1e-12
-        OPT.calFluidRhoGPU[grid1D, tpb](N, typesFluids, xDimension, dRho, dPDF)
-        OPT.calFluidPotentialGPUEql[grid1D, tpb](N, typesFluids, xDimension, dRho, dPot)
-        OPT.interactionCollisionProcess[grid1D, tpb](N, typesFluids, xDimension, dWI, dTau, dG, dGs, dW, dRho, dPot, dPDF,
-                                                     dPDFNew, dFluidIndices, dNbr, dFx, dFy)
-        OPT.calStreaming1GPU[grid1D, tpb](N, typesFluids, xDimension, dFluidIndices, dNbr, dPDF, dPDFNew)
-        OPT.calStreaming2GPU[grid1D, tpb](N, typesFluids, xDimension, dPDFNew, dPDF)
-        if par["outlet"] == "Convective":
-            OPT.convectiveOutletGPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dRho)
-            OPT.convectiveOutletGhost2GPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dRho)
-            OPT.convectiveOutletGhost3GPU[grid1D, tpb](N, typesFluids, nx, xDimension, dFluidIndices, dNbr, dPDF, dRho)
-        OPT.calFluidRhoGPU[grid1D, tpb](N, typesFluids, xDimension, dRho, dPDF)
-        OPT.calPhysicalVelocity[grid1D, tpb](N, typesFluids, xDimension, dPDF, dRho, dFx, dFy, dVX, dVY)
-        if tmpStep in snaps:
-            got = dict(f=dPDF, rho=dRho, Fx=dFx, Fy=dFy, vx=dVX, vy=dVY)
-            for name, arr in got.items():
-                e = rel_err(arr.copy_to_host(), g["s%d_%s" % (tmpStep, name)])
-                assert e < 1e-11, "step %d %s rel err %.3e" % (tmpStep, name, e)
+            rt_ = sum(r[k] / tau[k] for k in range(2))
+            assert rel_err(t.host("primeVX"), mx / rt_) < 1e-12 and rel_err(t.host("primeVY"), my / rt_) < 1e-12
+        run(rt, "sc", t, tail)
+        if step in snaps:
+            check(t, g, "s%d_" % step, fields, 1e-11, "%s step %d" % (scenario, step))
+
+
+# ------------------------------------------------------------------------------------------------ tracer kernels
+def test_tracer_kernels_against_reference_vectors(rt):
+    d = np.load(os.path.join(GOLDEN, "tr_kernels.npz"))
+    N = int(d["fluidNodes"].size); ny, nx = d["isDomain"].shape
+    newidx = -np.ones((ny, nx), dtype=np.int64); newidx.reshape(-1)[d["fluidNodes"]] = np.arange(N)
+    t = Table(rt, totalNodes=N, totalNum=N, nx=nx, ny=ny, xDim=128, numTracers=2, numSchemes=5, fluidNodes=d["fluidNodes"], domainNewIndex=newidx,
+              neighboringNodes=np.zeros(4 * N, dtype=np.int64), tracerConc=np.zeros((2, N)), tracerPDF=d["conc_in_g"],
+              unitVX=np.array([0., 1., -1, 0., 0.]), unitVY=np.array([0., 0., 0., 1., -1.]), velocityVX=d["col_vx"], velocityVY=d["col_vy"],
+              transportM=d["M"], inverseRelaxationMS=d["A"], weightsCoeff=d["w"], critiriaValue=0.5, valueTransportDomain=np.zeros(N),
+              fluidRhoR=d["ind_rhoR"], betaTracer=d["itf_beta"], unitEX=EXV, unitEY=EYV, gradientX=d["itf_Gx"], gradientY=d["itf_Gy"],
+              tracerPDFNew=np.zeros((2, N, 5)), concBoundary=d["ina_cb"])
+    t["neighboringTRNodes"] = t["neighboringNodes"]
+    steps = [("fillNeighboringNodesTransport", ("neighboringNodes", "nbr", 0)), ("calConcentrationGPU", ("tracerConc", "conc_out", 1e-13)),
+             ("calCollisionTransportLinearEqlMRTGPU", ("tracerPDF", "col_out_g", 1e-13)), ("calValueTransportDomain", ("valueTransportDomain", "ind_out", 0)),
+             ("calTransportWithInterfaceD2Q5", ("tracerPDF", "itf_out_g", 1e-13)), ("calFreeConcBoundary3", ("tracerPDF", "free_out_g", 0)),
+             ("calStreamingTransportGPU", None), ("calStreamingTransport2GPU", ("tracerPDF", "str_out_g", 0)),
+             ("calInamuroConstConcBoundary", ("tracerPDF", "ina_out_g", 1e-13))]
+    for kern, expect in steps:
+        run(rt, "tr", t, [(kern, {})])
+        if expect:
+            got, want = t.host(expect[0]), d[expect[1]]
+            assert (np.array_equal(got, want) if expect[2] == 0 else rel_err(got, want) < expect[2]), kern
+    t.put(numTracers=3, reactionRate=d["rea_rate"], diffJcoeffs=d["rea_J"], tracerConc=d["rea_conc"], tracerPDF=d["rea_in_g"])
+    run(rt, "tr", t, [("calReactionTracersGPU", {})])                      # A + B -> C between three tracers
+    assert rel_err(t.host("tracerPDF"), d["rea_out_g"]) < 1e-13
