@@ -14,6 +14,8 @@ Note the two views inside one record: the flow arrays are the state at the START
 (after streaming and boundary kernels, :1302-1312), the concentrations the state AFTER the tracer
 update of that same step (:1418-1432).
 """
+import warnings
+
 import numpy as np
 
 from . import config
@@ -23,10 +25,28 @@ from .rk2d import RK2DSolver
 
 
 class Transport2DRK(RKColorGradientLBM):
-    def __init__(self, pathIniFile, output_dir=None, image=None, device=0):
-        RKColorGradientLBM.__init__(self, pathIniFile, output_dir=output_dir, image=image, device=device)
+    def __init__(self, pathIniFile, output_dir=None, image=None, device=0, initial_dir=None, inlet_concentration_from_ini=False):
+        """`inlet_concentration_from_ini`: the reference reads [BoundaryCondition] ConcentrationInlet (:162-167) and then
+        hands the inlet kernel a hard-coded array [1.0] (:1161-1162, one entry: with one tracer the inlet value is 1.0
+        whatever the file says; the kernel indexes it by tracer, so more than one tracer reads past its end).  Default:
+        what the reference computes where it is defined (tracer 0 -> 1.0), the file's values for the others; True: the
+        file's values for all."""
+        RKColorGradientLBM.__init__(self, pathIniFile, output_dir=output_dir, image=image, device=device, initial_dir=initial_dir)
         self.tr = config.read_transport(pathIniFile)
         self.numTracers = self.tr["num_tracers"]
+        t = self.tr
+        self.inletConcentration = list(t["inlet_conc"])
+        if not inlet_concentration_from_ini and t["inlet_type"] == "Dirichlet":
+            if self.inletConcentration[0] != 1.0:
+                warnings.warn("ConcentrationInlet[0] = %g is ignored as in the reference (Transport2DRK.py:1161 uses 1.0); "
+                              "pass inlet_concentration_from_ini=True to use it" % self.inletConcentration[0])
+            self.inletConcentration[0] = 1.0
+        if t["outlet_type"] != "Freeflow":
+            warnings.warn("OutletType = '%s': the loop applies its free-flow rows only for the spelling 'Freeflow' "
+                          "(Transport2DRK.py:1363); running without a tracer outlet rule, as the reference would" % t["outlet_type"])
+        if t["inlet_type"] != "Dirichlet":
+            warnings.warn("InletType = '%s': the loop knows only 'Dirichlet' (Transport2DRK.py:1378); running without a "
+                          "tracer inlet rule, as the reference would" % t["inlet_type"])
 
     def initializeTransportDomain(self):
         """Transport2DRK.py:399-469"""
@@ -35,7 +55,29 @@ class Transport2DRK(RKColorGradientLBM):
         rows = np.arange(ny)[:, None]
         fluid = self.isDomain == 1
         conc = np.zeros((self.numTracers, ny, nx))
-        if p["image"]:
+        if p.get("cycle"):
+            # :431-452: record LastStep of ~/LBMInitial/TransportResults.h5.  `self.tracerConc[:, :] = <record of tracer i>`
+            # assigns the 2-D record to EVERY tracer on each pass of the loop over i: all tracers start from the record
+            # of the last one.  (The working loop writes ConcentrationResults.h5, :651; that name is looked for second.)
+            import os
+            from .results import load_results
+            data = None
+            for stem in ("TransportResults", "ConcentrationResults"):
+                for ext in (".h5", ".npz"):
+                    f = os.path.join(self.initial_dir, stem + ext)
+                    if data is None and os.path.isfile(f):
+                        data = load_results(f)
+            if data is None:
+                raise config.ConfigError("IsCycle = 'yes': no TransportResults.h5/.npz (or ConcentrationResults) in %s" % self.initial_dir)
+            for i in range(self.numTracers):
+                key = "/TransportMacro/TracerConcType%din%d" % (i, p["last_step"])
+                if key not in data:
+                    raise config.ConfigError("IsCycle = 'yes': dataset %s missing" % key)
+                rec = np.asarray(data[key], dtype=np.float64)
+                if rec.shape != (ny, nx):
+                    raise config.ConfigError("IsCycle = 'yes': %s has shape %s, the domain is %s" % (key, rec.shape, (ny, nx)))
+                conc[:, :] = np.where(fluid, rec, 0.0)
+        elif p["image"]:
             conc[:, (fluid & (rows >= ny - 10))] = 1.0
         else:
             conc[0, (fluid & (rows <= ny - p["nbuf"]))] = 1.0
@@ -46,11 +88,6 @@ class Transport2DRK(RKColorGradientLBM):
         p, t = self.par, self.tr
         if p["tension_type"] != "CSF":
             raise config.ConfigError("the coupled loop uses the CSF colour-gradient flow (Transport2DRK.py:1434-1485)")
-        if p.get("cycle"):
-            # the reference restarts the tracers from TransportResults.h5 TracerConcType%din%d then (Transport2DRK.py:431-452);
-            # restarting only the flow would silently pair a developed flow with fresh tracers
-            raise config.ConfigError("[CyclesSetup] IsCycle = 'yes' is not supported by the coupled transport driver: "
-                                     "the tracer restart of Transport2DRK.py:431-452 is not implemented")
         self.initializeDomainBorder()
         self.initializeDomainCondition()
         self.initializeTransportDomain()
@@ -60,8 +97,8 @@ class Transport2DRK(RKColorGradientLBM):
         self._upload_initial_state(solver)
         n = self.numTracers
         solver.configure_tracers(diffX=tuple(t["diffX"]), diffY=tuple(t["diffY"]), dXY=t["dXY"], dYX=t["dYX"],
-                                 beta=(t["beta"],) * n, crit=0.5, inlet_conc=tuple(t["inlet_conc"]),
-                                 free_outlet=True, dirichlet_inlet=True, reaction_rate=t["reaction_rate"],
+                                 beta=(t["beta"],) * n, crit=0.5, inlet_conc=tuple(self.inletConcentration),
+                                 free_outlet=t["outlet_type"] == "Freeflow", dirichlet_inlet=t["inlet_type"] == "Dirichlet", reaction_rate=t["reaction_rate"],
                                  diffJ=tuple(t["diffJ"]))
         for k in range(n):
             solver.set_tracer(k, self.tracerConc[k])

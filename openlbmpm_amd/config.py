@@ -192,8 +192,8 @@ def read_sc2d(ini_dir):
 def read_transport(ini_dir):
     """transportsetup.ini -> dict (keys consumed by Transport2DRK.py:31-311; the file itself is not
     shipped with the reference).  Only the combinations its working loop runTransport2DMPMCRKNew
-    can execute are accepted: multiphase flow system, D2Q5, MRT, no reaction, Dirichlet (Inamuro)
-    inlet, free-flow outlet."""
+    can execute are accepted: multiphase flow system, D2Q5, MRT, Dirichlet (Inamuro) inlet or none,
+    free-flow outlet or none."""
     c = Ini(os.path.join(ini_dir, "transportsetup.ini"))
     p = {}
     if c.str("SystemType", "Option") != "MPMC":
@@ -218,11 +218,18 @@ def read_transport(ini_dir):
     p["diffJ"] = c.floats("TransportParameters", "DiffusionJ", n)
     p["tau"] = c.floats("TransportParameters", "Tau", n)
     p["beta"] = c.float("TransportParameters", "BetaInterface")
-    if c.str("BoundaryCondition", "InletType") != "Dirichlet":
-        raise ConfigError("[BoundaryCondition] InletType: only 'Dirichlet' (calInamuroConstConcBoundary) is called by the loop")
-    p["inlet_conc"] = c.floats("BoundaryCondition", "ConcentrationInlet", n)
-    if c.str("BoundaryCondition", "OutletType") != "FreeFlow":
-        raise ConfigError("[BoundaryCondition] OutletType: only 'FreeFlow' (calFreeConcBoundary3) is called by the loop")
+    # The loop acts on exact spellings (Transport2DRK.py:1363, 1378) that differ from the ones its reader knows
+    # (:156-191): 'Dirichlet' -> Inamuro inlet row, 'Freeflow' -> calFreeConcBoundary3 on the outlet rows; any other
+    # value the reader accepts runs WITHOUT that boundary rule (the tracer streaming wraps around in y then).
+    p["inlet_type"] = c.str("BoundaryCondition", "InletType")
+    if p["inlet_type"] == "Neumann":
+        raise ConfigError("[BoundaryCondition] InletType = 'Neumann': the reference's reader fails on it "
+                          "(Transport2DRK.py:160 uses the undefined self.concGradientUpper)")
+    p["inlet_conc"] = c.floats("BoundaryCondition", "ConcentrationInlet", n) if p["inlet_type"] == "Dirichlet" else [1.0] * n
+    p["outlet_type"] = c.str("BoundaryCondition", "OutletType")
+    if p["outlet_type"] not in ("Freeflow", "FreeFlow", "Dirichlet", "VonNeumann"):
+        raise ConfigError("[BoundaryCondition] OutletType must be 'Freeflow' (the spelling the loop acts on), 'FreeFlow', "
+                          "'Dirichlet' or 'VonNeumann' (read, then ignored by the loop)")
     p["init_type"] = c.str("InitialCondition", "Type")
     if p["init_type"] == "Homogeneous":
         p["init_conc"] = c.floats("InitialCondition", "TracerConc", n)

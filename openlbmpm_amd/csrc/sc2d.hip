@@ -606,6 +606,9 @@ struct lbmpm_sc2d {
     int scheme = 4;                  // [ForceScheme] ExplicitScheme
     double *psi = nullptr;           // [2][plane], schemes 8 / 10 only
     int64_t steps = 0, bytes = 0;
+    hipGraphExec_t graph_exec = nullptr;              // GRAPH_STEPS captured time steps, valid while fA is where it was at capture
+    const double *graph_fA = nullptr;
+    bool graph_keep = false;
     int64_t graph_launches = 0, timed_steps = 0;      // hipGraph replays so far; time steps covered by the event pairs of the pool
     lbmpm::EventPool pool;
 };
@@ -708,30 +711,39 @@ int run_steps(lbmpm_sc2d *c, int64_t n, bool timed)
         int rc = launch_step(c, false, false);
         if (rc != LBMPM_OK) return rc;
         ++k;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        LBMPM_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int g = 0; g < GRAPH_STEPS && rc == LBMPM_OK; ++g) rc = launch_step(c, false, false);     // recorded, not run; host state advances
-        hipError_t e = hipStreamEndCapture(c->stream, &graph);
-        if (rc != LBMPM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        LBMPM_HIP_TRY(e);
-        LBMPM_HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        bool first = true;
+        if (c->graph_exec && c->graph_keep == c->keep_force && c->graph_fA != c->fA) {      // other half of the ping-pong: one more direct step
+            rc = launch_step(c, false, false);
+            if (rc != LBMPM_OK) return rc;
+            ++k;
+        }
+        bool counted = false;                               // a capture pass advances the host state by one batch
+        if (!c->graph_exec || c->graph_fA != c->fA || c->graph_keep != c->keep_force) {       // (kept for the life of the context: instantiation costs ~1e4 launches)
+            if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            c->graph_fA = c->fA; c->graph_keep = c->keep_force;
+            LBMPM_HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            for (int g = 0; g < GRAPH_STEPS && rc == LBMPM_OK; ++g) rc = launch_step(c, false, false);     // recorded, not run
+            hipError_t e = hipStreamEndCapture(c->stream, &graph);
+            if (rc != LBMPM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            LBMPM_HIP_TRY(e);
+            e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            LBMPM_HIP_TRY(e);
+            counted = true;
+        }
         while (true) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             const bool ev = timed && c->pool.take(&e0, &e1);
             if (ev) { LBMPM_HIP_TRY(hipEventRecord(e0, c->stream)); c->timed_steps += GRAPH_STEPS; }
-            LBMPM_HIP_TRY(hipGraphLaunch(exec, c->stream));
+            LBMPM_HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
             if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
-            if (!first) c->steps += GRAPH_STEPS;            // (the capture pass already counted the first batch)
-            first = false;
+            if (!counted) c->steps += GRAPH_STEPS;
+            counted = false;
             k += GRAPH_STEPS;
             c->graph_launches += 1;
             if (n - k < GRAPH_STEPS + 1) break;             // keep at least one direct step for the diagnostics of the last one
         }
-        LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
-        (void)hipGraphExecDestroy(exec);
-        (void)hipGraphDestroy(graph);
+        c->streamed = true;
         c->diag_valid = false;
     }
     for (; k < n; ++k) {
@@ -831,6 +843,7 @@ extern "C" void lbmpm_sc2d_destroy(lbmpm_sc2d *c)
     for (void *ptr : {(void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->F,
                       (void *)c->foldA, (void *)c->foldB, (void *)c->diag, (void *)c->obs, (void *)c->psi})
         if (ptr) (void)hipFree(ptr);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     c->pool.destroy();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

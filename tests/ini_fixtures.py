@@ -164,7 +164,7 @@ BetaInterface = 0.8
 [BoundaryCondition]
 InletType = 'Dirichlet'
 ConcentrationInlet = 1.0, 0.25
-OutletType = 'FreeFlow'
+OutletType = 'Freeflow'
 
 [InitialCondition]
 Type = 'Homogeneous'

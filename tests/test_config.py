@@ -45,11 +45,14 @@ def test_transport_ini(tmp_path):
     write_transport(str(tmp_path))
     t = config.read_transport(str(tmp_path))
     assert t["num_tracers"] == 2 and t["diffX"] == [1. / 6., 0.12] and t["dXY"] == 0.01 and t["beta"] == 0.8
-    for old, new in (("'MPMC'", "'Single'"), ("NumberSchemes = 5", "NumberSchemes = 9"), ("'FreeFlow'", "'Dirichlet'"),
+    for old, new in (("'MPMC'", "'Single'"), ("NumberSchemes = 5", "NumberSchemes = 9"), ("'Freeflow'", "'Outflow'"), ("InletType = 'Dirichlet'", "InletType = 'Neumann'"),
                      ("Reaction = 'no'", "Reaction = 'yes'\n[Reaction]\nNumberReaction = 1\nReactionRate = 0.1"), ("0.12", "0.12, 0.3")):
         (tmp_path / "transportsetup.ini").write_text(TRANSPORT_INI.replace(old, new))
         with pytest.raises(config.ConfigError):
             config.read_transport(str(tmp_path))
+    # the spelling the reference's reader knows ('FreeFlow', Transport2DRK.py:191) is not the one its loop acts on (:1363)
+    (tmp_path / "transportsetup.ini").write_text(TRANSPORT_INI.replace("'Freeflow'", "'FreeFlow'"))
+    assert config.read_transport(str(tmp_path))["outlet_type"] == "FreeFlow"
 
 
 def test_force_scheme_key(tmp_path):

@@ -62,7 +62,7 @@ def test_transport_driver_records_match_coupled_oracle(tmp_path):
             "vyR", "vyB", "rhoBH", "rhoRH", "rhoBL", "rhoRL")
     o = CoupledOracle(ref.isDomain, {k: p[k] for k in keys}, ref.fluidsRhoR, ref.fluidsRhoB, ref.tracerConc,
                       dict(diffX=tuple(t["diffX"]), diffY=tuple(t["diffY"]), dXY=t["dXY"], dYX=t["dYX"], beta=(t["beta"],) * 2,
-                           crit=0.5, inlet_conc=tuple(t["inlet_conc"]), free_outlet=True, dirichlet_inlet=True))
+                           crit=0.5, inlet_conc=tuple(ref.inletConcentration), free_outlet=True, dirichlet_inlet=True))
     sel = ref.isDomain.reshape(-1) == 1
     done = 0
     for rec in range(3):
@@ -73,6 +73,69 @@ def test_transport_driver_records_match_coupled_oracle(tmp_path):
     assert ref.tracerConc[1].max() == 0.0 and abs(ref.tracerConc[0].max() - 1.0) < 1e-15   # Transport2DRK.py:417-424
     flow = load_results(flow_path)
     assert "/FluidMacro/FluidDensityRin2" in flow and "/FluidVelocity/FluidVelocityYAt2" in flow
+
+
+def test_transport_restart_and_boundary_spellings(tmp_path):
+    """(i) IsCycle = 'yes': the flow restarts from SimulationResultsRK, every tracer from the record of the LAST tracer
+    (Transport2DRK.py:431-439, the `[:, :]` assignment); (ii) the loop acts on 'Freeflow' / 'Dirichlet' only (:1363, :1378):
+    with the reader's spelling 'FreeFlow' no outlet rule runs; (iii) the inlet value of tracer 0 is 1.0 whatever the file
+    says (:1161)"""
+    import shutil
+    import warnings
+    from ini_fixtures import TRANSPORT_INI
+    from openlbmpm_amd.Transport2DRK import Transport2DRK
+    from openlbmpm_amd.results import load_results
+    first = tmp_path / "first"; first.mkdir()
+    write_rk(str(first), nx=20, ny=64, steps=30, interval=25)
+    (first / "transportsetup.ini").write_text(TRANSPORT_INI)
+    a = Transport2DRK(str(first), output_dir=str(tmp_path / "out1"))
+    flow_path, conc_path = a.runTransport2DMPMCRKNew()
+    init = tmp_path / "LBMInitial"; init.mkdir()
+    shutil.copy(flow_path, str(init)); shutil.copy(conc_path, str(init))
+    second = tmp_path / "second"; second.mkdir()
+    write_rk(str(second), nx=20, ny=64, steps=5, interval=25, cycle="yes", last=1)
+    (second / "transportsetup.ini").write_text(TRANSPORT_INI)
+    b = Transport2DRK(str(second), output_dir=str(tmp_path / "out2"), initial_dir=str(init))
+    b.initializeDomainBorder(); b.initializeDomainCondition(); b.initializeTransportDomain()
+    last = load_results(conc_path)["/TransportMacro/TracerConcType1in1"]
+    fluid = b.isDomain == 1
+    assert np.array_equal(b.tracerConc[0][fluid], last[fluid]) and np.array_equal(b.tracerConc[1][fluid], last[fluid])
+    b2 = Transport2DRK(str(second), output_dir=str(tmp_path / "out2"), initial_dir=str(init))
+    b2.runTransport2DMPMCRKNew()
+    assert np.isfinite(b2.tracerConc).all()
+    empty = tmp_path / "none"; empty.mkdir()
+    with pytest.raises(Exception, match="TransportResults"):
+        c = Transport2DRK(str(second), output_dir=str(tmp_path / "out3"), initial_dir=str(empty))
+        c.isDomain = b.isDomain
+        c.initializeTransportDomain()
+    # ---- spellings
+    third = tmp_path / "third"; third.mkdir()
+    write_rk(str(third), nx=20, ny=48, steps=40, interval=100)
+    (third / "transportsetup.ini").write_text(TRANSPORT_INI)
+    from openlbmpm_amd.rk2d import RK2DSolver
+    seen = []
+    plain = RK2DSolver.configure_tracers
+
+    def spy(self, **kw):
+        seen.append((kw["free_outlet"], kw["dirichlet_inlet"], tuple(kw["inlet_conc"])))
+        return plain(self, **kw)
+    RK2DSolver.configure_tracers = spy
+    ref = Transport2DRK(str(third), output_dir=str(tmp_path / "o4")); ref.runTransport2DMPMCRKNew()
+    (third / "transportsetup.ini").write_text(TRANSPORT_INI.replace("'Freeflow'", "'FreeFlow'"))
+    with pytest.warns(UserWarning, match="Freeflow"):
+        alt = Transport2DRK(str(third), output_dir=str(tmp_path / "o5"))
+    alt.runTransport2DMPMCRKNew()
+    (third / "transportsetup.ini").write_text(TRANSPORT_INI.replace("ConcentrationInlet = 1.0, 0.25", "ConcentrationInlet = 0.5, 0.25"))
+    with pytest.warns(UserWarning, match="ConcentrationInlet"):
+        same = Transport2DRK(str(third), output_dir=str(tmp_path / "o6"))
+    same.runTransport2DMPMCRKNew()
+    assert np.array_equal(same.tracerConc[0], ref.tracerConc[0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        own = Transport2DRK(str(third), output_dir=str(tmp_path / "o7"), inlet_concentration_from_ini=True)
+    own.runTransport2DMPMCRKNew()
+    RK2DSolver.configure_tracers = plain
+    assert seen == [(True, True, (1.0, 0.25)), (False, True, (1.0, 0.25)), (True, True, (1.0, 0.25)), (True, True, (0.5, 0.25))]
 
 
 def test_restart_from_previous_results(tmp_path):
