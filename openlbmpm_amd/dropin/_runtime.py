@@ -20,13 +20,14 @@ from openlbmpm_amd import _lib                     # noqa: E402
 from openlbmpm_amd._kernel_specs import KERNELS    # noqa: E402
 
 _ready = False
+_DTYPES = {"D": np.dtype(np.float64), "I": np.dtype(np.int64), "B": np.dtype(np.bool_)}
 
 
 def _L():
     global _ready
     L = _lib.lib()
     if not _ready:
-        for (mod, name), (sym, kinds, _names) in KERNELS.items():
+        for (mod, name), (sym, kinds, _names, _letters) in KERNELS.items():
             fn = getattr(L, sym)
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p] + list(kinds)
@@ -95,7 +96,7 @@ def device_array(shape, dtype=np.float64, strides=None, order="C", stream=0):
 class Kernel:
     def __init__(self, module, name):
         self.module, self.name = module, name
-        self.sym, self.kinds, self.argnames = KERNELS[(module, name)]
+        self.sym, self.kinds, self.argnames, self.letters = KERNELS[(module, name)]
         self.__name__ = name
 
     def __getitem__(self, launch_config):            # kernel[grid, block] / kernel[grid, block, stream]
@@ -105,12 +106,13 @@ class Kernel:
         if len(args) != len(self.kinds):
             raise TypeError("%s() takes %d arguments (%d given)" % (self.name, len(self.kinds), len(args)))
         conv = []
-        for i, (a, k) in enumerate(zip(args, self.kinds)):
+        for i, (a, k, letter) in enumerate(zip(args, self.kinds, self.letters)):
             if k is C.c_void_p:
                 if not isinstance(a, DeviceNDArray):
                     raise TypeError("%s(): argument %d must be a device array (use cuda.to_device)" % (self.name, i))
-                if a.dtype not in (np.dtype(np.float64), np.dtype(np.int64)):
-                    raise TypeError("%s(): argument %d has dtype %s; float64/int64 expected" % (self.name, i, a.dtype))
+                want = _DTYPES[letter]
+                if a.dtype != want:
+                    raise TypeError("%s(): argument %d has dtype %s; %s expected" % (self.name, i, a.dtype, want))
                 conv.append(C.c_void_p(a.ptr))
             elif k is C.c_int64:
                 if isinstance(a, (float, np.floating)) and float(a) != int(a):

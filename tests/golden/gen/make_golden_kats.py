@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Known-answer vectors for the reference kernels that no working loop launches (kernels of the five
+kernel modules outside the call stacks of section 3).  Every case is ONE launch of the real kernel body under the numba
+stand-in; the arguments are looked up BY THE KERNEL'S OWN PARAMETER NAMES (inspect.signature of the reference function)
+in a table of seeded inputs, so a case is just (module, kernel, overrides).  Stored per case:
+
+    <case>|kernel, <case>|module, <case>|args (names, in order), <case>|in|<arg> for every argument,
+    <case>|out|<arg> for every array argument after the launch.
+
+tests/test_kats_gpu.py replays each case through the same-named HIP entry point.  Container-only.
+Writes tests/golden/kats_<module tag>.npz.
+"""
+import inspect
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refenv  # noqa: E402
+
+OUT = os.environ.get("LBMPM_GOLDEN_OUT") or os.path.dirname(HERE)
+
+EX = np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.]); EY = np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.])
+W9 = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+
+
+def geometry(nx=14, ny=18):
+    """walls at x = 0 and x = nx-1, a disc, rows 0..3 and ny-4..ny-1 otherwise fluid"""
+    dom = np.ones((ny, nx), dtype=np.int64)
+    dom[:, 0] = 0; dom[:, -1] = 0
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    dom[(xx - 6.5) ** 2 + (yy - 9.0) ** 2 <= 2.3 ** 2] = 0
+    fluidNodes = np.flatnonzero(dom.reshape(-1) == 1).astype(np.int64)
+    newIndex = -np.ones(ny * nx, dtype=np.int64)
+    newIndex[fluidNodes] = np.arange(fluidNodes.size)
+    return dom, fluidNodes, newIndex.reshape(ny, nx)
+
+
+class Cases:
+    def __init__(self, tag, module):
+        self.tag, self.module, self.out = tag, module, {}
+
+    def run(self, kernel, values, case=None, grid=None, block=(32, 1), module=None):
+        case = case or kernel
+        k = getattr(module or self.module, kernel)
+        names = list(inspect.signature(k.py_func).parameters)
+        missing = [n for n in names if n not in values]
+        assert not missing, (kernel, missing)
+        N = int(values[names[0]])
+        xDim = int(values.get("xDim", 64))
+        grid = grid or (xDim // block[0], -(-N // xDim))
+        args = []
+        for n in names:
+            v = values[n]
+            if isinstance(v, np.ndarray):
+                v = np.array(v, copy=True)
+            self.out["%s|in|%s" % (case, n)] = np.array(v, copy=True)
+            args.append(v)
+        k[grid, block](*args)
+        for n, a in zip(names, args):
+            if isinstance(a, np.ndarray):
+                self.out["%s|out|%s" % (case, n)] = np.array(a, copy=True)
+        self.out["%s|kernel" % case] = np.array(kernel)
+        self.out["%s|module" % case] = np.array(self.tag)
+        self.out["%s|args" % case] = np.array(names)
+        changed = [n for n, a in zip(names, args) if isinstance(a, np.ndarray) and not np.array_equal(a, self.out["%s|in|%s" % (case, n)], equal_nan=True)]
+        self.out["%s|noop" % case] = np.array(not changed)           # (a reference kernel that changes nothing: pinned as that)
+        refenv.say("  %-44s changed: %s" % (case, ", ".join(changed) or "NOTHING"))
+        return {n: a for n, a in zip(names, args)}
+
+    def save(self):
+        np.savez_compressed(os.path.join(OUT, "kats_%s.npz" % self.tag), **self.out)
+        refenv.say("kats_%s: %d cases" % (self.tag, sum(1 for k in self.out if k.endswith("|kernel"))))
+
+
+def rk_cases():
+    import importlib
+    A = importlib.import_module("AcceleratedRKGPU2D")
+    rng = np.random.default_rng(1940)
+    dom, fluidNodes, newIndex = geometry()
+    ny, nx = dom.shape
+    N = fluidNodes.size
+    nbr = np.zeros(8 * N, dtype=np.int64)
+    A.fillNeighboringNodes[(2, -(-N // 64)), (32, 1)](N, nx, ny, 64, fluidNodes, newIndex, nbr)
+    nbr_solid = nbr.copy()                      # the colour-gradient loops mark non-fluid neighbours with -1 (RKD2Q9.py:632-655)
+    fR = rng.uniform(0.01, 0.2, (N, 9)); fB = rng.uniform(0.01, 0.2, (N, 9))
+    fB[: N // 3] *= 0.05; fR[-N // 3:] *= 0.05                 # red below, blue above, a mixed band between
+    rR, rB = fR.sum(axis=1), fB.sum(axis=1)
+    phi = (rR - rB) / (rR + rB)
+    M = np.array([[1, 1, 1, 1, 1, 1, 1, 1, 1], [-4, -1, -1, -1, -1, 2, 2, 2, 2], [4, -2, -2, -2, -2, 1, 1, 1, 1], [0, 1, 0, -1, 0, 1, -1, -1, 1],
+                  [0, -2, 0, 2, 0, 1, -1, -1, 1], [0, 0, 1, 0, -1, 1, 1, -1, -1], [0, 0, -2, 0, 2, 1, 1, -1, -1], [0, 1, -1, 1, -1, 0, 0, 0, 0],
+                  [0, 0, 0, 0, 0, 1, -1, 1, -1]], dtype=np.float64)
+    alphaR, alphaB = 0.2, 0.36
+    cR = np.array([alphaR] + [(1. - alphaR) / 5.] * 4 + [(1. - alphaR) / 20.] * 4)
+    cB = np.array([alphaB] + [(1. - alphaB) / 5.] * 4 + [(1. - alphaB) / 20.] * 4)
+    T = dict(totalNodes=N, xDim=64, nx=nx, ny=ny, fluidNodes=fluidNodes, neighboringNodes=nbr_solid,
+             delta=0.7, tauR=1.0, tauB=0.7, unitEX=EX, unitEY=EY, constantCR=cR, constantCB=cB, weightsCoeff=W9,
+             physicalVX=rng.uniform(-0.03, 0.03, N), physicalVY=rng.uniform(-0.03, 0.03, N), fluidRhoR=rR, fluidRhoB=rB, fluidPDFR=fR, fluidPDFB=fB,
+             transformationM=M, inverseTM=np.linalg.inv(M), collisionS=np.array([0., 1.64, 1.54, 0., 1.9, 0., 1.9, 1.0, 1.0]),
+             betaCoeff=0.7, betaValue=0.7, AkR=7.0e-3, AkB=4.0e-3, solidDiff=0.35, solidPhi=0.4, surfaceTA=9.0e-3,
+             constantB=np.array([-4. / 27.] + [2. / 27.] * 4 + [5. / 108.] * 4), schemeGradient=np.array([0.] + [4. / 12.] * 4 + [1. / 12.] * 4),
+             CGX=np.zeros(N), CGY=np.ones(N), phiValue=phi, fluidPDFTotal=fR + fB, fluidPDFROld=rng.uniform(0., 1., (N, 9)),
+             fluidPDFBOld=rng.uniform(0., 1., (N, 9)), collisionTotal1=np.zeros((N, 9)), collisionTotal2=np.zeros((N, 9)),
+             gradientX=np.zeros(N), gradientY=np.zeros(N), forceX=rng.uniform(-1e-3, 1e-3, N), forceY=rng.uniform(-1e-3, 1e-3, N))
+    # solid links as -1 for the kernels that test for it
+    dx = EX[1:].astype(int); dy = EY[1:].astype(int)
+    for k, loc in enumerate(fluidNodes):
+        i, j = divmod(int(loc), nx)
+        for d in range(8):
+            if dom[(i + dy[d]) % ny, (j + dx[d]) % nx] != 1:
+                nbr_solid[8 * k + d] = -1
+    c = Cases("rk", A)
+    c.run("calRKCollision1GPU2DSRT", T)
+    c.run("calRKCollision1GPU2DMRT", T)
+    c.run("calRKCollision23GPU", T)
+    # a node with zero gradient takes the other branch of :553 and :574
+    flat = dict(T, fluidRhoR=np.full(N, 0.6), fluidRhoB=np.full(N, 0.25), solidDiff=0.35)
+    c.run("calRKCollision23GPU", flat, case="calRKCollision23GPU#flat")
+    c.run("copyFluidPDFLastStep", T)
+    c.run("copyFluidPDFRecoverOutlet", T)
+    c.run("calNeumannPhiOutlet", dict(T, neighboringNodes=nbr))
+    c.run("calModifiedPeriodicBoundary", T)
+    s1 = c.run("calRKCollision1TotalGPU2DSRT", T)
+    s2 = c.run("calRKCollision2TotalGPUNew", T)
+    c.run("calRecoloringProcess", dict(T, collisionTotal1=s1["collisionTotal1"], collisionTotal2=s2["collisionTotal2"], gradientX=s2["gradientX"],
+                                      gradientY=s2["gradientY"]))
+    c.run("calPhysicalVelocityRKGPU2DVNew", T)
+    c.run("calMacroDensityRKGPU2DNew", dict(T, fluidRhoR=np.zeros(N), fluidRhoB=np.zeros(N)))
+    c.save()
+
+
+def sc_cases():
+    import importlib
+    O = importlib.import_module("OptimizedD2Q9GPU")
+    E = importlib.import_module("ExplicitD2Q9GPU")
+    rng = np.random.default_rng(1454)
+    dom, fluidNodes, newIndex = geometry()
+    ny, nx = dom.shape
+    N = fluidNodes.size
+    nbr = np.zeros(8 * N, dtype=np.int64)
+    O.fillNeighboringNodes[(2, -(-N // 64)), (32, 1)](N, nx, ny, 64, fluidNodes, newIndex, nbr)      # -1 where the neighbour is solid
+    assert (nbr == -1).any()
+    f = rng.uniform(0.02, 0.2, (2, N, 9)); f[1] *= 0.3
+    rho = f.sum(axis=2)
+    G = np.array([[0.0, 0.9], [0.9, 0.05]])
+    tau = np.array([1.0, 0.8])
+    T = dict(totalNodes=N, totaNodes=N, totalNum=N, numFluids=2, xDim=64, nx=nx, ny=ny, fluidNodes=fluidNodes, neighboringNodes=nbr,
+             weightInter=np.array([0.111, 0.112, 0.113, 0.114, 0.0271, 0.0272, 0.0273, 0.0274]), interactionCoeff=G, interCoeff=G,
+             interactionSolid=np.array([-0.4, 0.35]), interSolid=np.array([-0.4, 0.35]), tau=tau, tauReverse=1. / tau,
+             weightCoeff=W9, weightsCoeff=W9, weigthCoeff=W9, unitEX=EX, unitEY=EY, EX=EX, EY=EY,
+             fluidRho=rho, fluidPotential=rho * rng.uniform(0.9, 1.1, (2, N)), fluidPsi=np.zeros((2, N)), fluidPDF=f,
+             fluidPDFNew=rng.uniform(0.02, 0.2, (2, N, 9)), fluidPDFOld=rng.uniform(0.02, 0.2, (2, N, 9)),
+             fEq=rng.uniform(0.02, 0.2, (2, N, 9)), fForce=rng.uniform(-1e-3, 1e-3, (2, N, 9)),
+             forceX=rng.uniform(-1e-2, 1e-2, (2, N)), forceY=rng.uniform(-1e-2, 1e-2, (2, N)),
+             mixtureVX=rng.uniform(-0.05, 0.05, N), mixtureVY=rng.uniform(-0.05, 0.05, N),
+             equilibriumVX=rng.uniform(-0.05, 0.05, (2, N)), equilibriumVY=rng.uniform(-0.05, 0.05, (2, N)),
+             physicalVX=rng.uniform(-0.05, 0.05, N), physicalVY=rng.uniform(-0.05, 0.05, N), totalVX=np.zeros(N), totalVY=np.zeros(N),
+             fluidPressure=np.zeros(N), constR=1.0, temperatureT=0.05, temperature=0.05, coeffA=2. / 49., coeffB=2. / 21., coeffAlpha=1.0,
+             constC0=6.0, constG=-1.0, bodyFX=1.0e-4, bodyFY=-2.0e-4, densityH=1.1, specificVY=np.array([-1.0e-3, -5.0e-4]),
+             specificRhoH=1.05, specificRhoL=0.95)
+    c = Cases("sc", O)
+    c.run("calFluidPotentialGPUPR", T)
+    c.run("calMacroPressure", T)
+    c.run("calInteractionForce", T)
+    c.run("addBodyForceGPU", T)
+    c.run("calEquilibriumVGPU", T)
+    c.run("calEquilibriumFuncGPU", T)
+    c.run("calCollisionSRTGPU", T)
+    c.run("constantPressureZouHeBoundaryHigher", T)
+    c.run("ghostPointsConstantPressureInlet", T)
+    c.run("calVelocityBoundaryHigherChangGPU", T)
+    c.run("calPressureBoundaryHigherChangGPU", T)
+    c.run("calPressureBoundaryLowerChangGPU", T)
+    c.run("interactionCollisionEOFProcess", T)
+    c.run("calStreaming1withLinkGPU", T)
+    c.run("interactionForceGuo", T)
+    c.run("calCollisionGuo", T)
+    c.run("calMacroPressureEX", T, module=E)
+    c.run("calEffectiveMassPR", T, module=E)
+    c.run("calTotalVelocityGPU", T, module=E)
+    c.run("calPressureExpGPU", T, module=E)
+    s = c.run("convectiveOutletGPUEFS", T, module=E)                    # chained like the loop (ShanChenD2Q9.py:1865-1884)
+    chain = dict(T, fluidPDFNew=s["fluidPDFNew"], fluidRho=s["fluidRho"], fForce=s["fForce"], fEq=s["fEq"])
+    s = c.run("convectiveOutletGhost2GPUEFS", chain, module=E)
+    chain = dict(T, fluidPDFNew=s["fluidPDFNew"], fluidRho=s["fluidRho"], fForce=s["fForce"], fEq=s["fEq"])
+    c.run("convectiveOutletGhost3GPUEFS", chain, module=E)
+    c.save()
+
+
+if __name__ == "__main__":
+    refenv.setup()
+    which = sys.argv[1:] or ["rk"]
+    for w in which:
+        globals()[w + "_cases"]()

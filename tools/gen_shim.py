@@ -4,7 +4,7 @@
   openlbmpm_amd/csrc/sparse_entry_gen.h           extern "C" definitions forwarding to the launchers
   openlbmpm_amd/_kernel_specs.py                  ctypes signatures for the Python shim
 Argument lists are the reference kernels' own (module, name, citation), minus the launch
-configuration.  kinds: i = int64, d = float64, I = int64*, D = float64*."""
+configuration.  kinds: i = int64, d = float64, I = int64*, D = float64*, B = boolean* (one byte per entry, numpy bool)."""
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -92,6 +92,31 @@ SPEC = [
   "launch_rk_pressure_high(st, totalNodes, nx, ny, constPHB, constPHR, fluidNodes, fluidPDFB, fluidPDFR)"),
  ("rk", "constantVelocityZHBoundaryHigherNewRK", A + ":2307", "totalNodes:i nx:i ny:i xDim:i specificVYR:d specificVYB:d fluidNodes:I neighboringNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
   "launch_rk_inlet_velocity_red(st, totalNodes, nx, ny, specificVYR, fluidNodes, neighboringNodes, fluidRhoR, fluidPDFR, fluidPDFB, 0)"),
+ # ---------------- AcceleratedRKGPU2D.py, kernels no loop launches any more (csrc/sparse_rest_rk.h)
+ ("rk", "calRKCollision1GPU2DSRT", A + ":194", "totalNodes:i xDim:i delta:d tauR:d tauB:d unitEX:D unitEY:D constantCR:D constantCB:D weightsCoeff:D physicalVX:D physicalVY:D fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
+  "launch_rk_old_collide1_srt(st, totalNodes, delta, tauR, tauB, constantCR, constantCB, weightsCoeff, physicalVX, physicalVY, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
+ ("rk", "calRKCollision1GPU2DMRT", A + ":429", "totalNodes:i xDim:i delta:d tauR:d tauB:d unitEX:D unitEY:D constantCR:D constantCB:D weightsCoeff:D physicalVX:D physicalVY:D fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D transformationM:D inverseTM:D collisionS:D",
+  "launch_rk_old_collide1_mrt(st, totalNodes, delta, tauR, tauB, constantCR, constantCB, weightsCoeff, physicalVX, physicalVY, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB, transformationM, inverseTM, collisionS)"),
+ ("rk", "calRKCollision23GPU", A + ":511", "totalNodes:i xDim:i betaCoeff:d AkR:d AkB:d solidDiff:d fluidNodes:I neighboringNodes:I constantB:D weightsCoeff:D unitEX:D unitEY:D schemeGradient:D fluidRhoR:D fluidRhoB:D constantCR:D constantCB:D fluidPDFR:D fluidPDFB:D CGX:D CGY:D",
+  "launch_rk_old_collide23(st, totalNodes, betaCoeff, AkR, AkB, solidDiff, neighboringNodes, constantB, weightsCoeff, schemeGradient, fluidRhoR, fluidRhoB, constantCR, constantCB, fluidPDFR, fluidPDFB, CGX, CGY)"),
+ ("rk", "copyFluidPDFLastStep", A + ":887", "totalNodes:i nx:i xDim:i fluidNodes:I fluidPDFR:D fluidPDFB:D fluidPDFROld:D fluidPDFBOld:D",
+  "launch_rk_copy_outlet_rows(st, totalNodes, nx, fluidNodes, fluidPDFR, fluidPDFB, fluidPDFROld, fluidPDFBOld)"),
+ ("rk", "copyFluidPDFRecoverOutlet", A + ":906", "totalNodes:i nx:i xDim:i fluidNodes:I fluidPDFR:D fluidPDFB:D fluidPDFROld:D fluidPDFBOld:D",
+  "launch_rk_copy_outlet_rows(st, totalNodes, nx, fluidNodes, fluidPDFROld, fluidPDFBOld, fluidPDFR, fluidPDFB)"),
+ ("rk", "calNeumannPhiOutlet", A + ":1363", "totalNodes:i xDim:i nx:i fluidNodes:I neighboringNodes:I phiValue:D",
+  "launch_rk_neumann_phi_outlet(st, totalNodes, nx, fluidNodes, neighboringNodes, phiValue)"),
+ ("rk", "calModifiedPeriodicBoundary", A + ":1382", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFR:D fluidPDFB:D",
+  "launch_rk_modified_periodic(st, totalNodes, nx, ny, fluidNodes, fluidPDFR, fluidPDFB)"),
+ ("rk", "calRKCollision1TotalGPU2DSRT", A + ":1430", "totalNodes:i xDim:i tauR:d tauB:d unitEX:D unitEY:D constantCR:D constantCB:D weightsCoeff:D physicalVX:D physicalVY:D fluidRhoR:D fluidRhoB:D phiValue:D fluidPDFTotal:D collisionTotal1:D",
+  "launch_rk_total_collide1_srt(st, totalNodes, tauR, tauB, weightsCoeff, physicalVX, physicalVY, fluidRhoR, fluidRhoB, phiValue, fluidPDFTotal, collisionTotal1)"),
+ ("rk", "calRKCollision2TotalGPUNew", A + ":1468", "totalNodes:i xDim:i surfaceTA:d solidPhi:d fluidNodes:I neighboringNodes:I constantB:D weightsCoeff:D unitEX:D unitEY:D phiValue:D collisionTotal2:D gradientX:D gradientY:D",
+  "launch_rk_total_collide2(st, totalNodes, surfaceTA, solidPhi, neighboringNodes, constantB, weightsCoeff, phiValue, collisionTotal2, gradientX, gradientY)"),
+ ("rk", "calRecoloringProcess", A + ":1519", "totalNodes:i xDim:i betaValue:d weightsCoeff:D fluidRhoR:D fluidRhoB:D unitEX:D unitEY:D gradientX:D gradientY:D collisionTotal1:D collisionTotal2:D fluidPDFR:D fluidPDFB:D fluidPDFTotal:D",
+  "launch_rk_recolor_add(st, totalNodes, betaValue, weightsCoeff, fluidRhoR, fluidRhoB, gradientX, gradientY, collisionTotal1, collisionTotal2, fluidPDFR, fluidPDFB)"),
+ ("rk", "calPhysicalVelocityRKGPU2DVNew", A + ":1907", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I fluidPDFTotal:D fluidRhoR:D fluidRhoB:D physicalVX:D physicalVY:D forceX:D forceY:D",
+  "launch_rk_velocity_below_inlet(st, totalNodes, nx, ny, fluidNodes, fluidPDFTotal, fluidRhoR, fluidRhoB, physicalVX, physicalVY, forceX, forceY)"),
+ ("rk", "calMacroDensityRKGPU2DNew", A + ":2610", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I fluidPDFR:D fluidPDFB:D fluidRhoR:D fluidRhoB:D",
+  "launch_rk_density_below_inlet(st, totalNodes, nx, ny, fluidNodes, fluidPDFR, fluidPDFB, fluidRhoR, fluidRhoB)"),
  # ---------------- RKGPU2DBoundary.py: the same-named kernels of AcceleratedRKGPU2D.py, four of them with other semantics
  ("rkb", "constantVelocityZHBoundaryHigherRK", B + ":11", "totalNodes:i nx:i ny:i xDim:i specificVYR:d specificVYB:d fluidNodes:I fluidRhoR:D fluidRhoB:D fluidPDFR:D fluidPDFB:D",
   "launch_rk_pert_inlet_velocity(st, totalNodes, nx, ny, specificVYR, specificVYB, fluidNodes, fluidRhoR, fluidRhoB, fluidPDFR, fluidPDFB)"),
@@ -206,6 +231,53 @@ SPEC = [
  ("sc", "calAfterCollisionMRT", E + ":1457", "totalNodes:i numFluids:i xDim:i fluidPDF:D fForce:D fEq:D fluidPDFM:D fForceM:D",
   "sc_check_nf(numFluids); launch_sc_mrt_after_collision(st, totalNodes, fluidPDF, fForce, fEq, fluidPDFM, fForceM)"),
  # ---------------- tracer transport
+ # ---------------- OptimizedD2Q9GPU.py / ExplicitD2Q9GPU.py, kernels no loop launches (csrc/sparse_rest_sc.h)
+ ("sc", "calFluidPotentialGPUPR", O + ":112", "totalNodes:i numFluids:i xDim:i constR:d temperatureT:d coeffA:d coeffB:d coeffAlpha:d constC0:d constG:d fluidRho:D fluidPotential:D",
+  "sc_check_nf(numFluids); launch_sc_potential_pr(st, totalNodes, constR, temperatureT, coeffA, coeffB, coeffAlpha, constC0, constG, fluidRho, fluidPotential)"),
+ ("sc", "calMacroPressure", O + ":135", "totalNodes:i numFluids:i xDim:i interactionCoeff:D fluidRho:D fluidPressure:D",
+  "sc_check_nf(numFluids); launch_sc_pressure(st, totalNodes, 0, interactionCoeff, fluidRho, fluidRho, fluidPressure)"),
+ ("sc", "calInteractionForce", O + ":186", "totaNodes:i numFluids:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I weightInter:D interactionCoeff:D interactionSolid:D fluidPotential:D forceX:D forceY:D",
+  "sc_check_nf(numFluids); launch_sc_product_force(st, totaNodes, neighboringNodes, weightInter, interactionCoeff, interactionSolid, fluidPotential, forceX, forceY)"),
+ ("sc", "addBodyForceGPU", O + ":320", "totalNum:i numFluids:i xDim:i bodyFX:d bodyFY:d forceX:D forceY:D fluidRho:D",
+  "sc_check_nf(numFluids); launch_sc_add_body_force(st, totalNum, bodyFX, bodyFY, forceX, forceY, fluidRho)"),
+ ("sc", "calEquilibriumVGPU", O + ":361", "totalNum:i numFluids:i xDim:i tau:D fluidRho:D forceX:D forceY:D mixtureVX:D mixtureVY:D equilibriumVX:D equilibriumVY:D",
+  "sc_check_nf(numFluids); launch_sc_equilibrium_velocity(st, totalNum, tau, fluidRho, forceX, forceY, mixtureVX, mixtureVY, equilibriumVX, equilibriumVY)"),
+ ("sc", "calEquilibriumFuncGPU", O + ":379", "totalNum:i numFluids:i xDim:i weightCoeff:D fluidRho:D equilibriumVX:D equilibriumVY:D fEq:D",
+  "sc_check_nf(numFluids); launch_sc_equilibrium(st, totalNum, weightCoeff, fluidRho, equilibriumVX, equilibriumVY, fEq)"),
+ ("sc", "calCollisionSRTGPU", O + ":435", "totalNum:i numFluids:i xDim:i tau:D fluidPDF:D fEq:D",
+  "sc_check_nf(numFluids); launch_sc_collide_srt(st, totalNum, tau, fluidPDF, fEq)"),
+ ("sc", "constantPressureZouHeBoundaryHigher", O + ":625", "totalNodes:i numFluids:i nx:i ny:i xDim:i densityH:d fluidNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_inlet_pressure_row(st, totalNodes, nx, ny, densityH, fluidNodes, fluidRho, fluidPDF)"),
+ ("sc", "ghostPointsConstantPressureInlet", O + ":659", "totalNodes:i numFluids:i nx:i ny:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_ghost_pressure_inlet(st, totalNodes, nx, ny, fluidNodes, neighboringNodes, fluidRho, fluidPDF)"),
+ ("sc", "calVelocityBoundaryHigherChangGPU", O + ":1127", "totalNodes:i numFluids:i nx:i ny:i xDim:i specificVY:D fluidNodes:I fluidRho:D forceX:D forceY:D fluidPDFOld:D fluidPDFNew:D",
+  "sc_check_nf(numFluids); launch_sc_chang_velocity_high(st, totalNodes, nx, ny, specificVY, fluidNodes, fluidRho, fluidPDFOld, fluidPDFNew)"),
+ ("sc", "calPressureBoundaryHigherChangGPU", O + ":1172", "totalNodes:i numFluids:i nx:i ny:i xDim:i specificRhoH:d fluidNodes:I fluidRho:D forceX:D forceY:D fluidPDFOld:D fluidPDFNew:D",
+  "sc_check_nf(numFluids); launch_sc_chang_pressure(st, totalNodes, nx, ny - 2, 1, specificRhoH, fluidNodes, fluidRho, forceX, forceY, fluidPDFOld, fluidPDFNew)"),
+ ("sc", "calPressureBoundaryLowerChangGPU", O + ":1222", "totalNodes:i numFluids:i nx:i ny:i xDim:i specificRhoL:d fluidNodes:I fluidRho:D forceX:D forceY:D fluidPDFOld:D fluidPDFNew:D",
+  "sc_check_nf(numFluids); launch_sc_chang_pressure(st, totalNodes, nx, 1, 0, specificRhoL, fluidNodes, fluidRho, forceX, forceY, fluidPDFOld, fluidPDFNew)"),
+ ("sc", "interactionCollisionEOFProcess", O + ":1454", "totalNodes:i numFluids:i xDim:i weightInter:D tauReverse:D interCoeff:D interSolid:D weigthCoeff:D fluidRho:D fluidPotential:D fluidPDF:D fluidPDFNew:D fluidNodes:I neighboringNodes:I forceX:D forceY:D",
+  "sc_check_nf(numFluids); launch_sc_eof_collision(st, totalNodes, weightInter, tauReverse, interCoeff, interSolid, fluidRho, fluidPotential, fluidPDF, neighboringNodes, forceX, forceY)"),
+ ("sc", "calStreaming1withLinkGPU", O + ":1674", "totalNum:i numFluids:i xDim:i fluidNodes:I neighboringNodes:I fluidRho:D fluidPDF:D fluidPDFNew:D physicalVX:D physicalVY:D weightCoeff:D",
+  "sc_check_nf(numFluids); launch_sc_stream1_link(st, totalNum, neighboringNodes, fluidRho, fluidPDF, fluidPDFNew, physicalVX, physicalVY, weightCoeff)"),
+ ("sc", "interactionForceGuo", O + ":1804", "totalNodes:i numFluids:i xDim:i weightInter:D interCoeff:D interSolid:D weightsCoeff:D fluidPotential:D fluidNodes:I neighboringNodes:I forceX:D forceY:D",
+  "sc_check_nf(numFluids); launch_sc_product_force(st, totalNodes, neighboringNodes, weightInter, interCoeff, interSolid, fluidPotential, forceX, forceY)"),
+ ("sc", "calCollisionGuo", O + ":1917", "totalNodes:i numFluids:i xDim:i tau:D weightsCoeff:D unitEX:D unitEY:D fluidRho:D forceX:D forceY:D physicalVX:D physicalVY:D fluidPDF:D",
+  "sc_check_nf(numFluids); launch_sc_collide_guo(st, totalNodes, tau, weightsCoeff, fluidRho, forceX, forceY, physicalVX, physicalVY, fluidPDF)"),
+ ("sc", "calMacroPressureEX", E + ":19", "totalNodes:i numFluids:i xDim:i interactionCoeff:D fluidRho:D fluidPotential:D fluidPressure:D",
+  "sc_check_nf(numFluids); launch_sc_pressure(st, totalNodes, 2, interactionCoeff, fluidRho, fluidPotential, fluidPressure)"),
+ ("sc", "calEffectiveMassPR", E + ":38", "totalNodes:i numFluids:i xDim:i temperature:d interactionCoeff:D fluidRho:D fluidPsi:D",
+  "sc_check_nf(numFluids); launch_sc_effective_mass_pr(st, totalNodes, temperature, interactionCoeff, fluidRho, fluidPsi)"),
+ ("sc", "calTotalVelocityGPU", E + ":311", "totalNodes:i numFluids:i xDim:i EX:D EY:D forceX:D forceY:D fluidPDF:D totalVX:D totalVY:D",
+  "sc_check_nf(numFluids); launch_sc_total_velocity(st, totalNodes, forceX, forceY, fluidPDF, totalVX, totalVY)"),
+ ("sc", "calPressureExpGPU", E + ":371", "totalNodes:i numFluids:i xDim:i interCoeff:D fluidRho:D fluidPotential:D fluidPressure:D",
+  "sc_check_nf(numFluids); launch_sc_pressure(st, totalNodes, 1, interCoeff, fluidRho, fluidPotential, fluidPressure)"),
+ ("sc", "convectiveOutletGPUEFS", E + ":1476", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidRho:D fForce:D fEq:D",
+  "sc_check_nf(numFluids); launch_sc_freeflow_row(st, totalNodes, nx, 2, fluidNodes, neighboringNodes, fluidPDFNew, fluidRho, fForce, fEq)"),
+ ("sc", "convectiveOutletGhost2GPUEFS", E + ":1506", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidRho:D fForce:D fEq:D",
+  "sc_check_nf(numFluids); launch_sc_freeflow_row(st, totalNodes, nx, 1, fluidNodes, neighboringNodes, fluidPDFNew, fluidRho, fForce, fEq)"),
+ ("sc", "convectiveOutletGhost3GPUEFS", E + ":1537", "totalNodes:i numFluids:i nx:i xDim:i fluidNodes:I neighboringNodes:I fluidPDFNew:D fluidRho:D fForce:D fEq:D",
+  "sc_check_nf(numFluids); launch_sc_freeflow_row(st, totalNodes, nx, 0, fluidNodes, neighboringNodes, fluidPDFNew, fluidRho, fForce, fEq)"),
  ("tr", "fillNeighboringNodesTransport", T + ":51", "totalNodes:i nx:i ny:i xDim:i fluidNodes:I domainNewIndex:I neighboringNodes:I",
   "launch_tr_fill_neighbors(st, totalNodes, nx, ny, fluidNodes, domainNewIndex, neighboringNodes)"),
  ("tr", "calReactionTracersGPU", T + ":95", "totalNodes:i numTracers:i xDim:i reactionRate:D diffJcoeffs:D tracerConc:D tracerPDF:D",
@@ -228,8 +300,8 @@ SPEC = [
   "launch_tr_interface(st, totalNodes, (int)numTracers, betaTracer, valueTransportDomain, gradientX, gradientY, tracerConc, tracerPDF)"),
 ]
 
-CT = {"i": "int64_t", "d": "double", "I": "int64_t *", "D": "double *"}
-PY = {"i": "C.c_int64", "d": "C.c_double", "I": "C.c_void_p", "D": "C.c_void_p"}
+CT = {"i": "int64_t", "d": "double", "I": "int64_t *", "D": "double *", "B": "uint8_t *"}
+PY = {"i": "C.c_int64", "d": "C.c_double", "I": "C.c_void_p", "D": "C.c_void_p", "B": "C.c_void_p"}
 
 
 def main():
@@ -261,7 +333,7 @@ int lbmpm_memcpy_d2h(void *dst, const void *src, int64_t bytes);   /* synchronis
 int lbmpm_device_synchronize(void);
 ''']
     ent = ["// GENERATED by tools/gen_shim.py -- extern \"C\" kernel-level entry points\n#pragma once\n"]
-    py = ['"""GENERATED by tools/gen_shim.py: ctypes signatures of the kernel-level entry points:\n(module tag, reference kernel) -> (C symbol, argument kinds, the reference kernel\'s own argument names)."""\nimport ctypes as C\n\nKERNELS = {']
+    py = ['"""GENERATED by tools/gen_shim.py: ctypes signatures of the kernel-level entry points:\n(module tag, reference kernel) -> (C symbol, ctypes of the arguments, the reference kernel\'s own argument names,\nkind letters: i int64, d float64, I int64[], D float64[], B boolean[])."""\nimport ctypes as C\n\nKERNELS = {']
     for mod, name, cite, args, call in SPEC:
         al = [a.split(":") for a in args.split()]
         cargs = ", ".join("%s%s" % (CT[k] + ("" if CT[k].endswith("*") else " "), n) for n, k in al)
@@ -270,7 +342,8 @@ int lbmpm_device_synchronize(void);
         ent.append("extern \"C\" int %s(void *stream, %s)\n{\n    hipStream_t st = static_cast<hipStream_t>(stream);\n"
                    "    (void)st;%s\n    %s;\n    LBMPM_HIP_TRY(hipGetLastError());\n    return LBMPM_OK;\n}\n"
                    % (sym, cargs, "".join(" (void)%s;" % n for n, k in al), call))
-        py.append("    (%r, %r): (%r, [%s], %r)," % (mod, name, sym, ", ".join(PY[k] for n, k in al), tuple(n for n, k in al)))
+        py.append("    (%r, %r): (%r, [%s], %r, %r)," % (mod, name, sym, ", ".join(PY[k] for n, k in al), tuple(n for n, k in al),
+                                                   "".join(k for n, k in al)))
     hdr.append("\n#ifdef __cplusplus\n}\n#endif\n#endif /* LBMPM_KERNELS_H */\n")
     py.append("}\n")
     open(os.path.join(ROOT, "include", "lbmpm_kernels.h"), "w").write("\n".join(hdr))
