@@ -20,7 +20,7 @@ from openlbmpm_amd import _lib                     # noqa: E402
 from openlbmpm_amd._kernel_specs import KERNELS    # noqa: E402
 
 _ready = False
-_DTYPES = {"D": np.dtype(np.float64), "I": np.dtype(np.int64), "B": np.dtype(np.bool_)}
+_DTYPES = {"D": np.dtype(np.float64), "I": np.dtype(np.int64), "L": np.dtype(np.int64), "B": np.dtype(np.bool_)}
 
 
 def _L():
@@ -103,18 +103,19 @@ class Kernel:
         return self
 
     def __call__(self, *args):
-        if len(args) != len(self.kinds):
-            raise TypeError("%s() takes %d arguments (%d given)" % (self.name, len(self.kinds), len(args)))
+        if len(args) != len(self.letters):
+            raise TypeError("%s() takes %d arguments (%d given)" % (self.name, len(self.letters), len(args)))
         conv = []
-        for i, (a, k, letter) in enumerate(zip(args, self.kinds, self.letters)):
-            if k is C.c_void_p:
+        for i, (a, letter) in enumerate(zip(args, self.letters)):
+            if letter in _DTYPES:
                 if not isinstance(a, DeviceNDArray):
                     raise TypeError("%s(): argument %d must be a device array (use cuda.to_device)" % (self.name, i))
-                want = _DTYPES[letter]
-                if a.dtype != want:
-                    raise TypeError("%s(): argument %d has dtype %s; %s expected" % (self.name, i, a.dtype, want))
+                if a.dtype != _DTYPES[letter]:
+                    raise TypeError("%s(): argument %d has dtype %s; %s expected" % (self.name, i, a.dtype, _DTYPES[letter]))
                 conv.append(C.c_void_p(a.ptr))
-            elif k is C.c_int64:
+                if letter == "L":                    # the reference kernel iterates over the whole array
+                    conv.append(C.c_int64(a.size))
+            elif letter == "i":
                 if isinstance(a, (float, np.floating)) and float(a) != int(a):
                     raise TypeError("%s(): argument %d must be an integer" % (self.name, i))
                 conv.append(C.c_int64(int(a)))

@@ -189,6 +189,93 @@ def sc_cases():
     c.save()
 
 
+def tr_cases():
+    import importlib
+    A = importlib.import_module("AcceleratedRKGPU2D")
+    T = importlib.import_module("AccelerateTransport2DRK")
+    rng = np.random.default_rng(1053)
+    dom, fluidNodes, newIndex = geometry()
+    ny, nx = dom.shape
+    N = fluidNodes.size
+    nbr4 = np.zeros(4 * N, dtype=np.int64); nbr8 = np.zeros(8 * N, dtype=np.int64)
+    T.fillNeighboringNodesTransport[(2, -(-N // 64)), (32, 1)](N, nx, ny, 64, fluidNodes, newIndex, nbr4)
+    A.fillNeighboringNodes[(2, -(-N // 64)), (32, 1)](N, nx, ny, 64, fluidNodes, newIndex, nbr8)
+    nT = 2
+    VX5 = np.array([0., 1., -1., 0., 0.]); VY5 = np.array([0., 0., 0., 1., -1.]); W5 = np.array([1. / 3.] + [1. / 6.] * 4)
+    yrow = fluidNodes // nx
+    mask = (yrow < 9)                                            # boolean masks: True in the lower half
+    mask[rng.integers(0, N, 6)] ^= True
+    C = rng.uniform(0.2, 1.0, (nT, N))
+    g5 = C[:, :, None] * W5[None, None, :] * rng.uniform(0.8, 1.2, (nT, N, 5))
+    g9 = C[:, :, None] * W9[None, None, :] * rng.uniform(0.8, 1.2, (nT, N, 9))
+    newList = np.array(sorted(set(rng.choice(np.flatnonzero((yrow >= 3) & (yrow <= 8)), 7).tolist())), dtype=np.int64)
+    # every listed node needs a masked, unlisted surrounding node (the reference divides by their count, T:239)
+    ok = []
+    for n in newList:
+        s = nbr8[8 * n: 8 * n + 8]
+        if any(q >= 0 and mask[q] and q not in newList for q in s):
+            ok.append(n)
+    newList = np.array(ok, dtype=np.int64)
+    assert newList.size >= 3
+    M5 = np.array([[1, 1, 1, 1, 1], [0, 1, -1, 0, 0], [0, 0, 0, 1, -1], [-4, 1, 1, 1, 1], [0, 1, 1, -1, -1]], dtype=np.float64)
+    A5 = np.stack([-np.linalg.inv(M5) @ np.diag(1. / np.array([1.0, 0.5 + 3 * d, 0.5 + 3 * d, 1.1, 1.2])) for d in (1. / 6., 0.12)])
+    M9 = np.array([[1, 1, 1, 1, 1, 1, 1, 1, 1], [-4, -1, -1, -1, -1, 2, 2, 2, 2], [4, -2, -2, -2, -2, 1, 1, 1, 1], [0, 1, 0, -1, 0, 1, -1, -1, 1],
+                   [0, -2, 0, 2, 0, 1, -1, -1, 1], [0, 0, 1, 0, -1, 1, 1, -1, -1], [0, 0, -2, 0, 2, 1, 1, -1, -1], [0, 1, -1, 1, -1, 0, 0, 0, 0],
+                   [0, 0, 0, 0, 0, 1, -1, 1, -1]], dtype=np.float64)
+    A9 = np.stack([-np.linalg.inv(M9) @ np.diag(1. / np.array([1.0, 1.1, 1.2, 0.5 + 3 * d, 1.3, 0.5 + 3 * d, 1.3, 1.4, 1.4])) for d in (1. / 6., 0.12)])
+    J = np.stack([np.array([j] + [(1. - j) / 4.] * 4) for j in (1. / 3., 0.4)])
+    vx, vy = rng.uniform(-0.04, 0.04, N), rng.uniform(-0.04, 0.04, N)
+    vx[:5] = 0.0; vy[:5] = 0.0                                   # (nodes at rest: the other branch of T:513)
+    V = dict(totalNodes=N, xDim=64, nx=nx, ny=ny, numTracers=nT, numScheme=5, fluidNodes=fluidNodes, neighboringNodes=nbr4, neighboringTRNodes=nbr4,
+             surroundingNodes=nbr8, unitVX=VX5, unitVY=VY5, unitX=VX5, unitY=VY5, velocityVX=vx, velocityVY=vy, velocityX=vx, velocityY=vy,
+             physicalVX=vx, physicalVY=vy, tauTransport=np.array([1.0, 0.86]), tauDiff=np.array([1.0, 0.86]), valueJDE=J, tracerConc=C,
+             tracerConcNew=C * rng.uniform(0.9, 1.1, (nT, N)), tracerPDF=g5, tracerPDFNew=np.zeros((nT, N, 5)), criteriaFluid=0.5,
+             fluidRhoR=rng.uniform(0., 1., N), distriField=mask, distrField=mask, transportDomain=mask, newFluidList=newList, oldFluidList=newList,
+             newList=newList, randomPert=1.0e-3, sumOldConc=np.array([40., 25.]), sumOldList=np.array([3., 2.]), sumNewList=np.array([2.5, 2.2]),
+             totalTracer=np.array([40., 25.]), totalOld=np.array([3., 2.]), weightsCoeff=W5, transportM=M5, inverseRelaxationMS=A5,
+             concBoundary=np.array([1.0, 0.25]), betaTracer=np.array([0.8, 0.5]), valueTransportDomain=-(1. - mask.astype(np.float64)),
+             unitEX=EX, unitEY=EY, gradientX=rng.uniform(-0.2, 0.2, N), gradientY=rng.uniform(-0.2, 0.2, N))
+    V["gradientX"][:4] = 0.0; V["gradientY"][:4] = 0.0           # (no interface there: the other branch of T:1031)
+    c = Cases("tr", T)
+    c.run("calCollisionTransportGPU", V)
+    c.run("calUpdateDistributionGPU", dict(V, distriField=np.zeros(N, dtype=bool)))
+    c.run("calUpdateConcOnNewNodesGPU", V)
+    c.run("calUpdateConcOnOldNodesGPU", V)
+    c.run("calUpdateConcOnAllNewNodesGPU", V)
+    c.run("calUpdateConcWholeDomainGPU", V)
+    c.run("calTransportInterfaceGPU", V)
+    c.run("calUpdatedPDFWithNewRho", V)
+    c.run("calFreeConcBoundary1", V)
+    c.run("calFreeConcBoundary2", V)
+    c.run("calZeroConcenBoundary", V)
+    c.run("calUpdateConcInTransportDomainByV", V)
+    v5 = rng.uniform(-0.04, 0.04, 5)                             # T:624 indexes the 5-entry unitVY by node: five nodes at most
+    five = dict(V, totalNodes=5, tracerConc=C[:, :5].copy(), tracerPDF=g5[:, :5].copy(), velocityVX=v5, velocityVY=v5[::-1].copy())
+    c.run("calCollisionTransportQuadraticEqlMRTGPU", five)
+    try:
+        c.run("calCollisionTransportQuadraticEqlMRTGPU", V, case="discard")
+        raise SystemExit("expected an IndexError")
+    except IndexError:
+        for k in [k for k in c.out if k.startswith("discard|")]:
+            del c.out[k]
+    c.run("calAntiCollisionConcBoundary", V)
+    Q9 = dict(V, numScheme=9, unitVX=EX, unitVY=EY, weightsCoeff=W9, tracerPDF=g9, neighboringNodes=nbr8, transportM=M9, inverseRelaxationMS=A9)
+    c.run("calCollisionQ9", Q9)
+    s1 = c.run("calStreaming1GPU", dict(Q9, totalNum=N, numFluids=nT, fluidPDF=g9, fluidPDFNew=np.zeros((nT, N, 9))))
+    c.run("calStreaming2GPU", dict(Q9, totalNum=N, numFluids=nT, fluidPDF=g9, fluidPDFNew=s1["fluidPDFNew"]))
+    c.run("calTransportInterfaceQ9GPU", Q9)
+    try:
+        c.run("calUpdateConcInTransportDomainByVQ9", Q9, case="discard")
+        raise SystemExit("expected an IndexError")
+    except IndexError:                                           # T:938-939: 9 weights into a 5-entry shared array
+        for k in [k for k in c.out if k.startswith("discard|")]:
+            del c.out[k]
+    c.out["calUpdateConcInTransportDomainByVQ9|raises"] = np.array("IndexError")
+    c.run("calTransportWithInterfaceD2Q9", Q9)
+    c.run("calCollisionTransportLinearEqlMRTGPUD2Q9", Q9)
+    c.save()
+
+
 if __name__ == "__main__":
     refenv.setup()
     which = sys.argv[1:] or ["rk"]

@@ -24,6 +24,9 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="th
     ("make_golden_rkb.py", [], "rkb_kernels.npz"),
     ("make_golden_dense.py", [], "dense_kernels.npz"),
     ("make_golden_tr_coupled.py", ["capillary"], "trc_capillary.npz"),
+    ("make_golden_kats.py", ["rk"], "kats_rk.npz"),
+    ("make_golden_kats.py", ["sc"], "kats_sc.npz"),
+    ("make_golden_kats.py", ["tr"], "kats_tr.npz"),
 ])
 def test_fixture_is_reproduced_from_the_reference(tmp_path, script, args, fixture):
     env = dict(os.environ, LBMPM_GOLDEN_OUT=str(tmp_path))
@@ -33,3 +36,27 @@ def test_fixture_is_reproduced_from_the_reference(tmp_path, script, args, fixtur
     assert set(old.files) <= set(new.files)            # (later generator versions may record more parameters)
     for k in old.files:
         assert np.array_equal(new[k], old[k], equal_nan=new[k].dtype.kind == "f"), k
+
+
+def test_every_kernel_of_the_five_kernel_modules_has_an_entry_point():
+    """completeness of the kernel-level ABI: every function the reference compiles with @cuda.jit as a KERNEL (not
+    device=True) in its five kernel modules has a same-named entry point in include/lbmpm_kernels.h, with the same
+    parameter names in the same order"""
+    import re
+    from openlbmpm_amd._kernel_specs import KERNELS
+    files = {"rk": "RKCG2D/AcceleratedRKGPU2D.py", "rkb": "RKCG2D/RKGPU2DBoundary.py", "sc": "ShanChen2D/OptimizedD2Q9GPU.py",
+             "sc ": "ShanChen2D/ExplicitD2Q9GPU.py", "tr": "RKCG2D/AccelerateTransport2DRK.py"}
+    total = 0
+    for tag, rel in files.items():
+        src = open(os.path.join("/root/reference", rel)).read()
+        for m in re.finditer(r"@cuda\.jit\(([^@]*?)\)\s*\ndef (\w+)\(([^)]*)\)", src, re.S):
+            if re.search(r"device\s*=\s*True", m.group(1)):
+                continue
+            name = m.group(2)
+            params = tuple(p.strip() for p in m.group(3).replace("\\", " ").split(",") if p.strip())
+            assert (tag.strip(), name) in KERNELS, "%s: %s has no entry point" % (rel, name)
+            # the later definition of a name used twice is the one Python keeps (calRKCollision23GPU, A:244 / A:511)
+            if src.count("def %s(" % name) == 1:
+                assert KERNELS[(tag.strip(), name)][2] == params, (rel, name)
+            total += 1
+    assert total >= 155

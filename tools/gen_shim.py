@@ -4,7 +4,9 @@
   openlbmpm_amd/csrc/sparse_entry_gen.h           extern "C" definitions forwarding to the launchers
   openlbmpm_amd/_kernel_specs.py                  ctypes signatures for the Python shim
 Argument lists are the reference kernels' own (module, name, citation), minus the launch
-configuration.  kinds: i = int64, d = float64, I = int64*, D = float64*, B = boolean* (one byte per entry, numpy bool)."""
+configuration.  kinds: i = int64, d = float64, I = int64*, D = float64*, B = boolean* (one byte per entry, numpy bool),
+L = int64* iterated over its whole length by the reference kernel (`for m in list`): the C entry point takes the length right after it
+(<name>_len), the Python shim passes the array's size."""
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -298,6 +300,51 @@ SPEC = [
   "launch_tr_indicator(st, totalNodes, critiriaValue, valueTransportDomain, fluidRhoR)"),
  ("tr", "calTransportWithInterfaceD2Q5", T + ":976", "totalNodes:i xDim:i numTracers:i betaTracer:D valueTransportDomain:D unitEX:D unitEY:D gradientX:D gradientY:D weightsCoeff:D tracerConc:D tracerPDF:D",
   "launch_tr_interface(st, totalNodes, (int)numTracers, betaTracer, valueTransportDomain, gradientX, gradientY, tracerConc, tracerPDF)"),
+ # ---------------- AccelerateTransport2DRK.py, kernels the working loop does not launch (csrc/sparse_rest_tr.h)
+ ("tr", "calCollisionTransportGPU", T + ":118", "totalNodes:i xDim:i numTracers:i numScheme:i unitVX:D unitVY:D velocityVX:D velocityVY:D tauTransport:D valueJDE:D tracerConc:D tracerPDF:D tracerPDFNew:D",
+  "tr_check_q5(numScheme); launch_tr_collide_bgk(st, totalNodes, (int)numTracers, velocityVX, velocityVY, tauTransport, valueJDE, tracerConc, tracerPDF)"),
+ ("tr", "calUpdateDistributionGPU", T + ":197", "totalNodes:i xDim:i criteriaFluid:d fluidRhoR:D distriField:B",
+  "launch_tr_update_distribution(st, totalNodes, criteriaFluid, fluidRhoR, distriField)"),
+ ("tr", "calUpdateConcOnNewNodesGPU", T + ":216", "totalNodes:i xDim:i numTracers:i newFluidList:L surroundingNodes:I tracerConc:D distrField:B",
+  "launch_tr_conc_on_new_nodes(st, totalNodes, (int)numTracers, newFluidList, newFluidList_len, surroundingNodes, tracerConc, distrField)"),
+ ("tr", "calUpdateConcOnOldNodesGPU", T + ":245", "totalNodes:i xDim:i numTracers:i oldFluidList:L tracerConc:D tracerPDF:D",
+  "launch_tr_clear_listed(st, totalNodes, (int)numTracers, oldFluidList, oldFluidList_len, tracerConc, tracerPDF)"),
+ ("tr", "calUpdateConcOnAllNewNodesGPU", T + ":267", "totalNodes:i xDim:i numTracers:i transportDomain:B tracerConc:D tracerPDF:D",
+  "launch_tr_clear_outside(st, totalNodes, (int)numTracers, transportDomain, tracerConc, tracerPDF)"),
+ ("tr", "calUpdateConcWholeDomainGPU", T + ":285", "totalNodes:i nx:i xDim:i numTracers:i randomPert:d fluidNodes:I sumOldConc:D sumOldList:D sumNewList:D tracerConcNew:D tracerConc:D distrField:B",
+  "launch_tr_rescale_whole_domain(st, totalNodes, (int)numTracers, randomPert, sumOldConc, sumOldList, sumNewList, tracerConcNew, tracerConc)"),
+ ("tr", "calTransportInterfaceGPU", T + ":310", "totalNodes:i xDim:i numTracers:i numScheme:i neighboringNodes:I velocityVX:D velocityVY:D tracerConc:D tracerPDF:D distriField:B",
+  "tr_check_q5(numScheme); launch_tr_interface_exchange<5>(st, totalNodes, (int)numTracers, neighboringNodes, tracerPDF, distriField)"),
+ ("tr", "calUpdatedPDFWithNewRho", T + ":389", "totalNodes:i xDim:i numTracers:i newList:L unitX:D unitY:D velocityX:D velocityY:D tracerConc:D tracerConcNew:D valueJDE:D tracerPDF:D distrField:B",
+  "launch_tr_pdf_with_new_rho(st, totalNodes, (int)numTracers, newList, newList_len, velocityX, velocityY, tracerConc, tracerConcNew, valueJDE, tracerPDF, distrField)"),
+ ("tr", "calFreeConcBoundary1", T + ":419", "totalNodes:i numTracers:i nx:i xDim:i fluidNodes:I neighboringNodes:I tracerConc:D tracerPDF:D",
+  "launch_tr_free_row(st, totalNodes, (int)numTracers, nx, 2, fluidNodes, neighboringNodes, tracerPDF)"),
+ ("tr", "calFreeConcBoundary2", T + ":440", "totalNodes:i numTracers:i nx:i xDim:i fluidNodes:I neighboringNodes:I tracerConc:D tracerPDF:D",
+  "launch_tr_free_row(st, totalNodes, (int)numTracers, nx, 1, fluidNodes, neighboringNodes, tracerPDF)"),
+ ("tr", "calZeroConcenBoundary", T + ":480", "totalNodes:i numTracers:i nx:i ny:i xDim:i fluidNodes:I tracerConc:D tracerPDF:D neighboringNodes:I",
+  "launch_tr_zero_gradient_inlet(st, totalNodes, (int)numTracers, nx, ny, fluidNodes, tracerConc, tracerPDF, neighboringNodes)"),
+ ("tr", "calUpdateConcInTransportDomainByV", T + ":500", "totalNodes:i numTracers:i xDim:i totalTracer:D totalOld:D transportDomain:B physicalVX:D physicalVY:D unitVX:D unitVY:D weightsCoeff:D tracerConc:D tracerPDF:D",
+  "launch_tr_conc_by_velocity(st, totalNodes, (int)numTracers, totalTracer, totalOld, transportDomain, physicalVX, physicalVY, weightsCoeff, tracerConc, tracerPDF)"),
+ ("tr", "calCollisionTransportQuadraticEqlMRTGPU", T + ":596", "totalNodes:i xDim:i numTracers:i unitVX:D unitVY:D velocityVX:D velocityVY:D tracerConc:D tracerPDF:D transportM:D inverseRelaxationMS:D weightsCoeff:D",
+  "if (totalNodes > 5) { set_error(\"calCollisionTransportQuadraticEqlMRTGPU indexes the 5-entry unitVY by node (AccelerateTransport2DRK.py:624): defined for totalNodes <= 5 only\"); return LBMPM_ERR_UNSUPPORTED; } "
+  "launch_tr_collide_mrt_quadratic(st, totalNodes, (int)numTracers, velocityVY, tracerConc, tracerPDF, transportM, inverseRelaxationMS, weightsCoeff)"),
+ ("tr", "calAntiCollisionConcBoundary", T + ":661", "totalNodes:i xDim:i numTracers:i ny:i nx:i fluidNodes:I neighboringTRNodes:I concBoundary:D weightsCoeff:D tracerPDF:D",
+  "launch_tr_anti_bounce_inlet(st, totalNodes, (int)numTracers, ny, nx, fluidNodes, neighboringTRNodes, concBoundary, weightsCoeff, tracerPDF)"),
+ ("tr", "calCollisionQ9", T + ":704", "totalNodes:i xDim:i numTracers:i unitVX:D unitVY:D velocityVX:D velocityVY:D tauDiff:D tracerConc:D tracerPDF:D weightsCoeff:D",
+  "launch_tr9_collide_bgk(st, totalNodes, (int)numTracers, velocityVX, velocityVY, tauDiff, tracerConc, tracerPDF, weightsCoeff)"),
+ ("tr", "calStreaming1GPU", T + ":736", "totalNum:i numFluids:i xDim:i fluidNodes:I neighboringNodes:I fluidPDF:D fluidPDFNew:D",
+  "launch_tr9_stream1(st, totalNum, (int)numFluids, neighboringNodes, fluidPDF, fluidPDFNew)"),
+ ("tr", "calStreaming2GPU", T + ":823", "totalNum:i numFluids:i xDim:i fluidPDFNew:D fluidPDF:D",
+  "launch_tr9_stream2(st, totalNum, (int)numFluids, fluidPDFNew, fluidPDF)"),
+ ("tr", "calTransportInterfaceQ9GPU", T + ":839", "totalNodes:i xDim:i numTracers:i numScheme:i neighboringNodes:I velocityVX:D velocityVY:D tracerConc:D tracerPDF:D distriField:B",
+  "if (numScheme != 9) { set_error(\"numScheme must be 9 (D2Q9); got %lld\", (long long)numScheme); return LBMPM_ERR_UNSUPPORTED; } "
+  "launch_tr_interface_exchange<9>(st, totalNodes, (int)numTracers, neighboringNodes, tracerPDF, distriField)"),
+ ("tr", "calUpdateConcInTransportDomainByVQ9", T + ":927", "totalNodes:i numTracers:i xDim:i totalTracer:D totalOld:D transportDomain:B physicalVX:D physicalVY:D unitVX:D unitVY:D weightsCoeff:D tracerConc:D tracerPDF:D",
+  "set_error(\"calUpdateConcInTransportDomainByVQ9 cannot run in the reference: it stores 9 weights in a 5-entry shared array (AccelerateTransport2DRK.py:936-939) and indexes unitVY by node (:953)\"); return LBMPM_ERR_UNSUPPORTED"),
+ ("tr", "calTransportWithInterfaceD2Q9", T + ":1019", "totalNodes:i xDim:i numTracers:i betaTracer:D valueTransportDomain:D unitEX:D unitEY:D gradientX:D gradientY:D weightsCoeff:D tracerConc:D tracerPDF:D",
+  "launch_tr9_interface(st, totalNodes, (int)numTracers, betaTracer, valueTransportDomain, gradientX, gradientY, weightsCoeff, tracerConc, tracerPDF)"),
+ ("tr", "calCollisionTransportLinearEqlMRTGPUD2Q9", T + ":1053", "totalNodes:i xDim:i numTracers:i unitVX:D unitVY:D velocityVX:D velocityVY:D tracerConc:D tracerPDF:D transportM:D inverseRelaxationMS:D weightsCoeff:D",
+  "launch_tr9_collide_mrt(st, totalNodes, (int)numTracers, velocityVX, velocityVY, tracerConc, tracerPDF, transportM, inverseRelaxationMS, weightsCoeff)"),
 ]
 
 CT = {"i": "int64_t", "d": "double", "I": "int64_t *", "D": "double *", "B": "uint8_t *"}
@@ -336,13 +383,13 @@ int lbmpm_device_synchronize(void);
     py = ['"""GENERATED by tools/gen_shim.py: ctypes signatures of the kernel-level entry points:\n(module tag, reference kernel) -> (C symbol, ctypes of the arguments, the reference kernel\'s own argument names,\nkind letters: i int64, d float64, I int64[], D float64[], B boolean[])."""\nimport ctypes as C\n\nKERNELS = {']
     for mod, name, cite, args, call in SPEC:
         al = [a.split(":") for a in args.split()]
-        cargs = ", ".join("%s%s" % (CT[k] + ("" if CT[k].endswith("*") else " "), n) for n, k in al)
+        cargs = ", ".join("int64_t *%s, int64_t %s_len" % (n, n) if k == "L" else "%s%s" % (CT[k] + ("" if CT[k].endswith("*") else " "), n) for n, k in al)
         sym = "lbmpm_%s_%s" % (mod, name)
         hdr.append("/* %s %s */\nint %s(void *stream, %s);" % (cite, name, sym, cargs))
         ent.append("extern \"C\" int %s(void *stream, %s)\n{\n    hipStream_t st = static_cast<hipStream_t>(stream);\n"
                    "    (void)st;%s\n    %s;\n    LBMPM_HIP_TRY(hipGetLastError());\n    return LBMPM_OK;\n}\n"
-                   % (sym, cargs, "".join(" (void)%s;" % n for n, k in al), call))
-        py.append("    (%r, %r): (%r, [%s], %r, %r)," % (mod, name, sym, ", ".join(PY[k] for n, k in al), tuple(n for n, k in al),
+                   % (sym, cargs, "".join(" (void)%s;" % n + (" (void)%s_len;" % n if k == "L" else "") for n, k in al), call))
+        py.append("    (%r, %r): (%r, [%s], %r, %r)," % (mod, name, sym, ", ".join("C.c_void_p, C.c_int64" if k == "L" else PY[k] for n, k in al), tuple(n for n, k in al),
                                                    "".join(k for n, k in al)))
     hdr.append("\n#ifdef __cplusplus\n}\n#endif\n#endif /* LBMPM_KERNELS_H */\n")
     py.append("}\n")
