@@ -342,6 +342,8 @@ def main():
                                            ("c3", build_c3, (2048, 2048)), ("c4", build_c4, (2048, 2048))):
                     s, _, _ = build(size2[0], size2[1], local_rank)
                     k = {"c1": 20000, "c2": 1000}.get(name, 300)     # (c1: 16 k nodes, ~7 us a step; the warm-up builds its hipGraph)
+                    if os.environ.get("LBMPM_BENCH_SECONDARY_STEPS"):    # counter passes of tools/profile_round.sh: every dispatch is slow there
+                        k = int(os.environ["LBMPM_BENCH_SECONDARY_STEPS"])
                     w, mt, md = time_solver_2d(s, k, k // 10)
                     nf = s.num_fluid_nodes
                     sec.append({"workload": name, "value": round(nf * k / w / 1e6, 2), "unit": "MLUPS",

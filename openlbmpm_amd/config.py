@@ -118,8 +118,13 @@ def read_rk3d(ini_dir):
         p["nx"] = c.int("DomainSize", "xDomain"); p["ny"] = c.int("DomainSize", "yDomain")
         p["nz"] = c.int("DomainSize", "zDomain")
     for k in ("AlphaR", "AlphaB"):
-        if c.float("RKParameters", k, default=0.0) != 0.0:
-            raise ConfigError("[RKParameters] %s != 0 (density-ratio rest weights) is not supported" % k)
+        # the kernels of the perturbation loop this model extends load the rest weights C_i(alpha) and never use them
+        # (AcceleratedRKGPU2D.py:1140 / :1190; equilibria are calEquilibriumRK2D, :170): any value gives the same numbers
+        p[k] = c.float("RKParameters", k, default=0.0)
+        if p[k] != 0.0:
+            import warnings
+            warnings.warn("[RKParameters] %s = %g has no effect, as in the reference's perturbation kernels "
+                          "(AcceleratedRKGPU2D.py:1125-1267 load the rest weights and do not use them)" % (k, p[k]))
     p["AkR"] = c.float("RKParameters", "AkR"); p["AkB"] = c.float("RKParameters", "AkB")
     p["beta"] = c.float("RKParameters", "BetaThickness")
     p["tauR"] = c.float("FluidParameters", "TauR"); p["tauB"] = c.float("FluidParameters", "TauB")
