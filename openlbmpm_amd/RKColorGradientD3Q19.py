@@ -14,7 +14,7 @@ import numpy as np
 
 from . import config
 from .geometry import initial_densities_rk3d, voxel_domain
-from .results import ResultFile
+from .results import RecordGuard, ResultFile
 from .rk3d import RK3DSlab, RK3DDistributed
 
 PARAM_KEYS = ("AkR", "AkB", "beta", "tauR", "tauB", "SolidRhoR", "SolidRhoB", "velocityZR", "velocityZB",
@@ -92,8 +92,10 @@ class RKColorGradient3D:
             self.z0, self.nzl = 0, self.zDomain
         out = ResultFile(self.output_dir, name, (("FluidMacro", "MacroData"), ("FluidVelocity", "MacroVelocity")))
         self.result_path = out.path
+        self._guard = RecordGuard("rk3d", slab.num_fluid_nodes, getattr(self, "nan_guard", "raise"))
         done = 0
         while done < self.timeSteps:
+            self._step_now = done
             if done % self.timeInterval == 0:
                 observe()
                 self._record(slab, out)
@@ -103,6 +105,7 @@ class RKColorGradient3D:
             if progress:
                 progress(done)
         observe()
+        self._step_now = done
         self._record(slab, out)
         slab.sync()
         self.solver = sim
@@ -116,4 +119,8 @@ class RKColorGradient3D:
         out.write("FluidMacro", "FluidDensityBin%g" % k, self.fluidsRhoB)
         for axis, a in (("X", self.physicalVX), ("Y", self.physicalVY), ("Z", self.physicalVZ)):
             out.write("FluidVelocity", "FluidVelocity%sAt%g" % (axis, k), a)
+        guard = getattr(self, "_guard", None)
+        if guard:
+            guard(k, getattr(self, "_step_now", 0), dict(rhoR=self.fluidsRhoR, rhoB=self.fluidsRhoB, vx=self.physicalVX, vy=self.physicalVY, vz=self.physicalVZ),
+                  dict(massR=float(self.fluidsRhoR.sum()), massB=float(self.fluidsRhoB.sum())))
         self.records += 1

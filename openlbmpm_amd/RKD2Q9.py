@@ -14,7 +14,7 @@ import numpy as np
 
 from . import config
 from .geometry import simple_geometry, image_domain, initial_densities_rk
-from .results import ResultFile
+from .results import RecordGuard, ResultFile
 from .rk2d import RK2DSolver
 
 
@@ -34,6 +34,7 @@ class RKColorGradientLBM:
         self.par = config.read_rk2d(pathIniFile)
         self.output_dir = output_dir or os.path.expanduser("~/LBMResults")
         self.device = device
+        self.nan_guard = "raise"              # 'raise' | 'warn' | 'off': finiteness check of every record (results.RecordGuard)
         self._image = image
         p = self.par
         self.timeSteps, self.timeInterval = p["steps"], p["interval"]
@@ -124,8 +125,10 @@ class RKColorGradientLBM:
         out = ResultFile(self.output_dir, "SimulationResultsRK",
                          (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity")))
         self.result_path = out.path
+        self._guard = RecordGuard("rk2d", int((self.isDomain == 1).sum()), self.nan_guard)
         done = 0
         while done < self.timeSteps:
+            self._step_now = done
             # the reference records inside step `done+1`, after its boundary kernels, velocity and
             # phase field (RKD2Q9.py:1382-1393): that is the REC_* view of the current state
             if done % self.timeInterval == 0:
@@ -150,4 +153,10 @@ class RKColorGradientLBM:
         out.write("FluidPDF", "FluidPDFRat%g" % k, self.fluidPDFR)
         out.write("FluidVelocity", "FluidVelocityXAt%g" % k, self.physicalVX)
         out.write("FluidVelocity", "FluidVelocityYAt%g" % k, self.physicalVY)
+        guard = getattr(self, "_guard", None)
+        if guard:
+            total = float(self.fluidsRhoR.sum() + self.fluidsRhoB.sum())
+            guard(k, getattr(self, "_step_now", 0), dict(rhoR=self.fluidsRhoR, rhoB=self.fluidsRhoB, vx=self.physicalVX, vy=self.physicalVY),
+                  dict(massR=float(self.fluidsRhoR.sum()), massB=float(self.fluidsRhoB.sum()),
+                       saturationR=float(self.fluidsRhoR.sum()) / total if total else 0.0))
         self.records += 1

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import config
 from .geometry import simple_geometry, image_domain
-from .results import ResultFile
+from .results import RecordGuard, ResultFile
 from .sc2d import SC2DSolver
 
 
@@ -82,6 +82,7 @@ class ShanChenD2Q9:
         out = ResultFile(self.output_dir, "SimulationResults",
                          (("FluidMacro", "MacroData"), ("FluidVelocity", "MacroVelocity")))
         self.result_path = out.path
+        self._guard = RecordGuard("sc2d", int((self.isDomain == 1).sum()), getattr(self, "nan_guard", "raise"))
         total = self.numTimeStep + 1            # both reference loops run numTimeStep + 1 passes
         done = 0
         efs = p["inter"] == "EFS"
@@ -92,11 +93,13 @@ class ShanChenD2Q9:
                 solver.step(n)
                 done += n
                 if (done - 1) % self.record_every == 0:
+                    self._step_now = done
                     self._record(solver, out, ("rho0", "rho1"))
             else:
                 # original Shan-Chen records inside pass `done+1`, after its inlet kernels, with the
                 # velocity of the previous pass (ShanChenD2Q9.py:1523-1572)
                 if done % self.record_every == 0:
+                    self._step_now = done
                     self._record(solver, out, ("rec_rho0", "rec_rho1"))
                 n = min(self.record_every - done % self.record_every, total - done)
                 solver.step(n)
@@ -115,4 +118,8 @@ class ShanChenD2Q9:
             out.write("FluidMacro", "FluidDensityType%gin%g" % (i, k), self.fluidsDensity[i])
         out.write("FluidVelocity", "FluidVelocityXAt%g" % k, self.physicalVX)
         out.write("FluidVelocity", "FluidVelocityYAt%g" % k, self.physicalVY)
+        guard = getattr(self, "_guard", None)
+        if guard:
+            guard(k, getattr(self, "_step_now", 0), dict(rho0=self.fluidsDensity[0], rho1=self.fluidsDensity[1], vx=self.physicalVX, vy=self.physicalVY),
+                  dict(mass0=float(self.fluidsDensity[0].sum()), mass1=float(self.fluidsDensity[1].sum())))
         self.records += 1

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import config
 from .RKD2Q9 import RKColorGradientLBM
-from .results import ResultFile
+from .results import RecordGuard, ResultFile
 from .rk2d import RK2DSolver
 
 
@@ -106,8 +106,11 @@ class Transport2DRK(RKColorGradientLBM):
                           (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity")))
         conc = ResultFile(self.output_dir, "ConcentrationResults", (("TransportMacro", "MacroData"),))
         self.result_path, self.concentration_path = flow.path, conc.path
+        self._guard = RecordGuard("rk2d+tracers", int((self.isDomain == 1).sum()), self.nan_guard)
+        tracer_guard = RecordGuard("tracers", int((self.isDomain == 1).sum()), self.nan_guard)
         done = 0
         while done < self.timeSteps:
+            self._step_now = done
             if done % self.timeInterval == 0:
                 k = self.records
                 self._record(solver, flow)              # flow view at the start of step done + 1
@@ -116,6 +119,8 @@ class Transport2DRK(RKColorGradientLBM):
                 for i in range(n):                      # concentrations after the tracer update of that step
                     self.tracerConc[i] = solver.get_tracer(i)
                     conc.write("TransportMacro", "TracerConcType%gin%g" % (i, k), self.tracerConc[i])
+                tracer_guard(k, done, {"tracer%d" % i: self.tracerConc[i] for i in range(n)},
+                             {"tracer%d" % i: float(self.tracerConc[i].sum()) for i in range(n)})
             m = min(self.timeInterval - done % self.timeInterval, self.timeSteps - done) if done % self.timeInterval else 0
             if m:
                 solver.step(m)

@@ -113,3 +113,42 @@ def load_results(path):
             out[node._v_pathname] = node.read()
         f.close()
         return out
+
+
+class SimulationDiverged(FloatingPointError):
+    """a recorded field holds NaN or Inf (the reference lets them propagate silently into its result files)"""
+
+
+class RecordGuard:
+    """What every driver does at its output cadence besides writing: a finiteness check of the recorded fields
+    (`nan_guard` = 'raise' (default) | 'warn' | 'off'; environment LBMPM_NAN_GUARD overrides) and ONE logging line
+    (logger 'openlbmpm_amd', level INFO) with the record index, the step, lattice updates per second since the last
+    record and the sums the caller passes (masses, saturation)."""
+
+    def __init__(self, name, fluid_nodes, nan_guard="raise"):
+        import logging
+        import time
+        self.name, self.fluid_nodes = name, int(fluid_nodes)
+        self.mode = os.environ.get("LBMPM_NAN_GUARD", nan_guard)
+        if self.mode not in ("raise", "warn", "off"):
+            raise ValueError("nan_guard must be 'raise', 'warn' or 'off'")
+        self.log = logging.getLogger("openlbmpm_amd")
+        self._clock, self._t, self._step = time.perf_counter, time.perf_counter(), 0
+
+    def __call__(self, record, step, fields, sums=None):
+        if self.mode != "off":
+            for key, a in fields.items():
+                if not np.isfinite(a).all():
+                    bad = int(a.size - np.isfinite(a).sum())
+                    msg = "%s: record %d (step %d): %s holds %d non-finite values" % (self.name, record, step, key, bad)
+                    if self.mode == "raise":
+                        raise SimulationDiverged(msg)
+                    import warnings
+                    warnings.warn(msg)
+                    break
+        now = self._clock()
+        rate = (step - self._step) * self.fluid_nodes / max(now - self._t, 1e-12) / 1e6 if step > self._step else 0.0
+        self._t, self._step = now, step
+        if self.log.isEnabledFor(20):
+            extra = "".join("  %s %.10g" % kv for kv in (sums or {}).items())
+            self.log.info("%s record %d step %d  %.0f MLUPS%s", self.name, record, step, rate, extra)

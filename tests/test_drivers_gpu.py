@@ -277,3 +277,31 @@ dist.destroy_process_group()
     assert set(parts[0]) == set(ref) and len(ref) == 5 * single.records
     for key in ref:
         assert np.array_equal(np.concatenate([parts[0][key], parts[1][key]], axis=0), ref[key]), key
+
+
+def test_records_are_checked_for_nan_and_logged(tmp_path, caplog):
+    """at the output cadence every driver checks its recorded fields (the reference lets NaN run into its result
+    files) and logs one line with the step, the update rate and the masses"""
+    import logging
+    from openlbmpm_amd.RKD2Q9 import RKColorGradientLBM
+    from openlbmpm_amd.results import SimulationDiverged
+    write_rk(str(tmp_path), nx=20, ny=48, steps=60, interval=20)
+    sim = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "out"))
+    with caplog.at_level(logging.INFO, logger="openlbmpm_amd"):
+        sim.runRKColorGradient2D()
+    lines = [r.getMessage() for r in caplog.records if r.name == "openlbmpm_amd"]
+    assert len(lines) == 3 and "record 2 step 40" in lines[2] and "MLUPS" in lines[2] and "massR" in lines[2]
+    # a run that blows up (tau -> 1/2 with a strong inlet) is stopped at the first record holding NaN / Inf
+    import re
+    bad = tmp_path / "bad"; bad.mkdir()
+    write_rk(str(bad), nx=20, ny=48, steps=4000, interval=500)
+    text = (bad / "RKtwophasesetup2D.ini").read_text()
+    text = re.sub(r"(?m)^(\s*velocityYR\s*=).*$", r"\1 -0.6", text)
+    (bad / "RKtwophasesetup2D.ini").write_text(text)
+    blow = RKColorGradientLBM(str(bad), output_dir=str(tmp_path / "out2"))
+    with pytest.raises(SimulationDiverged, match="non-finite"):
+        blow.runRKColorGradient2D()
+    quiet = RKColorGradientLBM(str(bad), output_dir=str(tmp_path / "out3"))
+    quiet.nan_guard = "off"
+    quiet.runRKColorGradient2D()                     # the reference's behaviour: NaN in the file, no complaint
+    assert not np.isfinite(quiet.fluidsRhoR).all()
