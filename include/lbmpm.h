@@ -75,8 +75,16 @@ enum { LBMPM_INLET_VELOCITY = 0,      /* BoundaryTypeInlet 'Neumann'   */
        LBMPM_INLET_PRESSURE = 1 };    /* BoundaryTypeInlet 'Dirichlet' */
 enum { LBMPM_OUTLET_PRESSURE = 0,     /* BoundaryTypeOutlet 'Dirichlet'  */
        LBMPM_OUTLET_CONVECTIVE = 1,   /* BoundaryTypeOutlet 'Convective' */
-       LBMPM_OUTLET_NONE = 2 };       /* sc2d only: no boundary kernels at all, inlet included: fully periodic box
+       LBMPM_OUTLET_NONE = 2,         /* sc2d only: no boundary kernels at all, inlet included: fully periodic box
                                          (the static-droplet Laplace case of the reference's CPU path SimpleD2Q9) */
+       LBMPM_OUTLET_FREEFLOW = 3 };   /* sc2d, explicit forcing, SRT, ExplicitScheme 4 only: BoundaryTypeOutlet 'Freeflow'
+                                         (ShanChenD2Q9.py:1865-1884, ExplicitD2Q9GPU.py:1476-1563): before every collision
+                                         rows 2, 1, 0 take f-bar, F_i and f_eq of the row above, i.e. they leave the
+                                         collision with the populations of row 3 */
+enum { LBMPM_INLET_ZOUHE = 0,         /* BoundaryMethod 'ZouHe'                                                     */
+       LBMPM_INLET_CHANG = 1 };       /* sc2d, explicit forcing, ExplicitScheme 4 only: BoundaryMethod 'Chang' -- the velocity
+                                         inlet of Chang et al. 2009 (OptimizedD2Q9GPU.py:1127-1161, ShanChenD2Q9.py:1803,
+                                         :1999): unknown populations from this step's streamed and the last step's final ones */
 
 typedef struct lbmpm_rk2d_config {
     int64_t nx, ny;            /* xDomain, yDomain (incl. ghost rows 0 and ny-1)            */
@@ -225,6 +233,8 @@ typedef struct lbmpm_sc2d_config {
                                   8: boundary rows one row further inside + two ghost rows;
                                   10: no boundary kernels (as the reference's loop); both run as
                                   two sweeps per step instead of the fused kernel              */
+    int32_t inlet_method;      /* [BoundaryDefinition] BoundaryMethod: LBMPM_INLET_* (fills the struct's tail padding:
+                                  size and the offsets of the older fields are unchanged)      */
 } lbmpm_sc2d_config;
 
 typedef struct lbmpm_sc2d lbmpm_sc2d;

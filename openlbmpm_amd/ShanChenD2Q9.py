@@ -76,7 +76,7 @@ class ShanChenD2Q9:
         p = self.par
         self.initializeDomainBorder()
         self.initializeDomainCondition()
-        keys = ("inter", "relax", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "vy0", "vy1", "scheme")
+        keys = ("inter", "relax", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "method", "vy0", "vy1", "scheme")
         solver = SC2DSolver(self.isDomain, {k: p[k] for k in keys}, device=self.device, diagnostics=True)
         solver.set_density(self.fluidsDensity[0], self.fluidsDensity[1])
         out = ResultFile(self.output_dir, "SimulationResults",

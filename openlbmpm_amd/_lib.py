@@ -46,7 +46,8 @@ class SC2DConfig(C.Structure):
     _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("model", C.c_int32), ("relaxation", C.c_int32),
                 ("tau", C.c_double * 2), ("g_fluid", C.c_double), ("g_solid", C.c_double * 2),
                 ("outlet_type", C.c_int32), ("inlet_velocity_y", C.c_double * 2),
-                ("device", C.c_int32), ("variant", C.c_int32), ("force_scheme", C.c_int32)]
+                ("device", C.c_int32), ("variant", C.c_int32), ("force_scheme", C.c_int32),
+                ("inlet_method", C.c_int32)]
 
 
 class RK3DConfig(C.Structure):

@@ -182,10 +182,22 @@ def read_sc2d(ini_dir):
     p["tau0"], p["tau1"] = m.floats("FluidProperties", "FluidsTau", 2)
     p["G"] = m.floats(sec, "InteractionFluid", 1)[0]
     p["Gs0"], p["Gs1"] = m.floats(sec, "InteractionSolid", 2)
-    if m.str("BoundaryDefinition", "BoundaryTypeInlet") != "Neumann" or m.str("BoundaryDefinition", "BoundaryMethod") != "ZouHe":
-        raise ConfigError("only BoundaryTypeInlet 'Neumann' with BoundaryMethod 'ZouHe' runs in the reference "
+    if m.str("BoundaryDefinition", "BoundaryTypeInlet") != "Neumann":
+        raise ConfigError("only BoundaryTypeInlet 'Neumann' runs in the reference "
                           "(the Dirichlet inlet references undefined attributes, ShanChenD2Q9.py:1497)")
+    p["method"] = m.str("BoundaryDefinition", "BoundaryMethod")
+    if p["method"] not in ("ZouHe", "Chang"):
+        raise ConfigError("[BoundaryDefinition] BoundaryMethod must be 'ZouHe' or 'Chang'")
     p["outlet"] = m.str("BoundaryDefinition", "BoundaryTypeOutlet")
+    if p["outlet"] not in ("Dirichlet", "Convective", "Freeflow"):
+        raise ConfigError("[BoundaryDefinition] BoundaryTypeOutlet must be 'Dirichlet', 'Convective' or 'Freeflow'")
+    if p["inter"] != "EFS" and (p["method"] == "Chang" or p["outlet"] == "Freeflow"):
+        # the original Shan-Chen loop has no 'Freeflow' branch at all (ShanChenD2Q9.py:1579-1622 tests 'Convective' only);
+        # its Chang branch (:1529) is not carried by the fused solver
+        raise ConfigError("BoundaryMethod 'Chang' / BoundaryTypeOutlet 'Freeflow' are supported for InteractionType 'EFS'")
+    if p["outlet"] == "Freeflow" and p["relax"] != "SRT":
+        raise ConfigError("BoundaryTypeOutlet 'Freeflow' with MRT: the reference's loop copies the outlet rows after its moment "
+                          "transforms (ShanChenD2Q9.py:1855-1884) and the run turns NaN; use SRT")
     p["vy0"], p["vy1"] = m.floats("VelocityBoundary", "velocityY", 2)
     p["scheme"] = m.int("ForceScheme", "ExplicitScheme") if p["inter"] == "EFS" else 4
     if p["scheme"] not in (4, 8, 10):

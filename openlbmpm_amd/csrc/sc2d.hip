@@ -39,6 +39,9 @@ struct SCDev {
     int model, mrt, outlet, first, keep_force;
     int scheme;              // [ForceScheme] ExplicitScheme: 4, 8, 10
     int sh, nobc;            // scheme 8: boundary rows one row further inside (two ghost rows); scheme 10: no boundary kernels
+    int chang;               // BoundaryMethod 'Chang': velocity inlet from this step's and the last step's populations
+    const double *chg_in;    // [6][pitch]: populations 4, 7, 8 of both components on the inlet row as the last step left them
+    double *chg_out;
 };
 
 constexpr int D_RHO = 18, D_VX = 20, D_VY = 21, D_FX = 22, D_FY = 24, D_UEQ = 26, D_PLANES = 28;
@@ -50,6 +53,31 @@ __device__ __forceinline__ void bc_inlet(double v, double g[9])
     g[4] = g[2] - 2. / 3. * rho * v;
     g[7] = g[5] + (g[1] - g[3]) / 2. - 1. / 6. * rho * v;
     g[8] = g[6] - (g[1] - g[3]) / 2. - 1. / 6. * rho * v;
+}
+
+// O:1127-1161 calVelocityBoundaryHigherChangGPU (one component): o4, o7, o8 = populations 4, 7, 8 of this node when the
+// previous loop pass began (savePDFLastStep, S:1853: the state its inlet kernels left)
+__device__ __forceinline__ void bc_inlet_chang(double v, double g[9], double o4, double o7, double o8)
+{
+    const double rho = (g[0] + g[1] + g[3] + 2. * (g[2] + g[5] + g[6])) / (1. + v);
+    g[4] = o4 - 2. / 3. * (rho * v + o4 + o7 + o8) + 2. / 3. * (g[2] + g[5] + g[6]);
+    g[7] = o7 + 1. / 2. * (g[1] - g[3]) + 1. / 6. * (g[2] - o4) + 2. / 3. * (g[5] - o7) - 1. / 3. * (g[6] - o8) - 1. / 6. * rho * v;
+    g[8] = o8 - 1. / 6. * rho * v - 1. / 2. * (g[1] - g[3]) + 1. / 6. * (g[2] - o4) - 1. / 3. * (g[5] - o7) + 2. / 3. * (g[6] - o8);
+}
+__device__ __forceinline__ void inlet_row(const SCDev &p, int x, double f0[9], double f1[9])
+{
+    if (p.chang) {
+        const double *o = p.chg_in + x;
+        bc_inlet_chang(p.vyIn[0], f0, o[0], o[p.pitch], o[2 * (size_t)p.pitch]);
+        bc_inlet_chang(p.vyIn[1], f1, o[3 * (size_t)p.pitch], o[4 * (size_t)p.pitch], o[5 * (size_t)p.pitch]);
+    } else { bc_inlet(p.vyIn[0], f0); bc_inlet(p.vyIn[1], f1); }
+}
+// the owner of an inlet-row node keeps what the next step's Chang inlet needs
+__device__ __forceinline__ void keep_inlet_row(const SCDev &p, int x, const double f0[9], const double f1[9])
+{
+    double *o = p.chg_out + x;
+    o[0] = f0[4]; o[p.pitch] = f0[7]; o[2 * (size_t)p.pitch] = f0[8];
+    o[3 * (size_t)p.pitch] = f1[4]; o[4 * (size_t)p.pitch] = f1[7]; o[5 * (size_t)p.pitch] = f1[8];
 }
 
 // O:555-585 constantPressureZouHeBoundaryLower: density hard-coded per component
@@ -106,7 +134,7 @@ __device__ __forceinline__ void node_state(const SCDev &p, int x, int y, double 
             bc_outlet(0.02, f1);
         }
     }
-    if (INLET && bc && ys == p.ny - 2 - p.sh) { bc_inlet(p.vyIn[0], f0); bc_inlet(p.vyIn[1], f1); }
+    if (INLET && bc && ys == p.ny - 2 - p.sh) inlet_row(p, x, f0, f1);
     r0 = sum9(f0);
     r1 = sum9(f1);
 }
@@ -347,6 +375,7 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
             Fpy[0] = p.F[2 * p.plane + idx]; Fpy[1] = p.F[3 * p.plane + idx];
         }
         node_state<true>(p, xw, yw, f0, f1, rho[0], rho[1]);
+        if (p.chang && inside && y == p.ny - 2) keep_inlet_row(p, x, f0, f1);
         s_psi0[ri] = rho[0];            // O:99-106 calFluidPotentialGPUEql: psi = rho
         s_psi1[ri] = rho[1];
     }
@@ -561,7 +590,10 @@ __global__ __launch_bounds__(256) void sc2d_init_collide(SCDev p)
     const size_t s = (size_t)ys * p.pitch + x;
     double f0[9], f1[9];
     for (int j = 0; j < 9; ++j) { f0[j] = p.fin[fslot(p.plane, j, s, 0)]; f1[j] = p.fin[fslot(p.plane, j, s, 1)]; }
-    if (bc && ys == p.ny - 2 - p.sh) { bc_inlet(p.vyIn[0], f0); bc_inlet(p.vyIn[1], f1); }
+    if (bc && ys == p.ny - 2 - p.sh) {
+        inlet_row(p, x, f0, f1);                                   // (chg_in = the initial populations here, S:1642 / S:1803)
+        if (p.chang && y == p.ny - 2) keep_inlet_row(p, x, f0, f1);
+    }
     if (bc && p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1 + p.sh) { bc_outlet(1.0, f0); bc_outlet(0.02, f1); }
     if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2) {
         const size_t o = (size_t)y * p.pitch + x;
@@ -589,6 +621,31 @@ __global__ __launch_bounds__(256) void sc2d_init_collide(SCDev p)
     }
 }
 
+// 'Chang' inlet, before the first step: the populations 4, 7, 8 of the inlet row as initialised (S:1642: deviceFluidPDFold
+// starts as a copy of the initial f, which is what the pre-loop inlet kernel S:1803 reads)
+__global__ void sc2d_chang_seed(SCDev p, double *out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= p.nx) return;
+    const size_t idx = (size_t)(p.ny - 2) * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    const int dirs[3] = {4, 7, 8};
+    for (int k = 0; k < 2; ++k)
+        for (int m = 0; m < 3; ++m) out[(size_t)(3 * k + m) * p.pitch + x] = p.fin[fslot(p.plane, dirs[m], idx, k)];
+}
+
+// 'Freeflow' outlet (S:1865-1884 with E:1476-1563): rows 2, 1, 0 take f-bar, F_i and f_eq of the row above before the
+// collision, so all three leave it with the populations of row 3 -- applied to the post-collision buffer
+__global__ void sc2d_freeflow_rows(SCDev p, double *f)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (x >= p.nx) return;
+    const size_t dst = (size_t)r * p.pitch + x, src = (size_t)3 * p.pitch + x;
+    if (!(p.flags[dst] & 1)) return;
+    for (int j = 0; j < 9; ++j)
+        for (int k = 0; k < 2; ++k) f[fslot(p.plane, j, dst, k)] = f[fslot(p.plane, j, src, k)];
+}
+
 }  // namespace
 
 // ====================================================================== host side
@@ -600,7 +657,7 @@ struct lbmpm_sc2d {
     hipStream_t stream = nullptr;
     uint8_t *flags = nullptr, *solidnbr = nullptr;
     double *fA = nullptr, *fB = nullptr, *F = nullptr, *foldA = nullptr, *foldB = nullptr, *diag = nullptr,
-           *obs = nullptr;
+           *obs = nullptr, *chgA = nullptr, *chgB = nullptr;
     std::vector<uint8_t> h_domain;
     bool streamed = false, initialised = false, diag_valid = false, keep_force = false;
     int scheme = 4;                  // [ForceScheme] ExplicitScheme
@@ -628,6 +685,8 @@ SCDev make_dev(const lbmpm_sc2d *c)
     p.first = c->streamed ? 0 : 1; p.keep_force = c->keep_force ? 1 : 0;
     p.scheme = c->scheme; p.sh = c->scheme == 8 ? 1 : 0; p.nobc = (c->scheme == 10 || c->cfg.outlet_type == LBMPM_OUTLET_NONE) ? 1 : 0;
     p.psi = c->psi;
+    p.chang = c->cfg.inlet_method == LBMPM_INLET_CHANG ? 1 : 0;
+    p.chg_in = c->chgA; p.chg_out = c->chgB;
     return p;
 }
 
@@ -655,13 +714,16 @@ int efs_initialise(lbmpm_sc2d *c)
     p.psi = psi; p.scrA = scrA; p.scrB = scrB;
     const dim3 g((c->nx + 63) / 64, (c->ny + 3) / 4), b(64, 4);
     const bool mrt = p.mrt;
+    if (p.chang) sc2d_chang_seed<<<dim3((c->nx + 63) / 64), dim3(64), 0, c->stream>>>(p, c->chgB);
     sc2d_init_psi<<<g, b, 0, c->stream>>>(p);                       // fA -> psi
     if (mrt) sc2d_init_chain<true><<<g, b, 0, c->stream>>>(p);      // fA -> fB (f-bar), scrA, scrB, F
     else sc2d_init_chain<false><<<g, b, 0, c->stream>>>(p);
     SCDev q = p;
     q.fin = c->fB; q.fout = c->fA; q.fold_out = c->foldA;           // fB -> fA (post-collision), fold -> foldA
+    q.chg_in = c->chgB; q.chg_out = c->chgA;                        // initial populations -> what the pre-loop inlet left
     if (mrt) sc2d_init_collide<true><<<g, b, 0, c->stream>>>(q);
     else sc2d_init_collide<false><<<g, b, 0, c->stream>>>(q);
+    if (p.outlet == LBMPM_OUTLET_FREEFLOW) sc2d_freeflow_rows<<<dim3((c->nx + 63) / 64, 3), dim3(64), 0, c->stream>>>(p, c->fA);
     LBMPM_HIP_TRY(hipGetLastError());
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     (void)hipFree(psi); (void)hipFree(scrA); (void)hipFree(scrB);
@@ -687,10 +749,12 @@ int launch_step(lbmpm_sc2d *c, bool diag, bool timed)
         else sc2d_iso_collide<false><<<g, b, 0, c->stream>>>(p);
     } else if (p.mrt) sc2d_fused<true><<<dim3(tiles_x * tiles_y), dim3(THREADS), 0, c->stream>>>(p, tiles_x);
     else sc2d_fused<false><<<dim3(tiles_x * tiles_y), dim3(THREADS), 0, c->stream>>>(p, tiles_x);
+    if (p.outlet == LBMPM_OUTLET_FREEFLOW) sc2d_freeflow_rows<<<dim3((c->nx + 63) / 64, 3), dim3(64), 0, c->stream>>>(p, p.fout);
     if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     LBMPM_HIP_TRY(hipGetLastError());
     std::swap(c->fA, c->fB);
     std::swap(c->foldA, c->foldB);
+    std::swap(c->chgA, c->chgB);
     c->streamed = true;
     c->diag_valid = diag;
     c->steps += 1;
@@ -783,7 +847,21 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
         set_error("the original Shan-Chen path is SRT only in the reference (ShanChenD2Q9.py:1584)");
         return LBMPM_ERR_UNSUPPORTED;
     }
-    LBMPM_REQUIRE(cfg->outlet_type >= 0 && cfg->outlet_type <= 2, "bad outlet_type %d", cfg->outlet_type);
+    LBMPM_REQUIRE(cfg->outlet_type >= 0 && cfg->outlet_type <= 3, "bad outlet_type %d", cfg->outlet_type);
+    LBMPM_REQUIRE(cfg->inlet_method == LBMPM_INLET_ZOUHE || cfg->inlet_method == LBMPM_INLET_CHANG, "bad inlet_method %d", cfg->inlet_method);
+    if (cfg->outlet_type == LBMPM_OUTLET_FREEFLOW &&
+        !(cfg->model == LBMPM_SC_MODEL_EFS && cfg->relaxation == LBMPM_RELAX_SRT && (cfg->force_scheme == 0 || cfg->force_scheme == 4))) {
+        // MRT: the loop transforms f-bar and F_i to moment space BEFORE it copies the rows (ShanChenD2Q9.py:1855-1884), so
+        // rows 0-2 collide with a mix of their own moments and row 3's populations; the reference run turns NaN
+        set_error("the 'Freeflow' outlet belongs to the explicit forcing loop with SRT and ExplicitScheme 4 "
+                  "(ShanChenD2Q9.py:1865; with MRT the reference run diverges to NaN)");
+        return LBMPM_ERR_UNSUPPORTED;
+    }
+    if (cfg->inlet_method == LBMPM_INLET_CHANG &&
+        !(cfg->model == LBMPM_SC_MODEL_EFS && (cfg->force_scheme == 0 || cfg->force_scheme == 4) && cfg->outlet_type != LBMPM_OUTLET_NONE)) {
+        set_error("BoundaryMethod 'Chang' is built for the explicit forcing loop with ExplicitScheme 4 (ShanChenD2Q9.py:1999-2006)");
+        return LBMPM_ERR_UNSUPPORTED;
+    }
     LBMPM_REQUIRE(cfg->tau[0] > 0.5 && cfg->tau[1] > 0.5, "FluidsTau must exceed 0.5");
     LBMPM_REQUIRE(cfg->variant == 0, "variant must be 0");
     LBMPM_REQUIRE(cfg->force_scheme == 0 || cfg->force_scheme == 4 || cfg->force_scheme == 8 || cfg->force_scheme == 10,
@@ -822,6 +900,8 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
     if (c->scheme != 4) TRY_RC(dev_alloc(c, &c->psi, 2 * c->plane));
     TRY_RC(dev_alloc(c, &c->foldA, (size_t)18 * 3 * c->pitch));
     TRY_RC(dev_alloc(c, &c->foldB, (size_t)18 * 3 * c->pitch));
+    TRY_RC(dev_alloc(c, &c->chgA, (size_t)6 * c->pitch));
+    TRY_RC(dev_alloc(c, &c->chgB, (size_t)6 * c->pitch));
 #undef TRY_RC
     hipError_t e = hipMemcpyAsync(c->flags, hflags.data(), c->plane, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -841,7 +921,8 @@ extern "C" void lbmpm_sc2d_destroy(lbmpm_sc2d *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *ptr : {(void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->F,
-                      (void *)c->foldA, (void *)c->foldB, (void *)c->diag, (void *)c->obs, (void *)c->psi})
+                      (void *)c->foldA, (void *)c->foldB, (void *)c->diag, (void *)c->obs, (void *)c->psi,
+                      (void *)c->chgA, (void *)c->chgB})
         if (ptr) (void)hipFree(ptr);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     c->pool.destroy();

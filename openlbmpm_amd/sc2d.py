@@ -16,7 +16,7 @@ FIELDS = dict(f0=0, f1=1, rho0=2, rho1=3, vx=4, vy=5, Fx0=6, Fx1=7, Fy0=8, Fy1=9
 
 # parameter names follow the reference ini files (twophasesetup.ini, efs2D.ini / shanchen2D.ini)
 DEFAULT_PARAMS = dict(inter="EFS", relax="SRT", tau0=1.0, tau1=1.0, G=0.20, Gs0=-0.14, Gs1=0.14,
-                      outlet="Dirichlet", vy0=0.0, vy1=-5.03e-4, scheme=4)
+                      outlet="Dirichlet", method="ZouHe", vy0=0.0, vy1=-5.03e-4, scheme=4)
 
 
 def _f64(a):
@@ -40,8 +40,10 @@ class SC2DSolver:
             raise ValueError("InteractionType must be 'ShanChen' or 'EFS'")
         if p["relax"] not in ("SRT", "MRT"):
             raise ValueError("RelaxationType must be 'SRT' or 'MRT' ('TRT' is a stub in the reference)")
-        if p["outlet"] not in ("Dirichlet", "Convective", "Periodic"):
-            raise ValueError("BoundaryTypeOutlet must be 'Dirichlet' or 'Convective'")
+        if p["outlet"] not in ("Dirichlet", "Convective", "Periodic", "Freeflow"):
+            raise ValueError("BoundaryTypeOutlet must be 'Dirichlet', 'Convective' or 'Freeflow'")
+        if p["method"] not in ("ZouHe", "Chang"):
+            raise ValueError("BoundaryMethod must be 'ZouHe' or 'Chang'")
         cfg = SC2DConfig()
         cfg.nx, cfg.ny = self.nx, self.ny
         cfg.model = 1 if p["inter"] == "EFS" else 0
@@ -49,7 +51,8 @@ class SC2DSolver:
         cfg.tau[0], cfg.tau[1] = p["tau0"], p["tau1"]
         cfg.g_fluid = p["G"]
         cfg.g_solid[0], cfg.g_solid[1] = p["Gs0"], p["Gs1"]
-        cfg.outlet_type = {"Dirichlet": 0, "Convective": 1, "Periodic": 2}[p["outlet"]]     # Periodic: no boundary kernels (API only)
+        cfg.outlet_type = {"Dirichlet": 0, "Convective": 1, "Periodic": 2, "Freeflow": 3}[p["outlet"]]     # Periodic: no boundary kernels (API only)
+        cfg.inlet_method = 1 if p["method"] == "Chang" else 0
         cfg.inlet_velocity_y[0], cfg.inlet_velocity_y[1] = p["vy0"], p["vy1"]
         cfg.device = int(device); cfg.variant = 0
         cfg.force_scheme = int(p["scheme"])

@@ -57,11 +57,11 @@ class _Sim(C.Structure):
                 ("vyIn", C.c_double * 2), ("mrt", C.c_int), ("outletType", C.c_int), ("Lam", F64P)] + \
                [(n, F64P) for n in ("f", "fOld", "fNew", "rho", "psi", "Fx", "Fy", "ux", "uy", "feq",
                                     "ff", "fM", "ffM", "vx", "vy")] + \
-               [("scheme", C.c_int), ("nbrX", I64P), ("wX", C.c_double * 36)]
+               [("scheme", C.c_int), ("nbrX", I64P), ("wX", C.c_double * 36), ("inletMethod", C.c_int)]
 
 
 DEFAULT_PARAMS = dict(inter="EFS", relax="SRT", rho0=1.0, rho1=1.0, bg0=0.02, bg1=0.02, tau0=1.0, tau1=1.0,
-                      G=0.20, Gs0=-0.14, Gs1=0.14, outlet="Dirichlet", vy0=0.0, vy1=-5.03e-4, scheme=4)
+                      G=0.20, Gs0=-0.14, Gs1=0.14, outlet="Dirichlet", method="ZouHe", vy0=0.0, vy1=-5.03e-4, scheme=4)
 
 
 def initial_densities(dom, image, p):
@@ -118,7 +118,10 @@ class SCOracle:
         s.Gs[0], s.Gs[1] = p["Gs0"], p["Gs1"]
         s.vyIn[0], s.vyIn[1] = p["vy0"], p["vy1"]
         s.mrt = 1 if p["relax"] == "MRT" else 0
-        s.outletType = {"Dirichlet": 0, "Convective": 1, "Periodic": 2}[p["outlet"]]
+        s.outletType = {"Dirichlet": 0, "Convective": 1, "Periodic": 2, "Freeflow": 3}[p["outlet"]]
+        if p["outlet"] == "Freeflow" and (p["relax"] != "SRT" or not self.efs):
+            raise ValueError("'Freeflow' is restated for the explicit forcing loop with SRT (with MRT the reference run turns NaN)")
+        s.inletMethod = 1 if p["method"] == "Chang" else 0
         s.Lam = _p(self.Lam, F64P)
         for name in ("f", "fOld", "fNew", "rho", "psi", "Fx", "Fy", "ux", "uy", "feq", "ff", "fM", "ffM",
                      "vx", "vy"):

@@ -514,17 +514,58 @@ void sc_efs_collide_mrt(i64 N, const double *Lam, double *f, double *feq, const 
         }
 }
 
+/* E:1476-1563 convectiveOutletGPUEFS / ...Ghost2GPUEFS / ...Ghost3GPUEFS (the 'Freeflow' outlet of the explicit forcing
+ * loop, D:1865-1884): row `row` takes f-bar, F_i, f_eq of its N neighbour; rho re-summed from the source */
+void sc_freeflow_row(i64 N, i64 nx, i64 row, const i64 *fluidNodes, const i64 *nbr, double *f, double *rho, double *ff, double *feq)
+{
+    for (i64 n = 0; n < N; ++n) {
+        const i64 loc = fluidNodes[n];
+        if (!(loc < (row + 1) * nx && loc >= row * nx)) continue;
+        const i64 q = nbr[8 * n + 1];
+        for (int k = 0; k < NF; ++k) {
+            R(rho, k, n) = 0.;
+            for (int j = 0; j < 9; ++j) {
+                F(f, k, n, j) = F(f, k, q, j);
+                F(ff, k, n, j) = F(ff, k, q, j);
+                F(feq, k, n, j) = F(feq, k, q, j);
+                R(rho, k, n) += F(f, k, q, j);
+            }
+        }
+    }
+}
+
+/* O:1127-1161 calVelocityBoundaryHigherChangGPU (row ny-2; scheme 4 only, D:1803 / :1999) */
+void sc_inlet_chang_row(i64 N, i64 nx, i64 row, const double *vyIn, const i64 *fluidNodes, double *rho, const double *fOld, double *f)
+{
+    for (i64 n = 0; n < N; ++n) {
+        const i64 loc = fluidNodes[n];
+        if (!(loc < (row + 1) * nx && loc >= row * nx)) continue;
+        for (int k = 0; k < NF; ++k) {
+            const double v = vyIn[k];
+            R(rho, k, n) = (F(f, k, n, 0) + F(f, k, n, 1) + F(f, k, n, 3) + 2. * (F(f, k, n, 2) + F(f, k, n, 5) + F(f, k, n, 6))) / (1. + v);
+            F(f, k, n, 4) = F(fOld, k, n, 4) - 2. / 3. * (R(rho, k, n) * v + F(fOld, k, n, 4) + F(fOld, k, n, 7) + F(fOld, k, n, 8)) +
+                            2. / 3. * (F(f, k, n, 2) + F(f, k, n, 5) + F(f, k, n, 6));
+            F(f, k, n, 7) = F(fOld, k, n, 7) + 1. / 2. * (F(f, k, n, 1) - F(f, k, n, 3)) + 1. / 6. * (F(f, k, n, 2) - F(fOld, k, n, 4)) +
+                            2. / 3. * (F(f, k, n, 5) - F(fOld, k, n, 7)) - 1. / 3. * (F(f, k, n, 6) - F(fOld, k, n, 8)) - 1. / 6. * R(rho, k, n) * v;
+            F(f, k, n, 8) = F(fOld, k, n, 8) - 1. / 6. * R(rho, k, n) * v - 1. / 2. * (F(f, k, n, 1) - F(f, k, n, 3)) +
+                            1. / 6. * (F(f, k, n, 2) - F(fOld, k, n, 4)) - 1. / 3. * (F(f, k, n, 5) - F(fOld, k, n, 7)) +
+                            2. / 3. * (F(f, k, n, 6) - F(fOld, k, n, 8));
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ drivers */
 typedef struct {
     i64 N, nx, ny;
     const i64 *fluidNodes, *nbr;
     double tau[NF], G[NF * NF], Gs[NF], vyIn[NF];
-    int mrt, outletType /*0 Dirichlet 1 Convective 2 none (periodic box)*/;
+    int mrt, outletType /*0 Dirichlet 1 Convective 2 none (periodic box) 3 Freeflow (EFS, SRT)*/;
     const double *Lam;   /* [2][9][9], MRT only */
     double *f, *fOld, *fNew, *rho, *psi, *Fx, *Fy, *ux, *uy, *feq, *ff, *fM, *ffM, *vx, *vy;
     int scheme;          /* 4, 8 or 10 ([ForceScheme] ExplicitScheme) */
     const i64 *nbrX;     /* [N][24] or [N][36] for scheme 8 / 10 */
     double wX[36];
+    int inletMethod;     /* 0 Zou-He, 1 Chang (EFS, scheme 4) */
 } sc_sim;
 
 static void sc_efs_force_chain(sc_sim *s)
@@ -556,7 +597,8 @@ static void sc_efs_bcs(sc_sim *s, int in_loop)
         for (int r = sh; r >= 0; --r) sc_ghost_outlet_row(N, s->nx, r, s->fluidNodes, s->nbr, s->rho, s->f);
     }
     if (on) {
-        sc_inlet_velocity_row(N, s->nx, ny - 2 - sh, s->vyIn, s->fluidNodes, s->rho, s->f);       /* D:1990 / :1811 */
+        if (s->inletMethod == 1) sc_inlet_chang_row(N, s->nx, ny - 2, s->vyIn, s->fluidNodes, s->rho, s->fOld, s->f);   /* D:1803 / :1999 */
+        else sc_inlet_velocity_row(N, s->nx, ny - 2 - sh, s->vyIn, s->fluidNodes, s->rho, s->f);       /* D:1990 / :1811 */
         for (int r = ny - 1 - sh; r <= ny - 1; ++r) sc_ghost_inlet_row(N, s->nx, r, s->fluidNodes, s->nbr, s->rho, s->f);
     }
     if (!in_loop && s->outletType == 0 && on) {   /* pre-loop order: inlet first, D:1827-1849 */
@@ -568,6 +610,7 @@ static void sc_efs_bcs(sc_sim *s, int in_loop)
 /* pre-loop part of runOptimizedEFLBM, D:1714-1849 */
 void sc_efs_prepare(sc_sim *s)
 {
+    memcpy(s->fOld, s->f, sizeof(double) * NF * s->N * 9);      /* D:1642: deviceFluidPDFold starts as a copy of the initial f */
     sc_efs_force_chain(s);
     sc_efs_transform(s->N, s->f, s->ff);
     sc_efs_bcs(s, 0);
@@ -578,6 +621,8 @@ void sc_efs_iter(sc_sim *s)
 {
     i64 N = s->N;
     memcpy(s->fOld, s->f, sizeof(double) * NF * N * 9);                               /* savePDFLastStep */
+    if (s->outletType == 3)                                                             /* D:1865-1884 (SRT; see oracle/sc.py) */
+        for (int r = 2; r >= 0; --r) sc_freeflow_row(N, s->nx, r, s->fluidNodes, s->nbr, s->f, s->rho, s->ff, s->feq);
     if (!s->mrt) sc_efs_collide_srt(N, s->tau, s->f, s->feq, s->ff);
     else sc_efs_collide_mrt(N, s->Lam, s->f, s->feq, s->ff, s->fM, s->ffM);
     sc_stream(N, s->nbr, s->f, s->fNew);

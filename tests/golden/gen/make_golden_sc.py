@@ -72,7 +72,7 @@ interactionSolid = {Gs0},{Gs1}
 potentialType = 'Simple'
 [BoundaryDefinition]
 BoundaryTypeInlet = 'Neumann'
-BoundaryMethod = 'ZouHe'
+BoundaryMethod = '{method}'
 BoundaryTypeOutlet = '{outlet}'
 [VelocityBoundary]
 velocityX = 0.0,0.0
@@ -91,7 +91,7 @@ numberTimeStep = {steps}
 """
 
 DEFAULTS = dict(image='no', nx=20, ny=48, inter='EFS', relax='SRT', rho0=1.0, rho1=1.0, bg0=0.02, bg1=0.02,
-                tau0=1.0, tau1=1.0, G=0.20, Gs0=-0.14, Gs1=0.14, outlet='Dirichlet', vy0=0.0, vy1=-5.03e-4,
+                tau0=1.0, tau1=1.0, G=0.20, Gs0=-0.14, Gs1=0.14, outlet='Dirichlet', method='ZouHe', vy0=0.0, vy1=-5.03e-4,
                 steps=60, scheme=4)
 
 
@@ -119,6 +119,11 @@ SCENARIOS = {
     "efs_mrt_iso8_porous": (dict(steps=60, scheme=8, relax='MRT', tau0=1.0, tau1=0.8, image='yes'), (0, 1, 60),
                             dict(nx=34, ny=44, seed=5, n_discs=9, rmin=2.0, rmax=4.5)),
     "efs_srt_iso10": (dict(steps=40, scheme=10), (0, 1, 40), None),
+    # alternates of the explicit-forcing loop: the 'Freeflow' outlet (S:1865-1884: rows 2, 1, 0 take f-bar, F_i, f_eq and rho of
+    # the row above BEFORE the collision) and Chang's velocity inlet (S:1999-2006)
+    "efs_srt_freeflow": (dict(steps=60, outlet='Freeflow', tau0=0.9, tau1=1.1), (0, 1, 60), None),
+    "efs_mrt_freeflow": (dict(steps=60, outlet='Freeflow', relax='MRT', tau0=1.0, tau1=0.8), (0, 1, 60), None),
+    "efs_srt_chang": (dict(steps=60, method='Chang'), (0, 1, 60), None),
     "sc_srt_convective": (dict(steps=80, inter='ShanChen', G=3.8, Gs0=-0.40, Gs1=0.40, bg0=0.06, bg1=0.06,
                                outlet='Convective', vy1=-1.01e-3), (1, 2, 10, 80), None),
     "sc_srt_porous": (dict(steps=60, inter='ShanChen', G=2.6, Gs0=-0.20, Gs1=0.20, bg0=0.15, bg1=0.15,

@@ -107,7 +107,7 @@ potentialType = 'Simple'
 
 [BoundaryDefinition]
 BoundaryTypeInlet = 'Neumann'
-BoundaryMethod = 'ZouHe'
+BoundaryMethod = '{method}'
 BoundaryTypeOutlet = '{outlet}'
 
 [VelocityBoundary]
@@ -138,7 +138,7 @@ def write_rk(d, nx=20, ny=48, steps=60, interval=25, relax="MRT", cycle="no", la
 
 
 def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirichlet", scheme=4, image="no", cycle="no",
-             last=0):
+             last=0, method="ZouHe"):
     import os
     with open(os.path.join(d, "twophasesetup.ini"), "w") as fh:
         fh.write(TWOPHASE_INI.format(nx=nx, ny=ny, inter=inter, relax=relax, image=image, cycle=cycle, last=last))
@@ -146,7 +146,7 @@ def write_sc(d, inter="EFS", nx=20, ny=48, steps=80, relax="SRT", outlet="Dirich
     with open(os.path.join(d, "efs2D.ini" if efs else "shanchen2D.ini"), "w") as fh:
         fh.write(MODEL_INI.format(section="EFSParameters" if efs else "ShanChenParameters", bg=0.02 if efs else 0.06,
                                   G=0.20 if efs else 3.8, Gs0=-0.14 if efs else -0.40, Gs1=0.14 if efs else 0.40,
-                                  outlet=outlet, vy1=-5.03e-4 if efs else -1.01e-3, steps=steps, scheme=scheme))
+                                  outlet=outlet, vy1=-5.03e-4 if efs else -1.01e-3, steps=steps, scheme=scheme, method=method))
 
 
 TRANSPORT_INI = """[SystemType]

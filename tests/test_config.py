@@ -37,6 +37,17 @@ def test_sc_ini(tmp_path, inter):
     p = config.read_sc2d(str(tmp_path))
     assert p["inter"] == inter and p["steps"] == 300 and (p["tau0"], p["tau1"]) == (1.0, 1.0)
     assert p["G"] == (0.20 if inter == "EFS" else 3.8)
+    assert p["method"] == "ZouHe" and p["outlet"] in ("Dirichlet", "Convective")
+    # the loop alternates: 'Freeflow' outlet and 'Chang' inlet run for the explicit forcing loop (SRT for 'Freeflow')
+    for kw, ok in ((dict(outlet="Freeflow"), inter == "EFS"), (dict(method="Chang"), inter == "EFS"),
+                   (dict(outlet="Freeflow", relax="MRT"), False), (dict(method="Guo"), False), (dict(outlet="Open"), False)):
+        write_sc(str(tmp_path), inter=inter, steps=300, **kw)
+        if ok:
+            q = config.read_sc2d(str(tmp_path))
+            assert (q["outlet"], q["method"]) == (kw.get("outlet", "Dirichlet" if inter == "EFS" else q["outlet"]), kw.get("method", "ZouHe"))
+        else:
+            with pytest.raises(config.ConfigError):
+                config.read_sc2d(str(tmp_path))
 
 
 def test_transport_ini(tmp_path):

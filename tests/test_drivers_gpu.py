@@ -3,7 +3,7 @@ names) against what the real reference drivers recorded (golden 'h5|' captures).
 import numpy as np
 import pytest
 
-from helpers import golden_files, rel_err
+from helpers import load_params, golden_files, rel_err
 from ini_fixtures import write_rk, write_sc
 
 pytestmark = pytest.mark.gpu
@@ -171,6 +171,24 @@ def test_sc_driver_with_iso8_scheme_matches_reference(tmp_path):
     from openlbmpm_amd.ShanChenD2Q9 import ShanChenD2Q9
     d = np.load([f for f in golden_files("sc_") if f.endswith("sc_efs_srt_iso8.npz")][0])
     write_sc(str(tmp_path), inter="EFS", nx=20, ny=48, steps=60, scheme=8)
+    sim = ShanChenD2Q9(str(tmp_path), output_dir=str(tmp_path / "out"))
+    sim.runTypeSCmodel()
+    sel = d["isDomain"].reshape(-1) == 1
+    for k in (0, 1):
+        got = sim.solver.get("rho%d" % k).reshape(-1)[sel]
+        assert rel_err(got, d["s60_rho"][k]) < 1e-9
+
+
+@pytest.mark.parametrize("scenario,kw", [("efs_srt_freeflow", dict(outlet="Freeflow")), ("efs_srt_chang", dict(method="Chang"))])
+def test_sc_driver_runs_the_loop_alternates(tmp_path, scenario, kw):
+    """BoundaryTypeOutlet = 'Freeflow' (ShanChenD2Q9.py:1865-1884) and BoundaryMethod = 'Chang' (:1999-2006) through the
+    driver: the run ends where the real driver's ends"""
+    from openlbmpm_amd.ShanChenD2Q9 import ShanChenD2Q9
+    d = np.load([f for f in golden_files("sc_") if f.endswith("sc_%s.npz" % scenario)][0])
+    par = load_params(d)
+    write_sc(str(tmp_path), inter="EFS", nx=20, ny=48, steps=60, **kw)
+    text = (tmp_path / "efs2D.ini").read_text().replace("FluidsTau = 1.,1.", "FluidsTau = %r,%r" % (par["tau0"], par["tau1"]))
+    (tmp_path / "efs2D.ini").write_text(text)
     sim = ShanChenD2Q9(str(tmp_path), output_dir=str(tmp_path / "out"))
     sim.runTypeSCmodel()
     sel = d["isDomain"].reshape(-1) == 1

@@ -178,7 +178,8 @@ def sc_table(rt, g, par, with_iso):
     return t, N, f0, tau, scheme
 
 
-@pytest.mark.parametrize("scenario", ["efs_srt_dirichlet", "efs_mrt_dirichlet", "efs_srt_convective", "efs_srt_iso8", "efs_srt_iso10"])
+@pytest.mark.parametrize("scenario", ["efs_srt_dirichlet", "efs_mrt_dirichlet", "efs_srt_convective", "efs_srt_iso8", "efs_srt_iso10",
+                                      "efs_srt_freeflow", "efs_srt_chang"])
 def test_explicit_forcing_loop(rt, scenario):
     from oracle.sc import collision_matrices
     g = np.load(os.path.join(GOLDEN, "sc_%s.npz" % scenario))
@@ -192,7 +193,8 @@ def test_explicit_forcing_loop(rt, scenario):
     chain = [("calFluidPotentialGPUEql", {}), force,
              ("transformEquilibriumVelocity", {}) if mrt else ("calEquilibriumVEFGPU", {}),
              ("calEquilibriumFuncEFGPU", {}), ("calForceDistrGPU", {})]
-    inlet = {4: [("constantVelocityZouHeBoundaryHigher", {}), ("ghostPointsConstantVelocityInlet", {})],            # S:1794-1825, :1989-2020
+    chang = ("calVelocityBoundaryHigherChangGPU", dict(fluidPDFOld="fluidPDFOld", fluidPDFNew="fluidPDF"))              # S:1803-1808, :1999-2006
+    inlet = {4: [chang if par.get("method") == "Chang" else ("constantVelocityZouHeBoundaryHigher", {}), ("ghostPointsConstantVelocityInlet", {})],   # S:1794-1825, :1989-2020
              8: [("constantVelocityZouHeBoundaryHigher8", {}), ("ghostPointsConstantVelocity8", {}), ("ghostPointsConstantVelocity82", {})],
              10: []}[scheme]
     outlet_p = {4: [("constantPressureZouHeBoundaryLower", {}), ("ghostPointsConstantPressureOutlet", {})],         # S:1826-1849, :1931-1953
@@ -200,8 +202,11 @@ def test_explicit_forcing_loop(rt, scenario):
                 10: []}[scheme]
     onto = dict(fluidPDFNew="fluidPDF")          # (the outlet kernels call their target array fluidPDFNew; the loops pass the main one)
     outlet = ([("convectiveOutletEachGPU", onto), ("convectiveOutletEach2GPU", onto), ("convectiveOutletEach3GPU", onto)]
-              if par["outlet"] == "Convective" else outlet_p)
-    collide = ([("transfromForceTerm", {}), ("transformPDFandEquil", {}), ("calAfterCollisionMRT", {})] if mrt else [("calCollisionEXGPU", {})])
+              if par["outlet"] == "Convective" else outlet_p if par["outlet"] == "Dirichlet" else [])
+    # 'Freeflow' (S:1865-1884): rows 2, 1, 0 take f-bar, F_i, f_eq and rho of the row above, between the moment transforms and the collision
+    freeflow = [(k, onto) for k in ("convectiveOutletGPUEFS", "convectiveOutletGhost2GPUEFS", "convectiveOutletGhost3GPUEFS")] if par["outlet"] == "Freeflow" else []
+    collide = ([("transfromForceTerm", {}), ("transformPDFandEquil", {})] + freeflow + [("calAfterCollisionMRT", {})] if mrt
+               else freeflow + [("calCollisionEXGPU", {})])
     macro = [("calFluidRhoGPU", {}), ("calPhysicalVelocity", {})]
     # before the loop, ShanChenD2Q9.py:1714-1849
     run(rt, "sc", t, chain + [("transformPDFGPU", {})] + inlet + (outlet_p if par["outlet"] == "Dirichlet" else []))

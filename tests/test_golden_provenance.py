@@ -18,6 +18,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="th
 @pytest.mark.parametrize("script,args,fixture", [
     ("make_golden_rk.py", ["csf_mrt_convective"], "rk_csf_mrt_convective.npz"),
     ("make_golden_sc.py", ["efs_srt_convective"], "sc_efs_srt_convective.npz"),
+    ("make_golden_sc.py", ["efs_srt_freeflow"], "sc_efs_srt_freeflow.npz"),
+    ("make_golden_sc.py", ["efs_srt_chang"], "sc_efs_srt_chang.npz"),
     ("make_golden_tr.py", [], "tr_kernels.npz"),
     ("make_golden_rk_pert.py", ["kernels"], "rkpert_kernels.npz"),
     ("make_golden_rk_pert.py", ["srt_porous"], "rkpert_srt_porous.npz"),

@@ -10,13 +10,14 @@ from helpers import golden_files, load_params, rel_err
 from oracle.sc import SCOracle, simple_geometry, image_geometry, collision_matrices
 
 FILES = golden_files("sc_")
-KEYS = ("inter", "relax", "rho0", "rho1", "bg0", "bg1", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "vy0", "vy1", "scheme")
+KEYS = ("inter", "relax", "rho0", "rho1", "bg0", "bg1", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "method", "vy0", "vy1", "scheme")
 
 
 def _case(path):
     d = np.load(path)
     par = load_params(d)
     par.setdefault("scheme", 4)          # golden files older than the iso-8/10 scenarios
+    par.setdefault("method", "ZouHe")    # ... and than the 'Chang' scenario
     image = par["image"] == "yes"
     dom = image_geometry(d["image"], 20, 0.5) if image else simple_geometry(par["nx"], par["ny"])
     return d, par, dom, image

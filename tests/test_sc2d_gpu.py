@@ -11,7 +11,7 @@ from helpers import golden_files, load_params, rel_err
 pytestmark = pytest.mark.gpu
 
 FILES = golden_files("sc_")
-KEYS = ("inter", "relax", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "vy0", "vy1", "scheme")
+KEYS = ("inter", "relax", "tau0", "tau1", "G", "Gs0", "Gs1", "outlet", "method", "vy0", "vy1", "scheme")
 TOL = 1e-9
 
 
@@ -40,6 +40,7 @@ def test_golden_scenarios(path):
     d = np.load(path)
     par = load_params(d)
     par.setdefault("scheme", 4)
+    par.setdefault("method", "ZouHe")             # (fixtures older than the 'Chang' scenario)
     efs = par["inter"] == "EFS"
     s = SC2DSolver(d["isDomain"], {k: par[k] for k in KEYS}, diagnostics=True)
     s.set_pdf(_dense(d, d["init_f"][0]), _dense(d, d["init_f"][1]))
