@@ -223,9 +223,12 @@ def read_transport(ini_dir):
         if nr < 1 or len(rates) < 1:
             raise ConfigError("[Reaction] needs NumberReaction >= 1 and ReactionRate")
         p["reaction_rate"] = rates[0]
-    p["precipitation"] = c.str("SystemType", "Precipitation")
+    p["precipitation"] = c.str("SystemType", "Precipitation")      # read (Transport2DRK.py:91) and never used by the reference either
     if c.int("SystemType", "NumberSchemes") != 5:
-        raise ConfigError("[SystemType] NumberSchemes: only the D2Q5 scheme is on the working path (Transport2DRK.py:1343-1384)")
+        # NumberSchemes = 9: the loop hands the D2Q9 kernels its five-entry D2Q5 direction tables (Transport2DRK.py:1395 ->
+        # AccelerateTransport2DRK.py:1084 indexes them with 0..8: IndexError under emulation, out-of-bounds reads on a GPU)
+        raise ConfigError("[SystemType] NumberSchemes: only the D2Q5 scheme runs in the reference (Transport2DRK.py:1343-1384); "
+                          "its D2Q9 branch indexes five-entry direction tables with nine directions (:1395)")
     n = c.int("TransportParameters", "NumberTracers")
     if not 1 <= n <= 4:
         raise ConfigError("[TransportParameters] NumberTracers must be 1..4")
@@ -250,7 +253,7 @@ def read_transport(ini_dir):
     p["init_type"] = c.str("InitialCondition", "Type")
     if p["init_type"] == "Homogeneous":
         p["init_conc"] = c.floats("InitialCondition", "TracerConc", n)
-    p["fluid"] = c.int("FluidForTransport", "FluidType")
+    p["fluid"] = c.int("FluidForTransport", "FluidType")            # ditto (Transport2DRK.py:215)
     if c.str("RelaxationType", "Relaxation") != "MRT":
         raise ConfigError("[RelaxationType] Relaxation: the D2Q5 path is MRT (calCollisionTransportLinearEqlMRTGPU)")
     p["diffX"] = c.floats("TransportMRT", "DiffusionX", n)
