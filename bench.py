@@ -332,8 +332,9 @@ def main():
                 # what the transport really was, and where a step's time went on every rank (HIP events inside
                 # lbmpm_rk3d_step_slab): exchange_exposed_ms = step - max(interior, boundary)
                 out["multi_gpu"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                                    "transport": "torch.distributed batch_isend_irecv (ncclSend/ncclRecv pairs, RCCL) per face; "
-                                                 "no collective on the data path",
+                                    "transport": ("torch.distributed batch_isend_irecv (ncclSend/ncclRecv pairs, RCCL) per face; "
+                                                  "no collective on the data path") if dist.get_backend() == "nccl" else
+                                                 "REHEARSAL on the %s backend (host-staged copies): not an RCCL measurement" % dist.get_backend(),
                                     "boundary_depth_planes": int(os.environ.get("LBMPM_RK3D_BOUNDARY", "2")),
                                     "per_rank": per_rank}
             if world == 1 and not args.no_secondary:

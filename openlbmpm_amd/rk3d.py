@@ -275,8 +275,13 @@ class RK3DDistributed:
     def timing(self):
         t = self.slab.slab_timing()
         t["exchange_exposed_ms"] = t["step_ms"] - max(t["interior_ms"], t["boundary_ms"])
-        f = self.slab.buffer("f_send_up"); ph = self.slab.buffer("phi_send_up")
-        t["bytes_per_face"] = int(f.numel() * f.element_size() + ph.numel() * ph.element_size())
+        faces = {}
+        for side, there in (("down", self.rank > 0), ("up", self.rank + 1 < self.world)):       # faces that have a neighbour
+            if there:
+                f = self.slab.buffer("f_send_" + side); ph = self.slab.buffer("phi_send_" + side)
+                faces[side] = int(f.numel() * f.element_size() + ph.numel() * ph.element_size())
+        t["bytes_sent_per_step"] = faces                    # populations (5 x 2 colours, fluid cells of the face plane) + phi plane
+        t["bytes_per_face"] = max(faces.values()) if faces else 0
         return t
 
     def observe(self):
