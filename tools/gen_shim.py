@@ -353,10 +353,14 @@ PY = {"i": "C.c_int64", "d": "C.c_double", "I": "C.c_void_p", "D": "C.c_void_p",
 
 def main():
     hdr = ['''/*
- * lbmpm_kernels.h -- kernel-level (drop-in) C ABI of liblbmpm_hip.so: one entry point per reference
- * @cuda.jit kernel that a WORKING reference driver loop launches, on the reference's own sparse
- * arrays (AoS f[N][9] / f[nF][N][9] float64, int64 neighbour tables), same argument order as the
- * Numba signature minus the launch configuration `[grid, block]`.  GENERATED by tools/gen_shim.py.
+ * lbmpm_kernels.h -- kernel-level (drop-in) C ABI of liblbmpm_hip.so: one entry point per @cuda.jit KERNEL of the
+ * reference's five kernel modules (RKCG2D/AcceleratedRKGPU2D.py -> lbmpm_rk_*, RKCG2D/RKGPU2DBoundary.py -> lbmpm_rkb_*,
+ * ShanChen2D/OptimizedD2Q9GPU.py and ExplicitD2Q9GPU.py -> lbmpm_sc_*, RKCG2D/AccelerateTransport2DRK.py -> lbmpm_tr_*),
+ * the ones its working loops launch and the ones nothing launches alike, on the reference's own sparse
+ * arrays (AoS f[N][9] / f[nF][N][9] float64, int64 neighbour tables, boolean masks one byte per entry), same argument
+ * order as the Numba signature minus the launch configuration `[grid, block]`; a list argument the reference kernel
+ * iterates over as a whole (`for m in newFluidList`) is followed by its length (<name>_len).
+ * GENERATED by tools/gen_shim.py.
  *
  * All pointers are DEVICE pointers (see lbmpm_device_malloc & co below); `stream` is a hipStream_t
  * (NULL = the legacy default stream, which is what Numba's default-stream launches use).
