@@ -367,7 +367,7 @@ def main():
  * Arguments the reference passes but the arithmetic does not need (xDim, the lattice-constant
  * arrays) are accepted and ignored.  Every call enqueues asynchronously and returns 0 or a
  * negative lbmpm_status.  Shan-Chen entry points require numFluids == 2 (like the reference's
- * outlet kernel); tracer entry points the D2Q5 scheme (numSchemes == 5).
+ * outlet kernel); tracer entry points that take numScheme(s) the value that belongs to them (5, or 9 for the D2Q9 kernel).
  */
 #ifndef LBMPM_KERNELS_H
 #define LBMPM_KERNELS_H
