@@ -7,8 +7,10 @@
  *
  * Parity status: every kernel is PINNED individually against vectors produced by the real
  * reference kernels (tests/golden/gen/make_golden_tr.py -> tests/golden/tr_kernels.npz).  The
- * ORDER of the sub-step is pinned by reading only: Transport2DRK.py does not parse
- * (IndentationError at :1358), so the coupled loop cannot be executed.
+ * ORDER of the sub-step inside the flow step is pinned by two captures of the real driver
+ * runTransport2DMPMCRKNew, which runs once three listed defects are repaired in memory (:1358 indentation,
+ * :1293 undefined kernel name, the missing transportsetup.ini): tests/golden/gen/make_golden_tr_coupled.py ->
+ * tests/golden/trc_*.npz, compared in tests/test_tr_coupled.py.
  *
  * Layout = the reference's: g[nT][N][5] (0 rest, 1 E, 2 W, 3 N, 4 S; TD:60-61), C[nT][N],
  * nbr4[4N] in the order E,W,N,S with -1 for every non-fluid neighbour (T:51-75).
