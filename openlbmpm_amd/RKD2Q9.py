@@ -116,6 +116,8 @@ class RKColorGradientLBM:
     # -- run
     def runRKColorGradient2D(self, progress=None):
         p = self.par
+        if p["tension_type"] == "Perturbation":
+            return self.runRKColorGradient2DPerturbation(progress)
         self.initializeDomainBorder()
         self.initializeDomainCondition()
         keys = ("sigma", "theta", "wetting", "beta", "delta", "tauR", "tauB", "tautype", "relax", "inlet", "outlet",
@@ -140,6 +142,99 @@ class RKColorGradientLBM:
                 progress(done)
         solver.sync()
         self.solver = solver
+        return self.result_path
+
+    # -- the perturbation loop (RKD2Q9.py:978-1223), kernel by kernel on the kernel-level layer
+    def runRKColorGradient2DPerturbation(self, progress=None, initial_pdf=None):
+        """[SurfaceTension] SurfaceTensionType = 'Perturbation'.  The reference's method of this name stops at its first
+        inlet launch (RKD2Q9.py:1099: 10 arguments for a 12-argument kernel); this is that loop with the four call-site
+        repairs under which its golden captures were taken (tests/golden/gen/make_golden_rk_pert.py):
+          R1 the two force arrays ghostPointsConstantVelocityRK also takes are passed (unused by the kernel);
+          R2 calPhysicalVelocityRKGPU2D gets its eight arguments (the call at :1120 adds two);
+          R3 f_tot = f_R + f_B is taken where the collision kernels need it (after collision 1 for SRT, before it for MRT);
+          R4 body force zero.
+        Also left out: the loop's last launch, calRecoloringProcess (:1206), reads gradient and collision arrays nothing ever
+        writes -- it adds zeros where device_array_like happens to return zeros, garbage otherwise.
+        There is no fused kernel for this 2-D loop (its 3-D extension is rk3dc_fused): it runs as ~16 launches per step on the
+        kernel-level entry points (include/lbmpm_kernels.h), arrays in the reference's sparse layout.
+        `initial_pdf` = (fR, fB) dense [ny][nx][9] replaces the rest-state start (tests)."""
+        import sys
+        drop = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
+        if drop not in sys.path:
+            sys.path.append(drop)
+        import _runtime as rt
+        p = self.par
+        if p["tension_type"] != "Perturbation":
+            raise config.ConfigError("runRKColorGradient2DPerturbation needs SurfaceTensionType = 'Perturbation'")
+        self.initializeDomainBorder()
+        self.initializeDomainCondition()
+        ny, nx = self.isDomain.shape
+        fluid = np.flatnonzero(self.isDomain.reshape(-1) == 1).astype(np.int64)          # optimizeFluidArray, :603-655
+        N = int(fluid.size)
+        new_index = -np.ones(nx * ny, dtype=np.int64); new_index[fluid] = np.arange(N)
+        W = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+        ex = np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.]); ey = np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.])
+        rR = self.fluidsRhoR.reshape(-1)[fluid]; rB = self.fluidsRhoB.reshape(-1)[fluid]
+        if initial_pdf is not None:
+            fR = np.ascontiguousarray(np.asarray(initial_pdf[0], dtype=np.float64).reshape(-1, 9)[fluid])
+            fB = np.ascontiguousarray(np.asarray(initial_pdf[1], dtype=np.float64).reshape(-1, 9)[fluid])
+        else:
+            fR = np.ascontiguousarray(rR[:, None] * W[None, :]); fB = np.ascontiguousarray(rB[:, None] * W[None, :])   # :577-601, u = 0
+        dev = lambda a: rt.to_device(np.ascontiguousarray(a))
+        z = lambda *shape: dev(np.zeros(shape))
+        mrt = p["relax"] == "MRT"
+        T = dict(totalNodes=N, totalNum=N, nx=nx, ny=ny, xDim=128, fluidNodes=dev(fluid), domainNewIndex=dev(new_index),
+                 neighboringNodes=dev(np.zeros(8 * N, dtype=np.int64)), fluidPDFR=dev(fR), fluidPDFB=dev(fB), fluidPDFRNew=z(N, 9),
+                 fluidPDFBNew=z(N, 9), fluidPDFTotal=dev(fR + fB), fluidRhoR=dev(rR), fluidRhoB=dev(rB), physicalVX=z(N), physicalVY=z(N),
+                 phiValue=z(N), forceX=z(N), forceY=z(N), collisionR1=z(N, 9), collisionB1=z(N, 9), CGX=z(nx * ny), CGY=z(nx * ny),
+                 unitEX=dev(ex), unitEY=dev(ey), weightsCoeff=dev(W), schemeGradient=dev(np.ones(9)),
+                 constantCR=z(9), constantCB=z(9),                         # rest weights C_i(alpha): loaded and never used by these kernels
+                 constantB=dev(np.array([-2. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)),              # constantBNew, :131-133
+                 delta=p["delta"], tauR=p["tauR"], tauB=p["tauB"], betaCoeff=p["beta"], AkR=p["AkR"], AkB=p["AkB"], solidPhi=p["solidPhi"],
+                 specificVYR=p["vyR"], specificVYB=p["vyB"], constPLB=p["rhoBL"], constPLR=p["rhoRL"], constPHB=p["rhoBH"], constPHR=p["rhoRH"],
+                 bodyFX=0.0, bodyFY=0.0)
+        if mrt:
+            from .rk2d import mrt_matrices
+            M, Minv, S = mrt_matrices()
+            T.update(transformationM=dev(M), inverseTM=dev(Minv), collisionS=dev(S))
+        go = lambda name, **rename: rt.launch_by_name("rk", name, dict(T, **{k: T[v] for k, v in rename.items()}))
+        go("fillNeighboringNodes")                                       # non-fluid neighbours come out as -1 (new_index)
+        R = dict(fluidPDF="fluidPDFR", fluidPDFNew="fluidPDFRNew"); Bq = dict(fluidPDF="fluidPDFB", fluidPDFNew="fluidPDFBNew")
+        outlet = ([("convectiveOutletGPU", {}), ("convectiveOutletGhost2GPU", {}), ("convectiveOutletGhost3GPU", {})] if p["outlet"] == "Convective"
+                  else [("calConstPressureLowerGPU", {}), ("ghostPointsConstPressureLowerRK", {})])                      # :1064-1088
+        inlet = ([("constantVelocityZHBoundaryHigherRK", {}), ("ghostPointsConstantVelocityRK", {})] if p["inlet"] == "Neumann"
+                 else [("calConstPressureInletGPU", {}), ("ghostPointsConstPressureInletRK", {})])                       # :1089-1110
+        head = [("calStreaming1GPU", R), ("calStreaming1GPU", Bq), ("calStreaming2GPU", R), ("calStreaming2GPU", Bq)] + outlet + inlet + \
+               [("calMacroDensityRKGPU2D", {}), ("calPhysicalVelocityRKGPU2D", {})]
+        tail = [("calPhaseFieldPhi", {})] + ([("calTotalFluidPDF", {}), ("calRKCollision1GPU2DMRTNew", {})] if mrt
+                                             else [("calRKCollision1GPU2DSRTNew", {}), ("calTotalFluidPDF", {})]) + [("calRKCollision23GPUNew", {})]
+        out = ResultFile(self.output_dir, "SimulationResultsRK",
+                         (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity")))
+        self.result_path = out.path
+        self._guard = RecordGuard("rk2d perturbation", N, self.nan_guard)
+
+        def dense(compact, tail_shape=()):
+            a = np.zeros((nx * ny,) + tail_shape)
+            a[fluid] = compact
+            return a.reshape((ny, nx) + tail_shape)
+
+        class _View:                                                     # what _record reads from a fused solver
+            def get(_, name):
+                src = dict(rec_rhoR="fluidRhoR", rec_rhoB="fluidRhoB", rec_vx="physicalVX", rec_vy="physicalVY", rec_fR="fluidPDFR", rec_fB="fluidPDFB")[name]
+                a = T[src].copy_to_host()
+                return dense(a, (9,) if a.ndim == 2 else ())
+        view = _View()
+        self._pert_table, self.fluidNodes = T, fluid
+        for step in range(1, self.timeSteps + 1):
+            self._step_now = step - 1
+            for name, rename in head:
+                go(name, **rename)
+            if (step - 1) % self.timeInterval == 0:                      # :1121-1131
+                self._record(view, out)
+            for name, rename in tail:
+                go(name, **rename)
+            if progress:
+                progress(step)
         return self.result_path
 
     def _record(self, solver, out):

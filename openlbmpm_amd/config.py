@@ -81,11 +81,14 @@ def read_rk2d(ini_dir):
     if p["tension_type"] not in ("CSF", "Perturbation"):
         raise ConfigError("SurfaceTensionType must be 'CSF' or 'Perturbation'")
     if p["tension_type"] == "Perturbation":
-        raise ConfigError("the 'Perturbation' driver path is dead in the reference (RKD2Q9.py:1099 passes 10 "
-                          "arguments to a 12-argument kernel); only 'CSF' is supported")
-    p["sigma"] = c.float("SurfaceTension", "SurfaceTensionValue", "SurfaceTension")
-    p["theta"] = c.float("SurfaceTension", "ContactAngle")
-    p["wetting"] = c.int("SurfaceTension", "WettingType")
+        # the reference's runRKColorGradient2DPerturbation stops at its first inlet launch (RKD2Q9.py:1099 passes 10
+        # arguments to a 12-argument kernel); RKColorGradientLBM.runRKColorGradient2DPerturbation here runs that loop
+        # with the four call-site repairs its golden captures list (tests/golden/gen/make_golden_rk_pert.py)
+        p["AkR"] = c.float("RKParameters", "AkR"); p["AkB"] = c.float("RKParameters", "AkB")      # RKD2Q9.py:116-124
+        p["solidPhi"] = c.float("SolidBoundarySetup", "SolidColorDiff")                            # RKD2Q9.py:182
+    p["sigma"] = c.float("SurfaceTension", "SurfaceTensionValue", "SurfaceTension", default=0.0 if p["tension_type"] == "Perturbation" else None)
+    p["theta"] = c.float("SurfaceTension", "ContactAngle", default=90.0 if p["tension_type"] == "Perturbation" else None)
+    p["wetting"] = c.int("SurfaceTension", "WettingType", default=2 if p["tension_type"] == "Perturbation" else None)
     p["beta"] = c.float("RKParameters", "BetaThickness")
     p["delta"] = c.float("RKParameters", "DeltaValue")
     p["tauR"] = c.float("FluidParameters", "TauR"); p["tauB"] = c.float("FluidParameters", "TauB")

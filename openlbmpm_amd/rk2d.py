@@ -178,3 +178,14 @@ class RK2DSolver:
     @property
     def dominant_kernel(self):
         return self._L.lbmpm_rk2d_dominant_kernel(self._h).decode()
+
+
+def mrt_matrices():
+    """D2Q9 moment basis (rho, e, eps, j_x, q_x, j_y, q_y, p_xx, p_xy) as a literal, its inverse, and the relaxation rates
+    (0, 1.64, 1.54, 0, 1.9, 0, 1.9, *, *) -- the values of RKD2Q9.py:308-340 (slots 7, 8 are set per node to 1/tau).
+    The fused solver has them built in; the kernel-level entry points take them as arrays, like the reference's kernels."""
+    M = np.array([[1, 1, 1, 1, 1, 1, 1, 1, 1], [-4, -1, -1, -1, -1, 2, 2, 2, 2], [4, -2, -2, -2, -2, 1, 1, 1, 1],
+                  [0, 1, 0, -1, 0, 1, -1, -1, 1], [0, -2, 0, 2, 0, 1, -1, -1, 1], [0, 0, 1, 0, -1, 1, 1, -1, -1],
+                  [0, 0, -2, 0, 2, 1, 1, -1, -1], [0, 1, -1, 1, -1, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1, -1, 1, -1]], dtype=np.float64)
+    S = np.array([0., 1.64, 1.54, 0., 1.9, 0., 1.9, 0., 0.])
+    return M, np.linalg.inv(M), S

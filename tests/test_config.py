@@ -23,7 +23,10 @@ def test_rk_ini_errors(tmp_path):
     write_rk(str(tmp_path))
     path = os.path.join(str(tmp_path), "RKtwophasesetup2D.ini")
     text = open(path).read()
-    open(path, "w").write(text.replace("'CSF'", "'Perturbation'", 1))
+    open(path, "w").write(text.replace("'CSF'", "'Perturbation'", 1))       # read: runRKColorGradient2DPerturbation runs that loop
+    q = config.read_rk2d(str(tmp_path))
+    assert q["tension_type"] == "Perturbation" and q["AkR"] == 0.14 and q["solidPhi"] == 0.5
+    open(path, "w").write(text.replace("'CSF'", "'Level-set'", 1))
     with pytest.raises(config.ConfigError):
         config.read_rk2d(str(tmp_path))
     open(path, "w").write(text.replace("TauR = 1.0", "TauR = fast"))
