@@ -194,10 +194,9 @@ def read_sc2d(ini_dir):
     p["outlet"] = m.str("BoundaryDefinition", "BoundaryTypeOutlet")
     if p["outlet"] not in ("Dirichlet", "Convective", "Freeflow"):
         raise ConfigError("[BoundaryDefinition] BoundaryTypeOutlet must be 'Dirichlet', 'Convective' or 'Freeflow'")
-    if p["inter"] != "EFS" and (p["method"] == "Chang" or p["outlet"] == "Freeflow"):
-        # the original Shan-Chen loop has no 'Freeflow' branch at all (ShanChenD2Q9.py:1579-1622 tests 'Convective' only);
-        # its Chang branch (:1529) is not carried by the fused solver
-        raise ConfigError("BoundaryMethod 'Chang' / BoundaryTypeOutlet 'Freeflow' are supported for InteractionType 'EFS'")
+    if p["inter"] != "EFS" and p["outlet"] == "Freeflow":
+        # the original Shan-Chen loop has no 'Freeflow' branch at all (ShanChenD2Q9.py:1579-1622 tests 'Convective' only)
+        raise ConfigError("BoundaryTypeOutlet 'Freeflow' belongs to InteractionType 'EFS'")
     if p["outlet"] == "Freeflow" and p["relax"] != "SRT":
         raise ConfigError("BoundaryTypeOutlet 'Freeflow' with MRT: the reference's loop copies the outlet rows after its moment "
                           "transforms (ShanChenD2Q9.py:1855-1884) and the run turns NaN; use SRT")

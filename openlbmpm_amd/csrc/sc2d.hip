@@ -738,6 +738,9 @@ int launch_step(lbmpm_sc2d *c, bool diag, bool timed)
     if (c->cfg.model == LBMPM_SC_MODEL_EFS && !c->initialised) { const int rc = efs_initialise(c); if (rc) return rc; }
     SCDev p = make_dev(c);
     p.diag = diag ? c->diag : nullptr;
+    // original Shan-Chen loop, first pass: deviceFluidPDFold is the initial f (S:1446) when the Chang inlet (S:1529) first reads it
+    if (p.chang && !c->streamed && c->cfg.model == LBMPM_SC_MODEL_SHANCHEN)
+        sc2d_chang_seed<<<dim3((c->nx + 63) / 64), dim3(64), 0, c->stream>>>(p, c->chgA);
     const int tiles_x = (c->nx + TW - 1) / TW, tiles_y = (c->ny + TH - 1) / TH;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool ev = timed && c->pool.take(&e0, &e1);
@@ -857,9 +860,8 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
                   "(ShanChenD2Q9.py:1865; with MRT the reference run diverges to NaN)");
         return LBMPM_ERR_UNSUPPORTED;
     }
-    if (cfg->inlet_method == LBMPM_INLET_CHANG &&
-        !(cfg->model == LBMPM_SC_MODEL_EFS && (cfg->force_scheme == 0 || cfg->force_scheme == 4) && cfg->outlet_type != LBMPM_OUTLET_NONE)) {
-        set_error("BoundaryMethod 'Chang' is built for the explicit forcing loop with ExplicitScheme 4 (ShanChenD2Q9.py:1999-2006)");
+    if (cfg->inlet_method == LBMPM_INLET_CHANG && !((cfg->force_scheme == 0 || cfg->force_scheme == 4) && cfg->outlet_type != LBMPM_OUTLET_NONE)) {
+        set_error("BoundaryMethod 'Chang' exists for ExplicitScheme 4 only (ShanChenD2Q9.py:1529, :1803, :1999)");
         return LBMPM_ERR_UNSUPPORTED;
     }
     LBMPM_REQUIRE(cfg->tau[0] > 0.5 && cfg->tau[1] > 0.5, "FluidsTau must exceed 0.5");

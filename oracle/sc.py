@@ -57,7 +57,7 @@ class _Sim(C.Structure):
                 ("vyIn", C.c_double * 2), ("mrt", C.c_int), ("outletType", C.c_int), ("Lam", F64P)] + \
                [(n, F64P) for n in ("f", "fOld", "fNew", "rho", "psi", "Fx", "Fy", "ux", "uy", "feq",
                                     "ff", "fM", "ffM", "vx", "vy")] + \
-               [("scheme", C.c_int), ("nbrX", I64P), ("wX", C.c_double * 36), ("inletMethod", C.c_int)]
+               [("scheme", C.c_int), ("nbrX", I64P), ("wX", C.c_double * 36), ("inletMethod", C.c_int), ("fOldValid", C.c_int)]
 
 
 DEFAULT_PARAMS = dict(inter="EFS", relax="SRT", rho0=1.0, rho1=1.0, bg0=0.02, bg1=0.02, tau0=1.0, tau1=1.0,

@@ -565,7 +565,8 @@ typedef struct {
     int scheme;          /* 4, 8 or 10 ([ForceScheme] ExplicitScheme) */
     const i64 *nbrX;     /* [N][24] or [N][36] for scheme 8 / 10 */
     double wX[36];
-    int inletMethod;     /* 0 Zou-He, 1 Chang (EFS, scheme 4) */
+    int inletMethod;     /* 0 Zou-He, 1 Chang (scheme 4) */
+    int fOldValid;       /* original Shan-Chen loop: fOld has been filled */
 } sc_sim;
 
 static void sc_efs_force_chain(sc_sim *s)
@@ -642,8 +643,12 @@ void sc_sc_iter(sc_sim *s)
 {
     i64 N = s->N;
     if (s->outletType != 2) {        /* 2: periodic box (static-droplet case), boundary kernels skipped */
-        sc_inlet_velocity(N, s->nx, s->ny, s->vyIn, s->fluidNodes, s->rho, s->f);
+        if (s->inletMethod == 1) {   /* D:1529-1534: fOld = the initial f on the first pass (D:1446), then what D:1540 saved */
+            if (!s->fOldValid) { memcpy(s->fOld, s->f, sizeof(double) * NF * N * 9); s->fOldValid = 1; }
+            sc_inlet_chang_row(N, s->nx, s->ny - 2, s->vyIn, s->fluidNodes, s->rho, s->fOld, s->f);
+        } else sc_inlet_velocity(N, s->nx, s->ny, s->vyIn, s->fluidNodes, s->rho, s->f);
         sc_ghost_inlet(N, s->nx, s->ny, s->fluidNodes, s->nbr, s->rho, s->f);
+        if (s->inletMethod == 1) memcpy(s->fOld, s->f, sizeof(double) * NF * N * 9);          /* savePDFLastStep D:1540 */
     }
     sc_rho(N, s->rho, s->f);
     memcpy(s->psi, s->rho, sizeof(double) * NF * N);

@@ -126,6 +126,8 @@ SCENARIOS = {
     "efs_srt_chang": (dict(steps=60, method='Chang'), (0, 1, 60), None),
     "sc_srt_convective": (dict(steps=80, inter='ShanChen', G=3.8, Gs0=-0.40, Gs1=0.40, bg0=0.06, bg1=0.06,
                                outlet='Convective', vy1=-1.01e-3), (1, 2, 10, 80), None),
+    "sc_srt_chang": (dict(steps=60, inter='ShanChen', G=3.8, Gs0=-0.40, Gs1=0.40, bg0=0.06, bg1=0.06, method='Chang',
+                          outlet='Convective', vy1=-1.01e-3), (1, 2, 10, 60), None),
     "sc_srt_porous": (dict(steps=60, inter='ShanChen', G=2.6, Gs0=-0.20, Gs1=0.20, bg0=0.15, bg1=0.15,
                            outlet='Convective', vy1=-1.01e-3, tau0=1.0, tau1=0.9, image='yes'), (1, 60),
                       dict(nx=34, ny=44, seed=9, n_discs=9, rmin=2.0, rmax=4.5)),
@@ -193,6 +195,8 @@ def run(name):
             out["init_f"] = cp(args[9] if kname == "calEquilibriumVEFGPU" else args[8])
         if kname == "constantVelocityZouHeBoundaryHigher" and not efs:
             out["init_f"] = cp(args[8]); out["init_rho"] = cp(args[7])
+        if kname == "calVelocityBoundaryHigherChangGPU" and not efs:          # the same place with BoundaryMethod = 'Chang'
+            out["init_f"] = cp(args[11]); out["init_rho"] = cp(args[7])
     cuda.POST_LAUNCH_HOOK = post
     cuda.PRE_LAUNCH_HOOK = pre
     t0 = time.time()

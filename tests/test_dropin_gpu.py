@@ -220,7 +220,7 @@ def test_explicit_forcing_loop(rt, scenario):
             check(t, g, "s%d_" % i, fields, 1e-11, "%s pass %d" % (scenario, i))
 
 
-@pytest.mark.parametrize("scenario", ["sc_srt_convective"])
+@pytest.mark.parametrize("scenario", ["sc_srt_convective", "sc_srt_chang"])
 def test_original_shan_chen_loop(rt, scenario):
     """runOptimizedLBM (Neumann / Zou-He inlet, convective outlet): the fused interaction + collision kernel, the three
     outlet-row kernels and the (result-less) whole-fluid velocity"""
@@ -229,8 +229,9 @@ def test_original_shan_chen_loop(rt, scenario):
     t, N, f0, tau, _ = sc_table(rt, g, par, False)
     assert rel_err(f0, g["init_f"]) < 1e-15
     t.put(weightInter=np.array([1. / 9.] * 4 + [1. / 36.] * 4))                 # ShanChenD2Q9.py:1478
-    head = [("constantVelocityZouHeBoundaryHigher", {}), ("ghostPointsConstantVelocityInlet", {}), ("savePDFLastStep", {}),
-            ("calMacroWholeVelocity", {})]
+    inlet = (("calVelocityBoundaryHigherChangGPU", dict(fluidPDFOld="fluidPDFOld", fluidPDFNew="fluidPDF")) if par.get("method") == "Chang"      # S:1529
+             else ("constantVelocityZouHeBoundaryHigher", {}))
+    head = [inlet, ("ghostPointsConstantVelocityInlet", {}), ("savePDFLastStep", {}), ("calMacroWholeVelocity", {})]
     tail = [("calFluidRhoGPU", {}), ("calFluidPotentialGPUEql", {}), ("interactionCollisionProcess", {}), ("calStreaming1GPU", {}),
             ("calStreaming2GPU", {}), ("convectiveOutletGPU", dict(fluidPDFNew="fluidPDF")), ("convectiveOutletGhost2GPU", dict(fluidPDFNew="fluidPDF")),
             ("convectiveOutletGhost3GPU", dict(fluidPDFNew="fluidPDF")),

@@ -20,6 +20,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="th
     ("make_golden_sc.py", ["efs_srt_convective"], "sc_efs_srt_convective.npz"),
     ("make_golden_sc.py", ["efs_srt_freeflow"], "sc_efs_srt_freeflow.npz"),
     ("make_golden_sc.py", ["efs_srt_chang"], "sc_efs_srt_chang.npz"),
+    ("make_golden_sc.py", ["sc_srt_chang"], "sc_sc_srt_chang.npz"),
     ("make_golden_tr.py", [], "tr_kernels.npz"),
     ("make_golden_rk_pert.py", ["kernels"], "rkpert_kernels.npz"),
     ("make_golden_rk_pert.py", ["srt_porous"], "rkpert_srt_porous.npz"),
