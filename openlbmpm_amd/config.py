@@ -195,8 +195,12 @@ def read_sc2d(ini_dir):
     if p["outlet"] not in ("Dirichlet", "Convective", "Freeflow"):
         raise ConfigError("[BoundaryDefinition] BoundaryTypeOutlet must be 'Dirichlet', 'Convective' or 'Freeflow'")
     if p["inter"] != "EFS" and p["outlet"] == "Freeflow":
-        # the original Shan-Chen loop has no 'Freeflow' branch at all (ShanChenD2Q9.py:1579-1622 tests 'Convective' only)
-        raise ConfigError("BoundaryTypeOutlet 'Freeflow' belongs to InteractionType 'EFS'")
+        # the original Shan-Chen loop tests for 'Convective' only (ShanChenD2Q9.py:1599): any other value, this one included,
+        # runs without an outlet rule -- which is what 'Dirichlet' selects in the solver for that loop
+        import warnings
+        warnings.warn("BoundaryTypeOutlet 'Freeflow' has no branch in the original Shan-Chen loop (ShanChenD2Q9.py:1599): "
+                      "running without an outlet rule, as the reference would")
+        p["outlet"] = "Dirichlet"
     if p["outlet"] == "Freeflow" and p["relax"] != "SRT":
         raise ConfigError("BoundaryTypeOutlet 'Freeflow' with MRT: the reference's loop copies the outlet rows after its moment "
                           "transforms (ShanChenD2Q9.py:1855-1884) and the run turns NaN; use SRT")
