@@ -77,7 +77,7 @@ enum { LBMPM_OUTLET_PRESSURE = 0,     /* BoundaryTypeOutlet 'Dirichlet'  */
        LBMPM_OUTLET_CONVECTIVE = 1,   /* BoundaryTypeOutlet 'Convective' */
        LBMPM_OUTLET_NONE = 2,         /* sc2d only: no boundary kernels at all, inlet included: fully periodic box
                                          (the static-droplet Laplace case of the reference's CPU path SimpleD2Q9) */
-       LBMPM_OUTLET_FREEFLOW = 3 };   /* sc2d, explicit forcing, SRT, ExplicitScheme 4 only: BoundaryTypeOutlet 'Freeflow'
+       LBMPM_OUTLET_FREEFLOW = 3 };   /* sc2d, explicit forcing, SRT (any ExplicitScheme): BoundaryTypeOutlet 'Freeflow'
                                          (ShanChenD2Q9.py:1865-1884, ExplicitD2Q9GPU.py:1476-1563): before every collision
                                          rows 2, 1, 0 take f-bar, F_i and f_eq of the row above, i.e. they leave the
                                          collision with the populations of row 3 */

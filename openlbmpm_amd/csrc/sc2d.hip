@@ -852,11 +852,10 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
     }
     LBMPM_REQUIRE(cfg->outlet_type >= 0 && cfg->outlet_type <= 3, "bad outlet_type %d", cfg->outlet_type);
     LBMPM_REQUIRE(cfg->inlet_method == LBMPM_INLET_ZOUHE || cfg->inlet_method == LBMPM_INLET_CHANG, "bad inlet_method %d", cfg->inlet_method);
-    if (cfg->outlet_type == LBMPM_OUTLET_FREEFLOW &&
-        !(cfg->model == LBMPM_SC_MODEL_EFS && cfg->relaxation == LBMPM_RELAX_SRT && (cfg->force_scheme == 0 || cfg->force_scheme == 4))) {
+    if (cfg->outlet_type == LBMPM_OUTLET_FREEFLOW && !(cfg->model == LBMPM_SC_MODEL_EFS && cfg->relaxation == LBMPM_RELAX_SRT)) {
         // MRT: the loop transforms f-bar and F_i to moment space BEFORE it copies the rows (ShanChenD2Q9.py:1855-1884), so
         // rows 0-2 collide with a mix of their own moments and row 3's populations; the reference run turns NaN
-        set_error("the 'Freeflow' outlet belongs to the explicit forcing loop with SRT and ExplicitScheme 4 "
+        set_error("the 'Freeflow' outlet belongs to the explicit forcing loop with SRT "
                   "(ShanChenD2Q9.py:1865; with MRT the reference run diverges to NaN)");
         return LBMPM_ERR_UNSUPPORTED;
     }

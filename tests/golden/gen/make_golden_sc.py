@@ -124,6 +124,9 @@ SCENARIOS = {
     "efs_srt_freeflow": (dict(steps=60, outlet='Freeflow', tau0=0.9, tau1=1.1), (0, 1, 60), None),
     "efs_mrt_freeflow": (dict(steps=60, outlet='Freeflow', relax='MRT', tau0=1.0, tau1=0.8), (0, 1, 60), None),
     "efs_srt_chang": (dict(steps=60, method='Chang'), (0, 1, 60), None),
+    # the 'Freeflow' rows are not scheme dependent in the loop (S:1865): with the wider force stencils too
+    "efs_srt_iso8_freeflow": (dict(steps=40, scheme=8, outlet='Freeflow'), (0, 1, 40), None),
+    "efs_srt_iso10_freeflow": (dict(steps=40, scheme=10, outlet='Freeflow'), (0, 1, 40), None),
     "sc_srt_convective": (dict(steps=80, inter='ShanChen', G=3.8, Gs0=-0.40, Gs1=0.40, bg0=0.06, bg1=0.06,
                                outlet='Convective', vy1=-1.01e-3), (1, 2, 10, 80), None),
     "sc_srt_chang": (dict(steps=60, inter='ShanChen', G=3.8, Gs0=-0.40, Gs1=0.40, bg0=0.06, bg1=0.06, method='Chang',
