@@ -9,7 +9,7 @@ collision + recolouring) over the whole synthetic domain.  MLUPS counts FLUID-no
 Workloads (BASELINE.json configs):
   c5 (default)  D3Q19 colour gradient, 512^3 synthetic porous medium -- the configuration the
                 metric "MLUPS at 1/2/4/8 GPUs; % of HBM roofline" is quoted on.  It fits one GPU
-                (82 GB) and is z-slab decomposed over N GPUs with RCCL point-to-point halo
+                (57 GB: fluid cells only are stored) and is z-slab decomposed over N GPUs with RCCL point-to-point halo
                 exchange (strong scaling: the global 512^3 is fixed as N grows).
   c2            CSF colour-gradient D2Q9 MRT, 1024^2 capillary (configs[1]); N>1 = replicas.
   c3            explicit-forcing Shan-Chen D2Q9 MRT, 2048^2 porous (configs[2]); N>1 = replicas.
