@@ -249,3 +249,30 @@ def test_two_gpu_rccl_slab_run_equals_single_process(tmp_path):
     for f in ref:
         assert np.array_equal(got[f], ref[f]), f
     assert all(t["backend"] == "nccl" and t["world"] == 2 for t in timing)
+
+
+def test_bench_line_of_a_two_rank_run(tmp_path):
+    """`bench.py --gpus 2` end to end (two ranks sharing this GPU over the gloo rehearsal transport): one JSON line from rank
+    0 with the whole-job value and, per rank, what the slab step measured -- the fields the N > 1 record is read by"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                          "--size", "128", "128", "128"], env=dict(os.environ, LBMPM_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "MLUPS"
+    m = d["multi_gpu"]
+    assert m["backend"] == "gloo" and m["world_size"] == 2 and m["boundary_depth_planes"] == 2 and "REHEARSAL" in m["transport"]
+    assert [r["rank"] for r in m["per_rank"]] == [0, 1]
+    for r in m["per_rank"]:
+        assert r["steps"] == 6 and r["step_ms"] > 0 and r["interior_ms"] > 0 and r["boundary_ms"] > 0 and r["bytes_per_face"] > 0
+        assert abs(r["exchange_exposed_ms"] - (r["step_ms"] - max(r["interior_ms"], r["boundary_ms"]))) < 1e-4
+    planes = [r["planes"] for r in m["per_rank"]]
+    assert planes[0][0] == 0 and planes[0][1] == planes[1][0] and planes[1][1] == 128
+    assert sum(r["fluid_nodes"] for r in m["per_rank"]) == d["config"]["fluid_nodes"]
