@@ -108,8 +108,7 @@ __device__ __forceinline__ void bc_outlet_pressure(double pL, double fR[9], doub
 //                       COMPACT index < nx, which is row 0 whenever row 0 is all fluid)
 //   outlet 'Convective': rows 2,1,0 <- row 3, rho re-summed (A:700-784)
 template <bool WITH_BC>
-__device__ __forceinline__ void node_state(const RKDev &p, int x, int y, double fR[9], double fB[9],
-                                           double &rhoR, double &rhoB)
+__device__ __forceinline__ int node_source_row(const RKDev &p, int y)
 {
     int ys = y;
     if (WITH_BC) {
@@ -117,7 +116,23 @@ __device__ __forceinline__ void node_state(const RKDev &p, int x, int y, double 
         if (p.outlet == LBMPM_OUTLET_PRESSURE) { if (y == 0) ys = 1; }
         else { if (y <= 2) ys = 3; }
     }
+    return ys;
+}
+template <bool WITH_BC>
+__device__ __forceinline__ void node_finish(const RKDev &p, int y, int ys, double fR[9], double fB[9], double &rhoR, double &rhoB);
+
+template <bool WITH_BC>
+__device__ __forceinline__ void node_state(const RKDev &p, int x, int y, double fR[9], double fB[9],
+                                           double &rhoR, double &rhoB)
+{
+    const int ys = node_source_row<WITH_BC>(p, y);
     pull_node(p, x, ys, fR, fB);
+    node_finish<WITH_BC>(p, y, ys, fR, fB, rhoR, rhoB);
+}
+// boundary rows and densities of a node whose populations pull_node(p, x, ys, ...) has fetched
+template <bool WITH_BC>
+__device__ __forceinline__ void node_finish(const RKDev &p, int y, int ys, double fR[9], double fB[9], double &rhoR, double &rhoB)
+{
     rhoR = sum9(fR);
     rhoB = sum9(fB);
     if (!WITH_BC) return;
@@ -536,10 +551,31 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         if (!fl && rx >= 1 && rx < RW - 1 && ry >= 1 && ry < RH - 1) any_solid = true;
     }
 
-    // ---- phase A: interior nodes (owner keeps f_tot, rho in registers)
+    // ---- phase A: the node's own pull and the pull of "its" halo node are issued back to back -- one memory round trip, not two
+    const bool need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
+    constexpr int NHALO = 2 * H * RW + 2 * H * TH;
+    auto halo_cell = [&](int n, int &rx, int &ry) {
+        int mloc = n;
+        if (mloc < H * RW) { ry = mloc / RW; rx = mloc % RW; }
+        else if ((mloc -= H * RW) < H * RW) { ry = RH - H + mloc / RW; rx = mloc % RW; }
+        else { mloc -= H * RW; ry = H + mloc / (2 * H); const int c = mloc % (2 * H); rx = c < H ? c : RW - 2 * H + c; }
+    };
     double fT[NT][9], rR[NT], rB[NT], Fpx[NT], Fpy[NT];
     unsigned sn[NT];
     bool act[NT];
+    // the first halo node of this thread (all of them when NHALO <= THREADS)
+    int hrx = 0, hry = 0, hx = 0, hy = 0, hys = 0;
+    bool hdo = false;
+    double hR[9], hB[9];
+    if (tid < NHALO) {
+        halo_cell(tid, hrx, hry);
+        hdo = s_fluid[hry * RW + hrx] && (need3 || !(hrx == 0 || hrx == RW - 1 || hry == 0 || hry == RH - 1));
+        if (hdo) {
+            hx = wrapm(tx0 - H + hrx, p.nx); hy = wrapm(ty0 - H + hry, p.ny);
+            hys = node_source_row<true>(p, hy);
+            pull_node(p, hx, hys, hR, hB);
+        }
+    }
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
         const int x = tx0 + lx, y = ty0 + ly + m * TY;
@@ -563,14 +599,14 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             s_phi[ri] = (rR[m] - rB[m]) / (rR[m] + rB[m]);
         }
     }
-    const bool need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
-    // ---- phase A: halo nodes (phi only)
-    constexpr int NHALO = 2 * H * RW + 2 * H * TH;
-    for (int n = tid; n < NHALO; n += THREADS) {
-        int rx, ry, mloc = n;
-        if (mloc < H * RW) { ry = mloc / RW; rx = mloc % RW; }
-        else if ((mloc -= H * RW) < H * RW) { ry = RH - H + mloc / RW; rx = mloc % RW; }
-        else { mloc -= H * RW; ry = H + mloc / (2 * H); const int c = mloc % (2 * H); rx = c < H ? c : RW - 2 * H + c; }
+    if (hdo) {
+        double a, c;
+        node_finish<true>(p, hy, hys, hR, hB, a, c);
+        s_phi[hry * RW + hrx] = (a - c) / (a + c);
+    }
+    for (int n = tid + THREADS; n < NHALO; n += THREADS) {          // shapes whose halo outnumbers the threads
+        int rx, ry;
+        halo_cell(n, rx, ry);
         const int ri = ry * RW + rx;
         if (!s_fluid[ri]) continue;
         if (!need3 && (rx == 0 || rx == RW - 1 || ry == 0 || ry == RH - 1)) continue;
