@@ -99,14 +99,28 @@ __device__ __forceinline__ double mom_y(const double g[9]) { return g[2] - g[4] 
 // INLET=false gives the SC end-of-iteration view (what calPhysicalVelocity :1626 sees).
 template <bool INLET>
 __device__ __forceinline__ void node_state(const SCDev &p, int x, int y, double f0[9], double f1[9],
-                                           double &r0, double &r1)
+                                           double &r0, double &r1);
+
+// node_state in two halves, so that a thread can have the pulls of two nodes in flight at once:
+//   node_source_row: the row the node's populations are pulled at (ghost rows: their source row; convective outlet rows: row 3),
+//   -- pull_node(p, x, ys, f0, f1) --
+//   node_finish:     outlet / inlet rules on the pulled populations, densities.
+template <bool INLET>
+__device__ __forceinline__ int node_source_row(const SCDev &p, int y)
 {
-    int ys = y;
     const bool bc = !p.nobc;
+    if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2 && !p.first) return 3;
+    int ys = y;
     if (INLET && bc && y >= p.ny - 1 - p.sh) ys = p.ny - 2 - p.sh;       // ghost row(s) <- inlet row
-    const bool stream = !p.first;
-    if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2 && stream) {
-        pull_node(p, x, 3, f0, f1);
+    if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_PRESSURE && bc && y <= p.sh) ys = 1 + p.sh;   // ghost row(s) <- outlet row
+    return ys;
+}
+template <bool INLET>
+__device__ __forceinline__ void node_finish(const SCDev &p, int x, int y, int ys, double f0[9], double f1[9], double &r0, double &r1)
+{
+    const bool bc = !p.nobc;
+    if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2 && !p.first) {
+        ys = y;                                  // (pulled at row 3; no inlet rule down here)
         if (p.model == LBMPM_SC_MODEL_EFS) {
             // O:1044-1120 convectiveOutletEach{,2,3}GPU: rows 2,1,0 in sequence,
             // f = (f_old + |vy(row 3)| f(row above)) / (1 + |vy(row 3)|)
@@ -126,17 +140,21 @@ __device__ __forceinline__ void node_state(const SCDev &p, int x, int y, double 
             }
         }
         // SC: O:960-1038 plain copies of row 3 into rows 2,1,0
-    } else {
-        if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_PRESSURE && bc && y <= p.sh) ys = 1 + p.sh;   // ghost row(s) <- outlet row
-        pull_node(p, x, ys, f0, f1);
-        if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_PRESSURE && bc && ys == 1 + p.sh) {
-            bc_outlet(1.0, f0);
-            bc_outlet(0.02, f1);
-        }
+    } else if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_PRESSURE && bc && ys == 1 + p.sh) {
+        bc_outlet(1.0, f0);
+        bc_outlet(0.02, f1);
     }
     if (INLET && bc && ys == p.ny - 2 - p.sh) inlet_row(p, x, f0, f1);
     r0 = sum9(f0);
     r1 = sum9(f1);
+}
+template <bool INLET>
+__device__ __forceinline__ void node_state(const SCDev &p, int x, int y, double f0[9], double f1[9],
+                                           double &r0, double &r1)
+{
+    const int ys = node_source_row<INLET>(p, y);
+    pull_node(p, x, ys, f0, f1);
+    node_finish<INLET>(p, x, y, ys, f0, f1, r0, r1);
 }
 
 // Pseudopotential force on both components from psi of the 8 neighbours (nb0/nb1 = psi_0/psi_1
@@ -358,7 +376,8 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
 
-    // phase A: own node
+    // phase A: the pull of the thread's own node and of "its" halo node (psi only) are issued back to back: one memory
+    // round trip before the barrier
     const int x = tx0 + lx, y = ty0 + ly;
     const bool inside = (x < p.nx) && (y < p.ny);
     const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);
@@ -368,30 +387,39 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
     const int ri = (HALO + ly) * RW + HALO + lx;
     double f0[9], f1[9], rho[2] = {0., 0.}, Fpx[2] = {0., 0.}, Fpy[2] = {0., 0.};
     unsigned sn = 0;
+    constexpr int NHALO = 2 * RW + 2 * TH;
+    static_assert(NHALO <= THREADS, "one halo node per thread");
+    int hri = 0, hx = 0, hy = 0, hys = 0;
+    bool hdo = false;
+    double g0[9], g1[9];
+    if (tid < NHALO) {
+        int rx, ry;
+        if (tid < RW) { ry = 0; rx = tid; }
+        else if (tid < 2 * RW) { ry = RH - 1; rx = tid - RW; }
+        else { const int m = tid - 2 * RW; ry = 1 + m / 2; rx = (m & 1) ? RW - 1 : 0; }
+        hri = ry * RW + rx;
+        hx = wrapm(tx0 - HALO + rx, p.nx); hy = wrapm(ty0 - HALO + ry, p.ny);
+        hdo = p.flags[(size_t)hy * p.pitch + hx] & 1;
+    }
+    int ys = 0;
+    if (fluid) { ys = node_source_row<true>(p, yw); pull_node(p, xw, ys, f0, f1); }
+    if (hdo) { hys = node_source_row<true>(p, hy); pull_node(p, hx, hys, g0, g1); }
     if (fluid) {
         sn = p.solidnbr[idx];
         if (p.keep_force) {
             Fpx[0] = p.F[idx]; Fpx[1] = p.F[p.plane + idx];
             Fpy[0] = p.F[2 * p.plane + idx]; Fpy[1] = p.F[3 * p.plane + idx];
         }
-        node_state<true>(p, xw, yw, f0, f1, rho[0], rho[1]);
+        node_finish<true>(p, xw, yw, ys, f0, f1, rho[0], rho[1]);
         if (p.chang && inside && y == p.ny - 2) keep_inlet_row(p, x, f0, f1);
         s_psi0[ri] = rho[0];            // O:99-106 calFluidPotentialGPUEql: psi = rho
         s_psi1[ri] = rho[1];
     }
-    // phase A: halo ring (psi only)
-    constexpr int NHALO = 2 * RW + 2 * TH;
-    for (int n = tid; n < NHALO; n += THREADS) {
-        int rx, ry;
-        if (n < RW) { ry = 0; rx = n; }
-        else if (n < 2 * RW) { ry = RH - 1; rx = n - RW; }
-        else { const int m = n - 2 * RW; ry = 1 + m / 2; rx = (m & 1) ? RW - 1 : 0; }
-        const int hx = wrapm(tx0 - HALO + rx, p.nx), hy = wrapm(ty0 - HALO + ry, p.ny);
-        if (!(p.flags[(size_t)hy * p.pitch + hx] & 1)) continue;
-        double g0[9], g1[9], a, b;
-        node_state<true>(p, hx, hy, g0, g1, a, b);
-        s_psi0[ry * RW + rx] = a;
-        s_psi1[ry * RW + rx] = b;
+    if (hdo) {
+        double a, b;
+        node_finish<true>(p, hx, hy, hys, g0, g1, a, b);
+        s_psi0[hri] = a;
+        s_psi1[hri] = b;
     }
     __syncthreads();
     const bool line = lbmpm_dev::line_has_active<8>(act, tid & 63) && inside;     // populations: 16 bytes per lane
