@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""GPU time of ONE rank's slab step, rank by rank, against the single-domain step (one GPU, no second process).
+
+`tools/slabbench.py` drives k virtual ranks from one Python thread: its k = 8 figure contains ~150 host calls per lattice
+step that a real run spreads over eight processes.  Here every rank of the `bench.py --gpus K` partition is built alone and
+stepped through `lbmpm_rk3d_step_slab(timed)` -- the call a real rank makes -- with an exchange callback that only moves
+the rank's own send buffers into its receive buffers (finite values, same kernels, same launch sequence, no transfer).
+HIP events give step / interior / boundary-path time per rank; sum over ranks vs the single-domain step is the GPU cost
+of the decomposition, K x max over ranks vs the same is the load imbalance on top of it.
+
+    python tools/slab_rank_cost.py [n=512] [K=8] [steps=40]        (LBMPM_K3_RELAX=SRT|MRT)
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from openlbmpm_amd.rk3d import RK3DSlab, RK3DDistributed
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+par = dict(relax=os.environ.get("LBMPM_K3_RELAX", "MRT"))
+dom = bench.c5_domain((n, n, n))
+rR, rB = bench.c5_densities(dom, 0, n)
+
+s = RK3DSlab(dom, 0, n, par)
+s.set_density(rR, rB)
+s.step_single(3)
+single = min(s.step_timed(10)[0] / 10 for _ in range(3))
+nf = s.num_fluid_nodes
+s.close()
+print("single domain: %.3f ms per step, %d fluid nodes" % (single, nf), flush=True)
+
+rows = []
+only = [int(v) for v in os.environ["SLAB_RANKS"].split(",")] if os.environ.get("SLAB_RANKS") else None      # a subset of the ranks
+for r, (z0, nz) in enumerate(RK3DDistributed.partition(dom, K)):
+    if only is not None and r not in only:
+        continue
+    s = RK3DSlab(dom, z0, nz, par)
+    s.set_density(rR[z0:z0 + nz], rB[z0:z0 + nz])
+    st = torch.cuda.Stream(0)
+    s.use_torch_stream(st)
+    below, above = r > 0, r + 1 < K
+
+    def exchange(what, s=s, below=below, above=above):
+        kind = "phi" if what else "f"
+        if below:
+            a, b = s.buffer(kind + "_recv_below"), s.buffer(kind + "_send_down")
+            m = min(a.numel(), b.numel()); a[:m].copy_(b[:m])
+        if above:
+            a, b = s.buffer(kind + "_recv_above"), s.buffer(kind + "_send_up")
+            m = min(a.numel(), b.numel()); a[:m].copy_(b[:m])
+    with torch.cuda.stream(st):
+        s.step_slab(5, below, above, exchange)
+        s.step_slab(steps, below, above, exchange, timed=True)
+    t = s.slab_timing()
+    t.update(rank=r, planes=nz, fluid=s.num_fluid_nodes)
+    rows.append(t)
+    print("rank %d: planes %3d  fluid %9d  step %.3f ms  interior %.3f  boundary %.3f  pack..phi exchange %.3f" %
+          (r, nz, t["fluid"], t["step_ms"], t["interior_ms"], t["boundary_ms"], t["exchange_chain_ms"]), flush=True)
+    s.close()
+tot = sum(t["step_ms"] for t in rows)
+mx = max(t["step_ms"] for t in rows)
+print("sum over ranks %.3f ms = single x %.3f;  %d x slowest rank %.3f ms = single x %.3f" % (tot, tot / single, K, K * mx, K * mx / single))
