@@ -1,0 +1,31 @@
+"""The measurement tools stay runnable: the microbenchmarks compile for gfx950 (CPU check), the per-rank slab cost tool runs
+end to end on a small lattice (GPU)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("src", ["tile_pull_copy.hip", "march_pull_copy.hip"])
+def test_microbenchmarks_compile(src, tmp_path):
+    out = tmp_path / "a.out"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", os.path.join(ROOT, "tools", "microbench", src), "-o", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.exists()
+
+
+@pytest.mark.gpu
+def test_slab_rank_cost_runs_on_a_small_lattice():
+    env = dict(os.environ, LBMPM_K3_RELAX="SRT")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slab_rank_cost.py"), "64", "2", "4"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("rank ")]
+    assert len(lines) == 2 and "sum over ranks" in r.stdout
