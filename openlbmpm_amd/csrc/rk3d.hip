@@ -397,7 +397,9 @@ __device__ __forceinline__ constexpr double mrt_piww(int i)
 // the colour densities and the colour gradient; stores the post-collision populations of plane zl.
 // Lanes of non-fluid cells whose 128-byte line holds fluid store zeros: partially written
 // lines cost the memory system a read-modify-write (measured: +35 % kernel time at porosity 0.65).
-template <bool COMPACT, bool MRT>   // COMPACT: {red, blue} pairs, 16 bytes per node and direction; MRT: [RelaxationType] Type
+// STORE: 0 dense (two 8-byte stores per direction), 1 compact {red, blue} pairs (16 bytes per node and direction), 2 the
+// colour-blind population alone + one record {k_R, A} per node (rk3dq.h); MRT: [RelaxationType] Type
+template <int STORE, bool MRT>
 __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsigned stride, unsigned own, bool fluid,
                                               const double ft_in[Q], double rR, double rB, double gx, double gy, double gz)
 {
@@ -448,7 +450,8 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     }
     char *blue = red + (size_t)Q * stride;       // red = population 0 of the node's plane, stride = bytes between populations
     auto put = [&](int i, double g, double a) {
-        if (COMPACT) {
+        if (STORE == 2) stg(red + (size_t)i * stride, own, fluid ? g : 0.);
+        else if (STORE == 1) {
             double2 v;
             v.x = fluid ? kR * g + a : 0.; v.y = fluid ? kB * g - a : 0.;
             *reinterpret_cast<double2 *>(red + (size_t)i * stride + own) = v;
@@ -475,6 +478,14 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
         put(i, ((ft_in[i] - (ft_in[i] - (sym + odd)) * omega) - (ev + od)) + pert, a);
         put(i + 1, ((ft_in[i + 1] - (ft_in[i + 1] - (sym - odd)) * omega) - (ev - od)) + pert, -a);
         __builtin_amdgcn_sched_barrier(0);      // one pair's temporaries at a time: registers are the scarce resource here
+    }
+    if (STORE == 2) {                            // the record the next step's pulls rebuild the colours from: f_R,i = k_R g_i + c_i e_i.A
+        const double ai = arc * ign;
+        double2 v, w;
+        v.x = fluid ? kR : 0.; v.y = fluid ? ai * gx : 0.; w.x = fluid ? ai * gy : 0.; w.y = fluid ? ai * gz : 0.;
+        char *s = red + (size_t)Q * stride + (size_t)own * 4u;
+        *reinterpret_cast<double2 *>(s) = v;
+        *reinterpret_cast<double2 *>(s + 16) = w;
     }
 }
 
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3d_collide(RK3Dev p)
     double ft[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) ft[i] = fR[i] + fB[i];
-    collide_store<false, MRT>(p, const_cast<char *>(plane_ptr(p.fout, p, zl)), p.plane_bytes, c.o[1][1], fluid, ft, rR, rB, gx, gy, gz);
+    collide_store<0, MRT>(p, const_cast<char *>(plane_ptr(p.fout, p, zl)), p.plane_bytes, c.o[1][1], fluid, ft, rR, rB, gx, gy, gz);
 }
 
 // Fused time step (default): one block owns a TX x TY column of nodes and marches along z.
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(TX *TY, 768 / (TX * TY)) void rk3d_fused(RK3Dev p, 
                     gy += 3. * wq(i) * (double)CY[i] * ph;
                     gz += 3. * wq(i) * (double)CZ[i] * ph;
                 }
-                collide_store<false, MRT>(p, const_cast<char *>(plane_ptr(p.fout, p, z)), p.plane_bytes, own_off, isfl, ft, rRz, rBz, gx, gy, gz);
+                collide_store<0, MRT>(p, const_cast<char *>(plane_ptr(p.fout, p, z)), p.plane_bytes, own_off, isfl, ft, rRz, rBz, gx, gy, gz);
             }
         }
         fluid = (mo >> 31) && z + 1 >= 1 && z + 1 <= p.nzl;
@@ -850,7 +861,7 @@ __global__ __launch_bounds__(64 * TY, 512 / (64 * TY)) void rk3dc_fused(RK3Dev p
             }
             const unsigned long long p0 = p.pstart[z], p1 = p.pstart[z + 1];
             const unsigned cnt = (unsigned)(p1 - p0);
-            collide_store<true, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * (Q * 16), cnt * 16u, jzz * 16u, fluid, ft, rRz, rBz, gx, gy, gz);
+            collide_store<1, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * (Q * 16), cnt * 16u, jzz * 16u, fluid, ft, rRz, rBz, gx, gy, gz);
         }
         fluid = fluidn;
     }
@@ -976,6 +987,8 @@ __global__ void rk3d_setup_solidnbr(RK3Dev p, uint32_t *solidnbr)
     solidnbr[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] = b;
 }
 
+#include "rk3dq.h"
+
 }  // namespace
 
 // ====================================================================== host side
@@ -993,6 +1006,9 @@ struct lbmpm_rk3d {
     std::vector<uint8_t> h_domain;   // owned planes only, [nzl][ny][nx]
     // compact storage (fluid cells only): default whenever nx is a multiple of 64; LBMPM_RK3D_LAYOUT=dense overrides
     bool compact = false;
+    // q23: compact storage of 19 colour-blind populations + {k_R, A} per cell instead of 2 x 19 (rk3dq.h); default on compact
+    // storage, LBMPM_RK3D_STORAGE=38 keeps the 38-value kernels (the cross-check)
+    bool q23 = false;
     int nseg = 0;
     size_t ncells = 0;               // stored cells, halo planes included
     unsigned long long *pstart = nullptr;
@@ -1084,6 +1100,8 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_BOUNDARY")) c->boundary = atoi(e) >= 2 ? atoi(e) : 2;
     c->compact = variant == 0 && c->nx % 64 == 0;
     if (const char *e = getenv("LBMPM_RK3D_LAYOUT")) if (!strcmp(e, "dense")) c->compact = false;
+    c->q23 = c->compact && c->tile == 0 && cfg->z_offset == 0 && cfg->nz_local == cfg->nz_global;
+    if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
     c->vol = c->plane2 * (size_t)(c->nzl + 2);
@@ -1138,7 +1156,8 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
                         j += (unsigned)__builtin_popcountll(m[(size_t)y * ns + sg]);
                         last = y;
                     }
-                    const unsigned pad = (8u - (j & 7u)) & 7u;          // whole 128-byte lines per tile run
+                    const unsigned lc = c->q23 ? (unsigned)QLINE : 8u;   // cells per 128-byte line
+                    const unsigned pad = (lc - (j % lc)) % lc;          // whole 128-byte lines per tile run
                     hseg[(((size_t)z * c->ny + last) * ns + sg) * 4 + 3] = pad << 2;
                     j += pad;
                 }
@@ -1162,7 +1181,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
         TRY_RC(dev_alloc(c, &c->seg2, hseg2.size()));
         TRY_RC(dev_alloc(c, &c->pstart, c->h_pstart.size()));
     }
-    const size_t fcount = c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol;
+    const size_t fcount = c->q23 ? (size_t)QS * (c->ncells + 2) : (c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol);
     TRY_RC(dev_alloc(c, &c->fA, fcount));
     TRY_RC(dev_alloc(c, &c->fB, fcount));
     TRY_RC(dev_alloc(c, &c->phi, c->vol));
@@ -1221,7 +1240,7 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     // stage the two density fields on the device, expand there
     const size_t n = (size_t)c->nx * c->ny * c->nzl;
-    const size_t fbytes = (c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol) * sizeof(double);
+    const size_t fbytes = (c->q23 ? (size_t)QS * (c->ncells + 2) : (c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol)) * sizeof(double);
     double *stage = nullptr;
     LBMPM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&stage), 2 * n * sizeof(double)));
     hipError_t e = hipMemcpyAsync(stage, rho_r, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
@@ -1230,7 +1249,8 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
     if (e == hipSuccess) e = hipMemsetAsync(c->fB, 0, fbytes, c->stream);
     if (e == hipSuccess) {
         RK3Dev p = make_dev(c);
-        if (c->compact) rk3dc_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
+        if (c->q23) rk3dq_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
+        else if (c->compact) rk3dc_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
         else rk3d_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
         e = hipGetLastError();
     }
@@ -1247,6 +1267,7 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
 extern "C" int lbmpm_rk3d_pack_halo(lbmpm_rk3d *c)
 {
     LBMPM_REQUIRE(c, "null context");
+    if (c->q23 && c->cfg.z_offset == 0 && c->cfg.nz_local == c->cfg.nz_global) return LBMPM_OK;     // no neighbour, nothing crosses a cut
     RK3Dev p = make_dev(c);
     const int threads = 256;
     const dim3 grid((unsigned)((c->plane2 + threads - 1) / threads));
@@ -1259,6 +1280,7 @@ extern "C" int lbmpm_rk3d_pack_halo(lbmpm_rk3d *c)
 extern "C" int lbmpm_rk3d_unpack_halo(lbmpm_rk3d *c, int have_below, int have_above)
 {
     LBMPM_REQUIRE(c, "null context");
+    if (c->q23 && c->cfg.z_offset == 0 && c->cfg.nz_local == c->cfg.nz_global) return LBMPM_OK;
     RK3Dev p = make_dev(c);
     const int threads = 256;
     const dim3 grid((unsigned)((c->plane2 + threads - 1) / threads));
@@ -1276,7 +1298,8 @@ extern "C" int lbmpm_rk3d_phase_field(lbmpm_rk3d *c, int with_diagnostics)
     RK3Dev p = make_dev(c);
     p.diag = with_diagnostics ? c->diag : nullptr;
     auto k1 = [&](int planes, int zl0) {
-        if (c->compact) rk3dc_phase_field<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3, planes), dim3(BX3, BY3), 0, c->stream>>>(p, zl0);
+        if (c->q23) rk3dq_phase_field<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3, planes), dim3(BX3, BY3), 0, c->stream>>>(p, zl0);
+        else if (c->compact) rk3dc_phase_field<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3, planes), dim3(BX3, BY3), 0, c->stream>>>(p, zl0);
         else rk3d_phase_field<<<grid3(c, planes), dim3(BX3, BY3), 0, c->stream>>>(p, zl0);
     };
     if (with_diagnostics) c->observed_at = c->steps;
@@ -1328,6 +1351,16 @@ void launch_fused_c(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first,
 void launch_step_range(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last)
 {
     if (z_last < z_first) return;
+    if (c->q23) {
+        const int tilesX = c->nseg, tilesY = (c->ny + 7) / 8, rpx = (tilesY + 7) / 8;
+        const int nchunks = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
+        const dim3 grid((unsigned)(8 * tilesX * rpx * nchunks)), block(512);
+        auto go = [&](auto first, auto mrt) {
+            rk3dq_fused<decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
+        };
+        dispatch2(p.first != 0, p.mrt != 0, go);
+        return;
+    }
     if (c->compact) {
         if (c->tile == 1) launch_fused_c<4>(c, p, st, z_first, z_last);
         else launch_fused_c<8>(c, p, st, z_first, z_last);
@@ -1608,4 +1641,4 @@ extern "C" int lbmpm_rk3d_get_field(lbmpm_rk3d *c, int field, double *out)
 extern "C" int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *c) { return c ? c->nfluid : 0; }
 extern "C" int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *c) { return c ? c->steps : 0; }
 extern "C" int64_t lbmpm_rk3d_device_bytes(const lbmpm_rk3d *c) { return c ? c->bytes : 0; }
-extern "C" const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *c) { return !c ? "" : (c->variant == 1 ? "rk3d_collide" : (c->compact ? "rk3dc_fused" : "rk3d_fused")); }
+extern "C" const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *c) { return !c ? "" : (c->variant == 1 ? "rk3d_collide" : (c->q23 ? "rk3dq_fused" : (c->compact ? "rk3dc_fused" : "rk3d_fused"))); }

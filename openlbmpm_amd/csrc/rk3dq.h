@@ -1,0 +1,484 @@
+// rk3dq.h -- "q23" storage of the D3Q19 colour-gradient solver; included by rk3d.hip inside its
+// anonymous namespace (it uses RK3Dev, RowTab, row_cell, TileRows, March, collide_store, ... of that file).
+//
+// The recolouring (AcceleratedRKGPU2D.py:1241-1267; collide_store in rk3d.hip) writes
+//     f_R,i = k_R g_i + c_i (e_i . A),     f_B,i = (1 - k_R) g_i - c_i (e_i . A),
+//     k_R = rho_R / rho,   A = rho_R rho_B / rho^2 * G / |G|,   c_i = beta w_i / |e_i|   (two constants: rcA, rcD)
+// with g_i the post-collision colour-blind population: the 38 values a cell hands to the next step are an
+// affine image of 23 -- the 19 g_i, k_R and the vector A.  This storage keeps those 23 doubles per fluid cell
+// (184 B instead of 304 B; one step moves 368 B per cell instead of 608 B) and rebuilds the red population of
+// every pulled direction from the *upstream* cell's k_R and A, which the marching kernel holds in an LDS tile:
+//     pulled  g_i(x)   = g_i(x - e_i)                      or  g_i'(x)  (i' opposite; x - e_i not fluid: bounce-back)
+//     pulled  f_R,i(x) = k_R(x - e_i) g_i(x - e_i) + c_i e_i.A(x - e_i)     or  k_R(x) g_i'(x) - c_i e_i.A(x)
+// The collision needs only the 19 pulled g_i (= f_R,i + f_B,i exactly) and rho_R = sum_i f_R,i (rho_B = rho - rho_R);
+// the per-colour Zou-He planes need the red sum by the class of c_z (zouhe_inlet / zouhe_outlet of rk3d.hip are
+// linear in the populations apart from rho_c = (S0 + 2 S+) / (1 + u_c)), so every cell accumulates three class sums.
+// Mathematically the same step as the 38-value kernels; results differ at round-off (tests: 1e-12 against
+// rk3dc_fused, 1e-10 against the oracle).
+//
+// Layout: compact storage as rk3dc_* (fluid cells only, tile-major numbering, row-segment records), runs padded to
+// 16 cells (= one 128-byte line of 8-byte values); per plane zl with cnt cells
+//     g[zl][q][j]  q = 0..18, 8 bytes            s[zl][j] = {k_R, A_x, A_y, A_z}, 32 bytes        (184 * cnt bytes per plane)
+// Ghost planes of the global lattice (z = 0, nz-1) are never collided or stored: the planes next to them overwrite
+// everything they pull from there by the Zou-He closures, and the ghost's phase field equals its neighbour's.
+
+constexpr int QS = 23;                         // doubles per stored cell
+constexpr unsigned CELLB = QS * 8u;
+constexpr int QLINE = 16;                      // cells per 128-byte line of 8-byte values: padding unit of the tile runs
+constexpr int SR = 12, SC = 68;                // scalar tile: 64 x 8 tile + 2 cells of halo (the rim cells pull too)
+constexpr int SCOMP = SR * SC;                 // doubles between the four components of the LDS scalar tile
+constexpr int SSLOT = 4 * SCOMP;               // doubles between the ring slots (one per plane)
+
+struct PlaneAddrQ {
+    const char *base;            // g_0 of the plane below the pulled one
+    unsigned off[3], cnt[3];     // byte offset of the three planes' blocks from base, stored cells per plane
+};
+
+__device__ __forceinline__ PlaneAddrQ plane_addr_q(const RK3Dev &p, const double *f, int zl)
+{
+    PlaneAddrQ a;
+    const unsigned long long p0 = p.pstart[zl - 1], p1 = p.pstart[zl], p2 = p.pstart[zl + 1], p3 = p.pstart[zl + 2];
+    a.base = reinterpret_cast<const char *>(f) + (size_t)p0 * CELLB;
+    a.cnt[0] = (unsigned)(p1 - p0); a.cnt[1] = (unsigned)(p2 - p1); a.cnt[2] = (unsigned)(p3 - p2);
+    a.off[0] = 0u; a.off[1] = a.cnt[0] * CELLB; a.off[2] = a.off[1] + a.cnt[1] * CELLB;
+    return a;
+}
+
+// pull of the 19 colour-blind populations of the node at bit b of the row rows(zl, 0) (fluid there); 8-byte loads,
+// bounce-back folded into the address as in pull3c
+template <bool FIRST, bool UNI, typename Rows>
+__device__ __forceinline__ void pull_q(const RK3Dev &p, const Rows &rows, int zl, unsigned b, double g[Q], unsigned &own_j)
+{
+    constexpr int OPP[Q] = LBMPM_D3Q19_OPP;
+    const PlaneAddrQ a = plane_addr_q(p, p.fin, zl);
+    {
+        const RowTab t = rows(zl, 0);
+        own_j = t.first + bits_below<UNI>(t.m, b);
+    }
+    const unsigned own8 = own_j * 8u;
+    if (FIRST) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) g[i] = ldg(a.base, a.off[1] + (unsigned)i * a.cnt[1] * 8u + own8);
+        return;
+    }
+#pragma unroll
+    for (int rz = -1; rz <= 1; ++rz)
+#pragma unroll
+        for (int ry = -1; ry <= 1; ++ry) {
+            const RowTab t = rows(zl + rz, ry);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int i = DIRT[(1 - rz) * 9 + (1 - ry) * 3 + (1 - dx)];
+                if (i < 0) continue;
+                unsigned off;
+                if (i == 0) off = a.off[1] + own8;
+                else {
+                    unsigned j;
+                    bool fl;
+                    row_cell<UNI>(t, dx, b, j, fl);
+                    const unsigned up = a.off[1 + rz] + (unsigned)i * a.cnt[1 + rz] * 8u + j * 8u;
+                    const unsigned back = a.off[1] + (unsigned)OPP[i] * a.cnt[1] * 8u + own8;
+                    off = fl ? up : back;
+                }
+                g[i] = ldg(a.base, off);
+            }
+        }
+}
+
+// where the scalar records {k_R, A} of the cells around a node come from
+struct LdsScal {                  // the marching kernel's LDS tile
+    const double *tile;           // ssc
+    int own;                      // index of the node inside a component array of the tile
+    int slot[3];                  // index offset of the ring slots that hold the planes zp-1, zp, zp+1
+    typedef int H;
+    __device__ __forceinline__ H own_cell() const { return slot[1] + own; }
+    __device__ __forceinline__ H cell(int rz, int ry, int dx, bool fl, unsigned) const { return fl ? slot[1 + rz] + own + ry * SC + dx : slot[1] + own; }
+    __device__ __forceinline__ double comp(H h, int k) const { return tile[h + k * SCOMP]; }
+};
+struct GlbScal {                  // straight from global memory (set-up, diagnostics and face kernels)
+    const char *base;             // plane_addr_q(...).base
+    unsigned soff[3];             // byte offsets of the s arrays of the planes zp-1, zp, zp+1
+    unsigned own_j;
+    typedef unsigned H;
+    __device__ __forceinline__ H own_cell() const { return soff[1] + own_j * 32u; }
+    __device__ __forceinline__ H cell(int rz, int, int, bool fl, unsigned j) const { return fl ? soff[1 + rz] + j * 32u : soff[1] + own_j * 32u; }
+    __device__ __forceinline__ double comp(H h, int k) const { return *reinterpret_cast<const double *>(base + h + 8u * (unsigned)k); }
+};
+__device__ __forceinline__ GlbScal glb_scal(const PlaneAddrQ &a, unsigned own_j)
+{
+    GlbScal s;
+    s.base = a.base; s.own_j = own_j;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.soff[k] = a.off[k] + (unsigned)Q * a.cnt[k] * 8u;
+    return s;
+}
+
+// sums over the pulled populations of a node by the class of c_z (0, +1, -1): k = sum k_R g, a = sum c_i e_i.A (signed for
+// bounce-back), t = sum g.  ONE statement of this arithmetic (explicit fma, no contraction) serves the marching kernel, the
+// diagnostics and the face kernels of the slab exchange: the slab-decomposed run equals the single-domain run bit for bit.
+// With k_R = 1 and A = 0 around a node (pure red) k + a equals t bit for bit, i.e. rho_B = 0 exactly.
+struct Sums { double k0, kp, km, a0, ap, am, t0, tp, tm; };
+
+template <bool FIRST, bool UNI, typename Rows, typename Scal>
+__device__ __forceinline__ void class_sums(const RK3Dev &p, const Rows &rows, const Scal &sc, int zp, unsigned b, const double g[Q], Sums &S)
+{
+#pragma clang fp contract(off)
+    constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+    S.kp = S.km = S.a0 = S.ap = S.am = S.tp = S.tm = 0.;
+    S.k0 = sc.comp(sc.own_cell(), 0) * g[0];
+    S.t0 = g[0];
+#pragma unroll
+    for (int rz = -1; rz <= 1; ++rz)
+#pragma unroll
+        for (int ry = -1; ry <= 1; ++ry) {
+            RowTab t{};
+            if (!FIRST) t = rows(zp + rz, ry);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int i = DIRT[(1 - rz) * 9 + (1 - ry) * 3 + (1 - dx)];
+                if (i <= 0) continue;
+                unsigned j = 0;
+                bool fl = true;
+                typename Scal::H h;
+                if (FIRST) h = sc.own_cell();
+                else {
+                    row_cell<UNI>(t, dx, b, j, fl);
+                    h = sc.cell(rz, ry, dx, fl, j);
+                }
+                const double k = sc.comp(h, 0);
+                double ea = 0.;
+                bool any = false;
+                if (CX[i] != 0) { const double v = sc.comp(h, 1); ea = CX[i] > 0 ? v : -v; any = true; }
+                if (CY[i] != 0) { const double v = sc.comp(h, 2); ea = any ? (CY[i] > 0 ? ea + v : ea - v) : (CY[i] > 0 ? v : -v); any = true; }
+                if (CZ[i] != 0) { const double v = sc.comp(h, 3); ea = any ? (CZ[i] > 0 ? ea + v : ea - v) : (CZ[i] > 0 ? v : -v); }
+                const double c = i < 7 ? p.rcA : p.rcD;
+                const double cs = fl ? c : -c;       // bounce-back: the opposite population of the node itself
+                if (CZ[i] == 0) { S.k0 = __builtin_fma(k, g[i], S.k0); S.a0 = __builtin_fma(cs, ea, S.a0); S.t0 += g[i]; }
+                else if (CZ[i] > 0) { S.kp = __builtin_fma(k, g[i], S.kp); S.ap = __builtin_fma(cs, ea, S.ap); S.tp += g[i]; }
+                else { S.km = __builtin_fma(k, g[i], S.km); S.am = __builtin_fma(cs, ea, S.am); S.tm += g[i]; }
+            }
+        }
+}
+
+// densities of the streamed, boundary-corrected node on plane zl from its class sums; on the inlet / outlet plane pairs
+// the per-colour Zou-He closures (zouhe_inlet / zouhe_outlet above, summed over the colours: they are linear in the
+// populations once rho_c is known) rewrite the unknown colour-blind populations in g
+template <bool WITH_G>
+__device__ __forceinline__ void bc_q(const RK3Dev &p, int zl, const Sums &S, double *g, double &rR, double &rho)
+{
+#pragma clang fp contract(off)
+    const int zsg = p.z0 + source_plane(p, zl) - 1;
+    const double r0 = S.k0 + S.a0, rp = S.kp + S.ap, rm = S.km + S.am;
+    rR = (r0 + rp) + rm;
+    rho = (S.t0 + S.tp) + S.tm;
+    if (zsg == p.nzg - 2) {                    // velocity inlet: unknown e_z = -1
+        const double wR = r0 + 2. * rp, wT = S.t0 + 2. * S.tp;
+        const double dR = wR / (1. + p.vzR), dB = (wT - wR) / (1. + p.vzB);
+        rR = dR;
+        rho = dR + dB;
+        if (WITH_G) {
+            const double J = dR * p.vzR + dB * p.vzB;
+            const double Nx = 0.5 * ((g[1] + g[7] + g[9]) - (g[2] + g[8] + g[10]));
+            const double Ny = 0.5 * ((g[3] + g[7] + g[10]) - (g[4] + g[8] + g[9]));
+            g[6] = g[5] - 1. / 3. * J;
+            g[12] = g[11] - 1. / 6. * J + Nx;
+            g[13] = g[14] - 1. / 6. * J - Nx;
+            g[16] = g[15] - 1. / 6. * J + Ny;
+            g[17] = g[18] - 1. / 6. * J - Ny;
+        }
+    }
+    if (zsg == 1) {                            // pressure outlet: unknown e_z = +1; rho_c u_c = rho_c - (S0 + 2 S-)_c
+        rR = p.rhoOutR;
+        rho = p.rhoOutR + p.rhoOutB;
+        if (WITH_G) {
+            const double J = rho - (S.t0 + 2. * S.tm);
+            const double Nx = 0.5 * ((g[1] + g[7] + g[9]) - (g[2] + g[8] + g[10]));
+            const double Ny = 0.5 * ((g[3] + g[7] + g[10]) - (g[4] + g[8] + g[9]));
+            g[5] = g[6] + 1. / 3. * J;
+            g[11] = g[12] + 1. / 6. * J - Nx;
+            g[14] = g[13] + 1. / 6. * J + Nx;
+            g[15] = g[16] + 1. / 6. * J - Ny;
+            g[18] = g[17] + 1. / 6. * J + Ny;
+        }
+    }
+}
+__device__ __forceinline__ double phi_q(double rR, double rho) { return (rR - (rho - rR)) / rho; }
+
+// ---------------------------------------------------------------------------------------------- the marching kernel
+// Structure of rk3dc_fused (64 x 8 tile, one block per CU marching along z, pulls two planes ahead, phase field of tile +
+// 1-cell rim in a four-plane LDS ring, one barrier per plane), with
+//   * the scalar records of tile + 2 cells of halo in a four-plane LDS ring (104 KB): every pulled direction of the tile's
+//     and of the rim's cells finds its upstream k_R and A there,
+//   * no LDS park: the 19 pulled values of the plane that waits for its neighbours' phase field stay in registers
+//     (38 VGPRs where the 38-value kernel carried 76 in flight).
+template <bool FIRST, bool MRT>
+__global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last)
+{
+    constexpr int TX = 64, TY = 8;
+    using M = March<TX, TY>;
+    using TR = TileRows<TY>;
+    constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+    __shared__ double sphi[M::RING][M::FY][M::FX];
+    __shared__ double ssc[4 * SSLOT];              // [ring slot][k_R, A_x, A_y, A_z][SR][SC]
+    __shared__ u32x4 srow[TR::SLOTS][TR::ROWS][6];
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int tx = slot % tilesX, r = slot / tilesX, ty = xcd * rows_per_xcd + r % rows_per_xcd, chunk = r / rows_per_xcd;
+    if (ty >= tilesY) return;
+    const int tid = threadIdx.x, lx = tid % TX, ly = tid / TX;
+    const int x = tx * TX + lx, y = ty * TY + ly;
+    const bool own = y < p.ny;
+    const int yo = ring_coord(y, p.ny);
+    const bool has_own = yo >= 0;
+    // rim cell of this thread: bottom row, top row (one wave each), then the two columns (corners included)
+    int hlx = 0, hly = 0, hx = 0, hy = 0;
+    bool has_rim = false;
+    if (tid < M::NH) {
+        if (tid < 2 * TX) { hlx = 1 + tid % TX; hly = tid < TX ? 0 : M::FY - 1; }
+        else { const int k = tid - 2 * TX; hlx = k < M::FY ? 0 : M::FX - 1; hly = k % M::FY; }
+        hx = ring_coord(tx * TX + hlx - 1, p.nx);
+        hy = ring_coord(ty * TY + hly - 1, p.ny);
+        has_rim = hx >= 0 && hy >= 0;
+    }
+    const TileRowsU<TY, true> rows_own{{srow, ly + 2, 1}};
+    const TileRowsU<TY, true> rows_rimrow{{srow, hly + 1, 1}};
+    const TileRowsU<TY, false> rows_rimcol{{srow, hly + 1, hlx == 0 ? 0 : 2}};
+    // second entry of the scalar-tile fill: waves 3..6 take the tile rows -2, -1, 8, 9, wave 7 the 4 x 12 cells left and right
+    const int xrow = ly >= 3 && ly <= 6 ? (ly < 5 ? ly - 5 : ly + 3) : (lx >> 2) - 2;          // tile row of that entry
+    const int xc = lx & 3, xcol = ly == 7 ? (xc < 2 ? xc - 2 : TX + xc - 2) : lx;               // tile column
+    const bool has_x = (ly >= 3 && ly <= 6) || (ly == 7 && lx < 4 * SR);
+    const TileRowsU<TY, true> rows_xrow{{srow, xrow + 2, 1}};
+    const TileRowsU<TY, false> rows_xcol{{srow, xrow + 2, xc < 2 ? 0 : 2}};
+    const int za = z_first + chunk * chunk_len, zb = min(za + chunk_len - 1, z_last);
+    const int zl_gb = 1 - p.z0, zl_gt = p.nzg - p.z0;          // local index of the ghost planes z = 0 and z = nz-1 (when owned)
+    auto is_ghost = [&](int zl) { return zl == zl_gb || zl == zl_gt; };
+    auto fetch_rows = [&](int zl) -> u32x4 {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (tid < TR::ROWS * 6 && zl >= 0 && zl <= p.nzl + 1) {
+            const int row = tid / 6, k = tid % 6;
+            int yy = (ty * TY - 2 + row) % p.ny;
+            if (yy < 0) yy += p.ny;
+            int sg = tx - 1 + (k >> 1);
+            sg = sg < 0 ? sg + p.nseg : (sg >= p.nseg ? sg - p.nseg : sg);
+            const size_t rr = ((size_t)zl * p.ny + yy) * p.nseg + sg;
+            v = (k & 1) ? p.seg2[rr] : p.seg[rr];
+        }
+        return v;
+    };
+    auto put_rows = [&](int zl, u32x4 v) {
+        if (tid < TR::ROWS * 6) const_cast<u32x4 &>(srow[zl & (TR::SLOTS - 1)][tid / 6][tid % 6]) = v;
+    };
+    // scalar records of plane zl -> registers (two entries per thread at most) -> LDS tile
+    struct SRec { double2 a, b; bool ok; };
+    auto load_s = [&](int zl, unsigned j) -> SRec {
+        const unsigned long long p0 = p.pstart[zl];
+        const unsigned cnt = (unsigned)(p.pstart[zl + 1] - p0);
+        const char *s = reinterpret_cast<const char *>(p.fin) + (size_t)p0 * CELLB + (size_t)cnt * (Q * 8u) + (size_t)j * 32u;
+        SRec v;
+        v.a = *reinterpret_cast<const double2 *>(s); v.b = *reinterpret_cast<const double2 *>(s + 16);
+        v.ok = true;
+        return v;
+    };
+    auto fetch_s = [&](int zl, SRec &e0, SRec &e1) {
+        e0.ok = false; e1.ok = false;
+        if (zl < 0 || zl > p.nzl + 1) return;
+        {
+            const RowTab t = rows_own(zl, 0);
+            if (bit_of<true>(t.m, (unsigned)lx)) e0 = load_s(zl, t.first + bits_below<true>(t.m, (unsigned)lx));
+        }
+        if (!has_x) return;
+        if (ly != 7) {
+            const RowTab t = rows_xrow(zl, 0);
+            if (bit_of<true>(t.m, (unsigned)lx)) e1 = load_s(zl, t.first + bits_below<true>(t.m, (unsigned)lx));
+        } else {
+            const RowTab t = rows_xcol(zl, 0);
+            const unsigned bb = xc < 2 ? 62u + (unsigned)xc : (unsigned)xc - 2u;
+            if (bit_of<false>(t.m, bb)) e1 = load_s(zl, t.first + bits_below<false>(t.m, bb));
+        }
+    };
+    auto put_s = [&](int zl, const SRec &e0, const SRec &e1) {
+        double *sl = ssc + (zl & 3) * SSLOT;
+        if (e0.ok) {
+            double *d = sl + (ly + 2) * SC + lx + 2;
+            d[0] = e0.a.x; d[SCOMP] = e0.a.y; d[2 * SCOMP] = e0.b.x; d[3 * SCOMP] = e0.b.y;
+        }
+        if (e1.ok) {
+            double *d = sl + (xrow + 2) * SC + xcol + 2;
+            d[0] = e1.a.x; d[SCOMP] = e1.a.y; d[2 * SCOMP] = e1.b.x; d[3 * SCOMP] = e1.b.y;
+        }
+    };
+    auto lds_scal = [&](int zp, int row, int col) {       // accessor for the node at tile coordinates (col, row) pulled around plane zp
+        LdsScal s;
+        s.tile = ssc; s.own = (row + 2) * SC + col + 2;
+        s.slot[0] = ((zp - 1) & 3) * SSLOT; s.slot[1] = (zp & 3) * SSLOT; s.slot[2] = ((zp + 1) & 3) * SSLOT;
+        return s;
+    };
+    for (int zl = za - 3; zl <= za + 2; ++zl) put_rows(zl, fetch_rows(zl));
+    u32x4 staged = fetch_rows(za + 3);
+    __syncthreads();
+    for (int zl = za - 2; zl <= za; ++zl) {
+        SRec e0, e1;
+        fetch_s(zl, e0, e1);
+        put_s(zl, e0, e1);
+    }
+    bool fluid = false, fl_raw = false;         // node of the plane that waits / of the plane in flight is fluid
+    bool padz = false, pad_raw = false;         // idle lane that writes line padding for that plane
+    unsigned jz = 0, j_raw = 0;                 // their j
+    double rR = 1., rho = 2.;                   // densities of the waiting plane
+    double raw[Q], cur[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { raw[i] = 0.; cur[i] = 0.; }
+    auto issue = [&](int zl) {                  // pulls of the own cell of plane zl
+        fl_raw = false; pad_raw = false;
+        if (!has_own || zl < 1 || zl > p.nzl || is_ghost(zl)) return;
+        const RowTab t = rows_own(zl, 0);
+        fl_raw = bit_of<true>(t.m, (unsigned)lx);
+        if (!fl_raw) {
+            const unsigned rank = bits_below<true>(~t.m, (unsigned)lx);
+            pad_raw = own && rank < t.pad;
+            j_raw = t.first + (unsigned)__popcll(t.m) + rank;
+            return;
+        }
+        pull_q<FIRST, true>(p, rows_own, zl, (unsigned)lx, raw, j_raw);
+    };
+    __syncthreads();
+    issue(za - 1);
+
+    for (int z = za - 2; z <= zb; ++z) {
+        const int zn = z + 1;
+        put_rows(z + 5, staged);
+        staged = fetch_rows(z + 6);
+        SRec e0, e1;
+        fetch_s(z + 3, e0, e1);                 // in LDS before this step's barrier, read from the next step on
+        const bool halo_n = zn <= 0 || zn >= p.nzl + 1, ghost_n = !halo_n && is_ghost(zn);
+        const bool fill_gb = !halo_n && !ghost_n && zn - 1 == zl_gb && zn - 1 >= 1;     // the bottom ghost's phase field = this plane's
+        // ---- plane z + 1, rim cells: phase field only
+        if (has_rim) {
+            double ph = p.solidPhi;
+            if (halo_n) ph = (p.phi + (size_t)zn * p.plane2)[(size_t)hy * p.pitch + hx];
+            else if (ghost_n) { if (zn == zl_gt) ph = sphi[z & (M::RING - 1)][hly][hlx]; }
+            else {
+                double g[Q], a, c;
+                unsigned j;
+                Sums S;
+                if (tid < 2 * TX) {
+                    const RowTab t = rows_rimrow(zn, 0);
+                    if (bit_of<true>(t.m, (unsigned)(tid % TX))) {
+                        pull_q<FIRST, true>(p, rows_rimrow, zn, (unsigned)(tid % TX), g, j);
+                        class_sums<FIRST, true>(p, rows_rimrow, lds_scal(zn, hly - 1, hlx - 1), zn, (unsigned)(tid % TX), g, S);
+                        bc_q<false>(p, zn, S, nullptr, a, c);
+                        ph = phi_q(a, c);
+                    }
+                } else {
+                    const RowTab t = rows_rimcol(zn, 0);
+                    if (bit_of<false>(t.m, (unsigned)(hx & 63))) {
+                        pull_q<FIRST, false>(p, rows_rimcol, zn, (unsigned)(hx & 63), g, j);
+                        class_sums<FIRST, false>(p, rows_rimcol, lds_scal(zn, hly - 1, hlx - 1), zn, (unsigned)(hx & 63), g, S);
+                        bc_q<false>(p, zn, S, nullptr, a, c);
+                        ph = phi_q(a, c);
+                    }
+                }
+            }
+            sphi[zn & (M::RING - 1)][hly][hlx] = ph;
+            if (fill_gb) sphi[(zn - 1) & (M::RING - 1)][hly][hlx] = ph;
+        }
+        // ---- plane z + 1, own cell (pulled during the previous march step): class sums from the LDS records, boundary
+        //      rules, phase field into the ring; the plane that waited (z) moves on to its collision
+        double ft[Q];
+        const double rRz = rR, rhoz = rho;
+        const unsigned jzz = jz;
+        const bool fluidn = fl_raw && !halo_n && !ghost_n;
+        {
+            double rRn = 1., rhon = 2., ph = p.solidPhi;
+            if (halo_n) { if (has_own) ph = (p.phi + (size_t)zn * p.plane2)[(size_t)yo * p.pitch + x]; }
+            else if (ghost_n) { if (has_own && zn == zl_gt) ph = sphi[z & (M::RING - 1)][ly + 1][lx + 1]; }
+            else if (fl_raw) {
+                Sums S;
+                class_sums<FIRST, true>(p, rows_own, lds_scal(zn, ly, lx), zn, (unsigned)lx, raw, S);
+                bc_q<true>(p, zn, S, raw, rRn, rhon);
+                ph = phi_q(rRn, rhon);
+            }
+            if (has_own) {
+                sphi[zn & (M::RING - 1)][ly + 1][lx + 1] = ph;
+                if (fill_gb) sphi[(zn - 1) & (M::RING - 1)][ly + 1][lx + 1] = ph;
+            }
+#pragma unroll
+            for (int i = 0; i < Q; ++i) { ft[i] = cur[i]; cur[i] = raw[i]; }
+            rR = rRn; rho = rhon; jz = j_raw;
+        }
+        const bool padzz = padz;
+        padz = pad_raw;
+        // ---- pulls of plane z + 2 into flight
+        if (z + 2 <= zb + 1) issue(z + 2);
+        else { fl_raw = false; pad_raw = false; }
+        put_s(z + 3, e0, e1);
+        __syncthreads();
+        // ---- plane z: collide
+        if (z >= za && !is_ghost(z) && ((fluid && own) || padzz)) {
+            double gx = 0., gy = 0., gz = 0.;
+#pragma unroll
+            for (int i = 1; i < Q; ++i) {
+                const double ph = sphi[(z + CZ[i]) & (M::RING - 1)][ly + 1 + CY[i]][lx + 1 + CX[i]];
+                gx += 3. * wq(i) * (double)CX[i] * ph;
+                gy += 3. * wq(i) * (double)CY[i] * ph;
+                gz += 3. * wq(i) * (double)CZ[i] * ph;
+            }
+            const unsigned long long p0 = p.pstart[z], p1 = p.pstart[z + 1];
+            const unsigned cnt = (unsigned)(p1 - p0);
+            collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * CELLB, cnt * 8u, jzz * 8u, fluid, ft, rRz, rhoz - rRz, gx, gy, gz);
+        }
+        fluid = fluidn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- set-up and diagnostics
+// f = w rho at rest (3-D analogue of RKD2Q9.py:577-601): g_i = w_i (rho_R + rho_B), k_R = rho_R / rho, A = 0
+__global__ void rk3dq_init_rest(RK3Dev p, const double *rho_r, const double *rho_b, double *f)
+{
+    const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
+    if (x >= p.nx || y >= p.ny) return;
+    if (!(p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
+    const GlobalRows rows{p, x, y};
+    const RowTab t = rows(zl, 0);
+    const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
+    const size_t sd = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
+    const double a = rho_r[sd], b = rho_b[sd];
+    const unsigned long long p0 = p.pstart[zl];
+    const size_t cnt = (size_t)(p.pstart[zl + 1] - p0);
+    double *pl = f + (size_t)p0 * QS;
+    for (int i = 0; i < Q; ++i) pl[(size_t)i * cnt + j] = wq(i) * (a + b);
+    double *s = pl + (size_t)Q * cnt + (size_t)j * 4;
+    s[0] = a / (a + b); s[1] = 0.; s[2] = 0.; s[3] = 0.;
+}
+
+// phase field (and rho_R, rho_B, u with diag) of the streamed, boundary-corrected lattice on the planes zl0.. (diagnostics
+// and the planes a neighbour rank needs); ghost planes are pulled around their source plane like rk3dc_phase_field
+__global__ __launch_bounds__(BX3 *BY3) void rk3dq_phase_field(RK3Dev p, int zl0)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + zl0;
+    if (y >= p.ny || x >= p.nx) return;
+    const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    const int zs = source_plane(p, zl);
+    const unsigned b = (unsigned)(x & 63);
+    double g[Q], rR, rho;
+    unsigned j;
+    Sums S;
+    const GlobalRows rows{p, x, y};
+    if (p.first) {
+        pull_q<true, false>(p, rows, zs, b, g, j);
+        class_sums<true, false>(p, rows, glb_scal(plane_addr_q(p, p.fin, zs), j), zs, b, g, S);
+    } else {
+        pull_q<false, false>(p, rows, zs, b, g, j);
+        class_sums<false, false>(p, rows, glb_scal(plane_addr_q(p, p.fin, zs), j), zs, b, g, S);
+    }
+    bc_q<true>(p, zl, S, g, rR, rho);
+    p.phi[idx] = phi_q(rR, rho);
+    if (p.diag) {
+        constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+        double mx = 0., my = 0., mz = 0.;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) { mx += (double)CX[i] * g[i]; my += (double)CY[i] * g[i]; mz += (double)CZ[i] * g[i]; }
+        p.diag[idx] = rR; p.diag[p.vol + idx] = rho - rR;
+        p.diag[2 * p.vol + idx] = mx / rho; p.diag[3 * p.vol + idx] = my / rho; p.diag[4 * p.vol + idx] = mz / rho;
+    }
+}
