@@ -63,6 +63,9 @@ struct RK3Dev {
     const u32x4 *seg2;                // [rows][nseg] {j of cell x0-1, j of cell x0+64 (periodic), -, -}
     const unsigned long long *pstart; // [nzl+3] fluid cells before plane zl
     int nseg;
+    const uint32_t *pur_in;           // [rows][nseg] row flags of the q23 storage (rk3dq.h), ping-pong with fin / fout
+    uint32_t *pur_out;
+    int dbg;                          // LBMPM_RK3D_DBG: timing knock-outs of rk3dq_fused (results wrong), 0 in production
 };
 
 // ---- addressing.  Populations are stored plane-major, f[zl][colour][q][y][x]: everything a node
@@ -401,7 +404,8 @@ __device__ __forceinline__ constexpr double mrt_piww(int i)
 // colour-blind population alone + one record {k_R, A} per node (rk3dq.h); MRT: [RelaxationType] Type
 template <int STORE, bool MRT>
 __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsigned stride, unsigned own, bool fluid,
-                                              const double ft_in[Q], double rR, double rB, double gx, double gy, double gz)
+                                              const double ft_in[Q], double rR, double rB, double gx, double gy, double gz,
+                                              uint32_t *rowflag = nullptr)
 {
 #pragma clang fp contract(fast)      // fused multiply-adds here (the 2-D kernels stay uncontracted for bit parity with the reference)
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
@@ -421,7 +425,10 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     const double omega = 1. / (0.5 + 1. / ((1. + phi) * p.cR + (1. - phi) * p.cB));
     const double g2 = gx * gx + gy * gy + gz * gz, gn = sqrt(g2);
     const double ig2 = g2 != 0. ? 1. / g2 : 0., ign = gn * ig2;
-    const double kR = rR * irho, kB = rB * irho, arc = rR * rB * irho * irho, akgn = p.ak * gn;
+    // STORE 2 keeps k_R alone (k_B = 1 - k_R): exactly 1 / 0 where the other colour is absent, so that a single-colour region
+    // stays exactly single-colour (x * (1 / x) may be 1 - ulp)
+    const double kR = STORE == 2 ? (rB == 0. ? 1. : (rR == 0. ? 0. : rR * irho)) : rR * irho;
+    const double kB = rB * irho, arc = rR * rB * irho * irho, akgn = p.ak * gn;
     const double arcA = (arc * p.rcA) * ign, arcD = (arc * p.rcD) * ign;
     const double c0 = 1. - 1.5 * usq;
     // MRT ([RelaxationType] Type = 'MRT'): f -= M^-1 S M (f - feq) in the D3Q19 basis of d'Humieres et al. 2002
@@ -483,9 +490,16 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
         const double ai = arc * ign;
         double2 v, w;
         v.x = fluid ? kR : 0.; v.y = fluid ? ai * gx : 0.; w.x = fluid ? ai * gy : 0.; w.y = fluid ? ai * gz : 0.;
-        char *s = red + (size_t)Q * stride + (size_t)own * 4u;
-        *reinterpret_cast<double2 *>(s) = v;
-        *reinterpret_cast<double2 *>(s + 16) = w;
+        // row flag (rk3dq.h): every fluid cell of this wave's row segment pure red / pure blue -> the records are not written
+        const bool noA = v.y == 0. && w.x == 0. && w.y == 0.;
+        const bool notred = fluid && !(v.x == 1. && noA), notblue = fluid && !(v.x == 0. && noA);
+        const unsigned code = (__ballot(notred) == 0ull ? 1u : 0u) | (__ballot(notblue) == 0ull ? 2u : 0u);
+        *rowflag = code;
+        if (code == 0u) {
+            char *s = red + (size_t)Q * stride + (size_t)own * 4u;
+            *reinterpret_cast<double2 *>(s) = v;
+            *reinterpret_cast<double2 *>(s + 16) = w;
+        }
     }
 }
 
@@ -1002,6 +1016,7 @@ struct lbmpm_rk3d {
     uint8_t *flags = nullptr;
     uint32_t *solidnbr = nullptr;
     double *fA = nullptr, *fB = nullptr, *phi = nullptr, *diag = nullptr;
+    uint32_t *purA = nullptr, *purB = nullptr;       // row flags of the q23 storage, swapped with fA / fB
     double *send_up = nullptr, *send_dn = nullptr, *recv_below = nullptr, *recv_above = nullptr;
     std::vector<uint8_t> h_domain;   // owned planes only, [nzl][ny][nx]
     // compact storage (fluid cells only): default whenever nx is a multiple of 64; LBMPM_RK3D_LAYOUT=dense overrides
@@ -1009,6 +1024,7 @@ struct lbmpm_rk3d {
     // q23: compact storage of 19 colour-blind populations + {k_R, A} per cell instead of 2 x 19 (rk3dq.h); default on compact
     // storage, LBMPM_RK3D_STORAGE=38 keeps the 38-value kernels (the cross-check)
     bool q23 = false;
+    int dbg = 0;
     int nseg = 0;
     size_t ncells = 0;               // stored cells, halo planes included
     unsigned long long *pstart = nullptr;
@@ -1048,6 +1064,8 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     p.first = c->streamed ? 0 : 1;
     p.fill = c->fill;
     p.mrt = c->cfg.relaxation;
+    p.dbg = c->dbg;
+    p.pur_in = c->purA; p.pur_out = c->purB;
     return p;
 }
 
@@ -1102,6 +1120,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_LAYOUT")) if (!strcmp(e, "dense")) c->compact = false;
     c->q23 = c->compact && c->tile == 0 && cfg->z_offset == 0 && cfg->nz_local == cfg->nz_global;
     if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
+    if (const char *e = getenv("LBMPM_RK3D_DBG")) c->dbg = atoi(e);
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
     c->vol = c->plane2 * (size_t)(c->nzl + 2);
@@ -1184,6 +1203,10 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     const size_t fcount = c->q23 ? (size_t)QS * (c->ncells + 2) : (c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol);
     TRY_RC(dev_alloc(c, &c->fA, fcount));
     TRY_RC(dev_alloc(c, &c->fB, fcount));
+    if (c->q23) {
+        TRY_RC(dev_alloc(c, &c->purA, (size_t)(c->nzl + 2) * c->ny * c->nseg));
+        TRY_RC(dev_alloc(c, &c->purB, (size_t)(c->nzl + 2) * c->ny * c->nseg));
+    }
     TRY_RC(dev_alloc(c, &c->phi, c->vol));
     TRY_RC(dev_alloc(c, &c->send_up, 10 * c->plane2));
     TRY_RC(dev_alloc(c, &c->send_dn, 10 * c->plane2));
@@ -1211,7 +1234,7 @@ extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->phi, (void *)c->diag,
+    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->purA, (void *)c->purB, (void *)c->phi, (void *)c->diag,
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
@@ -1249,7 +1272,15 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
     if (e == hipSuccess) e = hipMemsetAsync(c->fB, 0, fbytes, c->stream);
     if (e == hipSuccess) {
         RK3Dev p = make_dev(c);
-        if (c->q23) rk3dq_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
+        if (c->q23) {
+            // both buffers start from the same image: the ghost planes are never written again (rk3dq.h), and a segment without a
+            // fluid cell keeps the flag "any colour" (all bits) for good
+            const size_t pbytes = (size_t)(c->nzl + 2) * c->ny * c->nseg * sizeof(uint32_t);
+            e = hipMemsetAsync(c->purA, 0xff, pbytes, c->stream);
+            rk3dq_init_rest<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA, c->purA);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->fB, c->fA, fbytes, hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->purB, c->purA, pbytes, hipMemcpyDeviceToDevice, c->stream);
+        }
         else if (c->compact) rk3dc_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
         else rk3d_init_rest<<<grid3(c, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, stage, stage + n, c->fA);
         e = hipGetLastError();
@@ -1374,6 +1405,7 @@ void launch_step_range(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_fir
 void finish_step(lbmpm_rk3d *c)
 {
     std::swap(c->fA, c->fB);
+    std::swap(c->purA, c->purB);
     c->streamed = true;
     c->steps += 1;
 }

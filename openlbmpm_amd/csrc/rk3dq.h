@@ -85,29 +85,53 @@ __device__ __forceinline__ void pull_q(const RK3Dev &p, const Rows &rows, int zl
         }
 }
 
+// Row flags.  One word per row segment (64 cells) and plane, written with the populations (ping-pong like them):
+// bit 0 / bit 1 = every fluid cell of the segment is pure red (k_R = 1, A = 0) / pure blue (k_R = 0, A = 0); 3 = no fluid cell.
+// A flagged segment's records are neither written nor read -- whoever needs them takes the constant; away from the
+// interface a step then moves 19 + 19 doubles per cell.
+__device__ __forceinline__ size_t row_index(const RK3Dev &p, int zl, int y, int sg) { return ((size_t)zl * p.ny + y) * p.nseg + sg; }
+
 // where the scalar records {k_R, A} of the cells around a node come from
-struct LdsScal {                  // the marching kernel's LDS tile
+struct LdsScal {                  // the marching kernel's LDS tile (flagged rows are filled with the constant there)
     const double *tile;           // ssc
     int own;                      // index of the node inside a component array of the tile
     int slot[3];                  // index offset of the ring slots that hold the planes zp-1, zp, zp+1
     typedef int H;
     __device__ __forceinline__ H own_cell() const { return slot[1] + own; }
-    __device__ __forceinline__ H cell(int rz, int ry, int dx, bool fl, unsigned) const { return fl ? slot[1 + rz] + own + ry * SC + dx : slot[1] + own; }
+    __device__ __forceinline__ H cell(int rz, int ry, int dx, bool fl, unsigned, unsigned) const { return fl ? slot[1 + rz] + own + ry * SC + dx : slot[1] + own; }
     __device__ __forceinline__ double comp(H h, int k) const { return tile[h + k * SCOMP]; }
 };
 struct GlbScal {                  // straight from global memory (set-up, diagnostics and face kernels)
+    const RK3Dev &p;
     const char *base;             // plane_addr_q(...).base
     unsigned soff[3];             // byte offsets of the s arrays of the planes zp-1, zp, zp+1
     unsigned own_j;
-    typedef unsigned H;
-    __device__ __forceinline__ H own_cell() const { return soff[1] + own_j * 32u; }
-    __device__ __forceinline__ H cell(int rz, int, int, bool fl, unsigned j) const { return fl ? soff[1 + rz] + j * 32u : soff[1] + own_j * 32u; }
-    __device__ __forceinline__ double comp(H h, int k) const { return *reinterpret_cast<const double *>(base + h + 8u * (unsigned)k); }
+    int zp, x, y;
+    struct H { unsigned off, cst; };      // cst: 0 read the record, else the row flag (bit 0 red)
+    __device__ __forceinline__ H at(int rz, int ry, int sgs, unsigned j) const
+    {
+        int sg = (x >> 6) + sgs;
+        sg = sg < 0 ? sg + p.nseg : (sg >= p.nseg ? sg - p.nseg : sg);
+        H h;
+        h.cst = p.pur_in[row_index(p, zp + rz, wrapi(y + ry, p.ny), sg)];
+        h.off = soff[1 + rz] + j * 32u;
+        return h;
+    }
+    __device__ __forceinline__ H own_cell() const { return at(0, 0, 0, own_j); }
+    __device__ __forceinline__ H cell(int rz, int ry, int dx, bool fl, unsigned j, unsigned b) const
+    {
+        if (!fl) return own_cell();
+        return at(rz, ry, (dx < 0 && b == 0u) ? -1 : ((dx > 0 && b == 63u) ? 1 : 0), j);
+    }
+    __device__ __forceinline__ double comp(H h, int k) const
+    {
+        if (h.cst) return k == 0 && (h.cst & 1u) ? 1. : 0.;
+        return *reinterpret_cast<const double *>(base + h.off + 8u * (unsigned)k);
+    }
 };
-__device__ __forceinline__ GlbScal glb_scal(const PlaneAddrQ &a, unsigned own_j)
+__device__ __forceinline__ GlbScal glb_scal(const RK3Dev &p, const PlaneAddrQ &a, unsigned own_j, int zp, int x, int y)
 {
-    GlbScal s;
-    s.base = a.base; s.own_j = own_j;
+    GlbScal s{p, a.base, {0u, 0u, 0u}, own_j, zp, x, y};
 #pragma unroll
     for (int k = 0; k < 3; ++k) s.soff[k] = a.off[k] + (unsigned)Q * a.cnt[k] * 8u;
     return s;
@@ -143,7 +167,7 @@ __device__ __forceinline__ void class_sums(const RK3Dev &p, const Rows &rows, co
                 if (FIRST) h = sc.own_cell();
                 else {
                     row_cell<UNI>(t, dx, b, j, fl);
-                    h = sc.cell(rz, ry, dx, fl, j);
+                    h = sc.cell(rz, ry, dx, fl, j, b);
                 }
                 const double k = sc.comp(h, 0);
                 double ea = 0.;
@@ -158,6 +182,31 @@ __device__ __forceinline__ void class_sums(const RK3Dev &p, const Rows &rows, co
                 else { S.km = __builtin_fma(k, g[i], S.km); S.am = __builtin_fma(cs, ea, S.am); S.tm += g[i]; }
             }
         }
+}
+
+// class sums of a node whose pulled directions all come from cells of ONE colour (k_R = 1 or 0 and A = 0 at every upstream
+// cell): k = t or 0 and a = 0, bit for bit what class_sums returns there (fma(1, g, s) = s + g; c * 0 adds +0).  The marching
+// kernel keeps one flag per tile row and plane; away from the interface -- most of a two-phase lattice -- the 49 LDS reads
+// and ~200 instructions of class_sums, and the pulls of the rim cells altogether, are skipped.
+__device__ __forceinline__ void class_sums_pure(const double g[Q], bool red, Sums &S)
+{
+#pragma clang fp contract(off)
+    constexpr int CZ[Q] = LBMPM_D3Q19_CZ;
+    S.t0 = g[0]; S.tp = 0.; S.tm = 0.;
+#pragma unroll
+    for (int rz = -1; rz <= 1; ++rz)
+#pragma unroll
+        for (int ry = -1; ry <= 1; ++ry)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int i = DIRT[(1 - rz) * 9 + (1 - ry) * 3 + (1 - dx)];
+                if (i <= 0) continue;
+                if (CZ[i] == 0) S.t0 += g[i];
+                else if (CZ[i] > 0) S.tp += g[i];
+                else S.tm += g[i];
+            }
+    S.k0 = red ? S.t0 : 0.; S.kp = red ? S.tp : 0.; S.km = red ? S.tm : 0.;
+    S.a0 = S.ap = S.am = 0.;
 }
 
 // densities of the streamed, boundary-corrected node on plane zl from its class sums; on the inlet / outlet plane pairs
@@ -225,6 +274,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     const int tx = slot % tilesX, r = slot / tilesX, ty = xcd * rows_per_xcd + r % rows_per_xcd, chunk = r / rows_per_xcd;
     if (ty >= tilesY) return;
     const int tid = threadIdx.x, lx = tid % TX, ly = tid / TX;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: branches on it are branches, not exec masks
     const int x = tx * TX + lx, y = ty * TY + ly;
     const bool own = y < p.ny;
     const int yo = ring_coord(y, p.ny);
@@ -261,9 +311,18 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             sg = sg < 0 ? sg + p.nseg : (sg >= p.nseg ? sg - p.nseg : sg);
             const size_t rr = ((size_t)zl * p.ny + yy) * p.nseg + sg;
             v = (k & 1) ? p.seg2[rr] : p.seg[rr];
+            if (k & 1) {        // the row flags ride in the spare words: .z this segment's, .w (centre record) all three segments'
+                v.z = p.pur_in[rr];
+                v.w = v.z;
+                if (k == 3) {
+                    const int sl = tx > 0 ? tx - 1 : p.nseg - 1, sr = tx + 1 < p.nseg ? tx + 1 : 0;
+                    v.w &= p.pur_in[rr - sg + sl] & p.pur_in[rr - sg + sr];
+                }
+            }
         }
         return v;
     };
+    auto row_flag = [&](int zl, int lrow, int k) -> unsigned { return srow[zl & (TR::SLOTS - 1)][lrow][2 * k + 1].z; };   // segment k = 0, 1, 2
     auto put_rows = [&](int zl, u32x4 v) {
         if (tid < TR::ROWS * 6) const_cast<u32x4 &>(srow[zl & (TR::SLOTS - 1)][tid / 6][tid % 6]) = v;
     };
@@ -278,21 +337,30 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         v.ok = true;
         return v;
     };
+    auto const_s = [&](unsigned flag) -> SRec {     // the record of every cell of a flagged segment
+        SRec v;
+        v.a.x = (flag & 1u) ? 1. : 0.; v.a.y = 0.; v.b.x = 0.; v.b.y = 0.; v.ok = true;
+        return v;
+    };
     auto fetch_s = [&](int zl, SRec &e0, SRec &e1) {
         e0.ok = false; e1.ok = false;
         if (zl < 0 || zl > p.nzl + 1) return;
         {
             const RowTab t = rows_own(zl, 0);
-            if (bit_of<true>(t.m, (unsigned)lx)) e0 = load_s(zl, t.first + bits_below<true>(t.m, (unsigned)lx));
+            const unsigned fg = (unsigned)__builtin_amdgcn_readfirstlane((int)row_flag(zl, ly + 2, 1));
+            if (bit_of<true>(t.m, (unsigned)lx)) e0 = fg ? const_s(fg) : load_s(zl, t.first + bits_below<true>(t.m, (unsigned)lx));
         }
-        if (!has_x) return;
-        if (ly != 7) {
+        if (wave >= 3 && wave <= 6) {
             const RowTab t = rows_xrow(zl, 0);
-            if (bit_of<true>(t.m, (unsigned)lx)) e1 = load_s(zl, t.first + bits_below<true>(t.m, (unsigned)lx));
-        } else {
-            const RowTab t = rows_xcol(zl, 0);
-            const unsigned bb = xc < 2 ? 62u + (unsigned)xc : (unsigned)xc - 2u;
-            if (bit_of<false>(t.m, bb)) e1 = load_s(zl, t.first + bits_below<false>(t.m, bb));
+            const unsigned fg = (unsigned)__builtin_amdgcn_readfirstlane((int)row_flag(zl, xrow + 2, 1));
+            if (bit_of<true>(t.m, (unsigned)lx)) e1 = fg ? const_s(fg) : load_s(zl, t.first + bits_below<true>(t.m, (unsigned)lx));
+        } else if (wave == 7) {
+            if (has_x) {
+                const RowTab t = rows_xcol(zl, 0);
+                const unsigned fg = row_flag(zl, xrow + 2, xc < 2 ? 0 : 2);
+                const unsigned bb = xc < 2 ? 62u + (unsigned)xc : (unsigned)xc - 2u;
+                if (bit_of<false>(t.m, bb)) e1 = fg ? const_s(fg) : load_s(zl, t.first + bits_below<false>(t.m, bb));
+            }
         }
     };
     auto put_s = [&](int zl, const SRec &e0, const SRec &e1) {
@@ -301,10 +369,17 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             double *d = sl + (ly + 2) * SC + lx + 2;
             d[0] = e0.a.x; d[SCOMP] = e0.a.y; d[2 * SCOMP] = e0.b.x; d[3 * SCOMP] = e0.b.y;
         }
-        if (e1.ok) {
+        if (wave >= 3 && e1.ok) {
             double *d = sl + (xrow + 2) * SC + xcol + 2;
             d[0] = e1.a.x; d[SCOMP] = e1.a.y; d[2 * SCOMP] = e1.b.x; d[3 * SCOMP] = e1.b.y;
         }
+    };
+    // colour of everything the cells of the tile rows row_lo .. row_hi of plane zp pull from: 1 red, 2 blue, 0 mixed
+    auto purity = [&](int zp, int row_lo, int row_hi) -> int {
+        unsigned c = 3u;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int rr = row_lo - 1; rr <= row_hi + 1; ++rr) c &= srow[(zp + dz) & (TR::SLOTS - 1)][rr + 2][3].w;
+        return __builtin_amdgcn_readfirstlane((int)c);
     };
     auto lds_scal = [&](int zp, int row, int col) {       // accessor for the node at tile coordinates (col, row) pulled around plane zp
         LdsScal s;
@@ -348,38 +423,45 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         put_rows(z + 5, staged);
         staged = fetch_rows(z + 6);
         SRec e0, e1;
-        fetch_s(z + 3, e0, e1);                 // in LDS before this step's barrier, read from the next step on
+        if (!(p.dbg & 4)) fetch_s(z + 3, e0, e1);                 // in LDS before this step's barrier, read from the next step on
+        else { e0.ok = false; e1.ok = false; }
         const bool halo_n = zn <= 0 || zn >= p.nzl + 1, ghost_n = !halo_n && is_ghost(zn);
         const bool fill_gb = !halo_n && !ghost_n && zn - 1 == zl_gb && zn - 1 >= 1;     // the bottom ghost's phase field = this plane's
         // ---- plane z + 1, rim cells: phase field only
-        if (has_rim) {
-            double ph = p.solidPhi;
-            if (halo_n) ph = (p.phi + (size_t)zn * p.plane2)[(size_t)hy * p.pitch + hx];
-            else if (ghost_n) { if (zn == zl_gt) ph = sphi[z & (M::RING - 1)][hly][hlx]; }
-            else {
-                double g[Q], a, c;
-                unsigned j;
-                Sums S;
-                if (tid < 2 * TX) {
-                    const RowTab t = rows_rimrow(zn, 0);
-                    if (bit_of<true>(t.m, (unsigned)(tid % TX))) {
-                        pull_q<FIRST, true>(p, rows_rimrow, zn, (unsigned)(tid % TX), g, j);
-                        class_sums<FIRST, true>(p, rows_rimrow, lds_scal(zn, hly - 1, hlx - 1), zn, (unsigned)(tid % TX), g, S);
-                        bc_q<false>(p, zn, S, nullptr, a, c);
-                        ph = phi_q(a, c);
-                    }
-                } else {
-                    const RowTab t = rows_rimcol(zn, 0);
-                    if (bit_of<false>(t.m, (unsigned)(hx & 63))) {
+        if (wave < 3) {
+            if (has_rim) {
+                double ph = p.solidPhi;
+                if (halo_n) ph = (p.phi + (size_t)zn * p.plane2)[(size_t)hy * p.pitch + hx];
+                else if (ghost_n) { if (zn == zl_gt) ph = sphi[z & (M::RING - 1)][hly][hlx]; }
+                else {
+                    double g[Q], a, c;
+                    unsigned j;
+                    Sums S;
+                    const int pc = wave < 2 ? purity(zn, hly - 1, hly - 1) : purity(zn, -1, TY);
+                    const bool fl = wave < 2 ? bit_of<true>(rows_rimrow(zn, 0).m, (unsigned)lx) : bit_of<false>(rows_rimcol(zn, 0).m, (unsigned)(hx & 63));
+                    if (pc != 0) {          // single colour around: phi = +-1 (or the planes' boundary values) without a pull
+                        if (fl) {
+                            S.t0 = 1.; S.tp = S.tm = 0.; S.k0 = (pc & 1) ? 1. : 0.; S.kp = S.km = S.a0 = S.ap = S.am = 0.;
+                            bc_q<false>(p, zn, S, nullptr, a, c);
+                            ph = phi_q(a, c);
+                        }
+                    } else if (wave < 2) {
+                        if (fl) {
+                            pull_q<FIRST, true>(p, rows_rimrow, zn, (unsigned)lx, g, j);
+                            class_sums<FIRST, true>(p, rows_rimrow, lds_scal(zn, hly - 1, hlx - 1), zn, (unsigned)lx, g, S);
+                            bc_q<false>(p, zn, S, nullptr, a, c);
+                            ph = phi_q(a, c);
+                        }
+                    } else if (fl) {
                         pull_q<FIRST, false>(p, rows_rimcol, zn, (unsigned)(hx & 63), g, j);
                         class_sums<FIRST, false>(p, rows_rimcol, lds_scal(zn, hly - 1, hlx - 1), zn, (unsigned)(hx & 63), g, S);
                         bc_q<false>(p, zn, S, nullptr, a, c);
                         ph = phi_q(a, c);
                     }
                 }
+                sphi[zn & (M::RING - 1)][hly][hlx] = ph;
+                if (fill_gb) sphi[(zn - 1) & (M::RING - 1)][hly][hlx] = ph;
             }
-            sphi[zn & (M::RING - 1)][hly][hlx] = ph;
-            if (fill_gb) sphi[(zn - 1) & (M::RING - 1)][hly][hlx] = ph;
         }
         // ---- plane z + 1, own cell (pulled during the previous march step): class sums from the LDS records, boundary
         //      rules, phase field into the ring; the plane that waited (z) moves on to its collision
@@ -393,7 +475,9 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             else if (ghost_n) { if (has_own && zn == zl_gt) ph = sphi[z & (M::RING - 1)][ly + 1][lx + 1]; }
             else if (fl_raw) {
                 Sums S;
-                class_sums<FIRST, true>(p, rows_own, lds_scal(zn, ly, lx), zn, (unsigned)lx, raw, S);
+                const int pc = purity(zn, ly, ly);
+                if (pc != 0) class_sums_pure(raw, (pc & 1) != 0, S);
+                else class_sums<FIRST, true>(p, rows_own, lds_scal(zn, ly, lx), zn, (unsigned)lx, raw, S);
                 bc_q<true>(p, zn, S, raw, rRn, rhon);
                 ph = phi_q(rRn, rhon);
             }
@@ -408,12 +492,12 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         const bool padzz = padz;
         padz = pad_raw;
         // ---- pulls of plane z + 2 into flight
-        if (z + 2 <= zb + 1) issue(z + 2);
+        if (z + 2 <= zb + 1 && !(p.dbg & 16)) issue(z + 2);
         else { fl_raw = false; pad_raw = false; }
         put_s(z + 3, e0, e1);
         __syncthreads();
         // ---- plane z: collide
-        if (z >= za && !is_ghost(z) && ((fluid && own) || padzz)) {
+        if (z >= za && !is_ghost(z) && ((fluid && own) || padzz) && !(p.dbg & 8)) {
             double gx = 0., gy = 0., gz = 0.;
 #pragma unroll
             for (int i = 1; i < Q; ++i) {
@@ -424,7 +508,8 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             }
             const unsigned long long p0 = p.pstart[z], p1 = p.pstart[z + 1];
             const unsigned cnt = (unsigned)(p1 - p0);
-            collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * CELLB, cnt * 8u, jzz * 8u, fluid, ft, rRz, rhoz - rRz, gx, gy, gz);
+            collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * CELLB, cnt * 8u, jzz * 8u, fluid, ft, rRz, rhoz - rRz, gx, gy, gz,
+                                  p.pur_out + row_index(p, z, y, tx));
         }
         fluid = fluidn;
     }
@@ -432,22 +517,27 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
 
 // ---------------------------------------------------------------------------------------------- set-up and diagnostics
 // f = w rho at rest (3-D analogue of RKD2Q9.py:577-601): g_i = w_i (rho_R + rho_B), k_R = rho_R / rho, A = 0
-__global__ void rk3dq_init_rest(RK3Dev p, const double *rho_r, const double *rho_b, double *f)
+__global__ __launch_bounds__(BX3 *BY3) void rk3dq_init_rest(RK3Dev p, const double *rho_r, const double *rho_b, double *f, uint32_t *pur)
 {
-    const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
-    if (x >= p.nx || y >= p.ny) return;
-    if (!(p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
-    const GlobalRows rows{p, x, y};
-    const RowTab t = rows(zl, 0);
-    const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
-    const size_t sd = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
-    const double a = rho_r[sd], b = rho_b[sd];
-    const unsigned long long p0 = p.pstart[zl];
-    const size_t cnt = (size_t)(p.pstart[zl + 1] - p0);
-    double *pl = f + (size_t)p0 * QS;
-    for (int i = 0; i < Q; ++i) pl[(size_t)i * cnt + j] = wq(i) * (a + b);
-    double *s = pl + (size_t)Q * cnt + (size_t)j * 4;
-    s[0] = a / (a + b); s[1] = 0.; s[2] = 0.; s[3] = 0.;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;    // a wave = a row segment
+    if (y >= p.ny) return;
+    const bool fluid = p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1;
+    double a = 0., b = 0.;
+    if (fluid) {
+        const GlobalRows rows{p, x, y};
+        const RowTab t = rows(zl, 0);
+        const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
+        const size_t sd = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
+        a = rho_r[sd]; b = rho_b[sd];
+        const unsigned long long p0 = p.pstart[zl];
+        const size_t cnt = (size_t)(p.pstart[zl + 1] - p0);
+        double *pl = f + (size_t)p0 * QS;
+        for (int i = 0; i < Q; ++i) pl[(size_t)i * cnt + j] = wq(i) * (a + b);
+        double *s = pl + (size_t)Q * cnt + (size_t)j * 4;
+        s[0] = a / (a + b); s[1] = 0.; s[2] = 0.; s[3] = 0.;
+    }
+    const unsigned code = (__ballot(fluid && b != 0.) == 0ull ? 1u : 0u) | (__ballot(fluid && a != 0.) == 0ull ? 2u : 0u);
+    if ((x & 63) == 0) pur[row_index(p, zl, y, x >> 6)] = code;
 }
 
 // phase field (and rho_R, rho_B, u with diag) of the streamed, boundary-corrected lattice on the planes zl0.. (diagnostics
@@ -466,10 +556,10 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_phase_field(RK3Dev p, int zl0)
     const GlobalRows rows{p, x, y};
     if (p.first) {
         pull_q<true, false>(p, rows, zs, b, g, j);
-        class_sums<true, false>(p, rows, glb_scal(plane_addr_q(p, p.fin, zs), j), zs, b, g, S);
+        class_sums<true, false>(p, rows, glb_scal(p, plane_addr_q(p, p.fin, zs), j, zs, x, y), zs, b, g, S);
     } else {
         pull_q<false, false>(p, rows, zs, b, g, j);
-        class_sums<false, false>(p, rows, glb_scal(plane_addr_q(p, p.fin, zs), j), zs, b, g, S);
+        class_sums<false, false>(p, rows, glb_scal(p, plane_addr_q(p, p.fin, zs), j, zs, x, y), zs, b, g, S);
     }
     bc_q<true>(p, zl, S, g, rR, rho);
     p.phi[idx] = phi_q(rR, rho);
