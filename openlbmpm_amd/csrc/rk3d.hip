@@ -467,6 +467,9 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
             stg(blue + (size_t)i * stride, own, fluid ? kB * g - a : 0.);
         }
     };
+    // rk3dq_fused: the pulls of the plane after next, issued before the barrier, have had the arithmetic above to arrive; from
+    // here on stores are outstanding, and a later wait for the pulls would wait for the stores too (vmcnt retires in order)
+    if (STORE == 2) __builtin_amdgcn_s_waitcnt(0x0F70);
     // relaxation as f - (f - feq) omega: a node at equilibrium stays there bit for bit
     put(0, ((ft_in[0] - (ft_in[0] - (rho * wq(0)) * c0) * omega) - (MRT ? -30. * kev[0] + 12. * kev[1] : 0.)) - akgn * bq(0), 0.);
 #pragma unroll

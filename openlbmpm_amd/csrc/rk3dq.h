@@ -29,6 +29,12 @@ constexpr int SR = 12, SC = 68;                // scalar tile: 64 x 8 tile + 2 c
 constexpr int SCOMP = SR * SC;                 // doubles between the four components of the LDS scalar tile
 constexpr int SSLOT = 4 * SCOMP;               // doubles between the ring slots (one per plane)
 
+// The plane table through the constant address space: it does not change while a kernel runs, and only so may the compiler use
+// scalar loads for it (s_load, lgkmcnt).  As ordinary global loads they count in vmcnt with the pulls and the stores, and every
+// s_waitcnt in front of their use drains the pulls in flight.
+typedef const unsigned long long __attribute__((address_space(4))) *const_u64_ptr;
+__device__ __forceinline__ unsigned long long pstart_of(const RK3Dev &p, int zl) { return ((const_u64_ptr)p.pstart)[zl]; }
+
 struct PlaneAddrQ {
     const char *base;            // g_0 of the plane below the pulled one
     unsigned off[3], cnt[3];     // byte offset of the three planes' blocks from base, stored cells per plane
@@ -37,7 +43,7 @@ struct PlaneAddrQ {
 __device__ __forceinline__ PlaneAddrQ plane_addr_q(const RK3Dev &p, const double *f, int zl)
 {
     PlaneAddrQ a;
-    const unsigned long long p0 = p.pstart[zl - 1], p1 = p.pstart[zl], p2 = p.pstart[zl + 1], p3 = p.pstart[zl + 2];
+    const unsigned long long p0 = pstart_of(p, zl - 1), p1 = pstart_of(p, zl), p2 = pstart_of(p, zl + 1), p3 = pstart_of(p, zl + 2);
     a.base = reinterpret_cast<const char *>(f) + (size_t)p0 * CELLB;
     a.cnt[0] = (unsigned)(p1 - p0); a.cnt[1] = (unsigned)(p2 - p1); a.cnt[2] = (unsigned)(p3 - p2);
     a.off[0] = 0u; a.off[1] = a.cnt[0] * CELLB; a.off[2] = a.off[1] + a.cnt[1] * CELLB;
@@ -46,7 +52,20 @@ __device__ __forceinline__ PlaneAddrQ plane_addr_q(const RK3Dev &p, const double
 
 // pull of the 19 colour-blind populations of the node at bit b of the row rows(zl, 0) (fluid there); 8-byte loads,
 // bounce-back folded into the address as in pull3c
-template <bool FIRST, bool UNI, typename Rows>
+// ASM: the load is an asm statement, i.e. absent from the compiler's s_waitcnt bookkeeping -- the marching kernel waits for
+// its own-cell pulls itself (see there); everywhere else the compiler does.
+template <bool ASM>
+__device__ __forceinline__ double ldq(const char *uniform_base, unsigned off)
+{
+    if (!ASM) return ldg(uniform_base, off);
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(uniform_base));
+    return v;
+}
+// s_waitcnt simm16 of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]; the other two counters left alone
+#define LBMPM_WAIT_VMCNT0 0x0F70
+
+template <bool FIRST, bool UNI, typename Rows, bool ASM = false>
 __device__ __forceinline__ void pull_q(const RK3Dev &p, const Rows &rows, int zl, unsigned b, double g[Q], unsigned &own_j)
 {
     constexpr int OPP[Q] = LBMPM_D3Q19_OPP;
@@ -58,7 +77,7 @@ __device__ __forceinline__ void pull_q(const RK3Dev &p, const Rows &rows, int zl
     const unsigned own8 = own_j * 8u;
     if (FIRST) {
 #pragma unroll
-        for (int i = 0; i < Q; ++i) g[i] = ldg(a.base, a.off[1] + (unsigned)i * a.cnt[1] * 8u + own8);
+        for (int i = 0; i < Q; ++i) g[i] = ldq<ASM>(a.base, a.off[1] + (unsigned)i * a.cnt[1] * 8u + own8);
         return;
     }
 #pragma unroll
@@ -80,7 +99,7 @@ __device__ __forceinline__ void pull_q(const RK3Dev &p, const Rows &rows, int zl
                     const unsigned back = a.off[1] + (unsigned)OPP[i] * a.cnt[1] * 8u + own8;
                     off = fl ? up : back;
                 }
-                g[i] = ldg(a.base, off);
+                g[i] = ldq<ASM>(a.base, off);
             }
         }
 }
@@ -301,8 +320,12 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     const int za = z_first + chunk * chunk_len, zb = min(za + chunk_len - 1, z_last);
     const int zl_gb = 1 - p.z0, zl_gt = p.nzg - p.z0;          // local index of the ghost planes z = 0 and z = nz-1 (when owned)
     auto is_ghost = [&](int zl) { return zl == zl_gb || zl == zl_gt; };
-    auto fetch_rows = [&](int zl) -> u32x4 {
-        u32x4 v = {0u, 0u, 0u, 0u};
+    // one record per lane (72 lanes) + the row flags that ride in its spare words: .z this segment's, .w (centre record) the three
+    // segments' combined.  fetch_rows only LOADS (its results are consumed a march step later, no wait in between); put_rows combines
+    struct RowRec { u32x4 v; unsigned f0, f1, f2; };
+    auto fetch_rows = [&](int zl) -> RowRec {
+        RowRec q;
+        q.v = u32x4{0u, 0u, 0u, 0u}; q.f0 = 0u; q.f1 = ~0u; q.f2 = ~0u;
         if (tid < TR::ROWS * 6 && zl >= 0 && zl <= p.nzl + 1) {
             const int row = tid / 6, k = tid % 6;
             int yy = (ty * TY - 2 + row) % p.ny;
@@ -310,27 +333,30 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             int sg = tx - 1 + (k >> 1);
             sg = sg < 0 ? sg + p.nseg : (sg >= p.nseg ? sg - p.nseg : sg);
             const size_t rr = ((size_t)zl * p.ny + yy) * p.nseg + sg;
-            v = (k & 1) ? p.seg2[rr] : p.seg[rr];
-            if (k & 1) {        // the row flags ride in the spare words: .z this segment's, .w (centre record) all three segments'
-                v.z = p.pur_in[rr];
-                v.w = v.z;
+            q.v = (k & 1) ? p.seg2[rr] : p.seg[rr];
+            if (k & 1) {
+                q.f0 = p.pur_in[rr];
                 if (k == 3) {
                     const int sl = tx > 0 ? tx - 1 : p.nseg - 1, sr = tx + 1 < p.nseg ? tx + 1 : 0;
-                    v.w &= p.pur_in[rr - sg + sl] & p.pur_in[rr - sg + sr];
+                    q.f1 = p.pur_in[rr - sg + sl]; q.f2 = p.pur_in[rr - sg + sr];
                 }
             }
         }
-        return v;
+        return q;
+    };
+    auto put_rows = [&](int zl, const RowRec &q) {
+        if (tid < TR::ROWS * 6) {
+            u32x4 v = q.v;
+            if (tid & 1) { v.z = q.f0; v.w = q.f0 & q.f1 & q.f2; }       // k = tid % 6 is odd exactly when tid is
+            const_cast<u32x4 &>(srow[zl & (TR::SLOTS - 1)][tid / 6][tid % 6]) = v;
+        }
     };
     auto row_flag = [&](int zl, int lrow, int k) -> unsigned { return srow[zl & (TR::SLOTS - 1)][lrow][2 * k + 1].z; };   // segment k = 0, 1, 2
-    auto put_rows = [&](int zl, u32x4 v) {
-        if (tid < TR::ROWS * 6) const_cast<u32x4 &>(srow[zl & (TR::SLOTS - 1)][tid / 6][tid % 6]) = v;
-    };
     // scalar records of plane zl -> registers (two entries per thread at most) -> LDS tile
     struct SRec { double2 a, b; bool ok; };
     auto load_s = [&](int zl, unsigned j) -> SRec {
-        const unsigned long long p0 = p.pstart[zl];
-        const unsigned cnt = (unsigned)(p.pstart[zl + 1] - p0);
+        const unsigned long long p0 = pstart_of(p, zl);
+        const unsigned cnt = (unsigned)(pstart_of(p, zl + 1) - p0);
         const char *s = reinterpret_cast<const char *>(p.fin) + (size_t)p0 * CELLB + (size_t)cnt * (Q * 8u) + (size_t)j * 32u;
         SRec v;
         v.a = *reinterpret_cast<const double2 *>(s); v.b = *reinterpret_cast<const double2 *>(s + 16);
@@ -388,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         return s;
     };
     for (int zl = za - 3; zl <= za + 2; ++zl) put_rows(zl, fetch_rows(zl));
-    u32x4 staged = fetch_rows(za + 3);
+    RowRec staged = fetch_rows(za + 3);
     __syncthreads();
     for (int zl = za - 2; zl <= za; ++zl) {
         SRec e0, e1;
@@ -413,18 +439,33 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             j_raw = t.first + (unsigned)__popcll(t.m) + rank;
             return;
         }
-        pull_q<FIRST, true>(p, rows_own, zl, (unsigned)lx, raw, j_raw);
+        pull_q<FIRST, true, decltype(rows_own), true>(p, rows_own, zl, (unsigned)lx, raw, j_raw);
+    };
+    // The own-cell pulls are waited for BY HAND.  vmcnt counts loads and stores alike and retires them in order; hipcc places its
+    // waits per register with the count of the path that issued the fewest younger operations, so with the pulls in its books it
+    // drains them right after the barrier (a load "pending" on some skipped branch) and drains the collision's stores at the loop
+    // latch (the path without a collision has no stores).  Measured: pulls-only + stores-only = the fused time, nothing overlapped.
+    // Schedule of a march step:   <everything hipcc knows about is complete: s_waitcnt vmcnt(0), stated with the builtin so that
+    // its books are empty too>  ->  pulls of plane z + 2 (asm)  ->  row records of z + 6 (hipcc's; consumed after the next wait)
+    // ->  barrier  ->  collision arithmetic of plane z  ->  s_waitcnt vmcnt(0) (builtin: the pulls have had the whole arithmetic
+    // to arrive, no store is outstanding)  ->  the collision's stores, which nobody waits for until the next step's first line.
+    auto pulls_landed = [&]() {
+        __builtin_amdgcn_s_waitcnt(LBMPM_WAIT_VMCNT0);
+#pragma unroll
+        for (int i = 0; i < Q; ++i) asm volatile("" : "+v"(raw[i]));       // nothing that reads raw moves above the wait
     };
     __syncthreads();
     issue(za - 1);
+    pulls_landed();
 
     for (int z = za - 2; z <= zb; ++z) {
         const int zn = z + 1;
+        // fetched here, in uniform control flow, as scalar loads: inside the collision's branch they become a vector load, and the
+        // s_waitcnt vmcnt(0) in front of its use drains the pulls in flight (the collision then overlaps nothing)
+        const unsigned long long pz0 = pstart_of(p, z > 0 ? z : 0), pz1 = pstart_of(p, z > 0 ? z + 1 : 1);
         put_rows(z + 5, staged);
-        staged = fetch_rows(z + 6);
         SRec e0, e1;
-        if (!(p.dbg & 4)) fetch_s(z + 3, e0, e1);                 // in LDS before this step's barrier, read from the next step on
-        else { e0.ok = false; e1.ok = false; }
+        fetch_s(z + 3, e0, e1);                 // in LDS before this step's barrier, read from the next step on
         const bool halo_n = zn <= 0 || zn >= p.nzl + 1, ghost_n = !halo_n && is_ghost(zn);
         const bool fill_gb = !halo_n && !ghost_n && zn - 1 == zl_gb && zn - 1 >= 1;     // the bottom ghost's phase field = this plane's
         // ---- plane z + 1, rim cells: phase field only
@@ -492,25 +533,31 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         const bool padzz = padz;
         padz = pad_raw;
         // ---- pulls of plane z + 2 into flight
-        if (z + 2 <= zb + 1 && !(p.dbg & 16)) issue(z + 2);
-        else { fl_raw = false; pad_raw = false; }
         put_s(z + 3, e0, e1);
+        __builtin_amdgcn_s_waitcnt(LBMPM_WAIT_VMCNT0);
+        if (z + 2 <= zb + 1) issue(z + 2);
+        else { fl_raw = false; pad_raw = false; }
+        staged = fetch_rows(z + 6);
         __syncthreads();
         // ---- plane z: collide
-        if (z >= za && !is_ghost(z) && ((fluid && own) || padzz) && !(p.dbg & 8)) {
+        const bool active = z >= za && !is_ghost(z) && ((fluid && own) || padzz);
+        if (__ballot(active) == 0ull) pulls_landed();       // a wave without a collision: its pulls still have to land before raw moves on
+        else if (active) {
             double gx = 0., gy = 0., gz = 0.;
 #pragma unroll
             for (int i = 1; i < Q; ++i) {
                 const double ph = sphi[(z + CZ[i]) & (M::RING - 1)][ly + 1 + CY[i]][lx + 1 + CX[i]];
-                gx += 3. * wq(i) * (double)CX[i] * ph;
-                gy += 3. * wq(i) * (double)CY[i] * ph;
-                gz += 3. * wq(i) * (double)CZ[i] * ph;
+                if (CX[i] != 0) gx += 3. * wq(i) * (double)CX[i] * ph;
+                if (CY[i] != 0) gy += 3. * wq(i) * (double)CY[i] * ph;
+                if (CZ[i] != 0) gz += 3. * wq(i) * (double)CZ[i] * ph;
             }
-            const unsigned long long p0 = p.pstart[z], p1 = p.pstart[z + 1];
-            const unsigned cnt = (unsigned)(p1 - p0);
+            const unsigned long long p0 = pz0;
+            const unsigned cnt = (unsigned)(pz1 - pz0);
             collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * CELLB, cnt * 8u, jzz * 8u, fluid, ft, rRz, rhoz - rRz, gx, gy, gz,
                                   p.pur_out + row_index(p, z, y, tx));
         }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) asm volatile("" : "+v"(raw[i]));
         fluid = fluidn;
     }
 }
@@ -529,8 +576,8 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_init_rest(RK3Dev p, const doub
         const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
         const size_t sd = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
         a = rho_r[sd]; b = rho_b[sd];
-        const unsigned long long p0 = p.pstart[zl];
-        const size_t cnt = (size_t)(p.pstart[zl + 1] - p0);
+        const unsigned long long p0 = pstart_of(p, zl);
+        const size_t cnt = (size_t)(pstart_of(p, zl + 1) - p0);
         double *pl = f + (size_t)p0 * QS;
         for (int i = 0; i < Q; ++i) pl[(size_t)i * cnt + j] = wq(i) * (a + b);
         double *s = pl + (size_t)Q * cnt + (size_t)j * 4;
