@@ -292,31 +292,42 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
     const int tx = slot % tilesX, r = slot / tilesX, ty = xcd * rows_per_xcd + r % rows_per_xcd, chunk = r / rows_per_xcd;
     if (ty >= tilesY) return;
-    const int tid = threadIdx.x, lx = tid % TX, ly = tid / TX;
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: branches on it are branches, not exec masks
-    const int x = tx * TX + lx, y = ty * TY + ly;
-    const bool own = y < p.ny;
-    const int yo = ring_coord(y, p.ny);
-    const bool has_own = yo >= 0;
-    // rim cell of this thread: bottom row, top row (one wave each), then the two columns (corners included)
-    int hlx = 0, hly = 0, hx = 0, hy = 0;
-    bool has_rim = false;
-    if (tid < M::NH) {
-        if (tid < 2 * TX) { hlx = 1 + tid % TX; hly = tid < TX ? 0 : M::FY - 1; }
-        else { const int k = tid - 2 * TX; hlx = k < M::FY ? 0 : M::FX - 1; hly = k % M::FY; }
-        hx = ring_coord(tx * TX + hlx - 1, p.nx);
-        hy = ring_coord(ty * TY + hly - 1, p.ny);
-        has_rim = hx >= 0 && hy >= 0;
-    }
-    const TileRowsU<TY, true> rows_own{{srow, ly + 2, 1}};
-    const TileRowsU<TY, true> rows_rimrow{{srow, hly + 1, 1}};
-    const TileRowsU<TY, false> rows_rimcol{{srow, hly + 1, hlx == 0 ? 0 : 2}};
-    // second entry of the scalar-tile fill: waves 3..6 take the tile rows -2, -1, 8, 9, wave 7 the 4 x 12 cells left and right
-    const int xrow = ly >= 3 && ly <= 6 ? (ly < 5 ? ly - 5 : ly + 3) : (lx >> 2) - 2;          // tile row of that entry
-    const int xc = lx & 3, xcol = ly == 7 ? (xc < 2 ? xc - 2 : TX + xc - 2) : lx;               // tile column
-    const bool has_x = (ly >= 3 && ly <= 6) || (ly == 7 && lx < 4 * SR);
-    const TileRowsU<TY, true> rows_xrow{{srow, xrow + 2, 1}};
-    const TileRowsU<TY, false> rows_xcol{{srow, xrow + 2, xc < 2 ? 0 : 2}};
+    // Everything a thread derives from its id -- tile coordinates, its rim cell (bottom row, top row: one wave each; then the two
+    // columns, corners included), its second entry of the scalar-tile fill (waves 3..6 take the tile rows -2, -1, 8, 9, wave 7 the
+    // 4 x 12 cells left and right) -- is RE-DERIVED at the top of every march step from an id the compiler cannot see through:
+    // hoisted out of the loop these ~30 values stay in registers for good, the kernel spills, and every spill reload is followed by
+    // s_waitcnt vmcnt(0).  ~60 integer instructions per step buy the registers back.
+    int lx, ly, x, y, yo, hlx, hly, hx, hy, xrow, xc, xcol;
+    bool own, has_own, has_rim, has_x;
+    TileRowsU<TY, true> rows_own{{srow, 0, 1}}, rows_rimrow{{srow, 0, 1}}, rows_xrow{{srow, 0, 1}};
+    TileRowsU<TY, false> rows_rimcol{{srow, 0, 0}}, rows_xcol{{srow, 0, 0}};
+    auto set_geometry = [&](int t) {
+        lx = t % TX; ly = t / TX;
+        x = tx * TX + lx; y = ty * TY + ly;
+        own = y < p.ny;
+        yo = ring_coord(y, p.ny);
+        has_own = yo >= 0;
+        hlx = 0; hly = 0; hx = 0; hy = 0;
+        has_rim = false;
+        if (t < M::NH) {
+            if (t < 2 * TX) { hlx = 1 + t % TX; hly = t < TX ? 0 : M::FY - 1; }
+            else { const int k = t - 2 * TX; hlx = k < M::FY ? 0 : M::FX - 1; hly = k < M::FY ? k : k - M::FY; }
+            hx = ring_coord(tx * TX + hlx - 1, p.nx);
+            hy = ring_coord(ty * TY + hly - 1, p.ny);
+            has_rim = hx >= 0 && hy >= 0;
+        }
+        xrow = ly >= 3 && ly <= 6 ? (ly < 5 ? ly - 5 : ly + 3) : (lx >> 2) - 2;            // tile row of the second entry
+        xc = lx & 3; xcol = ly == 7 ? (xc < 2 ? xc - 2 : TX + xc - 2) : lx;               // its tile column
+        has_x = (ly >= 3 && ly <= 6) || (ly == 7 && lx < 4 * SR);
+        rows_own.t.lrow = ly + 2;
+        rows_rimrow.t.lrow = hly + 1;
+        rows_rimcol.t.lrow = hly + 1; rows_rimcol.t.k = hlx == 0 ? 0 : 2;
+        rows_xrow.t.lrow = xrow + 2;
+        rows_xcol.t.lrow = xrow + 2; rows_xcol.t.k = xc < 2 ? 0 : 2;
+    };
+    set_geometry(tid);
     const int za = z_first + chunk * chunk_len, zb = min(za + chunk_len - 1, z_last);
     const int zl_gb = 1 - p.z0, zl_gt = p.nzg - p.z0;          // local index of the ghost planes z = 0 and z = nz-1 (when owned)
     auto is_ghost = [&](int zl) { return zl == zl_gb || zl == zl_gt; };
@@ -460,6 +471,11 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
 
     for (int z = za - 2; z <= zb; ++z) {
         const int zn = z + 1;
+        {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            set_geometry(t);
+        }
         // fetched here, in uniform control flow, as scalar loads: inside the collision's branch they become a vector load, and the
         // s_waitcnt vmcnt(0) in front of its use drains the pulls in flight (the collision then overlaps nothing)
         const unsigned long long pz0 = pstart_of(p, z > 0 ? z : 0), pz1 = pstart_of(p, z > 0 ? z + 1 : 1);
