@@ -1027,6 +1027,7 @@ struct lbmpm_rk3d {
     // q23: compact storage of 19 colour-blind populations + {k_R, A} per cell instead of 2 x 19 (rk3dq.h); default on compact
     // storage, LBMPM_RK3D_STORAGE=38 keeps the 38-value kernels (the cross-check)
     bool q23 = false;
+    bool halo_valid = false;         // q23 slabs: the halo planes (populations, records, flags, phase field) belong to the current state
     int dbg = 0;
     int nseg = 0;
     size_t ncells = 0;               // stored cells, halo planes included
@@ -1121,7 +1122,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_BOUNDARY")) c->boundary = atoi(e) >= 2 ? atoi(e) : 2;
     c->compact = variant == 0 && c->nx % 64 == 0;
     if (const char *e = getenv("LBMPM_RK3D_LAYOUT")) if (!strcmp(e, "dense")) c->compact = false;
-    c->q23 = c->compact && c->tile == 0 && cfg->z_offset == 0 && cfg->nz_local == cfg->nz_global;
+    c->q23 = c->compact && c->tile == 0;
     if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
     if (const char *e = getenv("LBMPM_RK3D_DBG")) c->dbg = atoi(e);
     c->pitch = (c->nx + 31) / 32 * 32;
@@ -1211,10 +1212,11 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
         TRY_RC(dev_alloc(c, &c->purB, (size_t)(c->nzl + 2) * c->ny * c->nseg));
     }
     TRY_RC(dev_alloc(c, &c->phi, c->vol));
-    TRY_RC(dev_alloc(c, &c->send_up, 10 * c->plane2));
-    TRY_RC(dev_alloc(c, &c->send_dn, 10 * c->plane2));
-    TRY_RC(dev_alloc(c, &c->recv_below, 10 * c->plane2));
-    TRY_RC(dev_alloc(c, &c->recv_above, 10 * c->plane2));
+    const size_t face_doubles = (c->q23 ? FACE_DOUBLES + 1 : 10) * c->plane2;     // q23: 13 per cell + the row flags (rk3dq.h)
+    TRY_RC(dev_alloc(c, &c->send_up, face_doubles));
+    TRY_RC(dev_alloc(c, &c->send_dn, face_doubles));
+    TRY_RC(dev_alloc(c, &c->recv_below, face_doubles));
+    TRY_RC(dev_alloc(c, &c->recv_above, face_doubles));
 #undef TRY_RC
     hipError_t e = hipMemcpyAsync(c->flags, hflags.data(), c->vol, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && c->compact) e = hipMemcpyAsync(c->seg, hseg.data(), hseg.size() * sizeof(hseg[0]), hipMemcpyHostToDevice, c->stream);
@@ -1293,6 +1295,7 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
     if (e != hipSuccess) { set_error("lbmpm_rk3d_set_density: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     c->streamed = false;
+    c->halo_valid = false;
     c->steps = 0;
     c->observed_at = -1;
     return LBMPM_OK;
@@ -1301,7 +1304,14 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
 extern "C" int lbmpm_rk3d_pack_halo(lbmpm_rk3d *c)
 {
     LBMPM_REQUIRE(c, "null context");
-    if (c->q23 && c->cfg.z_offset == 0 && c->cfg.nz_local == c->cfg.nz_global) return LBMPM_OK;     // no neighbour, nothing crosses a cut
+    if (c->q23) {       // the whole face message of the current state (rk3dq.h): populations, records, class sums, row flags
+        const int below = c->cfg.z_offset > 0, above = c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global;
+        if (!below && !above) return LBMPM_OK;
+        RK3Dev q = make_dev(c);
+        rk3dq_face_pack<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3, 2), dim3(BX3, BY3), 0, c->stream>>>(q, c->send_up, c->send_dn, below, above);
+        LBMPM_HIP_TRY(hipGetLastError());
+        return LBMPM_OK;
+    }
     RK3Dev p = make_dev(c);
     const int threads = 256;
     const dim3 grid((unsigned)((c->plane2 + threads - 1) / threads));
@@ -1314,7 +1324,16 @@ extern "C" int lbmpm_rk3d_pack_halo(lbmpm_rk3d *c)
 extern "C" int lbmpm_rk3d_unpack_halo(lbmpm_rk3d *c, int have_below, int have_above)
 {
     LBMPM_REQUIRE(c, "null context");
-    if (c->q23 && c->cfg.z_offset == 0 && c->cfg.nz_local == c->cfg.nz_global) return LBMPM_OK;
+    if (c->q23) {
+        if (!have_below && !have_above) return LBMPM_OK;
+        RK3Dev q = make_dev(c);
+        const dim3 grid(c->nseg, (c->ny + BY3 - 1) / BY3, 2), block(BX3, BY3);
+        rk3dq_face_unpack<<<grid, block, 0, c->stream>>>(q, c->fA, c->purA, c->recv_below, c->recv_above, have_below, have_above);
+        rk3dq_halo_phi<<<grid, block, 0, c->stream>>>(q, c->recv_below, c->recv_above, have_below, have_above);
+        LBMPM_HIP_TRY(hipGetLastError());
+        c->halo_valid = true;
+        return LBMPM_OK;
+    }
     RK3Dev p = make_dev(c);
     const int threads = 256;
     const dim3 grid((unsigned)((c->plane2 + threads - 1) / threads));
@@ -1338,6 +1357,7 @@ extern "C" int lbmpm_rk3d_phase_field(lbmpm_rk3d *c, int with_diagnostics)
     };
     if (with_diagnostics) c->observed_at = c->steps;
     if (c->variant == 1 || with_diagnostics) k1(c->nzl, 1);
+    else if (c->q23) { /* the halo planes' phase field comes with the face exchange (rk3dq_halo_phi) */ }
     else {
         // fused variant: the marching kernel computes the phase field itself; only the planes a
         // neighbour rank needs are produced here
@@ -1506,6 +1526,67 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
         c->slab_pool.reset();
         c->slab_timed_steps = tsteps;
     }
+    if (c->q23 && nb) {
+        // q23 storage: ONE exchange per step, software-pipelined.  The halo planes of the current state are valid on entry (primed below
+        // after set_density).  Step: boundary planes first (context's stream) -> face message of the NEW state packed, exchanged
+        // and unpacked (same stream) while the interior planes run on the second stream -> join.  The next step's boundary planes find
+        // their halo ready; the transfer hides behind the interior planes of THIS step.
+        LBMPM_REQUIRE(!c->interior_pending, "lbmpm_rk3d_step_slab: finish the step begun with lbmpm_rk3d_collide_interior first");
+        auto fail = [&](int code) {         // leave the context consistent: nothing pending on the second stream
+            if (c->aux) (void)hipStreamSynchronize(c->aux);
+            (void)hipStreamSynchronize(c->stream);
+            c->halo_valid = false;
+            return code;
+        };
+        if (!c->halo_valid) {
+            int rc = lbmpm_rk3d_pack_halo(c);
+            if (rc == LBMPM_OK && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (priming the halo planes)"); rc = LBMPM_ERR_STATE; }
+            if (rc == LBMPM_OK) rc = lbmpm_rk3d_unpack_halo(c, has_below, has_above);
+            if (rc != LBMPM_OK) return fail(rc);
+        }
+        if (!c->aux) {
+            LBMPM_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+            LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
+            LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+        }
+        const int cb = c->boundary;
+        const bool has_interior = c->nzl >= 2 * cb + 1;
+        const dim3 fgrid(c->nseg, (c->ny + BY3 - 1) / BY3, 2), fblock(BX3, BY3);
+        for (int64_t k = 0; k < nsteps; ++k) {
+            hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            if (k < tsteps) for (int i = 0; i < 4; ++i) c->slab_pool.take(&ev[2 * i], &ev[2 * i + 1]);
+            if (ev[0]) LBMPM_HIP_TRY(hipEventRecord(ev[0], c->stream));
+            const RK3Dev p = make_dev(c);
+            LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // the previous step, its unpack included
+            if (ev[6]) LBMPM_HIP_TRY(hipEventRecord(ev[6], c->stream));
+            if (has_interior) {
+                launch_step_range(c, p, c->stream, 1, cb);
+                launch_step_range(c, p, c->stream, c->nzl - cb + 1, c->nzl);
+            } else launch_step_range(c, p, c->stream, 1, c->nzl);
+            if (ev[7]) LBMPM_HIP_TRY(hipEventRecord(ev[7], c->stream));
+            if (has_interior) {
+                LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));
+                if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], c->aux));
+                launch_step_range(c, p, c->aux, cb + 1, c->nzl - cb);
+                if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], c->aux));
+                LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));
+            }
+            if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
+            if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
+            RK3Dev q = p;                                                     // the state this step writes
+            q.fin = c->fB; q.pur_in = c->purB; q.first = 0;
+            rk3dq_face_pack<<<fgrid, fblock, 0, c->stream>>>(q, c->send_up, c->send_dn, has_below, has_above);
+            if (exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
+            rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, c->recv_below, c->recv_above, has_below, has_above);
+            rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, c->recv_below, c->recv_above, has_below, has_above);
+            if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: face kernel launch failed"); return fail(LBMPM_ERR_HIP); }
+            if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
+            if (has_interior) LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+            finish_step(c);
+            if (ev[1]) LBMPM_HIP_TRY(hipEventRecord(ev[1], c->stream));
+        }
+        return LBMPM_OK;
+    }
     for (int64_t k = 0; k < nsteps; ++k) {
         hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (k < tsteps) for (int i = 0; i < 4; ++i) c->slab_pool.take(&ev[2 * i], &ev[2 * i + 1]);
@@ -1514,15 +1595,20 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
         if (nb) rc = collide_interior_ev(c, ev[2], ev[3]);
         if (rc != LBMPM_OK) return rc;
         if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
+        // a failed exchange must not leave the interior launch pending: the context would refuse every later call
+        auto abandon = [&](int code) {
+            if (c->interior_pending) { (void)hipStreamSynchronize(c->aux); c->interior_pending = false; }
+            return code;        // fA / fB are half-updated: the caller has to set_density (or restart) before stepping again
+        };
         if (nb && c->steps > 0) {
             rc = lbmpm_rk3d_pack_halo(c);
             if (rc == LBMPM_OK && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (populations)"); rc = LBMPM_ERR_STATE; }
             if (rc == LBMPM_OK) rc = lbmpm_rk3d_unpack_halo(c, has_below, has_above);
-            if (rc != LBMPM_OK) return rc;
+            if (rc != LBMPM_OK) return abandon(rc);
         }
         rc = lbmpm_rk3d_phase_field(c, 0);
-        if (rc != LBMPM_OK) return rc;
-        if (nb && exchange(user, 1) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (phase field)"); return LBMPM_ERR_STATE; }
+        if (rc != LBMPM_OK) return abandon(rc);
+        if (nb && exchange(user, 1) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (phase field)"); return abandon(LBMPM_ERR_STATE); }
         if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
         rc = collide_boundary_ev(c, ev[6], ev[7]);
         if (rc != LBMPM_OK) return rc;
@@ -1621,8 +1707,14 @@ extern "C" int lbmpm_rk3d_buffer(lbmpm_rk3d *c, int which, void **ptr, int64_t *
     LBMPM_REQUIRE(c && ptr && bytes, "lbmpm_rk3d_buffer: null argument");
     const int64_t pb = (int64_t)(c->plane2 * sizeof(double));
     // compact storage moves the fluid cells of the plane only (the two sides of a cut hold the same plane)
-    auto fb = [&](int zl) { return c->compact ? (int64_t)((c->h_pstart[zl + 1] - c->h_pstart[zl]) * 10 * sizeof(double))
-                                              : (int64_t)(10 * c->plane2 * sizeof(double)); };
+    auto fb = [&](int zl) {
+        if (c->q23) return (int64_t)(((c->h_pstart[zl + 1] - c->h_pstart[zl]) * FACE_DOUBLES + ((size_t)c->ny * c->nseg + 1) / 2) * sizeof(double));
+        return c->compact ? (int64_t)((c->h_pstart[zl + 1] - c->h_pstart[zl]) * 10 * sizeof(double)) : (int64_t)(10 * c->plane2 * sizeof(double));
+    };
+    if (c->q23 && which >= LBMPM_RK3D_BUF_PHI_SEND_UP && which <= LBMPM_RK3D_BUF_PHI_RECV_FROM_ABOVE) {
+        *ptr = c->phi; *bytes = 0;          // one exchange per step: the phase field of the halo planes travels as class sums
+        return LBMPM_OK;
+    }
     switch (which) {
         case LBMPM_RK3D_BUF_F_SEND_UP: *ptr = c->send_up; *bytes = fb(c->nzl); return LBMPM_OK;
         case LBMPM_RK3D_BUF_F_SEND_DOWN: *ptr = c->send_dn; *bytes = fb(1); return LBMPM_OK;

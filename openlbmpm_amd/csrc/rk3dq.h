@@ -43,7 +43,8 @@ struct PlaneAddrQ {
 __device__ __forceinline__ PlaneAddrQ plane_addr_q(const RK3Dev &p, const double *f, int zl)
 {
     PlaneAddrQ a;
-    const unsigned long long p0 = pstart_of(p, zl - 1), p1 = pstart_of(p, zl), p2 = pstart_of(p, zl + 1), p3 = pstart_of(p, zl + 2);
+    const unsigned long long p1 = pstart_of(p, zl), p2 = pstart_of(p, zl + 1);
+    const unsigned long long p0 = zl > 0 ? pstart_of(p, zl - 1) : p1, p3 = zl <= p.nzl ? pstart_of(p, zl + 2) : p2;   // no plane beyond the halo planes
     a.base = reinterpret_cast<const char *>(f) + (size_t)p0 * CELLB;
     a.cnt[0] = (unsigned)(p1 - p0); a.cnt[1] = (unsigned)(p2 - p1); a.cnt[2] = (unsigned)(p3 - p2);
     a.off[0] = 0u; a.off[1] = a.cnt[0] * CELLB; a.off[2] = a.off[1] + a.cnt[1] * CELLB;
@@ -162,45 +163,78 @@ __device__ __forceinline__ GlbScal glb_scal(const RK3Dev &p, const PlaneAddrQ &a
 // With k_R = 1 and A = 0 around a node (pure red) k + a equals t bit for bit, i.e. rho_B = 0 exactly.
 struct Sums { double k0, kp, km, a0, ap, am, t0, tp, tm; };
 
-template <bool FIRST, bool UNI, typename Rows, typename Scal>
-__device__ __forceinline__ void class_sums(const RK3Dev &p, const Rows &rows, const Scal &sc, int zp, unsigned b, const double g[Q], Sums &S)
+// CLS = c_z of the class: 0, +1 (upstream cells in the plane below), -1 (plane above)
+template <int CLS, bool FIRST, bool UNI, typename Rows, typename Scal>
+__device__ __forceinline__ void class_sum_one(const RK3Dev &p, const Rows &rows, const Scal &sc, int zp, unsigned b, const double g[Q],
+                                              double &ks, double &as, double &ts)
 {
 #pragma clang fp contract(off)
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
-    S.kp = S.km = S.a0 = S.ap = S.am = S.tp = S.tm = 0.;
-    S.k0 = sc.comp(sc.own_cell(), 0) * g[0];
-    S.t0 = g[0];
+    constexpr int rz = -CLS;
+    ks = 0.; as = 0.; ts = 0.;
+    if (CLS == 0) { ks = sc.comp(sc.own_cell(), 0) * g[0]; ts = g[0]; }
 #pragma unroll
-    for (int rz = -1; rz <= 1; ++rz)
+    for (int ry = -1; ry <= 1; ++ry) {
+        RowTab t{};
+        if (!FIRST) t = rows(zp + rz, ry);
 #pragma unroll
-        for (int ry = -1; ry <= 1; ++ry) {
-            RowTab t{};
-            if (!FIRST) t = rows(zp + rz, ry);
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int i = DIRT[(1 - rz) * 9 + (1 - ry) * 3 + (1 - dx)];
-                if (i <= 0) continue;
-                unsigned j = 0;
-                bool fl = true;
-                typename Scal::H h;
-                if (FIRST) h = sc.own_cell();
-                else {
-                    row_cell<UNI>(t, dx, b, j, fl);
-                    h = sc.cell(rz, ry, dx, fl, j, b);
-                }
-                const double k = sc.comp(h, 0);
-                double ea = 0.;
-                bool any = false;
-                if (CX[i] != 0) { const double v = sc.comp(h, 1); ea = CX[i] > 0 ? v : -v; any = true; }
-                if (CY[i] != 0) { const double v = sc.comp(h, 2); ea = any ? (CY[i] > 0 ? ea + v : ea - v) : (CY[i] > 0 ? v : -v); any = true; }
-                if (CZ[i] != 0) { const double v = sc.comp(h, 3); ea = any ? (CZ[i] > 0 ? ea + v : ea - v) : (CZ[i] > 0 ? v : -v); }
-                const double c = i < 7 ? p.rcA : p.rcD;
-                const double cs = fl ? c : -c;       // bounce-back: the opposite population of the node itself
-                if (CZ[i] == 0) { S.k0 = __builtin_fma(k, g[i], S.k0); S.a0 = __builtin_fma(cs, ea, S.a0); S.t0 += g[i]; }
-                else if (CZ[i] > 0) { S.kp = __builtin_fma(k, g[i], S.kp); S.ap = __builtin_fma(cs, ea, S.ap); S.tp += g[i]; }
-                else { S.km = __builtin_fma(k, g[i], S.km); S.am = __builtin_fma(cs, ea, S.am); S.tm += g[i]; }
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int i = DIRT[(1 - rz) * 9 + (1 - ry) * 3 + (1 - dx)];
+            if (i <= 0) continue;
+            unsigned j = 0;
+            bool fl = true;
+            typename Scal::H h;
+            if (FIRST) h = sc.own_cell();
+            else {
+                row_cell<UNI>(t, dx, b, j, fl);
+                h = sc.cell(rz, ry, dx, fl, j, b);
             }
+            const double k = sc.comp(h, 0);
+            double ea = 0.;
+            bool any = false;
+            if (CX[i] != 0) { const double v = sc.comp(h, 1); ea = CX[i] > 0 ? v : -v; any = true; }
+            if (CY[i] != 0) { const double v = sc.comp(h, 2); ea = any ? (CY[i] > 0 ? ea + v : ea - v) : (CY[i] > 0 ? v : -v); any = true; }
+            if (CZ[i] != 0) { const double v = sc.comp(h, 3); ea = any ? (CZ[i] > 0 ? ea + v : ea - v) : (CZ[i] > 0 ? v : -v); }
+            const double c = i < 7 ? p.rcA : p.rcD;
+            const double cs = fl ? c : -c;       // bounce-back: the opposite population of the node itself
+            ks = __builtin_fma(k, g[i], ks); as = __builtin_fma(cs, ea, as); ts += g[i];
         }
+    }
+}
+
+template <bool FIRST, bool UNI, typename Rows, typename Scal>
+__device__ __forceinline__ void class_sums(const RK3Dev &p, const Rows &rows, const Scal &sc, int zp, unsigned b, const double g[Q], Sums &S)
+{
+    class_sum_one<1, FIRST, UNI>(p, rows, sc, zp, b, g, S.kp, S.ap, S.tp);
+    class_sum_one<0, FIRST, UNI>(p, rows, sc, zp, b, g, S.k0, S.a0, S.t0);
+    class_sum_one<-1, FIRST, UNI>(p, rows, sc, zp, b, g, S.km, S.am, S.tm);
+}
+
+// the pulls of one class only (face kernels of the slab exchange: the other classes belong to the neighbour rank)
+template <int CLS, bool FIRST, typename Rows>
+__device__ __forceinline__ void pull_class(const RK3Dev &p, const Rows &rows, int zl, unsigned b, unsigned own_j, double g[Q])
+{
+    constexpr int OPP[Q] = LBMPM_D3Q19_OPP;
+    constexpr int rz = -CLS;
+    const PlaneAddrQ a = plane_addr_q(p, p.fin, zl);
+    const unsigned own8 = own_j * 8u;
+    if (CLS == 0) g[0] = ldg(a.base, a.off[1] + own8);
+#pragma unroll
+    for (int ry = -1; ry <= 1; ++ry) {
+        RowTab t{};
+        if (!FIRST) t = rows(zl + rz, ry);
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int i = DIRT[(1 - rz) * 9 + (1 - ry) * 3 + (1 - dx)];
+            if (i <= 0) continue;
+            unsigned j = 0;
+            bool fl = true;
+            if (!FIRST) row_cell<false>(t, dx, b, j, fl);
+            const unsigned up = a.off[1 + rz] + (unsigned)i * a.cnt[1 + rz] * 8u + j * 8u;
+            const unsigned back = a.off[1] + (unsigned)OPP[i] * a.cnt[1] * 8u + own8;
+            g[i] = ldg(a.base, FIRST ? a.off[1] + (unsigned)i * a.cnt[1] * 8u + own8 : (fl ? up : back));
+        }
+    }
 }
 
 // class sums of a node whose pulled directions all come from cells of ONE colour (k_R = 1 or 0 and A = 0 at every upstream
@@ -634,4 +668,118 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_phase_field(RK3Dev p, int zl0)
         p.diag[idx] = rR; p.diag[p.vol + idx] = rho - rR;
         p.diag[2 * p.vol + idx] = mx / rho; p.diag[3 * p.vol + idx] = my / rho; p.diag[4 * p.vol + idx] = mz / rho;
     }
+}
+
+// ---------------------------------------------------------------------------------------------- slab exchange (one per step)
+// What a rank ships across a cut, per fluid cell of its face plane (plane nzl upwards, plane 1 downwards), cnt cells:
+//   [0, 5 cnt)      the five populations that cross the cut
+//   [5 cnt, 9 cnt)  the cell's record {k_R, A} (the constant for a flagged row: the receiver stores it like any other)
+//   [9 cnt, 13 cnt) {r0, rX, t0, tX}: the class sums (red, total) of the cell's NEXT pull that the sender owns -- c_z = 0 and the
+//                   class whose upstream cells lie in the sender's own second plane (X = +1 upwards, -1 downwards).  The receiver adds
+//                   the class that crosses the cut, from its own face plane, and has the phase field of the neighbour's face plane
+//                   (the halo plane its colour gradient reads) without a second exchange: rho_R = (r0 + r+) + r-, bit for bit what the
+//                   owner computes in rk3dq_fused.  Before the first step nothing streams: {r0 + r+, r-, t0 + t+, t-} of the cell itself.
+//   [13 cnt, ...)   the row flags of the face plane, one 32-bit word per row segment
+constexpr int FACE_DOUBLES = 13;
+__device__ constexpr int FACE_UP[5] = {5, 11, 14, 15, 18}, FACE_DN[5] = {6, 12, 13, 16, 17};
+
+__global__ __launch_bounds__(BX3 *BY3) void rk3dq_face_pack(RK3Dev p, double *send_up, double *send_dn, int has_below, int has_above)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;    // face 0: top plane, upwards
+    if ((face == 0 && !has_above) || (face == 1 && !has_below) || y >= p.ny) return;
+    const int zf = face == 0 ? p.nzl : 1;
+    double *msg = face == 0 ? send_up : send_dn;
+    const unsigned long long p0 = pstart_of(p, zf);
+    const size_t cnt = (size_t)(pstart_of(p, zf + 1) - p0);
+    const unsigned flag = p.pur_in[row_index(p, zf, y, x >> 6)];
+    if ((x & 63) == 0) reinterpret_cast<uint32_t *>(msg + FACE_DOUBLES * cnt)[y * p.nseg + (x >> 6)] = flag;
+    if (!(p.flags[(size_t)zf * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
+    const GlobalRows rows{p, x, y};
+    const unsigned b = (unsigned)(x & 63);
+    const RowTab t = rows(zf, 0);
+    const unsigned j = t.first + bits_below<false>(t.m, b);
+    const double *pl = p.fin + (size_t)p0 * QS;
+    for (int k = 0; k < 5; ++k) msg[(size_t)k * cnt + j] = pl[(size_t)(face == 0 ? FACE_UP[k] : FACE_DN[k]) * cnt + j];
+    const double *s = pl + (size_t)Q * cnt + (size_t)j * 4;
+    double *ms = msg + 5 * cnt + (size_t)j * 4;
+    if (flag) { ms[0] = (flag & 1u) ? 1. : 0.; ms[1] = 0.; ms[2] = 0.; ms[3] = 0.; }
+    else { ms[0] = s[0]; ms[1] = s[1]; ms[2] = s[2]; ms[3] = s[3]; }
+    double g[Q], k0, a0, t0, kx, ax, tx;
+    const GlbScal sc = glb_scal(p, plane_addr_q(p, p.fin, zf), j, zf, x, y);
+    double *mp = msg + 9 * cnt + (size_t)j * 4;
+    if (p.first) {
+        double km, am, tm;
+        pull_class<0, true>(p, rows, zf, b, j, g); pull_class<1, true>(p, rows, zf, b, j, g); pull_class<-1, true>(p, rows, zf, b, j, g);
+        class_sum_one<0, true, false>(p, rows, sc, zf, b, g, k0, a0, t0);
+        class_sum_one<1, true, false>(p, rows, sc, zf, b, g, kx, ax, tx);
+        class_sum_one<-1, true, false>(p, rows, sc, zf, b, g, km, am, tm);
+        mp[0] = (k0 + a0) + (kx + ax); mp[1] = km + am; mp[2] = t0 + tx; mp[3] = tm;
+        return;
+    }
+    pull_class<0, false>(p, rows, zf, b, j, g);
+    class_sum_one<0, false, false>(p, rows, sc, zf, b, g, k0, a0, t0);
+    if (face == 0) { pull_class<1, false>(p, rows, zf, b, j, g); class_sum_one<1, false, false>(p, rows, sc, zf, b, g, kx, ax, tx); }
+    else { pull_class<-1, false>(p, rows, zf, b, j, g); class_sum_one<-1, false, false>(p, rows, sc, zf, b, g, kx, ax, tx); }
+    mp[0] = k0 + a0; mp[1] = kx + ax; mp[2] = t0; mp[3] = tx;
+}
+
+// received face -> halo plane (0 from below, nzl + 1 from above) of the state f / pur
+__global__ __launch_bounds__(BX3 *BY3) void rk3dq_face_unpack(RK3Dev p, double *f, uint32_t *pur, const double *recv_below, const double *recv_above,
+                                                              int has_below, int has_above)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;    // face 0: halo plane 0
+    if ((face == 0 && !has_below) || (face == 1 && !has_above) || y >= p.ny) return;
+    const int zh = face == 0 ? 0 : p.nzl + 1;
+    const double *msg = face == 0 ? recv_below : recv_above;
+    const unsigned long long p0 = pstart_of(p, zh);
+    const size_t cnt = (size_t)(pstart_of(p, zh + 1) - p0);
+    if ((x & 63) == 0) pur[row_index(p, zh, y, x >> 6)] = reinterpret_cast<const uint32_t *>(msg + FACE_DOUBLES * cnt)[y * p.nseg + (x >> 6)];
+    if (!(p.flags[(size_t)zh * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
+    const GlobalRows rows{p, x, y};
+    const RowTab t = rows(zh, 0);
+    const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
+    double *pl = f + (size_t)p0 * QS;
+    for (int k = 0; k < 5; ++k) pl[(size_t)(face == 0 ? FACE_UP[k] : FACE_DN[k]) * cnt + j] = msg[(size_t)k * cnt + j];
+    double *s = pl + (size_t)Q * cnt + (size_t)j * 4;
+    const double *ms = msg + 5 * cnt + (size_t)j * 4;
+    s[0] = ms[0]; s[1] = ms[1]; s[2] = ms[2]; s[3] = ms[3];
+}
+
+// phase field of the halo planes from the neighbour's class sums + the class that crosses the cut (p.fin / p.pur_in = the state
+// whose halo planes rk3dq_face_unpack has just filled)
+__global__ __launch_bounds__(BX3 *BY3) void rk3dq_halo_phi(RK3Dev p, const double *recv_below, const double *recv_above, int has_below, int has_above)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;
+    if ((face == 0 && !has_below) || (face == 1 && !has_above) || y >= p.ny) return;
+    const int zh = face == 0 ? 0 : p.nzl + 1;
+    const size_t idx = (size_t)zh * p.plane2 + (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    const double *msg = face == 0 ? recv_below : recv_above;
+    const size_t cnt = (size_t)(pstart_of(p, zh + 1) - pstart_of(p, zh));
+    const GlobalRows rows{p, x, y};
+    const unsigned b = (unsigned)(x & 63);
+    const RowTab t = rows(zh, 0);
+    const unsigned j = t.first + bits_below<false>(t.m, b);
+    const double *mp = msg + 9 * cnt + (size_t)j * 4;
+    Sums S;
+    S.a0 = S.ap = S.am = 0.;
+    if (p.first) {          // nothing has streamed: the neighbour sent the cell's own sums, {r0 + r+, r-, t0 + t+, t-}
+        S.k0 = mp[0]; S.kp = 0.; S.km = mp[1]; S.t0 = mp[2]; S.tp = 0.; S.tm = mp[3];
+    } else {
+        double g[Q];
+        const GlbScal sc = glb_scal(p, plane_addr_q(p, p.fin, zh), j, zh, x, y);
+        S.k0 = mp[0]; S.t0 = mp[2];
+        if (face == 0) {    // the neighbour below owns c_z = 0 and +1 of its top plane; c_z = -1 comes from this rank's plane 1
+            S.kp = mp[1]; S.tp = mp[3];
+            pull_class<-1, false>(p, rows, zh, b, j, g);
+            class_sum_one<-1, false, false>(p, rows, sc, zh, b, g, S.km, S.am, S.tm);
+        } else {
+            S.km = mp[1]; S.tm = mp[3];
+            pull_class<1, false>(p, rows, zh, b, j, g);
+            class_sum_one<1, false, false>(p, rows, sc, zh, b, g, S.kp, S.ap, S.tp);
+        }
+    }
+    double rR, rho;
+    bc_q<false>(p, zh, S, nullptr, rR, rho);
+    p.phi[idx] = phi_q(rR, rho);
 }

@@ -79,11 +79,12 @@ class RK3DSlab:
         check(self._L.lbmpm_rk3d_set_stream(self._h, C.c_void_p(int(stream.cuda_stream))), "set_stream")
 
     def buffer(self, name):
-        """torch view (zero copy) of a halo buffer"""
+        """torch view (zero copy) of a halo buffer; None for a buffer this storage does not use (the q23 storage moves the
+        halo planes' phase field inside the one face message, its phi buffers have no bytes)"""
         if name not in self._tensors:
             ptr, n = C.c_void_p(), C.c_int64(0)
             check(self._L.lbmpm_rk3d_buffer(self._h, BUF[name], C.byref(ptr), C.byref(n)), "lbmpm_rk3d_buffer")
-            self._tensors[name] = DeviceBuffer(ptr.value, n.value).tensor("cuda:%d" % self.device)
+            self._tensors[name] = DeviceBuffer(ptr.value, n.value).tensor("cuda:%d" % self.device) if n.value > 0 else None
         return self._tensors[name]
 
     def pack(self):
@@ -164,6 +165,12 @@ class RK3DSlab:
     def dominant_kernel(self):
         return self._L.lbmpm_rk3d_dominant_kernel(self._h).decode()
 
+    @property
+    def one_exchange(self):
+        """True for the q23 storage: one face message per step carries populations, records, row flags and the class sums the
+        neighbour needs for the phase field of its halo plane (csrc/rk3dq.h); it is needed before the first step too"""
+        return self.dominant_kernel == "rk3dq_fused"
+
 
 class RK3DCluster:
     """k slabs ('virtual ranks') in ONE process on one GPU, halos moved by device copies.
@@ -186,6 +193,8 @@ class RK3DCluster:
 
     def _exchange(self, kind):
         S = self.slabs
+        if S[0].buffer(kind + "_send_up") is None:
+            return
         local_exchange([s.buffer(kind + "_send_up") for s in S], [s.buffer(kind + "_send_down") for s in S],
                        [s.buffer(kind + "_recv_below") for s in S], [s.buffer(kind + "_recv_above") for s in S])
 
@@ -201,7 +210,7 @@ class RK3DCluster:
             for _ in range(int(n)):
                 for s in self.slabs:
                     s.collide_interior()
-                if self.slabs[0].steps_done > 0:
+                if self.slabs[0].steps_done > 0 or self.slabs[0].one_exchange:
                     self._halo_f()
                 for s in self.slabs:
                     s.phase_field()
@@ -212,7 +221,7 @@ class RK3DCluster:
     def observe(self):
         """rho, u, phi of the streamed + boundary-corrected lattice (what the next step starts from)"""
         with self._torch.cuda.stream(self.stream):
-            if self.slabs[0].steps_done > 0:
+            if self.slabs[0].steps_done > 0 or self.slabs[0].one_exchange:
                 self._halo_f()
             for s in self.slabs:
                 s.phase_field(diagnostics=True)
@@ -252,13 +261,15 @@ class RK3DDistributed:
 
     def _exchange(self, kind):
         s = self.slab
+        if s.buffer(kind + "_send_up") is None:
+            return
         neighbour_exchange(s.buffer(kind + "_send_up"), s.buffer(kind + "_send_down"),
                            s.buffer(kind + "_recv_below"), s.buffer(kind + "_recv_above"),
                            self.rank, self.world, self.group)
 
     def _halo_f(self):
         s = self.slab
-        if s.steps_done > 0 and self.world > 1:
+        if (s.steps_done > 0 or s.one_exchange) and self.world > 1:
             s.pack()
             self._exchange("f")
             s.unpack(self.rank > 0, self.rank + 1 < self.world)
@@ -274,12 +285,17 @@ class RK3DDistributed:
 
     def timing(self):
         t = self.slab.slab_timing()
-        t["exchange_exposed_ms"] = t["step_ms"] - max(t["interior_ms"], t["boundary_ms"])
+        if self.slab.one_exchange:      # boundary planes, then the exchange chain beside the interior planes
+            t["exchange_exposed_ms"] = max(0.0, t["step_ms"] - t["boundary_ms"] - t["interior_ms"])
+            t["schedule"] = "boundary planes -> one face exchange || interior planes"
+        else:
+            t["exchange_exposed_ms"] = t["step_ms"] - max(t["interior_ms"], t["boundary_ms"])
+            t["schedule"] = "interior planes || two exchanges -> boundary planes"
         faces = {}
         for side, there in (("down", self.rank > 0), ("up", self.rank + 1 < self.world)):       # faces that have a neighbour
             if there:
                 f = self.slab.buffer("f_send_" + side); ph = self.slab.buffer("phi_send_" + side)
-                faces[side] = int(f.numel() * f.element_size() + ph.numel() * ph.element_size())
+                faces[side] = int(f.numel() * f.element_size() + (ph.numel() * ph.element_size() if ph is not None else 0))
         t["bytes_sent_per_step"] = faces                    # populations (5 x 2 colours, fluid cells of the face plane) + phi plane
         t["bytes_per_face"] = max(faces.values()) if faces else 0
         return t
