@@ -221,10 +221,28 @@ def main():
     args = ap.parse_args()
 
     import torch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run on
+        # this node) and hand over; the rank-0 child prints the one JSON line
+        rehearsal = os.environ.get("LBMPM_DIST_BACKEND", "nccl") != "nccl"
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus and not rehearsal:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); one rank per GPU is needed "
+                             "(LBMPM_DIST_BACKEND=gloo rehearses the N-rank path on fewer GPUs, not a measurement)" % (args.gpus, have))
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and args.gpus != world:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library is the only compute path)"
     local_rank = local_rank % torch.cuda.device_count()    # (lets a 1-GPU box rehearse the N>1 code path)
@@ -258,6 +276,10 @@ def main():
         z0, nzl = RK3DDistributed.partition(dom, world)[rank]       # equal fluid cells per rank
         rR, rB = c5_densities(dom[z0:z0 + nzl], z0, nz)
         m0_local = float((rR + rB).sum())
+        # the K timed steps run as (up to) five back-to-back windows: the line carries their median / min / max beside the whole-run value
+        nwin = min(5, steps)
+        win_steps = [steps // nwin + (1 if i < steps % nwin else 0) for i in range(nwin)]
+        win_ms = []
         if world == 1:
             slab = RK3DSlab(dom, 0, nz, dict(relax=args.relax), device=local_rank)
             slab.set_density(rR, rB)
@@ -265,9 +287,13 @@ def main():
             slab.step_single(warmup)
             slab.sync(); barrier()
             t0 = time.perf_counter()
-            ms_total, ms_dom = slab.step_timed(steps)
+            ms_total = ms_dom = 0.0
+            for n_w in win_steps:
+                a, b = slab.step_timed(n_w)         # HIP events on the kernel's stream: whole window / sum over the launches
+                ms_total += a; ms_dom += b; win_ms.append(a)
             slab.sync(); barrier()
             wall = time.perf_counter() - t0
+            storage = slab.storage_info()
             slab.phase_field(diagnostics=True)
             rho = slab.get("rhoR") + slab.get("rhoB")
             nfl_local, dom_kernel = slab.num_fluid_nodes, slab.dominant_kernel
@@ -279,10 +305,20 @@ def main():
             d.step(warmup)
             d.sync(); barrier()
             t0 = time.perf_counter()
-            d.step(steps, timed=True)      # one call into the library; per-phase HIP events on the slab's streams
-            d.sync(); barrier()
+            tms = []
+            for n_w in win_steps:          # one call into the library per window; per-phase HIP events on the slab's streams
+                t1 = time.perf_counter()
+                d.step(n_w, timed=True)
+                d.sync()
+                win_ms.append((time.perf_counter() - t1) * 1e3)
+                tms.append(d.timing())
+            barrier()
             wall = time.perf_counter() - t0
-            tm = d.timing()
+            tm = dict(tms[-1])             # phase times: step-weighted averages over the windows
+            tm["steps"] = sum(t["steps"] for t in tms)
+            for key in ("step_ms", "interior_ms", "exchange_chain_ms", "boundary_ms", "exchange_exposed_ms"):
+                tm[key] = sum(t[key] * t["steps"] for t in tms) / max(tm["steps"], 1)
+            storage = d.slab.storage_info()
             ms_dom = tm["step_ms"] * steps
             ms_total = wall * 1e3
             mine = dict(rank=rank, planes=[int(z0), int(z0 + nzl)], fluid_nodes=int(d.slab.num_fluid_nodes),
@@ -302,29 +338,56 @@ def main():
         if rank == 0:
             per_launch_ms = ms_dom / steps
             achieved = B_ALG["c5"] * nfl_local / (per_launch_ms * 1e-3) / 1e9
+            win = sorted(nfluid_global * n / (ms * 1e-3) / 1e6 for n, ms in zip(win_steps, win_ms))
+            traffic = pmc_traffic(dom_kernel + ("[SRT]" if args.relax == "SRT" else ""), "c5 %dx%dx%d" % size) if world == 1 else None
+            moved = {"doubles_stored_per_cell": storage["doubles_per_cell"],
+                     "cells_in_single_colour_rows": storage["cells_in_flagged_rows"], "fluid_cells": storage["fluid_cells"],
+                     "storage_bytes_per_launch": storage["bytes_per_step"],
+                     "storage_GBs": round(storage["bytes_per_step"] / (per_launch_ms * 1e-3) / 1e9, 1),
+                     "storage_frac": round(storage["bytes_per_step"] / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "counted_GBs": round(traffic / (per_launch_ms * 1e-3) / 1e9, 1) if traffic else None,
+                     "counted_frac": round(traffic / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                     "note": "frac above is MLUPS x 608 B (SURVEY 8d: both colour lattices read and written once) / 8 TB/s and may exceed what "
+                             "the memory system moved: the compact storage keeps 19 colour-blind populations + k_R + the recolouring vector "
+                             "per cell (23 doubles, the recolouring AcceleratedRKGPU2D.py:1241-1267 makes the 38 an affine image of them) and "
+                             "no record at all for row segments of a single colour; storage_* = bytes of the owned cells by the storage's own "
+                             "count at the end of the run (rim / halo re-reads not included), counted_* = rocprofv3 FETCH/WRITE of "
+                             "profiles/pmc_traffic.json"}
             out = {
                 "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid_global * steps / wall / 1e6, 2),
                 "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
                 "ms_per_step": round(wall * 1e3 / steps, 5), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "windows": {"count": len(win), "steps_each": win_steps, "median": round(win[len(win) // 2], 2), "min": round(win[0], 2),
+                            "max": round(win[-1], 2), "unit": "MLUPS",
+                            "clock": "HIP events on the kernel's stream" if world == 1 else "host clock of rank 0 around each window"},
                 "config": {"workload": "c5: D3Q19 colour gradient (perturbation operator, %s; RKtwophasesetup3D.ini "
                                        "parameters), %dx%dx%d synthetic porous medium (spheres r 6-20, porosity 0.65, "
                                        "10 buffer planes, side walls), seed %d" % ((args.relax,) + size + (SEED,)),
                            "fluid_nodes": nfluid_global, "lattice_nodes": int(np.prod(size)),
                            "mlups_total_lattice": round(float(np.prod(size)) * steps / wall / 1e6, 2),
-                           "parallelism": "z-slabs x%d, RCCL p2p halo (5 populations x 2 colours + phi per face)" % world
-                                          if world > 1 else "1 gpu",
+                           "parallelism": ("z-slabs x%d, RCCL p2p: one face message per cut and step (5 populations, the cell record, row flags and the "
+                                           "class sums the neighbour completes its halo phase field from), sent after the boundary planes, hidden "
+                                           "behind the interior planes" if dom_kernel == "rk3dq_fused" else
+                                           "z-slabs x%d, RCCL p2p halo (5 populations x 2 colours + phi per face)") % world if world > 1 else "1 gpu",
                            "kernel_schedule": "one fused z-marching kernel per step (pull, phase field in an LDS ring, collide, store), "
-                                              + ("compact storage: fluid cells only" if dom_kernel == "rk3dc_fused" else "dense storage")
+                                              + {"rk3dq_fused": "compact storage: fluid cells only, 23 doubles per cell (19 colour-blind populations "
+                                                                "+ k_R + recolouring vector in an LDS tile), row segments of one colour keep no record",
+                                                 "rk3dc_fused": "compact storage: fluid cells only, both colour lattices"}.get(dom_kernel, "dense storage")
                                               if "fused" in dom_kernel else "phase_field + collide (split-2)",
-                           "parity": "pinned by reduction: y-uniform lattice through this kernel == captures of the reference's real D2Q9 perturbation driver (RKD2Q9.py:978-1223) to 3e-13, SRT (tests/test_rk3d_reduction.py); full 3-D and MRT vs oracle/rk3d_oracle.c 1e-10"},
+                           "parity": "pinned by reduction: y-uniform lattice through this kernel == captures of the reference's real D2Q9 perturbation "
+                                     "driver (RKD2Q9.py:978-1223, run with the four call-site repairs listed in tests/golden/gen/make_golden_rk_pert.py: "
+                                     "R3 moves calTotalFluidPDF behind collision 1, i.e. the pin is to that repaired loop) to 1e-10, SRT "
+                                     "(tests/test_rk3d_reduction.py); full 3-D and MRT vs oracle/rk3d_oracle.c 1e-10; the 23-value storage vs the "
+                                     "38-value kernels 1e-11 (tests/test_rk3d_gpu.py)"},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
-                             "traffic": pmc_traffic(dom_kernel + ("[SRT]" if args.relax == "SRT" else ""), "c5 %dx%dx%d" % size) if world == 1 else None,
+                             "traffic": traffic,
+                             "bytes_moved": moved,
                              "kernel": dom_kernel,
                              "measured_stream_ceiling": measured_hbm(local_rank) if world == 1 else None,
-                             "note": None if world == 1 else "N>1: the kernel runs as interior + boundary launches on two "
-                                     "streams under the halo exchange; avg_launch_ms brackets the whole step, exchange included",
+                             "note": None if world == 1 else "N>1: the kernel runs as boundary + interior launches on two "
+                                     "streams beside the halo exchange; avg_launch_ms brackets the whole step, exchange included",
                              "avg_launch_ms": round(per_launch_ms, 5),
                              "algorithmic_bytes_per_launch": B_ALG["c5"] * nfl_local},
             }

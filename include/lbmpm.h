@@ -353,6 +353,11 @@ int lbmpm_rk3d_sync(lbmpm_rk3d *ctx);
 int lbmpm_rk3d_buffer(lbmpm_rk3d *ctx, int which, void **device_ptr, int64_t *bytes);
 /* owned planes [nz_local][ny][nx] */
 int lbmpm_rk3d_get_field(lbmpm_rk3d *ctx, int field, double *out);
+/* out[4]: doubles stored per fluid cell (38, or 23 with the compressed compact storage: 19 colour-blind populations + k_R + the
+ * recolouring vector, from which the pull rebuilds both colours -- AcceleratedRKGPU2D.py:1241-1267 makes the two lattices an affine
+ * image of those), fluid cells owned, those of them in row segments flagged single-colour (no records kept), bytes one step moves
+ * for the owned cells by the storage's own count */
+int lbmpm_rk3d_storage_info(lbmpm_rk3d *ctx, int64_t *out);
 int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *ctx);
 int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *ctx);
 const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *ctx);

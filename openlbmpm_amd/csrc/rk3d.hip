@@ -1034,6 +1034,7 @@ struct lbmpm_rk3d {
     unsigned long long *pstart = nullptr;
     uint32_t *seg = nullptr, *seg2 = nullptr;        // 4 words per record
     std::vector<unsigned long long> h_pstart;
+    std::vector<uint8_t> h_rowpop;   // fluid cells per row segment [rows][nseg] (lbmpm_rk3d_storage_info)
     bool streamed = false;
     int variant = 0, tile = 0, chunk_len = 32, fill = 16;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL
     // planes next to each face that wait for the halo exchange (LBMPM_RK3D_BOUNDARY): plane 1 needs the neighbour's populations
@@ -1157,6 +1158,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
         hseg.assign(rows * ns * 4, 0u);
         hseg2.assign(rows * ns * 4, 0u);
         c->h_pstart.assign(c->nzl + 3, 0ull);
+        c->h_rowpop.assign(rows * ns, 0);
         unsigned long long total = 0;
         std::vector<unsigned long long> m((size_t)c->ny * ns);
         std::vector<unsigned> first((size_t)c->ny * ns);
@@ -1189,6 +1191,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
                     const size_t r = ((size_t)z * c->ny + y) * ns + sg;
                     const int sl = sg > 0 ? sg - 1 : ns - 1, sr = sg + 1 < ns ? sg + 1 : 0;
                     const unsigned long long ml = m[(size_t)y * ns + sl], mr = m[(size_t)y * ns + sr];
+                    c->h_rowpop[r] = (uint8_t)__builtin_popcountll(m[(size_t)y * ns + sg]);
                     hseg[r * 4 + 0] = (uint32_t)m[(size_t)y * ns + sg];
                     hseg[r * 4 + 1] = (uint32_t)(m[(size_t)y * ns + sg] >> 32);
                     hseg[r * 4 + 2] = first[(size_t)y * ns + sg];
@@ -1762,6 +1765,26 @@ extern "C" int lbmpm_rk3d_get_field(lbmpm_rk3d *c, int field, double *out)
                 const size_t s = (size_t)z * hp + (size_t)y * c->nx + x;
                 out[s] = c->h_domain[s] == 1 ? h[(size_t)(z + 1) * c->plane2 + (size_t)y * c->pitch + x] : 0.0;
             }
+    return LBMPM_OK;
+}
+
+// What the storage moves, by its own count (bench.py's "bytes moved" beside the algorithmic 608 B): out[0] doubles stored per fluid
+// cell, out[1] fluid cells of the owned planes, out[2] those of them in row segments that carry a single-colour flag instead of records
+// (q23 storage, rk3dq.h; 0 otherwise), out[3] bytes one time step reads + writes for the owned cells (rim / halo re-reads not counted).
+extern "C" int lbmpm_rk3d_storage_info(lbmpm_rk3d *c, int64_t *out)
+{
+    LBMPM_REQUIRE(c && out, "lbmpm_rk3d_storage_info: null argument");
+    out[0] = c->q23 ? QS : 2 * Q; out[1] = c->nfluid; out[2] = 0;
+    if (c->q23) {
+        LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+        LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> f((size_t)(c->nzl + 2) * c->ny * c->nseg);
+        LBMPM_HIP_TRY(hipMemcpy(f.data(), c->purA, f.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const size_t per = (size_t)c->ny * c->nseg;
+        for (size_t r = per; r < per * (size_t)(c->nzl + 1); ++r)
+            if (f[r] & 3u) out[2] += c->h_rowpop[r];
+    }
+    out[3] = c->q23 ? 2 * Q * 8 * out[1] + 64 * (out[1] - out[2]) : 2 * 2 * Q * 8 * out[1];
     return LBMPM_OK;
 }
 

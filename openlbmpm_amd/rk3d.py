@@ -157,6 +157,12 @@ class RK3DSlab:
         """device memory held by this context"""
         return int(self._L.lbmpm_rk3d_device_bytes(self._h))
 
+    def storage_info(self):
+        """what the storage keeps and moves, by its own count (lbmpm_rk3d_storage_info)"""
+        out = (C.c_int64 * 4)()
+        check(self._L.lbmpm_rk3d_storage_info(self._h, out), "lbmpm_rk3d_storage_info")
+        return dict(doubles_per_cell=int(out[0]), fluid_cells=int(out[1]), cells_in_flagged_rows=int(out[2]), bytes_per_step=int(out[3]))
+
     @property
     def steps_done(self):
         return int(self._L.lbmpm_rk3d_steps_done(self._h))

@@ -9,6 +9,14 @@ from ini_fixtures import write_rk, write_sc
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+
 def test_rk_driver_records_match_reference(tmp_path):
     from openlbmpm_amd.RKD2Q9 import RKColorGradientLBM
     from openlbmpm_amd.results import load_results
@@ -284,7 +292,7 @@ sim.runRKColorGradient3D()
 dist.destroy_process_group()
 ''' % (root, str(tmp_path), str(tmp_path / "out2")))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)], env=dict(os.environ), timeout=300)
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], env=dict(os.environ), timeout=300)
     single = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out1"), record_every=8)
     ref = load_results(single.runRKColorGradient3D())
     parts = []

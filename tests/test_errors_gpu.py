@@ -142,13 +142,13 @@ def test_device_memory_accounting():
         s.close()
     vox = porous_spheres(64, 32, 40, porosity=0.6, rmin=3.0, rmax=6.0, seed=1, nbuf=4)
     compact = RK3DSlab(vox, 0, 40)
-    assert compact.dominant_kernel == "rk3dc_fused"
+    assert compact.dominant_kernel == "rk3dq_fused"        # 23 doubles per fluid cell and buffer (csrc/rk3dq.h)
     os.environ["LBMPM_RK3D_LAYOUT"] = "dense"
     try:
         dense = RK3DSlab(vox, 0, 40)
     finally:
         del os.environ["LBMPM_RK3D_LAYOUT"]
-    assert 2 * 38 * 8 * compact.num_fluid_nodes <= compact.device_bytes < dense.device_bytes
+    assert 2 * 23 * 8 * compact.num_fluid_nodes <= compact.device_bytes < dense.device_bytes
     compact.close(); dense.close()
 
 

@@ -88,7 +88,7 @@ def test_rk3d_ragged(nx, ny, nz, relax):
         if nz < 4 * k:
             continue
         c = RK3DCluster(dom, k, par)
-        assert c.slabs[0].dominant_kernel == ("rk3dc_fused" if nx % 64 == 0 else "rk3d_fused")
+        assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if nx % 64 == 0 else "rk3d_fused")
         c.set_density(rR, rB)
         o = RK3DOracle(dom, rR, rB, par)
         c.step(7); o.run(7)

@@ -74,15 +74,18 @@ def test_kernel_schedules_agree_bitwise(env, monkeypatch):
     ref.close(); c.close()
 
 
+@pytest.mark.parametrize("storage", ["23", "38"])
 @pytest.mark.parametrize("relax", ["SRT", "MRT"])
-def test_compact_storage_vs_oracle(relax):
-    """nx a multiple of 64 selects the compact (fluid-cells-only) storage"""
+def test_compact_storage_vs_oracle(relax, storage, monkeypatch):
+    """nx a multiple of 64 selects the compact (fluid-cells-only) storage: by default 23 doubles per cell (rk3dq_fused: 19
+    colour-blind populations + k_R + the recolouring vector), with LBMPM_RK3D_STORAGE=38 both colour lattices (rk3dc_fused)"""
     from openlbmpm_amd.rk3d import RK3DCluster
     from oracle.rk3d import RK3DOracle
     dom, rR, rB = _case(nx=128, ny=21, nz=30, seed=5)
     par = dict(tauR=1.0, tauB=0.8, relax=relax)
+    monkeypatch.setenv("LBMPM_RK3D_STORAGE", storage)
     c = RK3DCluster(dom, 1, par)
-    assert c.slabs[0].dominant_kernel == "rk3dc_fused"
+    assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if storage == "23" else "rk3dc_fused")
     c.set_density(rR, rB)
     o = RK3DOracle(dom, rR, rB, par)
     for n in (1, 14):
@@ -99,8 +102,10 @@ def test_compact_storage_vs_oracle(relax):
                                    ({"LBMPM_RK3D_CHUNK": "7"}, 2)],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
 def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch):
+    """the 38-value compact storage is the dense layout with the solid cells left out: the same bits"""
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=64, ny=19, nz=41, seed=12)
+    monkeypatch.setenv("LBMPM_RK3D_STORAGE", "38")
     monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")
     ref = RK3DCluster(dom, 1)
     assert ref.slabs[0].dominant_kernel == "rk3d_fused"
@@ -122,10 +127,11 @@ def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch):
                                    ({}, 3), ({"LBMPM_RK3D_TILE": "1", "LBMPM_RK3D_CHUNK": "6"}, 2)],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
 def test_mrt_schedules_agree_bitwise(env, k, monkeypatch):
-    """MRT relaxation: dense / compact storage, split sweeps, slab decomposition -- one arithmetic"""
+    """MRT relaxation: dense / compact (38-value) storage, split sweeps, slab decomposition -- one arithmetic"""
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=64, ny=19, nz=41, seed=12)
     par = dict(relax="MRT", tauR=0.9, tauB=0.7)
+    monkeypatch.setenv("LBMPM_RK3D_STORAGE", "38")
     ref = RK3DCluster(dom, 1, par)
     ref.set_density(rR, rB)
     ref.step(11); ref.observe()
@@ -136,6 +142,55 @@ def test_mrt_schedules_agree_bitwise(env, k, monkeypatch):
     c.step(11); c.observe()
     for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz"):
         assert np.array_equal(ref.get(f), c.get(f)), f
+    ref.close(); c.close()
+
+
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+def test_q23_storage_equals_the_38_value_kernels_to_roundoff(relax, monkeypatch):
+    """rk3dq_fused stores 19 colour-blind populations + k_R + A per cell and rebuilds the colours while pulling: the same step as
+    rk3dc_fused, different rounding.  Both colours present in every cell (no single-colour shortcut anywhere), 30 steps."""
+    from openlbmpm_amd.rk3d import RK3DCluster
+    dom, _, _ = _case(nx=128, ny=24, nz=40, seed=21)
+    rng = np.random.default_rng(3)
+    w = 0.2 + 0.6 * rng.random(dom.shape)
+    rR = np.where(dom == 1, w, 0.0); rB = np.where(dom == 1, 1.0 - w, 0.0)
+    par = dict(relax=relax, tauR=0.9, tauB=0.75)
+    out = []
+    for storage in ("23", "38"):
+        monkeypatch.setenv("LBMPM_RK3D_STORAGE", storage)
+        c = RK3DCluster(dom, 1, par)
+        assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if storage == "23" else "rk3dc_fused")
+        c.set_density(rR, rB)
+        c.step(30); c.observe()
+        out.append({f: c.get(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz")})
+        c.close()
+    umax = max(float(np.max(np.abs(out[1][f]))) for f in ("vx", "vy", "vz"))
+    for f in out[0]:
+        assert rel_err(out[0][f], out[1][f], scale=umax if f[0] == "v" else None) < 1e-11, f
+
+
+@pytest.mark.parametrize("env,k", [({}, 2), ({}, 3), ({}, 5), ({"LBMPM_RK3D_BOUNDARY": "4"}, 3), ({"LBMPM_RK3D_CHUNK": "7"}, 2)],
+                         ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+def test_q23_slabs_equal_single_domain_bitwise(relax, env, k, monkeypatch):
+    """q23 storage, k virtual ranks: ONE face message per cut and step (populations, records, row flags and the class sums from which
+    the neighbour completes the phase field of its halo plane) -- the same bits as the single domain, mixed and single-colour
+    regions alike (the initial state is red below a blue buffer: most row segments carry a flag instead of records)"""
+    from openlbmpm_amd.rk3d import RK3DCluster
+    dom, rR, rB = _case(nx=128, ny=21, nz=38, seed=5)
+    par = dict(relax=relax, tauR=0.9, tauB=0.7)
+    ref = RK3DCluster(dom, 1, par)
+    assert ref.slabs[0].dominant_kernel == "rk3dq_fused"
+    ref.set_density(rR, rB)
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    c = RK3DCluster(dom, k, par)
+    assert c.slabs[0].dominant_kernel == "rk3dq_fused" and c.slabs[0].one_exchange
+    c.set_density(rR, rB)
+    for n in (1, 12):
+        ref.step(n); ref.observe(); c.step(n); c.observe()
+        for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz"):
+            assert np.array_equal(ref.get(f), c.get(f)), (f, n)
     ref.close(); c.close()
 
 
@@ -175,7 +230,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _two_rank_run(tmp_path, backend, same_gpu):
+def _two_rank_run(tmp_path, backend, same_gpu, nx=33):
     """two OS processes through RK3DDistributed (one lbmpm_rk3d_step_slab call for all steps, the exchanges as
     callbacks); returns the gathered fields and the per-rank timing dicts"""
     import json
@@ -197,7 +252,7 @@ if %r == "nccl":
     dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 else:
     dist.init_process_group("gloo")
-dom, rR, rB = _case(nx=33, ny=18, nz=41, seed=9)
+dom, rR, rB = _case(nx=int(os.environ["LBMPM_TEST_NX"]), ny=18, nz=41, seed=9)
 d = RK3DDistributed(dom, device=dev)
 d.set_density(rR, rB)
 d.step(9); d.step(6, timed=True)
@@ -210,14 +265,14 @@ d.close(); dist.destroy_process_group()
 ''' % (root, root, same_gpu, backend, str(tmp_path), str(tmp_path), str(tmp_path)))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
-                          env=dict(os.environ), timeout=300)
+                          env=dict(os.environ, LBMPM_TEST_NX=str(nx)), timeout=300)
     fields = {f: np.concatenate([np.load(tmp_path / ("%s_%d.npy" % (f, r))) for r in range(2)], axis=0) for f in ("phi", "vz")}
     return fields, [json.load(open(tmp_path / ("t_%d.json" % r))) for r in range(2)]
 
 
-def _single_process_reference():
+def _single_process_reference(nx=33):
     from openlbmpm_amd.rk3d import RK3DCluster
-    dom, rR, rB = _case(nx=33, ny=18, nz=41, seed=9)
+    dom, rR, rB = _case(nx=nx, ny=18, nz=41, seed=9)
     c = RK3DCluster(dom, 1)
     c.set_density(rR, rB)
     c.step(15); c.observe()
@@ -226,12 +281,14 @@ def _single_process_reference():
     return ref
 
 
-def test_two_process_slab_run_equals_single_process(tmp_path):
+@pytest.mark.parametrize("nx", [33, 64], ids=["dense-two-exchanges", "q23-one-exchange"])
+def test_two_process_slab_run_equals_single_process(tmp_path, nx):
     """The N>1 orchestration of bench.py / RK3DDistributed with two OS processes sharing this one
     GPU (gloo transport staged through the host, because RCCL refuses duplicate devices): the
-    gathered result must equal the single-process run bit for bit; the per-phase timing is filled in."""
-    got, timing = _two_rank_run(tmp_path, "gloo", same_gpu=True)
-    ref = _single_process_reference()
+    gathered result must equal the single-process run bit for bit; the per-phase timing is filled in.
+    nx = 64: the bench's storage -- boundary planes first, ONE face exchange beside the interior planes (lbmpm_rk3d_step_slab)."""
+    got, timing = _two_rank_run(tmp_path, "gloo", same_gpu=True, nx=nx)
+    ref = _single_process_reference(nx)
     for f in ref:
         assert np.array_equal(got[f], ref[f]), f
     for t in timing:
@@ -244,8 +301,8 @@ def test_two_gpu_rccl_slab_run_equals_single_process(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("RCCL refuses two ranks on one device: needs >= 2 GPUs")
-    got, timing = _two_rank_run(tmp_path, "nccl", same_gpu=False)
-    ref = _single_process_reference()
+    got, timing = _two_rank_run(tmp_path, "nccl", same_gpu=False, nx=64)
+    ref = _single_process_reference(64)
     for f in ref:
         assert np.array_equal(got[f], ref[f]), f
     assert all(t["backend"] == "nccl" and t["world"] == 2 for t in timing)
@@ -272,7 +329,31 @@ def test_bench_line_of_a_two_rank_run(tmp_path):
     assert [r["rank"] for r in m["per_rank"]] == [0, 1]
     for r in m["per_rank"]:
         assert r["steps"] == 6 and r["step_ms"] > 0 and r["interior_ms"] > 0 and r["boundary_ms"] > 0 and r["bytes_per_face"] > 0
-        assert abs(r["exchange_exposed_ms"] - (r["step_ms"] - max(r["interior_ms"], r["boundary_ms"]))) < 1e-4
+        assert r["schedule"].startswith("boundary planes -> one face exchange")       # 128^3: the q23 storage
+        assert 0.0 <= r["exchange_exposed_ms"] <= r["step_ms"]
     planes = [r["planes"] for r in m["per_rank"]]
     assert planes[0][0] == 0 and planes[0][1] == planes[1][0] and planes[1][1] == 128
     assert sum(r["fluid_nodes"] for r in m["per_rank"]) == d["config"]["fluid_nodes"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (the form the round-end driver runs): bench.py starts the two ranks itself and
+    rank 0 prints one line with n_gpus 2 (gloo rehearsal transport on this one GPU); on the real transport it refuses a node
+    with fewer GPUs than ranks instead of quietly running one"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--size", "128", "128", "128"],
+                         env=dict(env, LBMPM_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["multi_gpu"]["world_size"] == 2 and d["windows"]["count"] == 5
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "one rank per GPU" in (out.stderr + out.stdout)

@@ -129,8 +129,9 @@ def test_oracle3d_default_weights_equal_the_pinned_2d_oracle(name):
     ("srt_capillary", 4, {}),                                  # dense storage, fused z-marching kernel (rk3d_fused)
     ("srt_porous", 5, {}),
     ("srt_porous", 8, {"LBMPM_RK3D_VARIANT": "1"}),            # split schedule (rk3d_phase_field + rk3d_collide)
-    ("srt_porous64", 8, {}),                                   # nx = 64: compact storage, rk3dc_fused (the bench kernel)
+    ("srt_porous64", 8, {}),                                   # nx = 64: compact storage of 23 values, rk3dq_fused (the bench kernel)
     ("srt_porous64", 11, {"LBMPM_RK3D_CHUNK": "7"}),           # ... cut tiles, several chunks per column
+    ("srt_porous64", 8, {"LBMPM_RK3D_STORAGE": "38"}),         # compact storage of both colour lattices, rk3dc_fused
 ], ids=lambda v: v if isinstance(v, str) else (str(v) if isinstance(v, int) else ",".join("%s=%s" % (k[11:], x) for k, x in v.items()) or "default"))
 def test_hip_reproduces_the_reference_2d_driver(name, ny, env, monkeypatch):
     """y-uniform D3Q19 lattice through the C ABI == captures of the real D2Q9 perturbation driver, every snapshot"""
@@ -140,8 +141,8 @@ def test_hip_reproduces_the_reference_2d_driver(name, ny, env, monkeypatch):
     d, dom2, par2, par3 = scenario(name)
     dom3 = extrude(dom2, ny)
     c = RK3DCluster(dom3, 1, dict(par3, **RC_EXACT))
-    if name == "srt_porous64" :
-        assert c.slabs[0].dominant_kernel == "rk3dc_fused"
+    if name == "srt_porous64":
+        assert c.slabs[0].dominant_kernel == ("rk3dc_fused" if env.get("LBMPM_RK3D_STORAGE") == "38" else "rk3dq_fused")
     c.set_density(extrude(dense2(d, d["init_rhoR"]), ny), extrude(dense2(d, d["init_rhoB"]), ny))
     done, worst = 0, 0.0
     for k in d["snaps"]:

@@ -4,14 +4,14 @@ tools/rocprof_summary.py --pmc (separate rocprofv3 passes).
 
 traffic = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): the x2 on FETCH_SIZE is the gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md (HBM section), calibrated there on 16-byte-per-lane streaming
-reads; rk3dc_fused reads 16 B per lane, the 2-D kernels read 8 B per lane (their read side is an
-upper estimate).  WRITE_SIZE is taken as reported (it matches the algorithmic write bytes of
+reads; rk3dc_fused reads 16 B per lane, rk3dq_fused and the 2-D kernels read 8 B per lane (their read side is
+an upper estimate).  WRITE_SIZE is taken as reported (it matches the algorithmic write bytes of
 these kernels to within 2 %)."""
 import json
 import re
 import sys
 
-WORKLOADS = {"rk3dc_fused": "c5 512x512x512", "rk3d_fused": "c5 512x512x512", "rk3d_collide": "c5 512x512x512",
+WORKLOADS = {"rk3dq_fused": "c5 512x512x512", "rk3dc_fused": "c5 512x512x512", "rk3d_fused": "c5 512x512x512", "rk3d_collide": "c5 512x512x512",
              "rk3d_phase_field": "c5 512x512x512", "rk2d_fused": None, "sc2d_fused": "c3 2048x2048"}
 
 
@@ -25,7 +25,7 @@ def parse(path, counter):
 
 
 def short(name):
-    m = re.search(r"(rk3dc?_\w+|rk2d_\w+|sc2d_\w+)", name)
+    m = re.search(r"(rk3d[cq]?_\w+|rk2d_\w+|sc2d_\w+)", name)
     return m.group(1) if m else name
 
 
@@ -45,7 +45,7 @@ def main():
         if k == "sc2d_fused" and "sc2d_fused<false>" in name:      # SRT instance = the 128 x 128 droplet of configs[0]
             rec["workload"] = "c1 128x128"
             k = "sc2d_fused[c1]"
-        m3 = re.search(r"rk3dc?_fused<([^>]*)>", name)
+        m3 = re.search(r"rk3d[cq]?_fused<([^>]*)>", name)
         if m3:                            # <.., FIRST, MRT>: first-step instances carry one launch; SRT is the secondary entry
             targs = [t.strip() for t in m3.group(1).split(",")]
             if targs[-2] == "true":
