@@ -276,7 +276,9 @@ int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
  * is the D3Q19 extension of the 2-D kernels AcceleratedRKGPU2D.py:1125 (BGK), :1169
  * (gradient + perturbation + recolouring), :657/:1008 (Zou-He per colour), :607/:1045 (ghost
  * planes), :340/:409 (streaming).  Pinned by reduction to that 2-D loop
- * (tests/test_rk3d_reduction.py).
+ * (tests/test_rk3d_reduction.py) -- as repaired: the reference's runRKColorGradient2DPerturbation stops at
+ * its first inlet launch, the captures come from it with four call-site repairs (tests/golden/gen/make_golden_rk_pert.py),
+ * one of which (R3) moves calTotalFluidPDF behind collision 1 and so changes the loop's numbers.
  * A context owns the planes [z_offset, z_offset + nz_local) of a global lattice of
  * nz_global planes plus one halo plane on each side.  One time step of a slab is
  *     pack_halo -> [caller moves F_SEND_* to the neighbours' F_RECV_*] -> unpack_halo

@@ -92,7 +92,8 @@ class RKColorGradient3D:
             self.z0, self.nzl = 0, self.zDomain
         out = ResultFile(self.output_dir, name, (("FluidMacro", "MacroData"), ("FluidVelocity", "MacroVelocity")))
         self.result_path = out.path
-        self._guard = RecordGuard("rk3d", slab.num_fluid_nodes, getattr(self, "nan_guard", "raise"))
+        # distributed: every rank checks its own slab, the verdict is collective (all ranks raise together, none is left in an exchange)
+        self._guard = RecordGuard("rk3d", slab.num_fluid_nodes, getattr(self, "nan_guard", "raise"), collective=self._distributed())
         done = 0
         while done < self.timeSteps:
             self._step_now = done

@@ -108,6 +108,13 @@ def read_rk2d(ini_dir):
     p["rhoRL"] = c.float("BoundaryCondition", "densityRL", default=1.0)
     p["cycle"] = c.str("CyclesSetup", "IsCycle", default="'no'") == "yes"
     p["last_step"] = c.int("CyclesSetup", "LastStep", default=0)
+    if p["tension_type"] == "Perturbation":
+        # the perturbation driver does not go through RK2DSolver's checks; a misspelt value must not pick a physics path silently
+        # (the reference's own outlet switch is if / elif without else: any other value would run with NO outlet rule, RKD2Q9.py:1064-1088)
+        for key, allowed in (("relax", ("SRT", "MRT")), ("inlet", ("Neumann", "Dirichlet")), ("outlet", ("Convective", "Dirichlet"))):
+            if p[key] not in allowed:
+                raise ConfigError("SurfaceTensionType 'Perturbation': %s must be one of %s, got %r"
+                                  % ({"relax": "[RelaxationType] Type", "inlet": "BoundaryTypeInlet", "outlet": "BoundaryTypeOutlet"}[key], allowed, p[key]))
     return p
 
 

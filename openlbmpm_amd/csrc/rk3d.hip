@@ -6,7 +6,15 @@
 // of the reference's 2-D kernels, operator by operator (list + citations in
 // oracle/rk3d_oracle.c and DESIGN.md).  Pinned to the reference by reduction: a y-uniform lattice through
 // these kernels reproduces the captures of the reference's real D2Q9 perturbation driver (RKD2Q9.py:978-1223)
-// to 3e-13 (tests/test_rk3d_reduction.py), and pinned in full 3-D against oracle/rk3d_oracle.c.
+// to 3e-13 (tests/test_rk3d_reduction.py), and pinned in full 3-D against oracle/rk3d_oracle.c.  That driver
+// does not run as shipped; the captures come from it with four call-site repairs listed in every fixture
+// (tests/golden/gen/make_golden_rk_pert.py).  Three pad or drop arguments; R3 MOVES calTotalFluidPDF from
+// right after streaming (RKD2Q9.py:1065, where the SRT branch would collide a total that the boundary kernels
+// have not touched yet) to after collision 1, which changes the numbers the loop produces: the pin is to that
+// repaired loop, not to an executable original.
+//
+// Storage of the populations (compact layout): rk3dq.h keeps 19 colour-blind populations + k_R + the recolouring
+// vector per cell (the default), the kernels below both colour lattices (LBMPM_RK3D_STORAGE=38, the cross-check).
 //
 // Two storage layouts per rank (zl = 0..nzl+1: owned planes 1..nzl + one halo plane on each side that
 // holds the neighbour rank's outermost plane; only the five populations that cross the cut are

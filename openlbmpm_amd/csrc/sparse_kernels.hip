@@ -93,6 +93,15 @@ __device__ __forceinline__ i64 find_node(const i64 *fluidNodes, i64 N, i64 loc)
     return (lo < N && fluidNodes[lo] == loc) ? lo : -1;
 }
 // the thread's node on grid row `row` (one thread per column), or -1
+// The reference's boundary-row kernels index populations and densities with a neighbour id taken from the table unlooked-at; for a
+// solid neighbour the id is negative (-1, or -2 - w for a wetting solid) and numba indexes like Python: a[-1] is the LAST node.  The
+// same here (an image geometry without all-fluid rows next to the inlet / outlet rows gets there); an id that stays negative after
+// the wrap is out of bounds in the reference as well: node 0.
+__device__ __forceinline__ i64 nbr_node(i64 id, i64 N)
+{
+    if (id < 0) id += N;
+    return id < 0 ? 0 : id;
+}
 __device__ __forceinline__ i64 row_node(const i64 *fluidNodes, i64 N, i64 nx, i64 row)
 {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -763,7 +772,7 @@ __global__ void k_rk_ghost_inlet_velocity(i64 N, i64 nx, i64 ny, const i64 *flui
 {
     const i64 n = row_node(fluidNodes, N, nx, ny - 1);
     if (n < 0) return;
-    const i64 L = nbr[8 * n + 3];
+    const i64 L = nbr_node(nbr[8 * n + 3], N);
     double *r = fR + 9 * n, *b = fB + 9 * n;
     for (int i = 0; i < 9; ++i) r[i] = fR[9 * L + i];
     rhoR[n] = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8];
@@ -800,7 +809,7 @@ __global__ void k_rk_ghost_inlet_pressure(i64 N, i64 nx, i64 ny, const i64 *flui
 {
     const i64 n = row_node(fluidNodes, N, nx, ny - 1);
     if (n < 0) return;
-    const i64 H = nbr[8 * n + 3];
+    const i64 H = nbr_node(nbr[8 * n + 3], N);
     for (int i = 0; i < 9; ++i) { fR[9 * n + i] = fR[9 * H + i]; fB[9 * n + i] = fB[9 * H + i]; }
     rhoR[n] = rhoR[H]; rhoB[n] = rhoB[H];
 }
@@ -864,7 +873,7 @@ __global__ void k_rk_ghost_outlet_pressure(i64 N, i64 nx, const i64 *fluidNodes,
     if (by_grid) n = row_node(fluidNodes, N, nx, 0);
     else { n = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (n >= nx || n >= N) n = -1; }
     if (n < 0) return;
-    const i64 L = nbr[8 * n + 1];
+    const i64 L = nbr_node(nbr[8 * n + 1], N);
     for (int i = 0; i < 9; ++i) { fR[9 * n + i] = fR[9 * L + i]; fB[9 * n + i] = fB[9 * L + i]; }
     rhoR[n] = rhoR[L]; rhoB[n] = rhoB[L];
 }
@@ -883,7 +892,7 @@ __global__ void k_rk_outlet_convective_row(i64 N, i64 nx, i64 row, const i64 *fl
     const i64 n = row_node(fluidNodes, N, nx, row);
     if (n < 0) return;
     double r, b;
-    copy_node2(fR, fB, n, nbr[8 * n + 1], r, b);
+    copy_node2(fR, fB, n, nbr_node(nbr[8 * n + 1], N), r, b);
     rhoR[n] = r; rhoB[n] = b;
 }
 static inline void launch_rk_outlet_convective_row(hipStream_t st, i64 N, i64 nx, i64 row, const i64 *fluidNodes, const i64 *nbr, double *fR, double *fB,
@@ -900,9 +909,9 @@ __global__ void k_rk_outlet_average_row(i64 N, i64 nx, i64 row, const i64 *fluid
 {
     const i64 n = row_node(fluidNodes, N, nx, row);
     if (n < 0) return;
-    const i64 q1 = nbr[8 * n + 1];
+    const i64 q1 = nbr_node(nbr[8 * n + 1], N);
     i64 q = q1;                                  // the node on row 3 of this column
-    for (i64 h = row; h < 2; ++h) q = nbr[8 * q + 1];
+    for (i64 h = row; h < 2; ++h) q = nbr_node(nbr[8 * q + 1], N);
     const double v = fabs(vn[q]);
     for (int j = 0; j < 9; ++j) {
         fR[9 * n + j] = (fROld[9 * n + j] + v * fR[9 * q1 + j]) / (1. + v);
@@ -944,7 +953,7 @@ __global__ void k_rk_inlet_velocity_red(i64 N, i64 nx, i64 ny, double vyR, const
     if (n < 0) return;
     rhoR[n] = zouhe_velocity_top(fR + 9 * n, vyR);
     if (!blue) return;
-    const i64 up = nbr[8 * n + 1];
+    const i64 up = nbr_node(nbr[8 * n + 1], N);
     fB[9 * n + 4] = fB[9 * up + 2];
     const i64 q7 = nbr[8 * up], q8 = nbr[8 * up + 2];
     if (q7 >= 0) fB[9 * n + 7] = fB[9 * q7 + 5];

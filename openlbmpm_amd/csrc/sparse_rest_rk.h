@@ -182,7 +182,7 @@ __global__ void k_rk_neumann_phi_outlet(i64 N, i64 nx, const i64 *fluidNodes, co
 {
     const i64 n = row_node(fluidNodes, N, nx, 1);
     if (n < 0) return;
-    const i64 up = nbr[8 * n + 1], lo = nbr[8 * n + 3];
+    const i64 up = nbr_node(nbr[8 * n + 1], N), lo = nbr_node(nbr[8 * n + 3], N);
     phi[n] = phi[up];
     phi[lo] = phi[up];
 }

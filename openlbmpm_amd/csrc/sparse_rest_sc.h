@@ -403,7 +403,7 @@ __global__ void k_sc_freeflow_row(i64 N, i64 nx, i64 row, const i64 *fluidNodes,
 {
     const i64 n = row_node(fluidNodes, N, nx, row);
     if (n < 0) return;
-    const i64 q = nbr[8 * n + 1];
+    const i64 q = nbr_node(nbr[8 * n + 1], N);
     for (int k = 0; k < NF; ++k) {
         double *g = COMP(f, k, 9), *a = COMP(ff, k, 9), *b = COMP(feq, k, 9);
         double r = 0.;

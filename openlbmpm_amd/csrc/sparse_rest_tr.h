@@ -183,7 +183,7 @@ __global__ void k_tr_free_row(i64 N, int nT, i64 nx, i64 row, const i64 *fluidNo
 {
     const i64 n = row_node(fluidNodes, N, nx, row);
     if (n < 0) return;
-    const i64 q = nbr[4 * n + 2];
+    const i64 q = nbr_node(nbr[4 * n + 2], N);
     for (int t = 0; t < nT; ++t)
         for (int j = 0; j < 5; ++j) COMP(g, t, 5)[5 * n + j] = COMP(g, t, 5)[5 * q + j];
 }
@@ -197,7 +197,7 @@ __global__ void k_tr_zero_gradient_inlet(i64 N, int nT, i64 nx, i64 ny, const i6
 {
     const i64 n = row_node(fluidNodes, N, nx, ny - 2);
     if (n < 0) return;
-    const i64 q = nbr[4 * n + 3];
+    const i64 q = nbr_node(nbr[4 * n + 3], N);
     for (int t = 0; t < nT; ++t) {
         double c = 0.;
         for (int j = 0; j < 5; ++j) {
@@ -270,7 +270,7 @@ __global__ void k_tr_anti_bounce_inlet(i64 N, int nT, i64 ny, i64 nx, const i64 
 {
     const i64 n = row_node(fluidNodes, N, nx, ny - 2);
     if (n < 0) return;
-    const i64 up = nbr[4 * n + 2];
+    const i64 up = nbr_node(nbr[4 * n + 2], N);
     for (int t = 0; t < nT; ++t) COMP(g, t, 5)[5 * up + 4] = -COMP(g, t, 5)[5 * n + 3] + 2. * w[3] * cb[t];
 }
 static inline void launch_tr_anti_bounce_inlet(hipStream_t st, i64 N, int nT, i64 ny, i64 nx, const i64 *fluidNodes, const i64 *nbr, const double *cb,

@@ -112,7 +112,7 @@ __global__ void k_sc_ghost_row(i64 N, i64 nx, i64 row, int which, const i64 *flu
 {
     const i64 n = row_node(fluidNodes, N, nx, row);
     if (n < 0) return;
-    const i64 q = nbr[8 * n + which];
+    const i64 q = nbr_node(nbr[8 * n + which], N);
     for (int k = 0; k < NF; ++k) {
         double *g = COMP(f, k, 9) + 9 * n;
         const double *s = COMP(f, k, 9) + 9 * q;
@@ -155,7 +155,7 @@ __global__ void k_sc_outlet_copy_row(i64 N, i64 nx, i64 row, const i64 *fluidNod
 {
     const i64 n = row_node(fluidNodes, N, nx, row);
     if (n < 0) return;
-    const i64 q = nbr[8 * n + 1];
+    const i64 q = nbr_node(nbr[8 * n + 1], N);
     for (int k = 0; k < NF; ++k) {
         double r = 0.;
         for (int j = 0; j < 9; ++j) { const double v = COMP(f, k, 9)[9 * q + j]; COMP(f, k, 9)[9 * n + j] = v; r += v; }
@@ -171,9 +171,9 @@ __global__ void k_sc_outlet_convective_row(i64 N, i64 nx, i64 row, const i64 *fl
 {
     const i64 n = row_node(fluidNodes, N, nx, row);
     if (n < 0) return;
-    const i64 q1 = nbr[8 * n + 1];
+    const i64 q1 = nbr_node(nbr[8 * n + 1], N);
     i64 q = q1;                                  // the node on row 3 of this column
-    for (i64 h = row; h < 2; ++h) q = nbr[8 * q + 1];
+    for (i64 h = row; h < 2; ++h) q = nbr_node(nbr[8 * q + 1], N);
     const double v = fabs(vy[q]);
     for (int k = 0; k < NF; ++k) {
         double r = 0.;
@@ -624,7 +624,7 @@ __global__ void k_tr_free_outlet(i64 N, int nT, i64 nx, const i64 *fluidNodes, c
 {
     const i64 n = row_node(fluidNodes, N, nx, 0);
     if (n < 0) return;
-    const i64 q = nbr[4 * n + 2];
+    const i64 q = nbr_node(nbr[4 * n + 2], N);
     for (int t = 0; t < nT; ++t)
         for (int j = 0; j < 5; ++j) COMP(g, t, 5)[5 * n + j] = COMP(g, t, 5)[5 * q + j];
 }

@@ -125,7 +125,10 @@ class RecordGuard:
     (logger 'openlbmpm_amd', level INFO) with the record index, the step, lattice updates per second since the last
     record and the sums the caller passes (masses, saturation)."""
 
-    def __init__(self, name, fluid_nodes, nan_guard="raise"):
+    def __init__(self, name, fluid_nodes, nan_guard="raise", group=None, collective=False):
+        """collective: the run is distributed (one slab per process) -- the verdict of a record is then agreed on by all ranks
+        (one MAX all-reduce of a flag over `group`) before anyone raises: a rank that raised alone would leave its neighbours
+        waiting in the next halo exchange until the transport's watchdog fires"""
         import logging
         import time
         self.name, self.fluid_nodes = name, int(fluid_nodes)
@@ -134,18 +137,36 @@ class RecordGuard:
             raise ValueError("nan_guard must be 'raise', 'warn' or 'off'")
         self.log = logging.getLogger("openlbmpm_amd")
         self._clock, self._t, self._step = time.perf_counter, time.perf_counter(), 0
+        self.group, self.collective = group, bool(collective)
+
+    def _anyone_bad(self, bad):
+        """MAX over the ranks of this rank's 'a field is not finite' flag"""
+        if not self.collective:
+            return bad
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return bad
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
 
     def __call__(self, record, step, fields, sums=None):
         if self.mode != "off":
+            msg = None
             for key, a in fields.items():
                 if not np.isfinite(a).all():
                     bad = int(a.size - np.isfinite(a).sum())
                     msg = "%s: record %d (step %d): %s holds %d non-finite values" % (self.name, record, step, key, bad)
-                    if self.mode == "raise":
-                        raise SimulationDiverged(msg)
-                    import warnings
-                    warnings.warn(msg)
                     break
+            if self._anyone_bad(msg is not None):
+                if msg is None:
+                    msg = "%s: record %d (step %d): another rank's slab holds non-finite values" % (self.name, record, step)
+                if self.mode == "raise":
+                    raise SimulationDiverged(msg)
+                import warnings
+                warnings.warn(msg)
         now = self._clock()
         rate = (step - self._step) * self.fluid_nodes / max(now - self._t, 1e-12) / 1e6 if step > self._step else 0.0
         self._t, self._step = now, step

@@ -128,6 +128,25 @@ def rk_cases():
                                       gradientY=s2["gradientY"]))
     c.run("calPhysicalVelocityRKGPU2DVNew", T)
     c.run("calMacroDensityRKGPU2DNew", dict(T, fluidRhoR=np.zeros(N), fluidRhoB=np.zeros(N)))
+    # Boundary rows next to a SOLID cell (an image geometry without all-fluid rows beside the inlet / outlet rows): these kernels index
+    # with the neighbour id unlooked-at, and numba wraps the -1 of a solid neighbour like Python does -- the LAST node.
+    dom2 = dom.copy(); dom2[1, 4] = 0; dom2[ny - 2, 9] = 0; dom2[2, 8] = 0
+    fn2 = np.flatnonzero(dom2.reshape(-1) == 1).astype(np.int64)
+    ni2 = -np.ones(ny * nx, dtype=np.int64); ni2[fn2] = np.arange(fn2.size)
+    N2 = fn2.size
+    nbr2 = np.zeros(8 * N2, dtype=np.int64)
+    A.fillNeighboringNodes[(2, -(-N2 // 64)), (32, 1)](N2, nx, ny, 64, fn2, ni2.reshape(ny, nx), nbr2)
+    for k, loc in enumerate(fn2):
+        i, j = divmod(int(loc), nx)
+        for d in range(8):
+            if dom2[(i + dy[d]) % ny, (j + dx[d]) % nx] != 1:
+                nbr2[8 * k + d] = -1
+    f2R = rng.uniform(0.01, 0.2, (N2, 9)); f2B = rng.uniform(0.01, 0.2, (N2, 9))
+    T2 = dict(T, totalNodes=N2, fluidNodes=fn2, neighboringNodes=nbr2, fluidPDFR=f2R, fluidPDFB=f2B, fluidRhoR=f2R.sum(axis=1), fluidRhoB=f2B.sum(axis=1),
+              fluidPDFROld=rng.uniform(0., 1., (N2, 9)), fluidPDFBOld=rng.uniform(0., 1., (N2, 9)))
+    for kern in ("ghostPointsConstPressureLowerRK", "ghostPointsConstantVelocityRK", "ghostPointsConstPressureInletRK", "convectiveOutletGPU",
+                 "convectiveOutletGhost2GPU", "convectiveOutletGhost3GPU"):
+        c.run(kern, T2, case=kern + "#solid_neighbour")
     c.save()
 
 

@@ -26,6 +26,13 @@ def test_rk_ini_errors(tmp_path):
     open(path, "w").write(text.replace("'CSF'", "'Perturbation'", 1))       # read: runRKColorGradient2DPerturbation runs that loop
     q = config.read_rk2d(str(tmp_path))
     assert q["tension_type"] == "Perturbation" and q["AkR"] == 0.14 and q["solidPhi"] == 0.5
+    # the perturbation loop has no solver-side validation behind it: a misspelt relaxation / inlet / outlet is refused by the reader
+    pert = text.replace("'CSF'", "'Perturbation'", 1)
+    for good, typo in (("'MRT'", "'TRT'"), ("'Neumann'", "'Neuman'"), ("'Dirichlet'", "'Dirichlett'")):
+        assert good in pert
+        open(path, "w").write(pert.replace(good, typo, 1))
+        with pytest.raises(config.ConfigError):
+            config.read_rk2d(str(tmp_path))
     open(path, "w").write(text.replace("'CSF'", "'Level-set'", 1))
     with pytest.raises(config.ConfigError):
         config.read_rk2d(str(tmp_path))

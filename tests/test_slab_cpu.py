@@ -107,3 +107,42 @@ def test_balanced_partition_equalises_fluid_cells():
     assert all(w[z0:z0 + n].sum() > 0 for z0, n in parts)
     with pytest.raises(ValueError):
         partition_z_balanced(np.ones(7), 4)
+
+
+def _guard_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openlbmpm_amd.results import RecordGuard, SimulationDiverged
+        g = RecordGuard("rk3d", 100, "raise", collective=True)
+        a = np.ones(8)
+        g(0, 0, dict(rhoR=a))                     # every slab finite: nobody raises
+        bad = a.copy()
+        if rank == 1:
+            bad[3] = np.nan                       # ONE rank's slab diverges
+        try:
+            g(1, 8, dict(rhoR=bad))
+            q.put((rank, "no exception"))
+        except SimulationDiverged as e:
+            q.put((rank, "own" if "rhoR holds 1" in str(e) else ("other" if "another rank" in str(e) else str(e))))
+        dist.barrier()                            # all ranks are still in step: the next collective completes
+    finally:
+        dist.destroy_process_group()
+
+
+def test_record_guard_verdict_is_collective():
+    """a NaN in one rank's slab makes EVERY rank raise at that record (one MAX all-reduce of a flag): a rank that raised alone would
+    leave its neighbours hanging in the next halo exchange"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == {0: "other", 1: "own", 2: "other"}
