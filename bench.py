@@ -416,9 +416,11 @@ def main():
                                 "roofline_frac": round(B_ALG[name] * nf / (md / k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
                     if name == "c1":
                         sec[-1]["note"] = ("configs[0] on the GPU: 64 workgroups, bound by the kernel's own latency chain (hipGraph replay of 64 steps "
-                                           "removes the launch gaps); the static-droplet Laplace check of configs[0] is not attempted -- with the "
-                                           "reference's kernel and shanchen2D.ini parameters the droplet drifts (tests/test_c1_droplet_gpu.py); "
-                                           "Laplace's law is held for the explicit-forcing and both colour-gradient models (tests/test_physics_gpu.py)")
+                                           "removes the launch gaps).  The static-droplet Laplace test: with shanchen2D.ini's interactionFluid = 3.8 the "
+                                           "pinned original Shan-Chen kernel holds no static droplet in the periodic 128 x 128 box (radius 26 is gone within "
+                                           "500 steps, radius 20 leaves the centre and shows no pressure jump after 10^4: tests/test_oracle_sc.py); at G = 2.6, "
+                                           "the nearest coupling at which it stays put, three radii over 10^4 steps give dp * R within +-5 % of each other on the "
+                                           "CPU oracle and on this kernel (tests/test_c1_droplet_gpu.py); this line times the ini's own parameters")
                     s.close()
                 # the other relaxation of the same 3-D workload (the shipped ini says 'SRT', BASELINE.json names MRT)
                 other = "SRT" if args.relax == "MRT" else "MRT"

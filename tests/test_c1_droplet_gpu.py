@@ -57,3 +57,27 @@ def test_droplet_stays_a_droplet_and_conserves_both_components():
     assert abs(a.sum() - r0.sum()) / r0.sum() < 1e-11 and abs(b.sum() - r1.sum()) / r1.sum() < 1e-11
     area0, area = np.count_nonzero(r0 > 0.5), np.count_nonzero(a > 0.5)      # the droplet drifts: no fixed probe points
     assert a.max() > 0.9 and b.max() > 0.9 and 0.5 * area0 < area < 1.5 * area0
+
+
+def test_laplace_law_at_the_nearest_stable_coupling():
+    """configs[0]'s Laplace check on the GPU twin, at G = 2.6 (with the ini's 3.8 the pinned kernel holds no static droplet:
+    tests/test_oracle_sc.py::test_configs0_shipped_coupling_does_not_hold_a_static_droplet): three radii, 10^4 steps each, the droplet
+    stays centred, dp > 0, dp * R within +-5 % of each other, and each equals the CPU oracle's measurement of the same run to 1e-6"""
+    from openlbmpm_amd.sc2d import SC2DSolver
+    from test_oracle_sc import c1_laplace_numbers, _c1_droplet
+    n = 128
+    dom = np.ones((n, n), dtype=np.uint8)
+    out = []
+    for radius in (14, 20, 28):
+        r0, r1 = droplet(n, radius)
+        s = SC2DSolver(dom, dict(PAR, G=2.6), diagnostics=True)
+        s.set_density(r0, r1)
+        s.step(10000)
+        d = c1_laplace_numbers(s.get("rho0"), s.get("rho1"), 2.6)
+        s.close()
+        assert abs(d["cx"] - 64.0) < 1e-6 and abs(d["cy"] - 64.0) < 1e-6 and d["dp"] > 0.0, d
+        out.append(d)
+    s = [d["dpR"] for d in out]
+    assert (max(s) - min(s)) / np.mean(s) < 0.10 and 0.15 < np.mean(s) < 0.25, s
+    ref = _c1_droplet(2.6, 20, 10000)
+    assert abs(out[1]["dpR"] - ref["dpR"]) / ref["dpR"] < 1e-6 and abs(out[1]["R"] - ref["R"]) < 1e-9

@@ -3,8 +3,8 @@
 
 `tools/slabbench.py` drives k virtual ranks from one Python thread: its k = 8 figure contains ~150 host calls per lattice
 step that a real run spreads over eight processes.  Here every rank of the `bench.py --gpus K` partition is built alone and
-stepped through `lbmpm_rk3d_step_slab(timed)` -- the call a real rank makes -- with an exchange callback that only moves
-the rank's own send buffers into its receive buffers (finite values, same kernels, same launch sequence, no transfer).
+stepped through `lbmpm_rk3d_step_slab(timed)` -- the call a real rank makes -- with an exchange callback that copies the
+neighbours' last face messages (device copies: real messages of the right shape, same kernels, same launch sequence, no xGMI).
 HIP events give step / interior / boundary-path time per rank; sum over ranks vs the single-domain step is the GPU cost
 of the decomposition, K x max over ranks vs the same is the load imbalance on top of it.
 
@@ -34,31 +34,40 @@ print("single domain: %.3f ms per step, %d fluid nodes" % (single, nf), flush=Tr
 
 rows = []
 only = [int(v) for v in os.environ["SLAB_RANKS"].split(",")] if os.environ.get("SLAB_RANKS") else None      # a subset of the ranks
-for r, (z0, nz) in enumerate(RK3DDistributed.partition(dom, K)):
-    if only is not None and r not in only:
-        continue
+parts = RK3DDistributed.partition(dom, K)
+st = torch.cuda.Stream(0)
+slabs = []
+for r, (z0, nz) in enumerate(parts):          # all K ranks resident (the whole lattice is one GPU's worth of memory anyway)
     s = RK3DSlab(dom, z0, nz, par)
     s.set_density(rR[z0:z0 + nz], rB[z0:z0 + nz])
-    st = torch.cuda.Stream(0)
     s.use_torch_stream(st)
+    slabs.append(s)
+with torch.cuda.stream(st):                    # every rank's face message once: what a neighbour's callback copies below is a real
+    for s in slabs:                            # message of the right shape (a step or more stale: the ranks are timed one after another)
+        s.pack()
+for r, (z0, nz) in enumerate(parts):
+    if only is not None and r not in only:
+        continue
+    s = slabs[r]
     below, above = r > 0, r + 1 < K
 
-    def exchange(what, s=s, below=below, above=above):
+    def exchange(what, s=s, r=r, below=below, above=above):
         kind = "phi" if what else "f"
+        if s.buffer(kind + "_send_up") is None:
+            return
         if below:
-            a, b = s.buffer(kind + "_recv_below"), s.buffer(kind + "_send_down")
-            m = min(a.numel(), b.numel()); a[:m].copy_(b[:m])
+            s.buffer(kind + "_recv_below").copy_(slabs[r - 1].buffer(kind + "_send_up"))
         if above:
-            a, b = s.buffer(kind + "_recv_above"), s.buffer(kind + "_send_up")
-            m = min(a.numel(), b.numel()); a[:m].copy_(b[:m])
+            s.buffer(kind + "_recv_above").copy_(slabs[r + 1].buffer(kind + "_send_down"))
     with torch.cuda.stream(st):
         s.step_slab(5, below, above, exchange)
         s.step_slab(steps, below, above, exchange, timed=True)
     t = s.slab_timing()
     t.update(rank=r, planes=nz, fluid=s.num_fluid_nodes)
     rows.append(t)
-    print("rank %d: planes %3d  fluid %9d  step %.3f ms  interior %.3f  boundary %.3f  pack..phi exchange %.3f" %
-          (r, nz, t["fluid"], t["step_ms"], t["interior_ms"], t["boundary_ms"], t["exchange_chain_ms"]), flush=True)
+    print("rank %d: planes %3d  fluid %9d  step %.3f ms  interior %.3f  boundary %.3f  pack..unpack chain %.3f   (%s)" %
+          (r, nz, t["fluid"], t["step_ms"], t["interior_ms"], t["boundary_ms"], t["exchange_chain_ms"], s.dominant_kernel), flush=True)
+for s in slabs:
     s.close()
 tot = sum(t["step_ms"] for t in rows)
 mx = max(t["step_ms"] for t in rows)
