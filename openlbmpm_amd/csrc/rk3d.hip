@@ -1134,6 +1134,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     c->q23 = c->compact && c->tile == 0;
     if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
     if (const char *e = getenv("LBMPM_RK3D_DBG")) c->dbg = atoi(e);
+    if (c->q23 && !getenv("LBMPM_RK3D_CHUNK")) c->chunk_len = 64;      // measured 512^3: chunks of 16 / 32 / 64 planes 7.70 / 7.11 / 6.90 ms per step
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
     c->vol = c->plane2 * (size_t)(c->nzl + 2);
@@ -1412,20 +1413,25 @@ void launch_fused_c(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first,
     dispatch2(p.first != 0, p.mrt != 0, go);
 }
 
+// q23 storage: planes z_first..z_last and (if z_last2 >= z_first2) z_first2..z_last2 in ONE launch
+void launch_q23(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last, int z_first2, int z_last2)
+{
+    const int tilesX = c->nseg, tilesY = (c->ny + 7) / 8, rpx = (tilesY + 7) / 8;
+    const int nchunks1 = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
+    const int nchunks2 = z_last2 >= z_first2 ? (z_last2 - z_first2 + 1 + c->chunk_len - 1) / c->chunk_len : 0;
+    const dim3 grid((unsigned)(8 * tilesX * rpx * (nchunks1 + nchunks2))), block(512);
+    auto go = [&](auto first, auto mrt) {
+        rk3dq_fused<decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last,
+                                                                                            nchunks1, z_first2, z_last2);
+    };
+    dispatch2(p.first != 0, p.mrt != 0, go);
+}
+
 // planes z_first..z_last of the time step on stream st
 void launch_step_range(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last)
 {
     if (z_last < z_first) return;
-    if (c->q23) {
-        const int tilesX = c->nseg, tilesY = (c->ny + 7) / 8, rpx = (tilesY + 7) / 8;
-        const int nchunks = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
-        const dim3 grid((unsigned)(8 * tilesX * rpx * nchunks)), block(512);
-        auto go = [&](auto first, auto mrt) {
-            rk3dq_fused<decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last);
-        };
-        dispatch2(p.first != 0, p.mrt != 0, go);
-        return;
-    }
+    if (c->q23) { launch_q23(c, p, st, z_first, z_last, 1, 0); return; }
     if (c->compact) {
         if (c->tile == 1) launch_fused_c<4>(c, p, st, z_first, z_last);
         else launch_fused_c<8>(c, p, st, z_first, z_last);
@@ -1556,7 +1562,23 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             if (rc != LBMPM_OK) return fail(rc);
         }
         if (!c->aux) {
-            LBMPM_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+            // rk3dq_fused holds a CU's whole register file and most of its LDS: while the interior launch runs, the kernels of the exchange
+            // (pack, RCCL's send / recv, unpack) find room only where one of its workgroups retires, so on one GPU the pack .. unpack chain
+            // ends with the interior launch (tools/slab_rank_cost.py).  LBMPM_RK3D_COMM_CUS = k (default 0 = off) runs the interior on a
+            // stream whose CU mask leaves k CUs alone.  Measured at 512^3 / 8 ranks: any mask slows the interior launch from 1.3 to 1.8 ms
+            // (k = 8, 16, 32 alike), the chain drops to 0.55 ms only at k = 32 -- a net loss, hence off.
+            int reserve = 0, ncu = 0;
+            if (const char *e = getenv("LBMPM_RK3D_COMM_CUS")) reserve = atoi(e);
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->cfg.device);
+            if (reserve > 0 && ncu >= 64 && reserve < ncu / 2) {
+                std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+                // Bit i of the mask is CU (i / 8) of XCD (i % 8) (measured: leaving out every 32nd / 16th bit slowed the interior by 25 % / 100 %,
+                // i.e. took 8 / 16 CUs from ONE of the eight XCDs, whose share of the workgroups stays 1/8).  The highest `reserve` bits are
+                // reserve / 8 CUs of every XCD: the exchange's workgroups, dealt round-robin to the XCDs like all others, find room in each.
+                for (int i = 0; i < ncu - reserve; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+                if (hipExtStreamCreateWithCUMask(&c->aux, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); c->aux = nullptr; }
+            }
+            if (!c->aux) LBMPM_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
             LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
             LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
         }
@@ -1570,12 +1592,14 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             const RK3Dev p = make_dev(c);
             LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // the previous step, its unpack included
             if (ev[6]) LBMPM_HIP_TRY(hipEventRecord(ev[6], c->stream));
-            if (has_interior) {
-                launch_step_range(c, p, c->stream, 1, cb);
-                launch_step_range(c, p, c->stream, c->nzl - cb + 1, c->nzl);
-            } else launch_step_range(c, p, c->stream, 1, c->nzl);
+            if (has_interior) launch_q23(c, p, c->stream, 1, cb, c->nzl - cb + 1, c->nzl);      // both boundary ranges, one launch
+            else launch_step_range(c, p, c->stream, 1, c->nzl);
             if (ev[7]) LBMPM_HIP_TRY(hipEventRecord(ev[7], c->stream));
             if (has_interior) {
+                // the interior launch waits for the boundary planes: started together, its 512 long-lived workgroups take the CUs and the
+                // 1024 short ones of the boundary launch trickle through behind them -- the face message then leaves when the interior is
+                // done and nothing hides the exchange (rocprofv3 timeline, 512^3 on 8 ranks: 1.36 ms per step that way)
+                LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
                 LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));
                 if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], c->aux));
                 launch_step_range(c, p, c->aux, cb + 1, c->nzl - cb);

@@ -314,7 +314,8 @@ __device__ __forceinline__ double phi_q(double rR, double rho) { return (rR - (r
 //   * no LDS park: the 19 pulled values of the plane that waits for its neighbours' phase field stay in registers
 //     (38 VGPRs where the 38-value kernel carried 76 in flight).
 template <bool FIRST, bool MRT>
-__global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last)
+__global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last,
+                                                       int nchunks1, int z_first2, int z_last2)      // a second range of planes in the same launch
 {
     constexpr int TX = 64, TY = 8;
     using M = March<TX, TY>;
@@ -362,7 +363,10 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         rows_xcol.t.lrow = xrow + 2; rows_xcol.t.k = xc < 2 ? 0 : 2;
     };
     set_geometry(tid);
-    const int za = z_first + chunk * chunk_len, zb = min(za + chunk_len - 1, z_last);
+    // chunks 0 .. nchunks1-1 march the planes z_first .. z_last, the chunks behind them z_first2 .. z_last2 (the two boundary ranges of a slab
+    // in one launch)
+    const int za = chunk < nchunks1 ? z_first + chunk * chunk_len : z_first2 + (chunk - nchunks1) * chunk_len;
+    const int zb = min(za + chunk_len - 1, chunk < nchunks1 ? z_last : z_last2);
     const int zl_gb = 1 - p.z0, zl_gt = p.nzg - p.z0;          // local index of the ghost planes z = 0 and z = nz-1 (when owned)
     auto is_ghost = [&](int zl) { return zl == zl_gb || zl == zl_gt; };
     // one record per lane (72 lanes) + the row flags that ride in its spare words: .z this segment's, .w (centre record) the three
