@@ -146,6 +146,10 @@ __device__ __forceinline__ void node_finish(const RKDev &p, int y, int ys, doubl
         }
     }
     if (p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1) bc_outlet_pressure(p.pOut, fR, fB, rhoR, rhoB);
+    // With tracers the step is the transport driver's (Transport2DRK.py:1177-1418): boundary rows first (:1199-1279), the densities
+    // summed from the populations AFTERWARDS (:1281-1287) -- a pressure row then carries sum_i f_i, not the prescribed density.  Equal up
+    // to the last bit; the wetting kernels' branch switches turn that bit into 1e-6 at single nodes (tests/test_tr_coupled.py).
+    if (p.ntr > 0) { rhoR = sum9(fR); rhoB = sum9(fB); }
 }
 
 // ---------------------------------------------------------------- collision pieces

@@ -731,6 +731,42 @@ void rk_csf_step_a(rk_sim *s)
     }
 }
 
+/* The same first half in the order of the transport driver's loop (Transport2DRK.py:1177-1418): there the boundary rows come
+ * FIRST (outlet :1199-1238, inlet :1245-1279) and the densities are summed from the populations AFTERWARDS (:1281-1287), so a
+ * pressure row carries sum_i f_i instead of the prescribed density -- equal up to the last bit, but the wetting kernels' branch
+ * switches (|G| thresholds, closer-candidate rule) turn that bit into 1e-6 at single nodes.  Config 4 is pinned in this order. */
+void rk_csf_step_a_transport(rk_sim *s)
+{
+    i64 N = s->N;
+    if (s->outletType == 1) {
+        rk_outlet_convective_row(N, s->nx, 2, s->fluidNodes, s->nbr, s->fR, s->fB, s->rhoR, s->rhoB);
+        rk_outlet_convective_row(N, s->nx, 1, s->fluidNodes, s->nbr, s->fR, s->fB, s->rhoR, s->rhoB);
+        rk_outlet_convective_row(N, s->nx, 0, s->fluidNodes, s->nbr, s->fR, s->fB, s->rhoR, s->rhoB);
+    } else {
+        rk_outlet_pressure_total(N, s->nx, s->pOutTotal, s->fluidNodes, s->fT, s->vy, s->rhoR,
+                                 s->rhoB, s->fR, s->fB);
+        rk_ghost_outlet_pressure(N, s->nx, s->nbr, s->rhoR, s->rhoB, s->fR, s->fB);
+    }
+    if (s->inletType == 0) {
+        rk_inlet_velocity_total(N, s->nx, s->ny, s->vyIn, s->fluidNodes, s->rhoR, s->rhoB,
+                                s->fR, s->fB, s->fT, s->vy);
+        rk_ghost_inlet_velocity(N, s->nx, s->ny, s->fluidNodes, s->nbr, s->rhoR, s->rhoB, s->fR, s->fB);
+    } else {
+        rk_inlet_pressure(N, s->nx, s->ny, s->pInB, s->pInR, s->fluidNodes, s->rhoB, s->rhoR, s->fB, s->fR);
+        rk_ghost_inlet_pressure(N, s->nx, s->ny, s->fluidNodes, s->nbr, s->rhoR, s->rhoB, s->fR, s->fB);
+    }
+    rk_total_pdf(N, s->fR, s->fB, s->fT);
+    rk_macro_density(N, s->fR, s->fB, s->rhoR, s->rhoB);
+    rk_velocity(N, s->fT, s->rhoR, s->rhoB, s->vx, s->vy, s->Fx, s->Fy);
+    rk_phase_field(N, s->rhoR, s->rhoB, s->phi);
+    if (s->W > 0) rk_color_on_solid(s->W, s->nbrWet, s->phi, s->phiS);
+    rk_gradient(N, s->nbr, s->phi, s->phiS, s->Gx, s->Gy);
+    if (s->W > 0) {
+        if (s->wettingType == 1) rk_wetting1(s->Wf, s->cosT, s->sinT, s->fluidWet, s->nsx, s->nsy, s->Gx, s->Gy);
+        else if (s->wettingType == 2) rk_wetting2(s->Wf, s->cosT, s->sinT, s->fluidWet, s->nsx, s->nsy, s->Gx, s->Gy);
+    }
+}
+
 /* second half: CSF force ... streaming and densities (D:1425-1490) */
 void rk_csf_step_b(rk_sim *s)
 {

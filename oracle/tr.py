@@ -92,7 +92,7 @@ class CoupledOracle:
     def run(self, n):
         f, L = self.flow, self._L
         for _ in range(int(n)):
-            L.rk_csf_step_a(C.byref(f._s))
+            L.rk_csf_step_a_transport(C.byref(f._s))        # boundary rows first, densities summed afterwards (Transport2DRK.py:1199-1287)
             L.tr_substep(C.byref(self._s), _p(f.rhoR, F64P), _p(f.vx, F64P), _p(f.vy, F64P), _p(f.Gx, F64P), _p(f.Gy, F64P))
             L.rk_csf_step_b(C.byref(f._s))
         return self

@@ -13,13 +13,14 @@ import pytest
 from helpers import GOLDEN, load_params, rel_err
 
 F64P = C.POINTER(C.c_double)
-# Field-relative.  This loop and the CSF loop the oracle / the fused kernel follow apply the boundary rows and the density
-# sums in a different order (generator docstring): inputs that agree to 1e-16 then meet the reference algorithm's own
-# discontinuities -- the |G| > 1e-8 switches of the normals and the closer-candidate rule of the wetting kernels
-# (A:2443-2490, A:2512-2524) -- and a node with |G| ~ 1e-6 lands on the other branch (seen: 1.6e-6 in G at step 2 of the
-# porous case, decaying afterwards; the capillary case stays below 1e-9).  A misplaced sub-step shows up at 1e-3
-# (negative control below).  The north star asks for 1e-6.
-TOL = 2e-6
+# Field-relative.  The transport driver's loop applies the boundary rows first and sums the densities from the populations afterwards
+# (Transport2DRK.py:1199-1287); the CSF loop does it the other way round (RKD2Q9.py:1299-1360), which leaves the prescribed density on
+# a pressure row instead of sum_i f_i.  The two agree to the last bit or so -- but the reference algorithm has its own discontinuities
+# (the |G| > 1e-8 switches of the normals and the closer-candidate rule of the wetting kernels, A:2443-2490, A:2512-2524), and with the
+# CSF order a node of the porous case landed on the other branch: 2e-6 in G at step 2.  The oracle (rk_csf_step_a_transport) and the
+# tracer variant of rk2d_fused follow the transport driver's order: every field of both captures within 1e-9 (measured: 2.4e-10).
+# A misplaced sub-step shows up at 1e-3 (negative control below).  The north star asks for 1e-6.
+TOL = 1e-9
 
 
 def scenario(name):
@@ -54,7 +55,7 @@ def test_coupled_oracle_follows_the_real_transport_driver(name):
         o.run(int(k) - 1 - done); done = int(k)
         f = o.flow
         # first half of flow step k, the tracer sub-step, then the second half
-        L.rk_csf_step_a(C.byref(f._s))
+        L.rk_csf_step_a_transport(C.byref(f._s))
         L.tr_substep(C.byref(o._s), P(f.rhoR), P(f.vx), P(f.vy), P(f.Gx), P(f.Gy))
         for key, got in (("rhoR", f.rhoR), ("rhoB", f.rhoB), ("vx", f.vx), ("vy", f.vy), ("phi", f.phi), ("Gx", f.Gx), ("Gy", f.Gy),
                          ("conc", o.C), ("g", o.g)):
@@ -64,8 +65,7 @@ def test_coupled_oracle_follows_the_real_transport_driver(name):
         L.rk_csf_step_b(C.byref(f._s))
         for key, got in (("Fx", f.Fx), ("Fy", f.Fy)):
             assert rel_err(got, d["s%d_%s" % (k, key)]) < TOL, (name, int(k), key)
-    if name == "capillary":
-        assert worst < 1e-9
+    assert worst < 1e-9
 
 
 def test_a_misplaced_tracer_substep_is_seen():
@@ -96,9 +96,19 @@ def test_fused_tracer_kernel_follows_the_real_transport_driver(name):
     s.set_tracer(0, to_dense(d["init_conc"][0]))
     done = 0
     for k in d["snaps"]:
-        s.step(int(k) - done); done = int(k)
+        # the densities of step k after its boundary rows = what the solver would record before taking step k (rec_*: the streamed,
+        # boundary-corrected state, densities summed in the transport driver's order)
+        s.step(int(k) - 1 - done); done = int(k) - 1
+        for key in ("rhoR", "rhoB"):
+            e = rel_err(s.get_compact("rec_" + key), d["s%d_%s" % (k, key)])
+            assert e < TOL, (name, int(k), key, e)
+        s.step(1); done = int(k)
         assert rel_err(s.get_tracer(0, compact=True), d["s%d_conc" % k][0]) < TOL, (name, int(k), "conc")
         for key, f in (("vx", "vx"), ("vy", "vy"), ("phi", "phi"), ("Gx", "Gx"), ("Gy", "Gy"), ("Fx", "Fx"), ("Fy", "Fy")):
             e = rel_err(s.get_compact(f), d["s%d_%s" % (k, key)])
-            assert e < TOL, (name, int(k), key, e)
+            # measured on the porous case: densities 1e-11, phi 2e-11, concentration 5e-10; ONE wall node's wetting-corrected
+            # gradient 5.5e-9 (the rotation towards the contact angle divides by a |G| of 1e-6 there: the kernel's own rounding --
+            # closed-form moments, one reciprocal in the recolouring -- is amplified), and with it the CSF force (6.5e-9) and, one
+            # step later, u = (sum e f + F / 2) / rho (1.7e-9).  The capillary case: everything < 1e-13.
+            assert e < (1e-8 if key[0] in "FvG" else TOL), (name, int(k), key, e)
     s.close()
