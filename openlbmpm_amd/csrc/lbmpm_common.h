@@ -41,6 +41,16 @@ void set_error(const char *fmt, ...);
 #define LBMPM_D2Q9_OPP {0, 3, 4, 1, 2, 7, 8, 5, 6}
 #define LBMPM_D2Q9_W {4. / 9., 1. / 9., 1. / 9., 1. / 9., 1. / 9., 1. / 36., 1. / 36., 1. / 36., 1. / 36.}
 
+// Lattice-constant arrays of the kernel-level entry points (include/lbmpm_kernels.h).  The reference passes its direction vectors and
+// weights to every kernel as device arrays; the kernels here have them built in.  An array that does not hold the built-in values would
+// silently be ignored, so each such argument is checked the first time its device pointer is seen (one small device-to-host copy; the
+// verdict is cached per pointer): LBMPM_ERR_UNSUPPORTED with the first differing entry in the message.
+enum LatticeTable { LT_D2Q9_EX = 0, LT_D2Q9_EY, LT_D2Q9_W, LT_D2Q5_VX, LT_D2Q5_VY };
+int check_lattice_constant(hipStream_t st, const char *kernel, const char *arg, const double *device_array, int table);
+void forget_lattice_constant(const void *device_ptr);   // the facade's free / host-to-device copy: the cached verdict no longer holds
+                                                         // (memory that does not go through lbmpm_device_free / lbmpm_memcpy_h2d and is
+                                                         // rewritten in place keeps its first verdict)
+
 // Event pool used by the *_step_timed entry points: one (start, stop) pair per launch of
 // the dominant kernel, all recorded on the stream that kernel runs on.
 struct EventPool {

@@ -1,5 +1,6 @@
 // lbmpm_common.hip -- error state, version, event pool.
 #include "lbmpm_common.h"
+#include <cmath>
 #include "d2q9_device.h"
 
 namespace lbmpm {
@@ -162,3 +163,47 @@ extern "C" int lbmpm_hbm_stream_test(int device, int64_t bytes_per_buffer, int r
     if (e != hipSuccess) { lbmpm::set_error("lbmpm_hbm_stream_test: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
     return LBMPM_OK;
 }
+
+
+// ---------------------------------------------------------------- lattice-constant arguments of the kernel-level entry points
+#include <mutex>
+#include <unordered_map>
+namespace lbmpm {
+static std::mutex lattice_mu;
+static std::unordered_map<const void *, unsigned> lattice_seen;      // device pointer -> bit t: verified against table t
+void forget_lattice_constant(const void *ptr)
+{
+    std::lock_guard<std::mutex> g(lattice_mu);
+    lattice_seen.erase(ptr);
+}
+int check_lattice_constant(hipStream_t st, const char *kernel, const char *arg, const double *dev, int table)
+{
+    static const double T[5][9] = {{0, 1, 0, -1, 0, 1, -1, -1, 1}, {0, 0, 1, 0, -1, 1, 1, -1, -1},
+                                   {4. / 9., 1. / 9., 1. / 9., 1. / 9., 1. / 9., 1. / 36., 1. / 36., 1. / 36., 1. / 36.},
+                                   {0, 1, -1, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 1, -1, 0, 0, 0, 0}};
+    static const int LEN[5] = {9, 9, 9, 5, 5};
+    static const char *NAME[5] = {"D2Q9 e_x = (0, 1, 0, -1, 0, 1, -1, -1, 1)", "D2Q9 e_y = (0, 0, 1, 0, -1, 1, 1, -1, -1)", "D2Q9 weights 4/9, 1/9, 1/36",
+                                  "D2Q5 e_x = (0, 1, -1, 0, 0)", "D2Q5 e_y = (0, 0, 0, 1, -1)"};
+    std::mutex &mu = lattice_mu;
+    std::unordered_map<const void *, unsigned> &seen = lattice_seen;
+    if (!dev) { set_error("%s: %s is a null pointer", kernel, arg); return LBMPM_ERR_INVALID; }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = seen.find(dev);
+        if (it != seen.end() && (it->second >> table) & 1u) return LBMPM_OK;
+    }
+    double h[9];
+    hipError_t e = hipMemcpyAsync(h, dev, (size_t)LEN[table] * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("%s: reading %s failed: %s", kernel, arg, hipGetErrorString(e)); return LBMPM_ERR_HIP; }
+    for (int i = 0; i < LEN[table]; ++i)
+        if (!(fabs(h[i] - T[table][i]) <= 1e-15)) {
+            set_error("%s: %s[%d] = %.17g, the kernel has %s built in (entry %.17g): other lattice constants are not supported", kernel, arg, i, h[i],
+                      NAME[table], T[table][i]);
+            return LBMPM_ERR_UNSUPPORTED;
+        }
+    std::lock_guard<std::mutex> g(mu);
+    seen[dev] |= 1u << table;
+    return LBMPM_OK;
+}
+}  // namespace lbmpm

@@ -987,9 +987,15 @@ extern "C" int lbmpm_device_malloc(int64_t bytes, void **out)
     *out = p;
     return LBMPM_OK;
 }
-extern "C" int lbmpm_device_free(void *ptr) { if (ptr) LBMPM_HIP_TRY(hipFree(ptr)); return LBMPM_OK; }
+extern "C" int lbmpm_device_free(void *ptr)
+{
+    lbmpm::forget_lattice_constant(ptr);          // the address may come back holding something else
+    if (ptr) LBMPM_HIP_TRY(hipFree(ptr));
+    return LBMPM_OK;
+}
 extern "C" int lbmpm_memcpy_h2d(void *dst, const void *src, int64_t bytes)
 {
+    lbmpm::forget_lattice_constant(dst);
     LBMPM_HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
     return LBMPM_OK;
 }

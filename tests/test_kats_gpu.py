@@ -88,3 +88,31 @@ def test_kernels_that_cannot_run_in_the_reference_say_so(rt):
         rt.launch_by_name("tr", "calUpdateConcInTransportDomainByVQ9", z)
     with pytest.raises(TypeError, match="bool"):
         rt.launch_by_name("tr", "calUpdateConcInTransportDomainByVQ9", dict(z, transportDomain=dev(np.ones(N))))
+
+
+def test_lattice_constant_arrays_are_checked_not_ignored(rt):
+    """The reference hands its direction vectors and weights to every kernel as device arrays; the kernels here have them built in.
+    An array with other contents must not be swallowed: the entry point refuses it (LBMPM_ERR_UNSUPPORTED, the differing entry named);
+    the reference's own tables pass, also from a second allocation (the verdict is cached per device pointer)."""
+    N = 6
+    rng = np.random.default_rng(5)
+    W = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+    EX = np.array([0., 1., 0., -1., 0., 1., -1., -1., 1.]); EY = np.array([0., 0., 1., 0., -1., 1., 1., -1., -1.])
+    rR, rB = rng.uniform(0.2, 0.8, N), rng.uniform(0.2, 0.8, N)
+    base = dict(totalNodes=N, xDim=64, betaValue=0.7, fluidRhoR=rR, fluidRhoB=rB, gradientX=rng.normal(size=N), gradientY=rng.normal(size=N),
+                fluidPDFR=np.zeros((N, 9)), fluidPDFB=np.zeros((N, 9)), fluidPDFTotal=rng.uniform(0.05, 0.2, (N, 9)))
+
+    def launch(**lattice):
+        v = dict(base, **lattice)
+        dev = {k: (rt.to_device(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a) for k, a in v.items()}
+        rt.launch_by_name("rk", "calRecoloringProcessM", dev)                           # A:1857-1899
+        return dev["fluidPDFR"].copy_to_host()
+
+    good = launch(weightsCoeff=W, unitEX=EX, unitEY=EY)
+    assert np.isfinite(good).all() and np.abs(good).max() > 0
+    again = launch(weightsCoeff=W.copy(), unitEX=EX.copy(), unitEY=EY.copy())
+    assert np.array_equal(good, again)
+    for name, bad in (("weightsCoeff", W * np.array([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.000001])), ("unitEX", -EX), ("unitEY", EY[::-1].copy())):
+        with pytest.raises(RuntimeError) as err:
+            launch(**dict(dict(weightsCoeff=W, unitEX=EX, unitEY=EY), **{name: bad}))
+        assert name in str(err.value) and "built in" in str(err.value), str(err.value)

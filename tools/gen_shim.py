@@ -364,8 +364,10 @@ def main():
  *
  * All pointers are DEVICE pointers (see lbmpm_device_malloc & co below); `stream` is a hipStream_t
  * (NULL = the legacy default stream, which is what Numba's default-stream launches use).
- * Arguments the reference passes but the arithmetic does not need (xDim, the lattice-constant
- * arrays) are accepted and ignored.  Every call enqueues asynchronously and returns 0 or a
+ * Arguments the reference passes but the arithmetic does not need (xDim, arrays the reference kernel itself never reads) are
+ * accepted and ignored.  The lattice-constant arrays (direction vectors, weights) are built into the kernels: each such argument is
+ * CHECKED against the built-in table the first time its device pointer is seen (one small device-to-host copy, verdict cached per
+ * pointer) and refused with LBMPM_ERR_UNSUPPORTED if it holds anything else -- never silently ignored.  Every call enqueues asynchronously and returns 0 or a
  * negative lbmpm_status.  Shan-Chen entry points require numFluids == 2 (like the reference's
  * outlet kernel); tracer entry points that take numScheme(s) the value that belongs to them (5, or 9 for the D2Q9 kernel).
  */
@@ -385,8 +387,26 @@ int lbmpm_device_synchronize(void);
 ''']
     ent = ["// GENERATED by tools/gen_shim.py -- extern \"C\" kernel-level entry points\n#pragma once\n"]
     py = ['"""GENERATED by tools/gen_shim.py: ctypes signatures of the kernel-level entry points:\n(module tag, reference kernel) -> (C symbol, ctypes of the arguments, the reference kernel\'s own argument names,\nkind letters: i int64, d float64, I int64[], D float64[], B boolean[])."""\nimport ctypes as C\n\nKERNELS = {']
+    import re
+    Q9 = {"unitEX": "LT_D2Q9_EX", "EX": "LT_D2Q9_EX", "unitEY": "LT_D2Q9_EY", "EY": "LT_D2Q9_EY",
+          "weightsCoeff": "LT_D2Q9_W", "weightCoeff": "LT_D2Q9_W", "weigthCoeff": "LT_D2Q9_W"}
+    # (the tracer kernels' unitEX / unitEY are the flow lattice's or the tracer's depending on the kernel: left alone)
+    Q5 = {"unitVX": "LT_D2Q5_VX", "unitX": "LT_D2Q5_VX", "unitVY": "LT_D2Q5_VY", "unitY": "LT_D2Q5_VY"}
+    nchecks = 0
     for mod, name, cite, args, call in SPEC:
         al = [a.split(":") for a in args.split()]
+        # lattice-constant arrays the launcher does not take: checked against the built-in table (once per device pointer)
+        used = set(re.findall(r"\b[A-Za-z_]\w*\b", call))
+        table = Q9 if mod in ("rk", "rkb", "sc") or "Q9" in name else ({k: v for k, v in Q5.items()} if mod == "tr" else {})
+        if mod == "tr" and "Q9" in name:
+            table = {k: v for k, v in Q9.items() if k not in ("weightsCoeff", "unitEX", "unitEY")}
+            table.update({"unitVX": "LT_D2Q9_EX", "unitVY": "LT_D2Q9_EY", "unitX": "LT_D2Q9_EX", "unitY": "LT_D2Q9_EY"})
+        checks = "".join("    if (int rc_ = lbmpm::check_lattice_constant(st, \"%s\", \"%s\", %s, lbmpm::%s)) return rc_;\n" % (name, n, n, table[n])
+                         for n, k in al if k == "D" and n not in used and n in table)
+        if "cannot run in the reference" in call:      # an entry point that refuses outright says why; nothing to check first
+            checks = ""
+        nchecks += checks.count("check_lattice_constant")
+        call = "\n" + checks + "    " + call if checks else call
         cargs = ", ".join("int64_t *%s, int64_t %s_len" % (n, n) if k == "L" else "%s%s" % (CT[k] + ("" if CT[k].endswith("*") else " "), n) for n, k in al)
         sym = "lbmpm_%s_%s" % (mod, name)
         hdr.append("/* %s %s */\nint %s(void *stream, %s);" % (cite, name, sym, cargs))
@@ -400,7 +420,7 @@ int lbmpm_device_synchronize(void);
     open(os.path.join(ROOT, "include", "lbmpm_kernels.h"), "w").write("\n".join(hdr))
     open(os.path.join(ROOT, "openlbmpm_amd", "csrc", "sparse_entry_gen.h"), "w").write("\n".join(ent))
     open(os.path.join(ROOT, "openlbmpm_amd", "_kernel_specs.py"), "w").write("\n".join(py))
-    print(len(SPEC), "entry points")
+    print(len(SPEC), "entry points,", nchecks, "lattice-constant checks")
 
 
 if __name__ == "__main__":
