@@ -360,6 +360,9 @@ int lbmpm_rk3d_get_field(lbmpm_rk3d *ctx, int field, double *out);
  * image of those), fluid cells owned, those of them in row segments flagged single-colour (no records kept), bytes one step moves
  * for the owned cells by the storage's own count */
 int lbmpm_rk3d_storage_info(lbmpm_rk3d *ctx, int64_t *out);
+/* development aid: with LBMPM_RK3D_TRACE set at create time every workgroup of the last rk3dq_fused launch leaves four words
+ * (start, prologue done, end on the 100 MHz clock; first << 32 | last plane): copied to out[4 * nblocks] */
+int lbmpm_rk3d_debug_trace(lbmpm_rk3d *ctx, unsigned long long *out, int64_t nblocks);
 int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *ctx);
 int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *ctx);
 const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *ctx);

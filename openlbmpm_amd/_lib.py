@@ -121,6 +121,7 @@ _SIGNATURES = {
     "lbmpm_rk3d_dominant_kernel": (C.c_char_p, [C.c_void_p]),
     "lbmpm_rk3d_device_bytes": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk3d_storage_info": (C.c_int, [C.c_void_p, I64P]),
+    "lbmpm_rk3d_debug_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
 }
 
 

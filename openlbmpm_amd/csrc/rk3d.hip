@@ -73,6 +73,7 @@ struct RK3Dev {
     int nseg;
     const uint32_t *pur_in;           // [rows][nseg] row flags of the q23 storage (rk3dq.h), ping-pong with fin / fout
     uint32_t *pur_out;
+    unsigned long long *trace;        // LBMPM_RK3D_TRACE: four words per workgroup of rk3dq_fused (start, prologue done, end, planes)
     int dbg;                          // LBMPM_RK3D_DBG: timing knock-outs of rk3dq_fused (results wrong), 0 in production
 };
 
@@ -1035,6 +1036,7 @@ struct lbmpm_rk3d {
     // q23: compact storage of 19 colour-blind populations + {k_R, A} per cell instead of 2 x 19 (rk3dq.h); default on compact
     // storage, LBMPM_RK3D_STORAGE=38 keeps the 38-value kernels (the cross-check)
     bool q23 = false;
+    unsigned long long *trace = nullptr;      // dev tool, see RK3Dev
     bool halo_valid = false;         // q23 slabs: the halo planes (populations, records, flags, phase field) belong to the current state
     int dbg = 0;
     int nseg = 0;
@@ -1078,6 +1080,7 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     p.fill = c->fill;
     p.mrt = c->cfg.relaxation;
     p.dbg = c->dbg;
+    p.trace = c->trace;
     p.pur_in = c->purA; p.pur_out = c->purB;
     return p;
 }
@@ -1134,7 +1137,9 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     c->q23 = c->compact && c->tile == 0;
     if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
     if (const char *e = getenv("LBMPM_RK3D_DBG")) c->dbg = atoi(e);
-    if (c->q23 && !getenv("LBMPM_RK3D_CHUNK")) c->chunk_len = 64;      // measured 512^3: chunks of 16 / 32 / 64 planes 7.70 / 7.11 / 6.90 ms per step
+    if (c->q23 && !getenv("LBMPM_RK3D_CHUNK")) c->chunk_len = 64;
+      // measured 512^3: chunks of 16 / 32 / 64 planes 7.70 / 7.11 / 6.90 ms per step
+    if (c->q23 && getenv("LBMPM_RK3D_TRACE")) { (void)hipMalloc(reinterpret_cast<void **>(&c->trace), (size_t)1 << 22); (void)hipMemset(c->trace, 0, (size_t)1 << 22); }
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
     c->vol = c->plane2 * (size_t)(c->nzl + 2);
@@ -1251,7 +1256,7 @@ extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->purA, (void *)c->purB, (void *)c->phi, (void *)c->diag,
+    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->purA, (void *)c->purB, (void *)c->trace, (void *)c->phi, (void *)c->diag,
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
@@ -1595,25 +1600,32 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             if (has_interior) launch_q23(c, p, c->stream, 1, cb, c->nzl - cb + 1, c->nzl);      // both boundary ranges, one launch
             else launch_step_range(c, p, c->stream, 1, c->nzl);
             if (ev[7]) LBMPM_HIP_TRY(hipEventRecord(ev[7], c->stream));
+            if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
+            if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
+            RK3Dev q = p;                                                     // the state this step writes
+            q.fin = c->fB; q.pur_in = c->purB; q.first = 0;
+            const int skip = c->dbg;        // timing knock-outs (LBMPM_RK3D_DBG: 1 no pack, 2 no exchange, 4 no unpack / halo phase field)
+            if (!(skip & 1)) rk3dq_face_pack<<<fgrid, fblock, 0, c->stream>>>(q, c->send_up, c->send_dn, has_below, has_above);
             if (has_interior) {
-                // the interior launch waits for the boundary planes: started together, its 512 long-lived workgroups take the CUs and the
-                // 1024 short ones of the boundary launch trickle through behind them -- the face message then leaves when the interior is
-                // done and nothing hides the exchange (rocprofv3 timeline, 512^3 on 8 ranks: 1.36 ms per step that way)
+                // Order (per-workgroup time stamps, 512^3 on 8 ranks, tools/dev/k3trace_slab.py): rk3dq_fused fills every CU, so whatever
+                // is launched beside a running interior launch trickles through where its workgroups retire and slows them (7.5 instead
+                // of 6.3 us per march step, second-round workgroups start late).  Hence: boundary launch -> pack -> THEN the interior
+                // launch, enqueued at the same moment as the exchange: the transport's few workgroups (RCCL send / recv, or copies) are
+                // placed first on an empty GPU, the interior's workgroups take the rest, the transfer runs beside them.
                 LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
                 LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));
+            }
+            if (!(skip & 2) && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
+            if (has_interior) {
                 if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], c->aux));
                 launch_step_range(c, p, c->aux, cb + 1, c->nzl - cb);
                 if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], c->aux));
                 LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));
             }
-            if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
-            if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
-            RK3Dev q = p;                                                     // the state this step writes
-            q.fin = c->fB; q.pur_in = c->purB; q.first = 0;
-            rk3dq_face_pack<<<fgrid, fblock, 0, c->stream>>>(q, c->send_up, c->send_dn, has_below, has_above);
-            if (exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
-            rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, c->recv_below, c->recv_above, has_below, has_above);
-            rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, c->recv_below, c->recv_above, has_below, has_above);
+            if (!(skip & 4)) {
+                rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, c->recv_below, c->recv_above, has_below, has_above);
+                rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, c->recv_below, c->recv_above, has_below, has_above);
+            }
             if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: face kernel launch failed"); return fail(LBMPM_ERR_HIP); }
             if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
             if (has_interior) LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
@@ -1817,6 +1829,15 @@ extern "C" int lbmpm_rk3d_storage_info(lbmpm_rk3d *c, int64_t *out)
             if (f[r] & 3u) out[2] += c->h_rowpop[r];
     }
     out[3] = c->q23 ? 2 * Q * 8 * out[1] + 64 * (out[1] - out[2]) : 2 * 2 * Q * 8 * out[1];
+    return LBMPM_OK;
+}
+
+// dev tool (LBMPM_RK3D_TRACE=1): the time stamps the workgroups of the LAST rk3dq_fused launch wrote, 4 x n words (100 MHz clock)
+extern "C" int lbmpm_rk3d_debug_trace(lbmpm_rk3d *c, unsigned long long *out, int64_t nblocks)
+{
+    LBMPM_REQUIRE(c && out && c->trace && nblocks * 32 <= (1 << 22), "lbmpm_rk3d_debug_trace: tracing is off (LBMPM_RK3D_TRACE) or too many workgroups");
+    LBMPM_HIP_TRY(hipDeviceSynchronize());
+    LBMPM_HIP_TRY(hipMemcpy(out, c->trace, (size_t)nblocks * 32, hipMemcpyDeviceToHost));
     return LBMPM_OK;
 }
 
