@@ -363,6 +363,9 @@ int lbmpm_rk3d_storage_info(lbmpm_rk3d *ctx, int64_t *out);
 /* development aid: with LBMPM_RK3D_TRACE set at create time every workgroup of the last rk3dq_fused launch leaves four words
  * (start, prologue done, end on the 100 MHz clock; first << 32 | last plane): copied to out[4 * nblocks] */
 int lbmpm_rk3d_debug_trace(lbmpm_rk3d *ctx, unsigned long long *out, int64_t nblocks);
+/* development aid: one stored component of plane zl (0 .. nz_local+1, halo planes included) of the current state as a dense nx x ny
+ * plane: comp 0..18 populations, 19..22 the record {k_R, A}, 23 the phase-field array, 24 the row flags (out[y * nseg + s]) */
+int lbmpm_rk3d_debug_plane(lbmpm_rk3d *ctx, int comp, int zl, double *out);
 int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *ctx);
 int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *ctx);
 const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *ctx);

@@ -122,6 +122,7 @@ _SIGNATURES = {
     "lbmpm_rk3d_device_bytes": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk3d_storage_info": (C.c_int, [C.c_void_p, I64P]),
     "lbmpm_rk3d_debug_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "lbmpm_rk3d_debug_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, F64P]),
 }
 
 

@@ -256,12 +256,14 @@ __device__ __forceinline__ RowTab make_row(u32x4 sg, u32x4 nb)
 
 // rows straight from the tables in global memory (set-up, boundary-plane and diagnostics kernels)
 struct GlobalRows {
-    const RK3Dev &p;
+    const u32x4 *seg, *seg2;     // (copies of the fields, not a reference to the kernel argument: a reference makes hipcc keep a private
+    int ny, nseg;                //  copy of all of RK3Dev in scratch memory)
     int x, y;
+    __device__ __forceinline__ GlobalRows(const RK3Dev &p, int x_, int y_) : seg(p.seg), seg2(p.seg2), ny(p.ny), nseg(p.nseg), x(x_), y(y_) {}
     __device__ __forceinline__ RowTab operator()(int zl, int ry) const
     {
-        const size_t r = ((size_t)zl * p.ny + wrapi(y + ry, p.ny)) * p.nseg + (x >> 6);
-        return make_row<false>(p.seg[r], p.seg2[r]);
+        const size_t r = ((size_t)zl * ny + wrapi(y + ry, ny)) * nseg + (x >> 6);
+        return make_row<false>(seg[r], seg2[r]);
     }
 };
 
@@ -1037,6 +1039,8 @@ struct lbmpm_rk3d {
     // storage, LBMPM_RK3D_STORAGE=38 keeps the 38-value kernels (the cross-check)
     bool q23 = false;
     unsigned long long *trace = nullptr;      // dev tool, see RK3Dev
+    unsigned *slotq = nullptr;                // tile counters of the rk3dq_fused launches (launch_q23); null: tiles by block index
+    unsigned slot_launches = 0;
     bool halo_valid = false;         // q23 slabs: the halo planes (populations, records, flags, phase field) belong to the current state
     int dbg = 0;
     int nseg = 0;
@@ -1225,6 +1229,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     TRY_RC(dev_alloc(c, &c->fA, fcount));
     TRY_RC(dev_alloc(c, &c->fB, fcount));
     if (c->q23) {
+        if (!(getenv("LBMPM_RK3D_XCC") && atoi(getenv("LBMPM_RK3D_XCC")) == 0)) TRY_RC(dev_alloc(c, &c->slotq, 2 * 4096 * 8));     // zeroed
         TRY_RC(dev_alloc(c, &c->purA, (size_t)(c->nzl + 2) * c->ny * c->nseg));
         TRY_RC(dev_alloc(c, &c->purB, (size_t)(c->nzl + 2) * c->ny * c->nseg));
     }
@@ -1256,7 +1261,7 @@ extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->purA, (void *)c->purB, (void *)c->trace, (void *)c->phi, (void *)c->diag,
+    for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->purA, (void *)c->purB, (void *)c->trace, (void *)c->slotq, (void *)c->phi, (void *)c->diag,
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
@@ -1425,9 +1430,17 @@ void launch_q23(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int
     const int nchunks1 = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
     const int nchunks2 = z_last2 >= z_first2 ? (z_last2 - z_first2 + 1 + c->chunk_len - 1) / c->chunk_len : 0;
     const dim3 grid((unsigned)(8 * tilesX * rpx * (nchunks1 + nchunks2))), block(512);
+    // tile counters of this launch: slice after slice of two rings of 4096 x 8 words that are zeroed wholesale, a ring while the other
+    // one is half used up (no memset per launch: that is a kernel of its own)
+    unsigned *q = nullptr;
+    if (c->slotq) {
+        const unsigned n = c->slot_launches++, ring = (n / 4096u) & 1u, i = n % 4096u;
+        if (i == 2048u) (void)hipMemsetAsync(c->slotq + (size_t)(ring ^ 1u) * 4096u * 8u, 0, 4096u * 8u * sizeof(unsigned), st);
+        q = c->slotq + ((size_t)ring * 4096u + i) * 8u;
+    }
     auto go = [&](auto first, auto mrt) {
         rk3dq_fused<decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last,
-                                                                                            nchunks1, z_first2, z_last2);
+                                                                                            nchunks1, z_first2, z_last2, q);
     };
     dispatch2(p.first != 0, p.mrt != 0, go);
 }
@@ -1617,10 +1630,11 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             }
             if (!(skip & 2) && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
             if (has_interior) {
-                if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], c->aux));
-                launch_step_range(c, p, c->aux, cb + 1, c->nzl - cb);
-                if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], c->aux));
-                LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));
+                hipStream_t ist = (skip & 8) ? c->stream : c->aux;       // (knock-out 8: the interior on the context's own stream)
+                if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], ist));
+                launch_step_range(c, p, ist, cb + 1, c->nzl - cb);
+                if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], ist));
+                LBMPM_HIP_TRY(hipEventRecord(c->ev_done, ist));
             }
             if (!(skip & 4)) {
                 rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, c->recv_below, c->recv_above, has_below, has_above);
@@ -1838,6 +1852,39 @@ extern "C" int lbmpm_rk3d_debug_trace(lbmpm_rk3d *c, unsigned long long *out, in
     LBMPM_REQUIRE(c && out && c->trace && nblocks * 32 <= (1 << 22), "lbmpm_rk3d_debug_trace: tracing is off (LBMPM_RK3D_TRACE) or too many workgroups");
     LBMPM_HIP_TRY(hipDeviceSynchronize());
     LBMPM_HIP_TRY(hipMemcpy(out, c->trace, (size_t)nblocks * 32, hipMemcpyDeviceToHost));
+    return LBMPM_OK;
+}
+
+// development aid: one stored component of one plane (0 .. nzl+1, halo planes included) of the current state, dense nx x ny:
+// comp 0..18 populations (q23 storage: the colour-blind g_i), 19..22 the record {k_R, A} as stored, 23 the phase-field array,
+// 24 the row flags (one value per row segment, out[y * nseg + s])
+extern "C" int lbmpm_rk3d_debug_plane(lbmpm_rk3d *c, int comp, int zl, double *out)
+{
+    LBMPM_REQUIRE(c && out && c->q23 && zl >= 0 && zl <= c->nzl + 1 && comp >= 0 && comp <= 24, "lbmpm_rk3d_debug_plane: q23 storage, plane 0..nzl+1, comp 0..24");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->aux) LBMPM_HIP_TRY(hipStreamSynchronize(c->aux));
+    const size_t n = (size_t)c->nx * c->ny;
+    if (comp == 24) {
+        std::vector<uint32_t> f((size_t)c->ny * c->nseg);
+        LBMPM_HIP_TRY(hipMemcpy(f.data(), c->purA + (size_t)zl * c->ny * c->nseg, f.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < f.size(); ++i) out[i] = (double)f[i];
+        return LBMPM_OK;
+    }
+    if (comp == 23) {
+        std::vector<double> h(c->plane2);
+        LBMPM_HIP_TRY(hipMemcpy(h.data(), c->phi + (size_t)zl * c->plane2, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int y = 0; y < c->ny; ++y) for (int x = 0; x < c->nx; ++x) out[(size_t)y * c->nx + x] = h[(size_t)y * c->pitch + x];
+        return LBMPM_OK;
+    }
+    double *d = nullptr;
+    LBMPM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(double)));
+    const RK3Dev p = make_dev(c);
+    rk3dq_debug_plane<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3), dim3(BX3, BY3), 0, c->stream>>>(p, c->fA, zl, comp, d);
+    hipError_t e = hipMemcpyAsync(out, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { set_error("lbmpm_rk3d_debug_plane: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
     return LBMPM_OK;
 }
 

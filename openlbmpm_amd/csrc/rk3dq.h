@@ -122,7 +122,8 @@ struct LdsScal {                  // the marching kernel's LDS tile (flagged row
     __device__ __forceinline__ double comp(H h, int k) const { return tile[h + k * SCOMP]; }
 };
 struct GlbScal {                  // straight from global memory (set-up, diagnostics and face kernels)
-    const RK3Dev &p;
+    const uint32_t *pur_in;       // (field copies, not a reference to the kernel argument: see GlobalRows)
+    int ny, nseg;
     const char *base;             // plane_addr_q(...).base
     unsigned soff[3];             // byte offsets of the s arrays of the planes zp-1, zp, zp+1
     unsigned own_j;
@@ -131,9 +132,9 @@ struct GlbScal {                  // straight from global memory (set-up, diagno
     __device__ __forceinline__ H at(int rz, int ry, int sgs, unsigned j) const
     {
         int sg = (x >> 6) + sgs;
-        sg = sg < 0 ? sg + p.nseg : (sg >= p.nseg ? sg - p.nseg : sg);
+        sg = sg < 0 ? sg + nseg : (sg >= nseg ? sg - nseg : sg);
         H h;
-        h.cst = p.pur_in[row_index(p, zp + rz, wrapi(y + ry, p.ny), sg)];
+        h.cst = pur_in[((size_t)(zp + rz) * ny + wrapi(y + ry, ny)) * nseg + sg];
         h.off = soff[1 + rz] + j * 32u;
         return h;
     }
@@ -151,7 +152,7 @@ struct GlbScal {                  // straight from global memory (set-up, diagno
 };
 __device__ __forceinline__ GlbScal glb_scal(const RK3Dev &p, const PlaneAddrQ &a, unsigned own_j, int zp, int x, int y)
 {
-    GlbScal s{p, a.base, {0u, 0u, 0u}, own_j, zp, x, y};
+    GlbScal s{p.pur_in, p.ny, p.nseg, a.base, {0u, 0u, 0u}, own_j, zp, x, y};
 #pragma unroll
     for (int k = 0; k < 3; ++k) s.soff[k] = a.off[k] + (unsigned)Q * a.cnt[k] * 8u;
     return s;
@@ -315,7 +316,8 @@ __device__ __forceinline__ double phi_q(double rR, double rho) { return (rR - (r
 //     (38 VGPRs where the 38-value kernel carried 76 in flight).
 template <bool FIRST, bool MRT>
 __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last,
-                                                       int nchunks1, int z_first2, int z_last2)      // a second range of planes in the same launch
+                                                       int nchunks1, int z_first2, int z_last2,      // a second range of planes in the same launch
+                                                       unsigned *slotq)                              // eight zeroed counters of this launch
 {
     constexpr int TX = 64, TY = 8;
     using M = March<TX, TY>;
@@ -324,10 +326,31 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     __shared__ double sphi[M::RING][M::FY][M::FX];
     __shared__ double ssc[4 * SSLOT];              // [ring slot][k_R, A_x, A_y, A_z][SR][SC]
     __shared__ u32x4 srow[TR::SLOTS][TR::ROWS][6];
-    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    // Which tile?  Every XCD owns a band of tile rows (its L2 then serves the rim rows and row records its workgroups share).  "Workgroup b
+    // runs on XCD b % 8" is only an observation, and it does not hold for a launch that follows another queue's launch (the slab step:
+    // per-workgroup time stamps showed the eight "bands" running at 440 .. 560 us instead of 405 each, 7.6 instead of 6.2 us per march
+    // step).  So a workgroup asks the hardware where it is and takes the next tile of THAT XCD's band from a counter; a band that is
+    // exhausted (the dispatcher gave this XCD more workgroups than its share) sends it to the next band with tiles left.
+    __shared__ int sslot[2];
+    const int tid = threadIdx.x;
+    const int band_slots = (int)(gridDim.x >> 3);
+    if (tid == 0 && !slotq) { sslot[0] = (int)(blockIdx.x & 7u); sslot[1] = (int)(blockIdx.x >> 3); }      // LBMPM_RK3D_XCC=0: by block index
+    if (tid == 0 && slotq) {
+        const int here = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);          // HW_REG_XCC_ID, bits 3:0
+        int band = -1, slot = 0;
+        for (int k = 0; k < 8 && band < 0; ++k) {
+            const int b = (here + k) & 7;
+            const int q = (int)atomicAdd(&slotq[b], 1u);
+            if (q < band_slots) { band = b; slot = q; }
+        }
+        sslot[0] = band; sslot[1] = slot;
+    }
+    __syncthreads();
+    const int xcd = sslot[0], slot = sslot[1];
+    if (xcd < 0) return;
+    const int bid = xcd + 8 * slot;                     // (the time-stamp trace is indexed by it)
     const int tx = slot % tilesX, r = slot / tilesX, ty = xcd * rows_per_xcd + r % rows_per_xcd, chunk = r / rows_per_xcd;
     if (ty >= tilesY) return;
-    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: branches on it are branches, not exec masks
     // LBMPM_RK3D_TRACE: per-workgroup time stamps (dev tool); launches of fewer than 8 planes (a slab's boundary ranges) leave no stamps
     unsigned long long *trace = p.trace && z_last - z_first >= 8 ? p.trace + (size_t)bid * 4 : nullptr;
@@ -791,4 +814,23 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_halo_phi(RK3Dev p, const doubl
     double rR, rho;
     bc_q<false>(p, zh, S, nullptr, rR, rho);
     p.phi[idx] = phi_q(rR, rho);
+}
+
+// development aid (lbmpm_rk3d_debug_plane): component comp of the stored state f at plane zl (halo planes included) as a dense
+// nx x ny plane -- 0..18 the populations g_i, 19..22 the record as stored (not the constant of a flagged row); zeros off the fluid
+__global__ __launch_bounds__(BX3 *BY3) void rk3dq_debug_plane(RK3Dev p, const double *f, int zl, int comp, double *out)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y;
+    if (y >= p.ny || x >= p.nx) return;
+    double v = 0.;
+    if (p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1) {
+        const GlobalRows rows{p, x, y};
+        const RowTab t = rows(zl, 0);
+        const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
+        const unsigned long long p0 = pstart_of(p, zl);
+        const size_t cnt = (size_t)(pstart_of(p, zl + 1) - p0);
+        const double *pl = f + (size_t)p0 * QS;
+        v = comp < Q ? pl[(size_t)comp * cnt + j] : pl[(size_t)Q * cnt + (size_t)j * 4 + (comp - Q)];
+    }
+    out[(size_t)y * p.nx + x] = v;
 }

@@ -157,6 +157,14 @@ class RK3DSlab:
         """device memory held by this context"""
         return int(self._L.lbmpm_rk3d_device_bytes(self._h))
 
+    def debug_plane(self, comp, zl):
+        """development aid: stored component `comp` (0..18 populations, 19..22 record, 23 phase-field array, 24 row flags) of the
+        local plane zl (0 and nzl + 1: the halo planes) of the current state"""
+        n = self.ny * ((self.nx + 63) // 64 if comp == 24 else self.nx)
+        out = np.zeros(n, dtype=np.float64)
+        check(self._L.lbmpm_rk3d_debug_plane(self._h, int(comp), int(zl), out.ctypes.data_as(F64P)), "lbmpm_rk3d_debug_plane")
+        return out.reshape(self.ny, -1)
+
     def storage_info(self):
         """what the storage keeps and moves, by its own count (lbmpm_rk3d_storage_info)"""
         out = (C.c_int64 * 4)()

@@ -194,6 +194,76 @@ def test_q23_slabs_equal_single_domain_bitwise(relax, env, k, monkeypatch):
     ref.close(); c.close()
 
 
+def test_q23_slabs_of_a_wide_lattice_equal_single_domain_bitwise():
+    """The bench's lattice shape in small: 192 x 192 planes = three row segments and 1152 waves in the face kernels when a rank has a
+    neighbour on both sides.  Round 3 lost whole waves' worth of face-message entries exactly there (the face kernels then kept a
+    private copy of their argument struct in scratch memory; tests/test_codeobj.py keeps scratch out of these kernels): every face
+    message must come out the same every time, and three slabs must equal the single domain bit for bit, phase by phase
+    (RK3DCluster) and through the pipelined lbmpm_rk3d_step_slab with one host thread per rank."""
+    import threading
+    import torch
+    import bench
+    from openlbmpm_amd.rk3d import RK3DCluster, RK3DDistributed, RK3DSlab
+    n, K, steps = 192, 3, 5
+    dom = bench.c5_domain((n, n, n))
+    rR, rB = bench.c5_densities(dom, 0, n)
+    par = dict(relax="MRT")
+    ref = RK3DSlab(dom, 0, n, par); ref.set_density(rR, rB); ref.step_single(steps); ref.phase_field(diagnostics=True)
+    want = {f: ref.get(f) for f in ("phi", "rhoR", "vz")}
+    ref.close()
+    assert np.isfinite(want["phi"]).all()
+    c = RK3DCluster(dom, K, par); c.set_density(rR, rB)
+    mid = c.slabs[1]
+    for name in ("f_send_up", "f_send_down"):            # the rank with two neighbours packs both faces in one launch
+        t, first = mid.buffer(name), None
+        for _ in range(5):
+            with torch.cuda.stream(c.stream):
+                t.zero_(); mid.pack()
+            c.stream.synchronize()
+            img = t.clone()
+            first = img if first is None else first
+            assert torch.equal(img, first), name
+    c.step(steps); c.observe(); c.stream.synchronize()
+    for f in want:
+        assert np.array_equal(c.get(f), want[f]), ("cluster", f)
+    c.close()
+    # the pipelined step as the ranks of a real run make it, with an exact exchange: a barrier inside the callback
+    parts = RK3DDistributed.partition(dom, K)
+    st = torch.cuda.Stream(0)
+    slabs = []
+    for z0, nz in parts:
+        s = RK3DSlab(dom, z0, nz, par); s.set_density(rR[z0:z0 + nz], rB[z0:z0 + nz]); s.use_torch_stream(st); slabs.append(s)
+    gate, errors = threading.Barrier(K), []
+
+    def rank(r):
+        s, below, above = slabs[r], r > 0, r + 1 < K
+
+        def exchange(what):
+            gate.wait()
+            with torch.cuda.stream(st):
+                if below: s.buffer("f_recv_below").copy_(slabs[r - 1].buffer("f_send_up"))
+                if above: s.buffer("f_recv_above").copy_(slabs[r + 1].buffer("f_send_down"))
+            gate.wait()
+        try:
+            s.step_slab(steps, below, above, exchange)
+        except BaseException as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append(e); gate.abort()
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(K)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors
+    with torch.cuda.stream(st):
+        for s in slabs: s.pack()
+        for r, s in enumerate(slabs):
+            if r > 0: s.buffer("f_recv_below").copy_(slabs[r - 1].buffer("f_send_up"))
+            if r + 1 < K: s.buffer("f_recv_above").copy_(slabs[r + 1].buffer("f_send_down"))
+        for r, s in enumerate(slabs):
+            s.unpack(r > 0, r + 1 < K); s.phase_field(diagnostics=True)
+    for f in want:
+        assert np.array_equal(np.concatenate([s.get(f) for s in slabs], axis=0), want[f]), ("pipelined", f)
+    for s in slabs: s.close()
+
+
 def test_mrt_differs_from_srt_and_unknown_relaxation_is_rejected():
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=24, ny=12, nz=20, seed=2)
