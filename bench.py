@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-B_ALG = {"c1": 288.0, "c2": 288.0, "c3": 288.0, "c4": 368.0, "c5": 608.0}   # algorithmic bytes / lattice update
+B_ALG = {"c1": 288.0, "c2": 288.0, "c2p": 288.0, "c3": 288.0, "c4": 368.0, "c5": 608.0}   # algorithmic bytes / lattice update
 SEED = 20260928
 
 
@@ -73,6 +73,17 @@ def build_c2(nx, ny, device):
     s = RK2DSolver(dom, dict(relax="MRT"), device=device)
     s.set_macro(rR, rB)
     return s, float((rR + rB).sum()), lambda: float((s.get("rhoR") + s.get("rhoB")).sum())
+
+
+def build_c2p(nx, ny, device):
+    """the c2 lattice with SurfaceTensionType = 'Perturbation' (the 2-D twin of the c5 model): rk2dp_fused, one launch per step"""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.geometry import simple_geometry, initial_densities_rk
+    dom = simple_geometry(nx, ny)
+    rR, rB = initial_densities_rk(dom, False, 10, mode="intrusion")
+    s = RK2DSolver(dom, dict(relax="MRT"), device=device, perturbation=dict(AkR=0.007, AkB=0.009, solidPhi=0.5))
+    s.set_macro(rR, rB)
+    return s, float((rR + rB).sum()), None
 
 
 def build_c3(nx, ny, device):
@@ -402,10 +413,10 @@ def main():
                                     "per_rank": per_rank}
             if world == 1 and not args.no_secondary:
                 sec = []
-                for name, build, size2 in (("c1", build_c1, (128, 128)), ("c2", build_c2, (1024, 1024)),
+                for name, build, size2 in (("c1", build_c1, (128, 128)), ("c2", build_c2, (1024, 1024)), ("c2p", build_c2p, (1024, 1024)),
                                            ("c3", build_c3, (2048, 2048)), ("c4", build_c4, (2048, 2048))):
                     s, _, _ = build(size2[0], size2[1], local_rank)
-                    k = {"c1": 20000, "c2": 5000}.get(name, 2000)    # C2 5000, C3 / C4 2000 steps (+10 % warm-up); c1: 16 k nodes,
+                    k = {"c1": 20000, "c2": 5000, "c2p": 5000}.get(name, 2000)    # C2 5000, C3 / C4 2000 steps (+10 % warm-up); c1: 16 k nodes,
                                                                        # ~7 us a step, the warm-up builds its hipGraph
                     if os.environ.get("LBMPM_BENCH_SECONDARY_STEPS"):    # counter passes of tools/profile_round.sh: every dispatch is slow there
                         k = int(os.environ["LBMPM_BENCH_SECONDARY_STEPS"])
@@ -414,6 +425,9 @@ def main():
                     sec.append({"workload": name, "value": round(nf * k / w / 1e6, 2), "unit": "MLUPS",
                                 "ms_per_step": round(w * 1e3 / k, 5), "fluid_nodes": nf, "kernel": s.dominant_kernel,
                                 "roofline_frac": round(B_ALG[name] * nf / (md / k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                    if name == "c2p":
+                        sec[-1]["note"] = ("not a BASELINE config: the c2 lattice with SurfaceTensionType 'Perturbation' (RKD2Q9.py:978-1223), the 2-D twin of "
+                                           "the c5 model, fused into one launch per step (tests/test_rk2d_pert_gpu.py: the reference loop's captures at 1e-9)")
                     if name == "c1":
                         sec[-1]["note"] = ("configs[0] on the GPU: 64 workgroups, bound by the kernel's own latency chain (hipGraph replay of 64 steps "
                                            "removes the launch gaps).  The static-droplet Laplace test: with shanchen2D.ini's interactionFluid = 3.8 the "

@@ -183,6 +183,22 @@ typedef struct lbmpm_tracer_config {
                                        reaction source is spread with J_0, (1-J_0)/4 x 4 (Transport2DRK.py:404) */
 } lbmpm_tracer_config;
 
+/* [SurfaceTension] SurfaceTensionType = 'Perturbation': the loop of RKColorGradientLBM.runRKColorGradient2DPerturbation
+ * (RKCG2D/RKD2Q9.py:978-1223; kernels AcceleratedRKGPU2D.py:1125-1343 + the per-colour Zou-He rows :657-695, :1008-1039) as one
+ * fused launch per time step instead of the CSF step the context was created for.  Uses tau_r, tau_b, beta, relaxation of the
+ * create-time config; the step streams FIRST (set_pdf gives the state before the first streaming).  Velocity inlet and pressure
+ * outlet only, rows 0, 1, ny-2, ny-1 free of solid: anything else is LBMPM_ERR_UNSUPPORTED (the kernel-level entry points run it).
+ * Fields: LBMPM_RK_PDF_R/B = the stored (recoloured) populations; RHO_R/B, VX, VY, PHI, GX, GY = those of the last step (needs
+ * diagnostics); REC_* = what the next step records after streaming + boundary kernels. */
+typedef struct lbmpm_rk2d_perturbation {
+    double ak_r, ak_b;             /* [RKParameters] AkR, AkB                                  */
+    double solid_phi;              /* phase field carried by solid neighbours (solidPhi)       */
+    double inlet_velocity_y_r;     /* [BoundaryDefinition] VelocityYR                          */
+    double inlet_velocity_y_b;     /*                      VelocityYB                          */
+    double outlet_rho_r;           /*                      densityRL                           */
+    double outlet_rho_b;           /*                      densityBL                           */
+} lbmpm_rk2d_perturbation;
+int lbmpm_rk2d_set_perturbation(lbmpm_rk2d *ctx, const lbmpm_rk2d_perturbation *par);
 int lbmpm_rk2d_tracer_configure(lbmpm_rk2d *ctx, const lbmpm_tracer_config *cfg);
 /* dense [ny][nx] concentration; g = C w (Transport2DRK.py:399-470); before the first step */
 int lbmpm_rk2d_tracer_set_concentration(lbmpm_rk2d *ctx, int tracer, const double *conc);

@@ -155,8 +155,10 @@ class RKColorGradientLBM:
           R4 body force zero.
         Also left out: the loop's last launch, calRecoloringProcess (:1206), reads gradient and collision arrays nothing ever
         writes -- it adds zeros where device_array_like happens to return zeros, garbage otherwise.
-        There is no fused kernel for this 2-D loop (its 3-D extension is rk3dc_fused): it runs as ~16 launches per step on the
-        kernel-level entry points (include/lbmpm_kernels.h), arrays in the reference's sparse layout.
+        Schedule (`self.perturbation_schedule`): "fused" = one launch per time step (rk2dp_fused behind lbmpm_rk2d_set_perturbation:
+        velocity inlet + pressure outlet, no solid node in the four boundary rows); "kernels" = the loop kernel by kernel, ~16
+        launches per step on the kernel-level entry points (include/lbmpm_kernels.h), arrays in the reference's sparse layout --
+        every boundary type of the loop; "auto" (default) = fused where it applies, else kernels.
         `initial_pdf` = (fR, fB) dense [ny][nx][9] replaces the rest-state start (tests)."""
         import sys
         drop = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
@@ -168,6 +170,13 @@ class RKColorGradientLBM:
             raise config.ConfigError("runRKColorGradient2DPerturbation needs SurfaceTensionType = 'Perturbation'")
         self.initializeDomainBorder()
         self.initializeDomainCondition()
+        schedule = getattr(self, "perturbation_schedule", "auto")
+        if schedule not in ("auto", "fused", "kernels"):
+            raise ValueError("perturbation_schedule must be 'auto', 'fused' or 'kernels'")
+        if schedule != "kernels":
+            done = self._run_perturbation_fused(progress, initial_pdf, required=schedule == "fused")
+            if done:
+                return self.result_path
         ny, nx = self.isDomain.shape
         fluid = np.flatnonzero(self.isDomain.reshape(-1) == 1).astype(np.int64)          # optimizeFluidArray, :603-655
         N = int(fluid.size)
@@ -236,6 +245,46 @@ class RKColorGradientLBM:
             if progress:
                 progress(step)
         return self.result_path
+
+    def _run_perturbation_fused(self, progress, initial_pdf, required):
+        """the perturbation loop on the fused solver; False when the fused step does not cover this set-up (and it was not demanded)"""
+        from ._lib import LbmpmError
+        from .rk2d import RK2DSolver
+        p = self.par
+        par = dict(beta=p["beta"], tauR=p["tauR"], tauB=p["tauB"], relax=p["relax"], inlet=p["inlet"], outlet=p["outlet"], vyR=p["vyR"], vyB=p["vyB"],
+                   rhoRL=p["rhoRL"], rhoBL=p["rhoBL"], rhoRH=p["rhoRH"], rhoBH=p["rhoBH"])
+        try:
+            solver = RK2DSolver(self.isDomain, par, perturbation=dict(AkR=p["AkR"], AkB=p["AkB"], solidPhi=p["solidPhi"]))
+        except LbmpmError as e:
+            if required or "(status -5)" not in str(e):                  # LBMPM_ERR_UNSUPPORTED: the kernel-level loop covers it
+                raise
+            return False
+        ny, nx = self.isDomain.shape
+        fluid = self.isDomain == 1
+        W = np.array([4. / 9.] + [1. / 9.] * 4 + [1. / 36.] * 4)
+        if initial_pdf is not None:
+            fR, fB = (np.asarray(a, dtype=np.float64).reshape(ny, nx, 9) for a in initial_pdf)
+        else:                                                             # :577-601 with u = 0
+            fR = np.where(fluid[..., None], self.fluidsRhoR[..., None] * W, 0.0); fB = np.where(fluid[..., None], self.fluidsRhoB[..., None] * W, 0.0)
+        solver.set_pdf(fR, fB)
+        out = ResultFile(self.output_dir, "SimulationResultsRK",
+                         (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity")))
+        self.result_path = out.path
+        self._guard = RecordGuard("rk2d perturbation", int(fluid.sum()), self.nan_guard)
+        self.fluidNodes = np.flatnonzero(self.isDomain.reshape(-1) == 1).astype(np.int64)
+        step = 1
+        while step <= self.timeSteps:
+            self._step_now = step - 1
+            if (step - 1) % self.timeInterval == 0:                      # :1121-1131: after the step's streaming, boundary kernels, velocity
+                self._record(solver, out)
+            nxt = min(self.timeSteps + 1, ((step - 1) // self.timeInterval + 1) * self.timeInterval + 1)
+            solver.step(nxt - step)
+            step = nxt
+            if progress:
+                progress(step - 1)
+        solver.sync()
+        self.solver = solver
+        return True
 
     def _record(self, solver, out):
         k = self.records

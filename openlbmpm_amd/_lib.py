@@ -32,6 +32,12 @@ class RK2DConfig(C.Structure):
                 ("device", C.c_int32), ("variant", C.c_int32)]
 
 
+class RK2DPerturbation(C.Structure):
+    # mirrors struct lbmpm_rk2d_perturbation (include/lbmpm.h)
+    _fields_ = [("ak_r", C.c_double), ("ak_b", C.c_double), ("solid_phi", C.c_double), ("inlet_velocity_y_r", C.c_double),
+                ("inlet_velocity_y_b", C.c_double), ("outlet_rho_r", C.c_double), ("outlet_rho_b", C.c_double)]
+
+
 class TracerConfig(C.Structure):
     # mirrors struct lbmpm_tracer_config (include/lbmpm.h)
     _fields_ = [("num_tracers", C.c_int32), ("diffusion_x", C.c_double * 4), ("diffusion_y", C.c_double * 4),
@@ -83,6 +89,7 @@ _SIGNATURES = {
     "lbmpm_rk2d_dominant_kernel": (C.c_char_p, [C.c_void_p]),
     "lbmpm_rk2d_device_bytes": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk2d_tracer_configure": (C.c_int, [C.c_void_p, C.POINTER(TracerConfig)]),
+    "lbmpm_rk2d_set_perturbation": (C.c_int, [C.c_void_p, C.POINTER(RK2DPerturbation)]),
     "lbmpm_rk2d_tracer_set_concentration": (C.c_int, [C.c_void_p, C.c_int, F64P]),
     "lbmpm_rk2d_tracer_get_concentration": (C.c_int, [C.c_void_p, C.c_int, F64P]),
     "lbmpm_sc2d_create": (C.c_int, [C.POINTER(SC2DConfig), U8P, C.POINTER(C.c_void_p)]),

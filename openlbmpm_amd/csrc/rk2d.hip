@@ -40,6 +40,9 @@ struct RKDev {
     double sigma, cosT, sinT, beta, delta, tauR, tauB, vyIn, pInB, pInR, pOut;
     int wetting, tautype, inlet, outlet;
     int first;         // 1: fin holds the initial (already post-streaming) state
+    // perturbation operator (lbmpm_rk2d_set_perturbation; rk2dp_fused)
+    double akR, akB, solidPhi, vyInR, vyInB, pOutR, pOutB;
+    double *pd;        // [4][plane] rhoR, rhoB, vx, vy of the last step (nullptr = off)
     // D2Q5 tracer transport (AccelerateTransport2DRK.py), fused into phase D
     int ntr, trFree, trDirichlet;
     const double *gin;   // [ntr][5][plane]
@@ -190,11 +193,16 @@ __device__ __forceinline__ double feq(double rho, double w, double ex, double ey
 //   m_src = (0, 6u.F, -6u.F, Fx, -Fx, Fy, -Fy, 2(uxFx-uyFy), uxFy+uyFx)
 // and M^-1 = M^T diag(1/|row|^2).  Differences to the dense form are rounding-level.
 template <bool MRT>
+__device__ __forceinline__ void collide_tau(double tau, double fT[9], double rho, double vx, double vy, double Fx, double Fy);
+template <bool MRT>
 __device__ __forceinline__ void collide(const RKDev &p, double fT[9], double rhoR, double rhoB, double phi,
                                         double vx, double vy, double Fx, double Fy)
 {
-    const double tau = tau_of(p, phi, rhoR, rhoB);
-    const double rho = rhoR + rhoB;
+    collide_tau<MRT>(tau_of(p, phi, rhoR, rhoB), fT, rhoR + rhoB, vx, vy, Fx, Fy);
+}
+template <bool MRT>
+__device__ __forceinline__ void collide_tau(double tau, double fT[9], double rho, double vx, double vy, double Fx, double Fy)
+{
     const double usq = vx * vx + vy * vy;
     if (!MRT) {
         constexpr double W[9] = LBMPM_D2Q9_W;
@@ -734,6 +742,210 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     }
 }
 
+// ---------------------------------------------------------------- perturbation operator, fused
+// [SurfaceTension] SurfaceTensionType = 'Perturbation': the loop of RKColorGradientLBM.runRKColorGradient2DPerturbation
+// (RKD2Q9.py:978-1223; the 2-D twin of the D3Q19 model of rk3d.hip) as ONE launch per time step.  Per step, in the reference's
+// order: stream both colours (A:340-417) -> Zou-He pressure outlet per colour on row 1 (calConstPressureLowerGPU A:1008-1039),
+// ghost row 0 = row 1 (A:1045-1081) -> Zou-He velocity inlet per colour on row ny-2 (constantVelocityZHBoundaryHigherRK A:657-695),
+// ghost row ny-1 = row ny-2 (A:607-650) -> densities (A:80-100), velocity without force (A:125-147), phase field (A:1348) ->
+// collision 1: BGK per colour (calRKCollision1GPU2DSRTNew A:1125-1163) or MRT on the sum (calRKCollision1GPU2DMRTNew A:1272-1343,
+// body force zero), tau harmonic in phi -> colour gradient from the neighbours' phase field (solid neighbours carry solidPhi),
+// perturbation and recolouring (calRKCollision23GPUNew A:1169-1267).  The stored state is the recoloured one; the next step's pull
+// streams it.  Repairs R1-R4 of the dead reference driver as in openlbmpm_amd/RKD2Q9.py (R3: f_tot is summed after collision 1
+// for SRT, before it for MRT).  A workgroup owns a 64 x 8 tile and recomputes the phase field on tile + 1.
+
+// post-streaming, post-boundary-rows state of node (x, y): both colour lattices and their densities
+__device__ __forceinline__ void pert_node_state(const RKDev &p, int x, int y, double fR[9], double fB[9], double &rhoR, double &rhoB)
+{
+    const int ys = y == p.ny - 1 ? p.ny - 2 : (y == 0 ? 1 : y);      // the ghost rows copy their neighbour row's state
+    pull_node(p, x, ys, fR, fB);
+    if (ys == 1) {                        // A:1008-1039 (blue first, then red)
+        {
+            double *b = fB;
+            const double pL = p.pOutB;
+            const double v = 1. - 1. / pL * (b[0] + b[1] + b[3] + 2. * (b[4] + b[7] + b[8]));
+            b[2] = b[4] + 2. / 3. * (pL * v);
+            b[5] = b[7] + 0.5 * (b[3] - b[1]) + 1. / 6. * pL * v;
+            b[6] = b[8] + 0.5 * (b[1] - b[3]) + 1. / 6. * pL * v;
+        }
+        {
+            double *r = fR;
+            const double pL = p.pOutR;
+            const double v = 1. - 1. / pL * (r[0] + r[1] + r[3] + 2. * (r[4] + r[7] + r[8]));
+            r[2] = r[4] + 2. / 3. * pL * v;
+            r[5] = r[7] + 0.5 * (r[3] - r[1]) + 1. / 6. * pL * v;
+            r[6] = r[8] + 0.5 * (r[1] - r[3]) + 1. / 6. * pL * v;
+        }
+    }
+    if (ys == p.ny - 2) {                 // A:657-695
+        {
+            double *r = fR;
+            const double rho = (r[0] + r[1] + r[3] + 2. * (r[2] + r[5] + r[6])) / (1. + p.vyInR);
+            r[4] = r[2] - 2. / 3. * rho * p.vyInR;
+            r[7] = r[5] + (r[1] - r[3]) / 2. - 1. / 6. * rho * p.vyInR;
+            r[8] = r[6] - (r[1] - r[3]) / 2. - 1. / 6. * rho * p.vyInR;
+        }
+        {
+            double *b = fB;
+            const double rho = (b[0] + b[1] + b[3] + 2. * (b[2] + b[5] + b[6])) / (1. + p.vyInB);
+            b[4] = b[2] - 2. / 3. * rho * p.vyInB;
+            b[7] = b[5] + (b[1] - b[3]) / 2. - 1. / 6. * rho * p.vyInB;
+            b[8] = b[6] - (b[1] - b[3]) / 2. - 1. / 6. * rho * p.vyInB;
+        }
+    }
+    rhoR = sum9(fR);                      // calMacroDensityRKGPU2D runs over every node AFTER the boundary kernels
+    rhoB = sum9(fB);
+}
+
+// velocity of calPhysicalVelocityRKGPU2D (A:125-147): no force term, the reference's order of the twelve terms
+__device__ __forceinline__ void pert_velocity(const double r[9], const double b[9], double rhoR, double rhoB, double &vx, double &vy)
+{
+    const double rho = rhoB + rhoR;
+    const double tx = r[1] - r[3] + r[5] - r[6] - r[7] + r[8] + b[1] - b[3] + b[5] - b[6] - b[7] + b[8];
+    vx = tx / rho;
+    const double ty = r[2] - r[4] + r[5] + r[6] - r[7] - r[8] + b[2] - b[4] + b[5] + b[6] - b[7] - b[8];
+    vy = ty / rho;
+}
+
+template <bool MRT>
+__global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, int tiles_x)
+{
+    constexpr int TW = 64, TH = 8, RW = TW + 2, RH = TH + 2, THREADS = TW * TH;
+    constexpr double W[9] = LBMPM_D2Q9_W;
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    __shared__ double s_phi[RH * RW];
+    __shared__ uint8_t s_fluid[RH * RW];
+    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
+    const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
+    for (int n = tid; n < RH * RW; n += THREADS) {
+        const int x = wrapm(tx0 - 1 + n % RW, p.nx), y = wrapm(ty0 - 1 + n / RW, p.ny);
+        s_fluid[n] = p.flags[(size_t)y * p.pitch + x] & 1;
+    }
+    // own node and "its" rim node: both pulls back to back
+    const int x = tx0 + lx, y = ty0 + ly;
+    const bool inside = x < p.nx && y < p.ny;
+    const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);       // (partial tiles: periodic images serve as rim)
+    const size_t idx = (size_t)yw * p.pitch + xw;
+    const bool fluid = p.flags[idx] & 1, act = inside && fluid;
+    double fR[9], fB[9], rR = 1., rB = 1.;
+    if (fluid) pert_node_state(p, xw, yw, fR, fB, rR, rB);
+    constexpr int NRIM = 2 * RW + 2 * TH;
+    int hr = -1;
+    double hphi = 0.;
+    if (tid < NRIM) {
+        int rx, ry;
+        if (tid < RW) { ry = 0; rx = tid; }
+        else if (tid < 2 * RW) { ry = RH - 1; rx = tid - RW; }
+        else { const int k = tid - 2 * RW; ry = 1 + k / 2; rx = (k & 1) ? RW - 1 : 0; }
+        const int hx = wrapm(tx0 - 1 + rx, p.nx), hy = wrapm(ty0 - 1 + ry, p.ny);
+        if (p.flags[(size_t)hy * p.pitch + hx] & 1) {
+            double a[9], b[9], ra, rb;
+            pert_node_state(p, hx, hy, a, b, ra, rb);
+            hr = ry * RW + rx;
+            hphi = (ra - rb) / (ra + rb);
+        }
+    }
+    const int ri = (1 + ly) * RW + 1 + lx;
+    if (fluid) s_phi[ri] = (rR - rB) / (rR + rB);
+    if (hr >= 0) s_phi[hr] = hphi;
+    __syncthreads();
+
+    const bool line8 = lbmpm_dev::line_has_active<8>(act, tid & 63);
+    if (!(line8 && inside)) return;
+    double oR[9], oB[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { oR[i] = 0.; oB[i] = 0.; }
+    if (act) {
+        double vx, vy;
+        pert_velocity(fR, fB, rR, rB, vx, vy);
+        const double phi = (rR - rB) / (rR + rB);
+        const double tau = 0.5 + 1. / ((1. + phi) / (2. * (p.tauR - 0.5)) + (1. - phi) / (2. * (p.tauB - 0.5)));   // A:1144, A:1307
+        double fT[9];
+        if (!MRT) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const double eR = feq(rR, W[i], (double)EX[i], (double)EY[i], vx, vy);
+                const double cR = -1. / tau * (fR[i] - eR);
+                const double eB = feq(rB, W[i], (double)EX[i], (double)EY[i], vx, vy);
+                const double cB = -1. / tau * (fB[i] - eB);
+                fR[i] = fR[i] + cR;
+                fB[i] = fB[i] + cB;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fT[i] = fR[i] + fB[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fT[i] = fR[i] + fB[i];
+            collide_tau<true>(tau, fT, rR + rB, vx, vy, 0., 0.);       // the moment-space form of A:1272-1343 (S = 0, 1.64, 1.54, 0, 1.9, 0, 1.9, 1/tau, 1/tau)
+        }
+        // calRKCollision23GPUNew, A:1169-1267
+        double gx = 0., gy = 0.;
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            const int rn = ri + EY[i] * RW + EX[i];
+            const double ph = s_fluid[rn] ? s_phi[rn] : p.solidPhi;
+            gx += 3. * W[i] * (double)EX[i] * ph;
+            gy += 3. * W[i] * (double)EY[i] * ph;
+        }
+        constexpr double BC[9] = {-2. / 9., 1. / 9., 1. / 9., 1. / 9., 1. / 9., 1. / 36., 1. / 36., 1. / 36., 1. / 36.};     // constantBNew, RKD2Q9.py:131-133
+        const double g2 = gx * gx + gy * gy, gn = sqrt(g2);
+        const double rs = rR + rB, rm = rR * rB, rs2 = rs * rs;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            double c2 = 0.;
+            if (g2 != 0.) {
+                const double eg = (double)EX[i] * gx + (double)EY[i] * gy;
+                const double part = W[i] * (eg * eg) / g2;
+                c2 = (p.akR + p.akB) * 0.5 * gn * (part - BC[i]);
+            }
+            fT[i] += c2;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double en = sqrt((double)(EX[i] * EX[i] + EY[i] * EY[i]));
+            double c = 0.;
+            if (!(en == 0. || gn == 0.)) c = ((double)EX[i] * gx + (double)EY[i] * gy) / (en * gn);
+            oR[i] = rR / rs * fT[i] + (p.beta * rm / rs2) * W[i] * c;
+            oB[i] = rB / rs * fT[i] - (p.beta * rm / rs2) * W[i] * c;
+        }
+        if (p.pd) {
+            p.pd[idx] = rR; p.pd[p.plane + idx] = rB; p.pd[2 * p.plane + idx] = vx; p.pd[3 * p.plane + idx] = vy;
+            p.phi[idx] = phi; p.G[idx] = gx; p.G[p.plane + idx] = gy;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) lbmpm_dev::store_pair(p.fout, p.plane, i, idx, oR[i], oB[i]);
+}
+
+// what the perturbation loop would record at the start of the next step (RKD2Q9.py:1121-1131: after streaming, boundary kernels,
+// densities and velocity): out[22][plane] like rk2d_observe
+__global__ __launch_bounds__(BX *BY) void rk2dp_observe(RKDev p, double *out)
+{
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    double fR[9], fB[9], rR, rB, vx, vy;
+    pert_node_state(p, x, y, fR, fB, rR, rB);
+    pert_velocity(fR, fB, rR, rB, vx, vy);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { out[i * p.plane + idx] = fR[i]; out[(9 + i) * p.plane + idx] = fB[i]; }
+    out[18 * p.plane + idx] = rR; out[19 * p.plane + idx] = rB;
+    out[20 * p.plane + idx] = vx; out[21 * p.plane + idx] = vy;
+}
+// the stored (recoloured) populations as the device arrays hold them after a completed step: out[18][plane]
+__global__ __launch_bounds__(BX *BY) void rk2dp_stored(RKDev p, double *out)
+{
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= p.nx || y >= p.ny) return;
+    const size_t idx = (size_t)y * p.pitch + x;
+    if (!(p.flags[idx] & 1)) return;
+    const double2 *f2 = reinterpret_cast<const double2 *>(p.fin);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const double2 v = f2[i * p.plane + idx]; out[i * p.plane + idx] = v.x; out[(9 + i) * p.plane + idx] = v.y; }
+}
+
 // Observation kernels: populations/densities as the reference's device arrays hold them
 // after the last completed step (WITH_BC=false), or as resultInHDF5 records them at the
 // start of the next step (WITH_BC=true: + velocity, RKD2Q9.py:1382-1393).
@@ -840,6 +1052,9 @@ struct lbmpm_rk2d {
     double *gA = nullptr, *gB = nullptr;
     double trCrit = 0.5, trM[25] = {0}, trA[4][25] = {{0}}, trBeta[4] = {0}, trCb[4] = {0};
     double trRate = 0., trJ[4] = {1. / 3., 1. / 3., 1. / 3., 1. / 3.};
+    int model = 0;            // 0 CSF (the create-time model), 1 perturbation operator (lbmpm_rk2d_set_perturbation)
+    lbmpm_rk2d_perturbation pert{};
+    double *pd = nullptr;     // perturbation model: rhoR, rhoB, vx, vy of the last step (diagnostics)
     int shape = 0;            // fused tile shape (LBMPM_RK2D_SHAPE, tuning only)
     bool streamed = false;    // false: fA holds the initial (already "post-streaming") state
     bool diag_valid = false;
@@ -864,6 +1079,11 @@ RKDev make_dev(const lbmpm_rk2d *c)
     p.wetting = c->cfg.wetting_type; p.tautype = c->cfg.tau_type;
     p.inlet = c->cfg.inlet_type; p.outlet = c->cfg.outlet_type;
     p.first = c->streamed ? 0 : 1;
+    p.akR = c->pert.ak_r; p.akB = c->pert.ak_b; p.solidPhi = c->pert.solid_phi;
+    p.vyInR = c->pert.inlet_velocity_y_r; p.vyInB = c->pert.inlet_velocity_y_b;
+    p.pOutR = c->pert.outlet_rho_r; p.pOutB = c->pert.outlet_rho_b;
+    p.pd = nullptr;
+    if (c->model == 1) p.first = 0;         // the perturbation loop streams first: the initial state is pulled like any other
     p.ntr = c->ntr; p.trFree = c->trFree; p.trDirichlet = c->trDirichlet; p.gin = c->gA; p.gout = c->gB;
     p.trCrit = c->trCrit;
     memcpy(p.trM, c->trM, sizeof(p.trM)); memcpy(p.trA, c->trA, sizeof(p.trA));
@@ -895,10 +1115,17 @@ void launch_fused_tracer(lbmpm_rk2d *c, const RKDev &p)
 int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
 {
     RKDev p = make_dev(c);
-    p.first = c->streamed ? 0 : 1;
     if (!diag) p.diag = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->cfg.variant == 0) {
+    if (c->model == 1) {
+        p.pd = diag ? c->pd : nullptr;
+        const bool ev = timed && c->pool.take(&e0, &e1);
+        if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+        const int tiles_x = (c->nx + 63) / 64, tiles_y = (c->ny + 7) / 8;
+        if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2dp_fused<true><<<dim3(tiles_x * tiles_y), dim3(512), 0, c->stream>>>(p, tiles_x);
+        else rk2dp_fused<false><<<dim3(tiles_x * tiles_y), dim3(512), 0, c->stream>>>(p, tiles_x);
+        if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
+    } else if (c->cfg.variant == 0) {
         const bool ev = timed && c->pool.take(&e0, &e1);
         if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
         if (c->ntr > 0) {
@@ -1036,7 +1263,7 @@ extern "C" void lbmpm_rk2d_destroy(lbmpm_rk2d *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *ptr : {(void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->F,
-                      (void *)c->ns, (void *)c->phi, (void *)c->G, (void *)c->diag, (void *)c->obs, (void *)c->gA, (void *)c->gB})
+                      (void *)c->ns, (void *)c->phi, (void *)c->G, (void *)c->diag, (void *)c->obs, (void *)c->gA, (void *)c->gB, (void *)c->pd})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1152,6 +1379,7 @@ extern "C" int lbmpm_rk2d_enable_diagnostics(lbmpm_rk2d *c, int on)
     LBMPM_REQUIRE(c, "null context");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     if (on && !c->diag) { const int rc = dev_alloc(c, &c->diag, 3 * c->plane); if (rc) return rc; }
+    if (on && c->model == 1 && !c->pd) { const int rc = dev_alloc(c, &c->pd, 4 * c->plane); if (rc) return rc; }
     if (!on && c->diag) {
         LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(c->diag); c->diag = nullptr; c->diag_valid = false;
@@ -1185,6 +1413,45 @@ extern "C" int lbmpm_rk2d_get_field(lbmpm_rk2d *c, int field, double *out)
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     const bool rec = field >= LBMPM_RK_REC_PDF_R && field <= LBMPM_RK_REC_VY;
     const bool cur_obs = field >= LBMPM_RK_PDF_R && field <= LBMPM_RK_RHO_B;
+    if (c->model == 1) {
+        // perturbation loop (streams first): after a completed step the reference's arrays hold the recoloured populations and the
+        // densities / velocity / phase field computed DURING that step (kept by the kernel when diagnostics are on); the "rec" fields
+        // are what the next step would record after its streaming and boundary kernels
+        if (rec || field == LBMPM_RK_PDF_R || field == LBMPM_RK_PDF_B) {
+            if (!c->obs) { const int rc = dev_alloc(c, &c->obs, 22 * c->plane); if (rc) return rc; }
+            RKDev p = make_dev(c);
+            const dim3 g = grid_of(c), b(BX, BY);
+            if (rec) rk2dp_observe<<<g, b, 0, c->stream>>>(p, c->obs);
+            else rk2dp_stored<<<g, b, 0, c->stream>>>(p, c->obs);
+            LBMPM_HIP_TRY(hipGetLastError());
+            LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+            const int f = rec ? field - LBMPM_RK_REC_PDF_R : field;
+            switch (f) {
+                case 0: return copy_plane(c, c->obs, out, 9);
+                case 1: return copy_plane(c, c->obs + 9 * c->plane, out, 9);
+                case 2: return copy_plane(c, c->obs + 18 * c->plane, out, 1);
+                case 3: return copy_plane(c, c->obs + 19 * c->plane, out, 1);
+                case 4: return copy_plane(c, c->obs + 20 * c->plane, out, 1);
+                default: return copy_plane(c, c->obs + 21 * c->plane, out, 1);
+            }
+        }
+        if (!(c->pd && c->diag_valid)) {
+            set_error("field %d of the perturbation model needs lbmpm_rk2d_enable_diagnostics(ctx, 1) before the last lbmpm_rk2d_step", field);
+            return LBMPM_ERR_STATE;
+        }
+        switch (field) {
+            case LBMPM_RK_RHO_R: return copy_plane(c, c->pd, out, 1);
+            case LBMPM_RK_RHO_B: return copy_plane(c, c->pd + c->plane, out, 1);
+            case LBMPM_RK_VX: return copy_plane(c, c->pd + 2 * c->plane, out, 1);
+            case LBMPM_RK_VY: return copy_plane(c, c->pd + 3 * c->plane, out, 1);
+            case LBMPM_RK_PHI: return copy_plane(c, c->phi, out, 1);
+            case LBMPM_RK_GX: return copy_plane(c, c->G, out, 1);
+            case LBMPM_RK_GY: return copy_plane(c, c->G + c->plane, out, 1);
+            default: break;
+        }
+        set_error("lbmpm_rk2d_get_field: the perturbation model has no field %d (no CSF force, no curvature)", field);
+        return LBMPM_ERR_INVALID;
+    }
     if (rec || cur_obs) {
         if (!c->obs) { const int rc = dev_alloc(c, &c->obs, 22 * c->plane); if (rc) return rc; }
         RKDev p = make_dev(c);
@@ -1249,6 +1516,35 @@ bool invert5(const double in[25], double out[25])
     return true;
 }
 }  // namespace
+
+extern "C" int lbmpm_rk2d_set_perturbation(lbmpm_rk2d *c, const lbmpm_rk2d_perturbation *par)
+{
+    LBMPM_REQUIRE(c && par, "lbmpm_rk2d_set_perturbation: null argument");
+    LBMPM_REQUIRE(c->cfg.variant == 0 && c->ntr == 0, "the perturbation operator runs as the fused schedule, without tracers");
+    LBMPM_REQUIRE(std::isfinite(par->ak_r) && std::isfinite(par->ak_b) && std::isfinite(par->solid_phi) && par->outlet_rho_r > 0. &&
+                  par->outlet_rho_b > 0. && par->inlet_velocity_y_r > -1. && par->inlet_velocity_y_b > -1.,
+                  "lbmpm_rk2d_set_perturbation: A_k, solidPhi finite, outlet densities > 0, inlet velocities > -1");
+    if (c->cfg.inlet_type != LBMPM_INLET_VELOCITY || c->cfg.outlet_type != LBMPM_OUTLET_PRESSURE) {
+        set_error("the fused perturbation step has the velocity inlet ('Neumann') and the pressure outlet ('Dirichlet') built in; the other "
+                  "boundary kernels of the loop run on the kernel-level entry points (openlbmpm_amd/RKD2Q9.py)");
+        return LBMPM_ERR_UNSUPPORTED;
+    }
+    // the reference addresses the outlet rows by COMPACT index (n < nx, nx <= n < 2 nx: A:1008-1081) and the ghost rows copy their
+    // neighbour row through the neighbour table: both mean grid rows only when the two rows at either end hold no solid node
+    for (int y : {0, 1, c->ny - 2, c->ny - 1})
+        for (int x = 0; x < c->nx; ++x)
+            if (c->h_domain[(size_t)y * c->nx + x] != 1) {
+                set_error("the fused perturbation step needs rows 0, 1, ny-2 and ny-1 free of solid nodes (node (%d, %d) is not fluid): the "
+                          "reference's outlet kernels index those rows by compact node number", x, y);
+                return LBMPM_ERR_UNSUPPORTED;
+            }
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    c->pert = *par;
+    c->model = 1;
+    if (c->diag && !c->pd) { const int rc = dev_alloc(c, &c->pd, 4 * c->plane); if (rc) return rc; }
+    c->diag_valid = false;
+    return LBMPM_OK;
+}
 
 extern "C" int lbmpm_rk2d_tracer_configure(lbmpm_rk2d *c, const lbmpm_tracer_config *t)
 {
@@ -1324,5 +1620,6 @@ extern "C" int64_t lbmpm_rk2d_steps_done(const lbmpm_rk2d *c) { return c ? c->st
 extern "C" int64_t lbmpm_rk2d_device_bytes(const lbmpm_rk2d *c) { return c ? c->bytes : 0; }
 extern "C" const char *lbmpm_rk2d_dominant_kernel(const lbmpm_rk2d *c)
 {
+    if (c && c->model == 1) return "rk2dp_fused";
     return (c && c->cfg.variant == 0) ? "rk2d_fused" : "rk2d_collide_stream";
 }

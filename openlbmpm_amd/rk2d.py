@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import F64P, U8P, RK2DConfig, TracerConfig, check
+from ._lib import F64P, U8P, RK2DConfig, RK2DPerturbation, TracerConfig, check
 
 FIELDS = dict(fR=0, fB=1, rhoR=2, rhoB=3, vx=4, vy=5, phi=6, Gx=7, Gy=8, Fx=9, Fy=10, K=11,
               rec_fR=20, rec_fB=21, rec_rhoR=22, rec_rhoB=23, rec_vx=24, rec_vy=25)
@@ -25,7 +25,11 @@ def _f64(a):
 
 
 class RK2DSolver:
-    def __init__(self, is_domain, params=None, device=0, variant=0, diagnostics=False):
+    def __init__(self, is_domain, params=None, device=0, variant=0, diagnostics=False, perturbation=None):
+        """perturbation = dict(AkR=, AkB=, solidPhi=): the step of SurfaceTensionType 'Perturbation' (RKD2Q9.py:978-1223) as one fused
+        launch instead of the CSF step (lbmpm_rk2d_set_perturbation): per-colour velocity inlet vyR / vyB, per-colour pressure outlet
+        rhoRL / rhoBL, tauR, tauB, beta, relax of `params`; raises LbmpmError (unsupported) for other boundary types or solid nodes in
+        the four boundary rows."""
         L = _lib.lib()
         p = dict(DEFAULT_PARAMS)
         p.update(params or {})
@@ -61,6 +65,21 @@ class RK2DSolver:
         check(L.lbmpm_rk2d_create(C.byref(cfg), dom.ctypes.data_as(U8P), C.byref(self._h)),
               "lbmpm_rk2d_create")
         self._L = L
+        self.model = "CSF"
+        if perturbation is not None:
+            unknown = set(perturbation) - {"AkR", "AkB", "solidPhi"}
+            if unknown:
+                raise KeyError("unknown perturbation parameters: %s" % sorted(unknown))
+            q = RK2DPerturbation()
+            q.ak_r, q.ak_b, q.solid_phi = float(perturbation["AkR"]), float(perturbation["AkB"]), float(perturbation.get("solidPhi", 0.5))
+            q.inlet_velocity_y_r, q.inlet_velocity_y_b = p["vyR"], p["vyB"]
+            q.outlet_rho_r, q.outlet_rho_b = p["rhoRL"], p["rhoBL"]
+            try:
+                check(L.lbmpm_rk2d_set_perturbation(self._h, C.byref(q)), "lbmpm_rk2d_set_perturbation")
+            except Exception:
+                self.close()
+                raise
+            self.model = "Perturbation"
         if diagnostics:
             self.enable_diagnostics(True)
 

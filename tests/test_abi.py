@@ -54,6 +54,7 @@ int main(void) {
   printf("%zu %zu %zu\n", sizeof(lbmpm_rk2d_config), offsetof(lbmpm_rk2d_config, beta), offsetof(lbmpm_rk2d_config, device));
   printf("%zu %zu %zu\n", sizeof(lbmpm_sc2d_config), offsetof(lbmpm_sc2d_config, g_solid), offsetof(lbmpm_sc2d_config, inlet_velocity_y));
   printf("%zu %zu %zu %zu\n", sizeof(lbmpm_rk3d_config), offsetof(lbmpm_rk3d_config, solid_phi), offsetof(lbmpm_rk3d_config, device), offsetof(lbmpm_rk3d_config, recolor_diag));
+  printf("%zu %zu %zu\n", sizeof(lbmpm_rk2d_perturbation), offsetof(lbmpm_rk2d_perturbation, solid_phi), offsetof(lbmpm_rk2d_perturbation, outlet_rho_b));
   return 0; }'''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -63,7 +64,8 @@ int main(void) {
     got = list(map(int, out))
     want = [C.sizeof(_lib.RK2DConfig), _lib.RK2DConfig.beta.offset, _lib.RK2DConfig.device.offset,
             C.sizeof(_lib.SC2DConfig), _lib.SC2DConfig.g_solid.offset, _lib.SC2DConfig.inlet_velocity_y.offset,
-            C.sizeof(_lib.RK3DConfig), _lib.RK3DConfig.solid_phi.offset, _lib.RK3DConfig.device.offset, _lib.RK3DConfig.recolor_diag.offset]
+            C.sizeof(_lib.RK3DConfig), _lib.RK3DConfig.solid_phi.offset, _lib.RK3DConfig.device.offset, _lib.RK3DConfig.recolor_diag.offset,
+            C.sizeof(_lib.RK2DPerturbation), _lib.RK2DPerturbation.solid_phi.offset, _lib.RK2DPerturbation.outlet_rho_b.offset]
     assert got == want
 
 

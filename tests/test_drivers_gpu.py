@@ -346,6 +346,7 @@ def test_perturbation_driver_reproduces_the_repaired_reference_driver(tmp_path, 
     ini = tmp_path / "RKtwophasesetup2D.ini"
     ini.write_text(ini.read_text().replace("SurfaceTensionType = 'CSF'", "SurfaceTensionType = 'Perturbation'"))
     sim = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "out"))
+    sim.perturbation_schedule = "kernels"
     sim.par.update({k: par[k] for k in ("beta", "delta", "tauR", "tauB", "vyR", "vyB", "rhoBL", "rhoRL", "nbuf")},
                    AkR=float(d["AkR"]), AkB=float(d["AkB"]), solidPhi=0.5)
     dom = d["isDomain"]
@@ -365,3 +366,14 @@ def test_perturbation_driver_reproduces_the_repaired_reference_driver(tmp_path, 
             assert rel_err(got, d["s%d_%s" % (k, f)]) < 1e-12, (k, f)
     res = load_results(path)
     assert sim.records == (par["steps"] - 1) // 25 + 1 and "/FluidMacro/FluidDensityRin%d" % (sim.records - 1) in res
+    # the same run on the fused solver (one launch per step; the default where it applies): the same records
+    fused = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "out_fused"))
+    fused.par.update(sim.par)
+    ticks = []
+    path2 = fused.runRKColorGradient2DPerturbation(progress=ticks.append, initial_pdf=(dense(d["init_fR"]), dense(d["init_fB"])))
+    assert fused.solver.model == "Perturbation" and ticks[-1] == par["steps"] and fused.records == sim.records
+    res2 = load_results(path2)
+    assert sorted(res2) == sorted(res)
+    for key in res:
+        scale = max(float(np.max(np.abs(res[k2]))) for k2 in res if k2.split("/")[1] == key.split("/")[1] and k2.rstrip("0123456789")[-3:] == key.rstrip("0123456789")[-3:])
+        assert float(np.max(np.abs(res2[key] - res[key]))) <= 1e-9 * max(scale, 1e-300), key

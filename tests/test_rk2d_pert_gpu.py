@@ -1,0 +1,104 @@
+"""The fused perturbation step (rk2dp_fused: one launch per time step, lbmpm_rk2d_set_perturbation) against the captures of the
+reference's real perturbation loop (tests/golden/rkpert_*.npz: RKColorGradientLBM.runRKColorGradient2DPerturbation,
+RKD2Q9.py:978-1223, under the numba stand-in with the repairs R1-R4 listed in tests/golden/gen/make_golden_rk_pert.py), and against
+the same loop kernel by kernel on the kernel-level entry points (openlbmpm_amd/RKD2Q9.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_params, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def dense(dom, fluid, compact):
+    a = np.zeros((dom.size,) + compact.shape[1:])
+    a[fluid] = compact
+    return a.reshape(dom.shape + compact.shape[1:])
+
+
+def solver_for(d, diagnostics=True):
+    from openlbmpm_amd.rk2d import RK2DSolver
+    p = load_params(d)
+    par = dict(beta=p["beta"], tauR=p["tauR"], tauB=p["tauB"], relax=p["relax"], inlet="Neumann", outlet="Dirichlet", vyR=p["vyR"], vyB=p["vyB"],
+               rhoRL=p["rhoRL"], rhoBL=p["rhoBL"])
+    s = RK2DSolver(d["isDomain"], par, diagnostics=diagnostics,
+                   perturbation=dict(AkR=float(d["AkR"]), AkB=float(d["AkB"]), solidPhi=float(d["solidPhi"])))
+    s.set_pdf(dense(d["isDomain"], d["fluidNodes"], d["init_fR"]), dense(d["isDomain"], d["fluidNodes"], d["init_fB"]))
+    return s
+
+
+@pytest.mark.parametrize("name", ["srt_capillary", "srt_porous", "mrt_capillary", "srt_porous64"])
+def test_fused_perturbation_step_reproduces_the_reference_loop(name):
+    d = np.load(os.path.join(GOLDEN, "rkpert_%s.npz" % name))
+    s = solver_for(d)
+    assert s.model == "Perturbation"
+    done = 0
+    for k in d["snaps"]:
+        s.step(int(k) - done)
+        done = int(k)
+        umax = float(np.max(np.hypot(d["s%d_vx" % k], d["s%d_vy" % k])))
+        for f in ("fR", "fB", "rhoR", "rhoB", "phi", "vx", "vy"):
+            e = rel_err(s.get_compact(f), d["s%d_%s" % (k, f)], scale=umax if f[0] == "v" else None)
+            assert e < TOL, (name, int(k), f, e)
+        # f_tot as the loop leaves it = the sum of the two recoloured lattices
+        assert rel_err(s.get_compact("fR") + s.get_compact("fB"), d["s%d_fTot" % k]) < TOL
+    s.close()
+
+
+def test_record_fields_are_those_of_the_next_steps_head():
+    """what the driver records (RKD2Q9.py:1121-1131) after k steps = streaming, boundary kernels, densities and velocity of step k + 1:
+    the densities / velocity the capture holds after step k + 1"""
+    d = np.load(os.path.join(GOLDEN, "rkpert_srt_porous.npz"))
+    s = solver_for(d, diagnostics=False)
+    s.step(1)
+    umax = float(np.max(np.hypot(d["s2_vx"], d["s2_vy"])))
+    for f, g in (("rec_rhoR", "s2_rhoR"), ("rec_rhoB", "s2_rhoB"), ("rec_vx", "s2_vx"), ("rec_vy", "s2_vy")):
+        assert rel_err(s.get_compact(f), d[g], scale=umax if "v" in f[4:] else None) < TOL, f
+    fR, fB = s.get_compact("rec_fR"), s.get_compact("rec_fB")
+    assert rel_err(fR.sum(axis=1), d["s2_rhoR"]) < TOL and rel_err(fB.sum(axis=1), d["s2_rhoB"]) < TOL
+    from openlbmpm_amd._lib import LbmpmError
+    with pytest.raises(LbmpmError, match="diagnostics"):
+        s.get("phi")
+    with pytest.raises(LbmpmError, match="no field"):
+        s.enable_diagnostics(True); s.step(1); s.get("K")
+    s.close()
+
+
+def test_what_the_fused_step_does_not_cover_is_refused():
+    from openlbmpm_amd._lib import LbmpmError
+    from openlbmpm_amd.rk2d import RK2DSolver
+    dom = np.ones((24, 40), dtype=np.uint8)
+    pert = dict(AkR=0.007, AkB=0.009, solidPhi=0.5)
+    for bad in (dict(outlet="Convective"), dict(inlet="Dirichlet")):
+        with pytest.raises(LbmpmError, match="kernel-level entry points"):
+            RK2DSolver(dom, dict(dict(inlet="Neumann", outlet="Dirichlet"), **bad), perturbation=pert)
+    dom[1, 7] = 0
+    with pytest.raises(LbmpmError, match=r"node \(7, 1\)"):
+        RK2DSolver(dom, dict(inlet="Neumann", outlet="Dirichlet"), perturbation=pert)
+    with pytest.raises(LbmpmError, match="fused schedule"):
+        RK2DSolver(np.ones((24, 40), dtype=np.uint8), dict(inlet="Neumann", outlet="Dirichlet"), variant=1, perturbation=pert)
+    with pytest.raises(KeyError):
+        RK2DSolver(np.ones((24, 40), dtype=np.uint8), perturbation=dict(pert, sigma=1.0))
+
+
+def test_fused_step_at_a_ragged_size_equals_the_kernel_by_kernel_loop(tmp_path):
+    """150 x 97 porous lattice (partial tiles in both directions): the fused solver against the same loop on the kernel-level entry
+    points (16 launches per step, arrays in the reference's sparse layout) through the driver"""
+    from openlbmpm_amd.RKD2Q9 import RKColorGradientLBM
+    from ini_fixtures import write_rk
+    write_rk(str(tmp_path), nx=150, ny=97, steps=40, interval=20, relax="SRT")
+    ini = tmp_path / "RKtwophasesetup2D.ini"
+    ini.write_text(ini.read_text().replace("SurfaceTensionType = 'CSF'", "SurfaceTensionType = 'Perturbation'"))
+    out = {}
+    for mode in ("kernels", "fused"):
+        sim = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / mode))
+        sim.perturbation_schedule = mode
+        sim.runRKColorGradient2D()
+        out[mode] = {f: getattr(sim, f) for f in ("fluidsRhoR", "fluidsRhoB", "physicalVX", "physicalVY", "fluidPDFR", "fluidPDFB")}
+        assert sim.records == 2
+    umax = float(np.max(np.hypot(out["kernels"]["physicalVX"], out["kernels"]["physicalVY"])))
+    for f in out["kernels"]:
+        assert rel_err(out["fused"][f], out["kernels"][f], scale=umax if "V" in f else None) < TOL, f
