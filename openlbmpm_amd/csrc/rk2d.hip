@@ -25,6 +25,13 @@ namespace {
 using lbmpm::set_error;
 using namespace lbmpm_dev;
 
+// parameters of the perturbation operator (lbmpm_rk2d_set_perturbation; rk2dp_fused): an argument of their own, so that the CSF
+// kernels' argument block -- and with it their scalar-register budget -- stays what it was
+struct PertDev {
+    double akR, akB, solidPhi, vyInR, vyInB, pOutR, pOutB;
+    double *pd;        // [4][plane] rhoR, rhoB, vx, vy of the last step (nullptr = off)
+};
+
 struct RKDev {
     int nx, ny, pitch;
     size_t plane;
@@ -40,9 +47,6 @@ struct RKDev {
     double sigma, cosT, sinT, beta, delta, tauR, tauB, vyIn, pInB, pInR, pOut;
     int wetting, tautype, inlet, outlet;
     int first;         // 1: fin holds the initial (already post-streaming) state
-    // perturbation operator (lbmpm_rk2d_set_perturbation; rk2dp_fused)
-    double akR, akB, solidPhi, vyInR, vyInB, pOutR, pOutB;
-    double *pd;        // [4][plane] rhoR, rhoB, vx, vy of the last step (nullptr = off)
     // D2Q5 tracer transport (AccelerateTransport2DRK.py), fused into phase D
     int ntr, trFree, trDirichlet;
     const double *gin;   // [ntr][5][plane]
@@ -121,38 +125,49 @@ __device__ __forceinline__ int node_source_row(const RKDev &p, int y)
     }
     return ys;
 }
-template <bool WITH_BC>
+// TR: the transport driver's order of the density sums (below) -- 1 always, 0 never, -1 decided at run time from p.ntr.  The fused
+// kernels know it at compile time: the run-time test alone cost rk2d_fused 6 registers it does not have (128-register cap: 36 B of
+// spills per lane, c2 82 -> 94 us per step).  For the tracer variant the form below (one summation per node, after the boundary
+// rules; a second one only on the rows the rules need it) is the cheapest of four measured on c4: 0.430 ms per step against 0.452
+// (run-time test, two summations everywhere) and 0.494 (second summation inside the rules' branches); round 2's order, which the
+// real transport driver does not have, ran at 0.401.
+template <bool WITH_BC, int TR = -1>
 __device__ __forceinline__ void node_finish(const RKDev &p, int y, int ys, double fR[9], double fB[9], double &rhoR, double &rhoB);
 
-template <bool WITH_BC>
+template <bool WITH_BC, int TR = -1>
 __device__ __forceinline__ void node_state(const RKDev &p, int x, int y, double fR[9], double fB[9],
                                            double &rhoR, double &rhoB)
 {
     const int ys = node_source_row<WITH_BC>(p, y);
     pull_node(p, x, ys, fR, fB);
-    node_finish<WITH_BC>(p, y, ys, fR, fB, rhoR, rhoB);
+    node_finish<WITH_BC, TR>(p, y, ys, fR, fB, rhoR, rhoB);
 }
 // boundary rows and densities of a node whose populations pull_node(p, x, ys, ...) has fetched
-template <bool WITH_BC>
+template <bool WITH_BC, int TR>
 __device__ __forceinline__ void node_finish(const RKDev &p, int y, int ys, double fR[9], double fB[9], double &rhoR, double &rhoB)
 {
-    rhoR = sum9(fR);
-    rhoB = sum9(fB);
-    if (!WITH_BC) return;
-    if (ys == p.ny - 2) {
-        if (p.inlet == LBMPM_INLET_VELOCITY) {
-            bc_inlet_velocity(p.vyIn, fR, fB, rhoR, rhoB);
-            if (y == p.ny - 1) { rhoR = sum9(fR); rhoB = sum9(fB); }
-        } else {
-            bc_inlet_pressure_one(p.pInB, fB, rhoB);
-            bc_inlet_pressure_one(p.pInR, fR, rhoR);
-        }
-    }
-    if (p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1) bc_outlet_pressure(p.pOut, fR, fB, rhoR, rhoB);
     // With tracers the step is the transport driver's (Transport2DRK.py:1177-1418): boundary rows first (:1199-1279), the densities
     // summed from the populations AFTERWARDS (:1281-1287) -- a pressure row then carries sum_i f_i, not the prescribed density.  Equal up
     // to the last bit; the wetting kernels' branch switches turn that bit into 1e-6 at single nodes (tests/test_tr_coupled.py).
-    if (p.ntr > 0) { rhoR = sum9(fR); rhoB = sum9(fB); }
+    const bool after = WITH_BC && (TR == 1 || (TR < 0 && p.ntr > 0));
+    const bool ruled = WITH_BC && (ys == p.ny - 2 || (p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1));
+    if (!after || ruled) {          // the boundary rules need the densities of the streamed populations
+        rhoR = sum9(fR);
+        rhoB = sum9(fB);
+    }
+    if (WITH_BC) {
+        if (ys == p.ny - 2) {
+            if (p.inlet == LBMPM_INLET_VELOCITY) {
+                bc_inlet_velocity(p.vyIn, fR, fB, rhoR, rhoB);
+                if (y == p.ny - 1) { rhoR = sum9(fR); rhoB = sum9(fB); }
+            } else {
+                bc_inlet_pressure_one(p.pInB, fB, rhoB);
+                bc_inlet_pressure_one(p.pInR, fR, rhoR);
+            }
+        }
+        if (p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1) bc_outlet_pressure(p.pOut, fR, fB, rhoR, rhoB);
+    }
+    if (after) { rhoR = sum9(fR); rhoB = sum9(fB); }
 }
 
 // ---------------------------------------------------------------- collision pieces
@@ -605,7 +620,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             sn[m] = p.solidnbr[idx];
             Fpx[m] = p.F[idx];
             Fpy[m] = p.F[p.plane + idx];
-            node_state<true>(p, xw, yw, fR, fB, rR[m], rB[m]);
+            node_state<true, TRACER ? 1 : 0>(p, xw, yw, fR, fB, rR[m], rB[m]);
 #pragma unroll
             for (int i = 0; i < 9; ++i) fT[m][i] = fR[i] + fB[i];
             s_phi[ri] = (rR[m] - rB[m]) / (rR[m] + rB[m]);
@@ -613,7 +628,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     }
     if (hdo) {
         double a, c;
-        node_finish<true>(p, hy, hys, hR, hB, a, c);
+        node_finish<true, TRACER ? 1 : 0>(p, hy, hys, hR, hB, a, c);
         s_phi[hry * RW + hrx] = (a - c) / (a + c);
     }
     for (int n = tid + THREADS; n < NHALO; n += THREADS) {          // shapes whose halo outnumbers the threads
@@ -624,7 +639,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         if (!need3 && (rx == 0 || rx == RW - 1 || ry == 0 || ry == RH - 1)) continue;
         const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
         double fR[9], fB[9], a, c;
-        node_state<true>(p, x, y, fR, fB, a, c);
+        node_state<true, TRACER ? 1 : 0>(p, x, y, fR, fB, a, c);
         s_phi[ri] = (a - c) / (a + c);
     }
     __syncthreads();
@@ -755,14 +770,14 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // for SRT, before it for MRT).  A workgroup owns a 64 x 8 tile and recomputes the phase field on tile + 1.
 
 // post-streaming, post-boundary-rows state of node (x, y): both colour lattices and their densities
-__device__ __forceinline__ void pert_node_state(const RKDev &p, int x, int y, double fR[9], double fB[9], double &rhoR, double &rhoB)
+__device__ __forceinline__ void pert_node_state(const RKDev &p, const PertDev &q, int x, int y, double fR[9], double fB[9], double &rhoR, double &rhoB)
 {
     const int ys = y == p.ny - 1 ? p.ny - 2 : (y == 0 ? 1 : y);      // the ghost rows copy their neighbour row's state
     pull_node(p, x, ys, fR, fB);
     if (ys == 1) {                        // A:1008-1039 (blue first, then red)
         {
             double *b = fB;
-            const double pL = p.pOutB;
+            const double pL = q.pOutB;
             const double v = 1. - 1. / pL * (b[0] + b[1] + b[3] + 2. * (b[4] + b[7] + b[8]));
             b[2] = b[4] + 2. / 3. * (pL * v);
             b[5] = b[7] + 0.5 * (b[3] - b[1]) + 1. / 6. * pL * v;
@@ -770,7 +785,7 @@ __device__ __forceinline__ void pert_node_state(const RKDev &p, int x, int y, do
         }
         {
             double *r = fR;
-            const double pL = p.pOutR;
+            const double pL = q.pOutR;
             const double v = 1. - 1. / pL * (r[0] + r[1] + r[3] + 2. * (r[4] + r[7] + r[8]));
             r[2] = r[4] + 2. / 3. * pL * v;
             r[5] = r[7] + 0.5 * (r[3] - r[1]) + 1. / 6. * pL * v;
@@ -780,17 +795,17 @@ __device__ __forceinline__ void pert_node_state(const RKDev &p, int x, int y, do
     if (ys == p.ny - 2) {                 // A:657-695
         {
             double *r = fR;
-            const double rho = (r[0] + r[1] + r[3] + 2. * (r[2] + r[5] + r[6])) / (1. + p.vyInR);
-            r[4] = r[2] - 2. / 3. * rho * p.vyInR;
-            r[7] = r[5] + (r[1] - r[3]) / 2. - 1. / 6. * rho * p.vyInR;
-            r[8] = r[6] - (r[1] - r[3]) / 2. - 1. / 6. * rho * p.vyInR;
+            const double rho = (r[0] + r[1] + r[3] + 2. * (r[2] + r[5] + r[6])) / (1. + q.vyInR);
+            r[4] = r[2] - 2. / 3. * rho * q.vyInR;
+            r[7] = r[5] + (r[1] - r[3]) / 2. - 1. / 6. * rho * q.vyInR;
+            r[8] = r[6] - (r[1] - r[3]) / 2. - 1. / 6. * rho * q.vyInR;
         }
         {
             double *b = fB;
-            const double rho = (b[0] + b[1] + b[3] + 2. * (b[2] + b[5] + b[6])) / (1. + p.vyInB);
-            b[4] = b[2] - 2. / 3. * rho * p.vyInB;
-            b[7] = b[5] + (b[1] - b[3]) / 2. - 1. / 6. * rho * p.vyInB;
-            b[8] = b[6] - (b[1] - b[3]) / 2. - 1. / 6. * rho * p.vyInB;
+            const double rho = (b[0] + b[1] + b[3] + 2. * (b[2] + b[5] + b[6])) / (1. + q.vyInB);
+            b[4] = b[2] - 2. / 3. * rho * q.vyInB;
+            b[7] = b[5] + (b[1] - b[3]) / 2. - 1. / 6. * rho * q.vyInB;
+            b[8] = b[6] - (b[1] - b[3]) / 2. - 1. / 6. * rho * q.vyInB;
         }
     }
     rhoR = sum9(fR);                      // calMacroDensityRKGPU2D runs over every node AFTER the boundary kernels
@@ -808,7 +823,7 @@ __device__ __forceinline__ void pert_velocity(const double r[9], const double b[
 }
 
 template <bool MRT>
-__global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, int tiles_x)
+__global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, PertDev q, int tiles_x)
 {
     constexpr int TW = 64, TH = 8, RW = TW + 2, RH = TH + 2, THREADS = TW * TH;
     constexpr double W[9] = LBMPM_D2Q9_W;
@@ -829,7 +844,7 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, int tiles_x)
     const size_t idx = (size_t)yw * p.pitch + xw;
     const bool fluid = p.flags[idx] & 1, act = inside && fluid;
     double fR[9], fB[9], rR = 1., rB = 1.;
-    if (fluid) pert_node_state(p, xw, yw, fR, fB, rR, rB);
+    if (fluid) pert_node_state(p, q, xw, yw, fR, fB, rR, rB);
     constexpr int NRIM = 2 * RW + 2 * TH;
     int hr = -1;
     double hphi = 0.;
@@ -841,7 +856,7 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, int tiles_x)
         const int hx = wrapm(tx0 - 1 + rx, p.nx), hy = wrapm(ty0 - 1 + ry, p.ny);
         if (p.flags[(size_t)hy * p.pitch + hx] & 1) {
             double a[9], b[9], ra, rb;
-            pert_node_state(p, hx, hy, a, b, ra, rb);
+            pert_node_state(p, q, hx, hy, a, b, ra, rb);
             hr = ry * RW + rx;
             hphi = (ra - rb) / (ra + rb);
         }
@@ -884,7 +899,7 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, int tiles_x)
 #pragma unroll
         for (int i = 1; i < 9; ++i) {
             const int rn = ri + EY[i] * RW + EX[i];
-            const double ph = s_fluid[rn] ? s_phi[rn] : p.solidPhi;
+            const double ph = s_fluid[rn] ? s_phi[rn] : q.solidPhi;
             gx += 3. * W[i] * (double)EX[i] * ph;
             gy += 3. * W[i] * (double)EY[i] * ph;
         }
@@ -897,7 +912,7 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, int tiles_x)
             if (g2 != 0.) {
                 const double eg = (double)EX[i] * gx + (double)EY[i] * gy;
                 const double part = W[i] * (eg * eg) / g2;
-                c2 = (p.akR + p.akB) * 0.5 * gn * (part - BC[i]);
+                c2 = (q.akR + q.akB) * 0.5 * gn * (part - BC[i]);
             }
             fT[i] += c2;
         }
@@ -909,8 +924,8 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, int tiles_x)
             oR[i] = rR / rs * fT[i] + (p.beta * rm / rs2) * W[i] * c;
             oB[i] = rB / rs * fT[i] - (p.beta * rm / rs2) * W[i] * c;
         }
-        if (p.pd) {
-            p.pd[idx] = rR; p.pd[p.plane + idx] = rB; p.pd[2 * p.plane + idx] = vx; p.pd[3 * p.plane + idx] = vy;
+        if (q.pd) {
+            q.pd[idx] = rR; q.pd[p.plane + idx] = rB; q.pd[2 * p.plane + idx] = vx; q.pd[3 * p.plane + idx] = vy;
             p.phi[idx] = phi; p.G[idx] = gx; p.G[p.plane + idx] = gy;
         }
     }
@@ -920,14 +935,14 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, int tiles_x)
 
 // what the perturbation loop would record at the start of the next step (RKD2Q9.py:1121-1131: after streaming, boundary kernels,
 // densities and velocity): out[22][plane] like rk2d_observe
-__global__ __launch_bounds__(BX *BY) void rk2dp_observe(RKDev p, double *out)
+__global__ __launch_bounds__(BX *BY) void rk2dp_observe(RKDev p, PertDev q, double *out)
 {
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= p.nx || y >= p.ny) return;
     const size_t idx = (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
     double fR[9], fB[9], rR, rB, vx, vy;
-    pert_node_state(p, x, y, fR, fB, rR, rB);
+    pert_node_state(p, q, x, y, fR, fB, rR, rB);
     pert_velocity(fR, fB, rR, rB, vx, vy);
 #pragma unroll
     for (int i = 0; i < 9; ++i) { out[i * p.plane + idx] = fR[i]; out[(9 + i) * p.plane + idx] = fB[i]; }
@@ -1065,6 +1080,16 @@ struct lbmpm_rk2d {
 
 namespace {
 
+PertDev make_pert(const lbmpm_rk2d *c, bool diag)
+{
+    PertDev q;
+    q.akR = c->pert.ak_r; q.akB = c->pert.ak_b; q.solidPhi = c->pert.solid_phi;
+    q.vyInR = c->pert.inlet_velocity_y_r; q.vyInB = c->pert.inlet_velocity_y_b;
+    q.pOutR = c->pert.outlet_rho_r; q.pOutB = c->pert.outlet_rho_b;
+    q.pd = diag ? c->pd : nullptr;
+    return q;
+}
+
 RKDev make_dev(const lbmpm_rk2d *c)
 {
     RKDev p;
@@ -1079,10 +1104,6 @@ RKDev make_dev(const lbmpm_rk2d *c)
     p.wetting = c->cfg.wetting_type; p.tautype = c->cfg.tau_type;
     p.inlet = c->cfg.inlet_type; p.outlet = c->cfg.outlet_type;
     p.first = c->streamed ? 0 : 1;
-    p.akR = c->pert.ak_r; p.akB = c->pert.ak_b; p.solidPhi = c->pert.solid_phi;
-    p.vyInR = c->pert.inlet_velocity_y_r; p.vyInB = c->pert.inlet_velocity_y_b;
-    p.pOutR = c->pert.outlet_rho_r; p.pOutB = c->pert.outlet_rho_b;
-    p.pd = nullptr;
     if (c->model == 1) p.first = 0;         // the perturbation loop streams first: the initial state is pulled like any other
     p.ntr = c->ntr; p.trFree = c->trFree; p.trDirichlet = c->trDirichlet; p.gin = c->gA; p.gout = c->gB;
     p.trCrit = c->trCrit;
@@ -1118,12 +1139,12 @@ int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
     if (!diag) p.diag = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->model == 1) {
-        p.pd = diag ? c->pd : nullptr;
+        const PertDev q = make_pert(c, diag);
         const bool ev = timed && c->pool.take(&e0, &e1);
         if (ev) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
         const int tiles_x = (c->nx + 63) / 64, tiles_y = (c->ny + 7) / 8;
-        if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2dp_fused<true><<<dim3(tiles_x * tiles_y), dim3(512), 0, c->stream>>>(p, tiles_x);
-        else rk2dp_fused<false><<<dim3(tiles_x * tiles_y), dim3(512), 0, c->stream>>>(p, tiles_x);
+        if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2dp_fused<true><<<dim3(tiles_x * tiles_y), dim3(512), 0, c->stream>>>(p, q, tiles_x);
+        else rk2dp_fused<false><<<dim3(tiles_x * tiles_y), dim3(512), 0, c->stream>>>(p, q, tiles_x);
         if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     } else if (c->cfg.variant == 0) {
         const bool ev = timed && c->pool.take(&e0, &e1);
@@ -1421,7 +1442,7 @@ extern "C" int lbmpm_rk2d_get_field(lbmpm_rk2d *c, int field, double *out)
             if (!c->obs) { const int rc = dev_alloc(c, &c->obs, 22 * c->plane); if (rc) return rc; }
             RKDev p = make_dev(c);
             const dim3 g = grid_of(c), b(BX, BY);
-            if (rec) rk2dp_observe<<<g, b, 0, c->stream>>>(p, c->obs);
+            if (rec) rk2dp_observe<<<g, b, 0, c->stream>>>(p, make_pert(c, false), c->obs);
             else rk2dp_stored<<<g, b, 0, c->stream>>>(p, c->obs);
             LBMPM_HIP_TRY(hipGetLastError());
             LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));

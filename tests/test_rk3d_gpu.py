@@ -427,3 +427,26 @@ def test_bench_starts_its_own_ranks():
     if torch.cuda.device_count() < 2:
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode != 0 and "one rank per GPU" in (out.stderr + out.stdout)
+
+
+def test_bench_with_eight_ranks_on_a_wide_lattice():
+    """`python bench.py --gpus 8` as the round-end driver runs it on an 8-GPU node, rehearsed here with eight processes sharing this GPU
+    (gloo): a 192 x 192 x 128 lattice -- three row segments, six ranks with a neighbour on both sides -- must come through with finite
+    fields (the bench checks mass and finiteness at the end of the timed region) and one line from rank 0"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2", "--size", "192", "192", "128"],
+                         env=dict(env, LBMPM_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    m = d["multi_gpu"]
+    assert d["n_gpus"] == 8 and m["world_size"] == 8 and [r["rank"] for r in m["per_rank"]] == list(range(8)) and d["value"] > 0
+    planes = [r["planes"] for r in m["per_rank"]]
+    assert planes[0][0] == 0 and planes[-1][1] == 128 and all(planes[i][1] == planes[i + 1][0] for i in range(7))
+    assert sum(r["fluid_nodes"] for r in m["per_rank"]) == d["config"]["fluid_nodes"]
