@@ -1051,6 +1051,8 @@ struct lbmpm_rk3d {
     std::vector<uint8_t> h_rowpop;   // fluid cells per row segment [rows][nseg] (lbmpm_rk3d_storage_info)
     bool streamed = false;
     int variant = 0, tile = 0, chunk_len = 32, fill = 16;   // tuning: LBMPM_RK3D_VARIANT / _TILE / _CHUNK / _FILL
+    bool chunk_auto = false;
+    int ncu = 256;
     // planes next to each face that wait for the halo exchange (LBMPM_RK3D_BOUNDARY): plane 1 needs the neighbour's populations
     // and phase field, plane 2 the phase field of plane 1; from plane 3 on nothing of the neighbour is read.  Measured with k = 8
     // virtual ranks on one GPU (tools/slabbench.py, 512^3): depth 2 / 3 / 4 / 8 -> +4.5 / +5.9 / +6.6 / +8.1 % over the single slab
@@ -1141,8 +1143,9 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     c->q23 = c->compact && c->tile == 0;
     if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
     if (const char *e = getenv("LBMPM_RK3D_DBG")) c->dbg = atoi(e);
-    if (c->q23 && !getenv("LBMPM_RK3D_CHUNK")) c->chunk_len = 64;
-      // measured 512^3: chunks of 16 / 32 / 64 planes 7.70 / 7.11 / 6.90 ms per step
+    // q23 storage: the chunk length is chosen per launch (chunk_planes below) unless LBMPM_RK3D_CHUNK fixes it
+    c->chunk_auto = c->q23 && !getenv("LBMPM_RK3D_CHUNK");
+    if (c->chunk_auto) { c->chunk_len = 64; (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, cfg->device); if (c->ncu <= 0) c->ncu = 256; }
     if (c->q23 && getenv("LBMPM_RK3D_TRACE")) { (void)hipMalloc(reinterpret_cast<void **>(&c->trace), (size_t)1 << 22); (void)hipMemset(c->trace, 0, (size_t)1 << 22); }
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
@@ -1424,11 +1427,28 @@ void launch_fused_c(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first,
 }
 
 // q23 storage: planes z_first..z_last and (if z_last2 >= z_first2) z_first2..z_last2 in ONE launch
+// Planes per workgroup of a launch over n planes.  A march costs two fill steps per chunk, so chunks should be long; but the launch
+// should still hand every CU several workgroups.  Measured at 512^3 (512 tiles, MRT): chunks of 16 / 32 / 64 / 128 / 256 / 512 planes
+// 7.87 / 7.32 / 7.08 / 6.91 / 6.72 / 6.81 ms per step -> as few chunks as keep ~4 workgroups per CU in the launch, none shorter than
+// 64 planes unless the range is, all of equal length.
+int chunk_planes(const lbmpm_rk3d *c, int n)
+{
+    if (!c->chunk_auto) return c->chunk_len;
+    const int tiles = c->nseg * ((c->ny + 7) / 8);
+    const int want = (4 * c->ncu + tiles - 1) / tiles;              // chunks for ~4 workgroups per CU
+    int len = (n + want - 1) / want;
+    if (len < 64) len = 64;
+    const int nch = (n + len - 1) / len;
+    return nch > 0 ? (n + nch - 1) / nch : 64;
+}
+
 void launch_q23(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last, int z_first2, int z_last2)
 {
     const int tilesX = c->nseg, tilesY = (c->ny + 7) / 8, rpx = (tilesY + 7) / 8;
-    const int nchunks1 = (z_last - z_first + 1 + c->chunk_len - 1) / c->chunk_len;
-    const int nchunks2 = z_last2 >= z_first2 ? (z_last2 - z_first2 + 1 + c->chunk_len - 1) / c->chunk_len : 0;
+    const int n1 = z_last - z_first + 1, n2 = z_last2 >= z_first2 ? z_last2 - z_first2 + 1 : 0;
+    const int chunk_len = chunk_planes(c, n1 > n2 ? n1 : n2);
+    const int nchunks1 = (n1 + chunk_len - 1) / chunk_len;
+    const int nchunks2 = n2 > 0 ? (n2 + chunk_len - 1) / chunk_len : 0;
     const dim3 grid((unsigned)(8 * tilesX * rpx * (nchunks1 + nchunks2))), block(512);
     // tile counters of this launch: slice after slice of two rings of 4096 x 8 words that are zeroed wholesale, a ring while the other
     // one is half used up (no memset per launch: that is a kernel of its own)
@@ -1439,7 +1459,7 @@ void launch_q23(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int
         q = c->slotq + ((size_t)ring * 4096u + i) * 8u;
     }
     auto go = [&](auto first, auto mrt) {
-        rk3dq_fused<decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, c->chunk_len, z_first, z_last,
+        rk3dq_fused<decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, chunk_len, z_first, z_last,
                                                                                             nchunks1, z_first2, z_last2, q);
     };
     dispatch2(p.first != 0, p.mrt != 0, go);

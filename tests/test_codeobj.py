@@ -35,3 +35,14 @@ def test_q23_kernels_use_no_scratch_memory(kernels):
     for n, m in q.items():
         if "rk3dq_fused" in n:
             assert m[".group_segment_fixed_size"] <= 160 * 1024 and m[".vgpr_count"] <= 256, n
+
+
+def test_default_2d_kernels_do_not_spill(kernels):
+    """rk2d_fused is capped at 128 registers so that two 512-thread workgroups share a CU; the default shape (64 x 8, no tracer) and the
+    fused perturbation step must fit without scratch -- round 3 lost 14 % of c2 to a run-time test that pushed it six registers over"""
+    plain = [m for n, m in kernels.items() if "rk2d_fused" in n and "Lb0ENS" in n.split("rk2d_fused")[1][:12] and "FusedShapeILi8ELi1" in n]
+    assert len(plain) == 2                          # SRT and MRT
+    pert = [m for n, m in kernels.items() if "rk2dp_fused" in n]
+    assert len(pert) == 2
+    for m in plain + pert:
+        assert m[".vgpr_count"] <= 128 and m[".private_segment_fixed_size"] == 0 and m[".vgpr_spill_count"] == 0
