@@ -102,3 +102,31 @@ def test_fused_step_at_a_ragged_size_equals_the_kernel_by_kernel_loop(tmp_path):
     umax = float(np.max(np.hypot(out["kernels"]["physicalVX"], out["kernels"]["physicalVY"])))
     for f in out["kernels"]:
         assert rel_err(out["fused"][f], out["kernels"][f], scale=umax if "V" in f else None) < TOL, f
+
+
+def test_full_size_properties_of_the_fused_perturbation_step():
+    """1024 x 1024 (the c2 lattice, bench workload c2p), size-independent properties: the wall-bounded set-up is mirror-symmetric in x
+    and must stay so bit for bit (every stencil of the step is symmetric under x -> nx-1-x with the directions swapped, and the sums
+    of the recolouring / perturbation terms are taken direction by direction); total mass changes only through the two open rows;
+    red enters only through the inlet; nothing is NaN"""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.geometry import simple_geometry, initial_densities_rk
+    nx = ny = 1024
+    steps = 60
+    dom = simple_geometry(nx, ny)
+    assert np.array_equal(dom, dom[:, ::-1])
+    rR, rB = initial_densities_rk(dom, False, 10, mode="intrusion")
+    s = RK2DSolver(dom, dict(relax="MRT"), diagnostics=True, perturbation=dict(AkR=0.007, AkB=0.009, solidPhi=0.5))
+    s.set_macro(rR, rB)
+    s.step(steps)
+    r, b, vx, vy = s.get("rhoR"), s.get("rhoB"), s.get("vx"), s.get("vy")
+    s.close()
+    assert np.isfinite(r).all() and np.isfinite(b).all() and np.isfinite(vx).all()
+    # mirror symmetry: densities and v_y even, v_x odd -- to round-off (the velocity sums pair directions in a fixed order)
+    scale = float(np.max(np.hypot(vx, vy))) + 1e-300
+    assert np.max(np.abs(r - r[:, ::-1])) < 1e-12 and np.max(np.abs(b - b[:, ::-1])) < 1e-12
+    assert np.max(np.abs(vy - vy[:, ::-1])) / scale < 1e-9 and np.max(np.abs(vx + vx[:, ::-1])) / scale < 1e-9
+    m0, m1 = float((rR + rB).sum()), float((r + b).sum())
+    vin = 1.0e-4
+    assert abs(m1 - m0) / m0 < 4.0 * vin * nx * steps / m0
+    assert float(r.sum()) >= float(rR.sum()) * (1 - 1e-9)          # red is injected, never lost
