@@ -14,8 +14,12 @@ LIB = os.path.join(PKG, "liblbmpm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: keep the reference's evaluation order (no FMA contraction); the
 # kernels are HBM-bound, so this costs nothing measurable and tightens parity.
+# -mllvm -disable-machine-licm: the marching kernels re-derive per-thread values inside their loops on purpose (DESIGN.md section 4:
+# hoisted, they cost registers the kernels do not have); with machine LICM off hipcc stops hoisting address arithmetic as well --
+# rk3dq_fused 253 -> 246 VGPRs, c5 MRT + 4 %, SRT + 1.4 % (A/B on one box, three runs each), the 2-D kernels unchanged.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=" + os.environ.get("LBMPM_FP_CONTRACT", "off"),
+         "-mllvm", "-disable-machine-licm",
          "-Wall", "-Wno-unused-function"]
 
 
