@@ -229,6 +229,7 @@ def main():
                     help="c5 relaxation: BASELINE.json names the MRT configuration; the shipped ini says 'SRT' with ';;MRT' beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="N > 1: keep the equal-fluid-cells cuts (no measured re-cut of the slabs)")
     args = ap.parse_args()
 
     import torch
@@ -313,6 +314,19 @@ def main():
             d = RK3DDistributed(dom, dict(relax=args.relax), device=local_rank)
             d.slab.set_density(rR, rB)
             del rR, rB
+            partition = "equal fluid cells per rank"
+            if not args.no_calibration:
+                # one measured re-cut (untimed set-up): equal fluid cells leave the rank that holds the colour interface ~10 % behind
+                d.step(2)
+                cost = d.calibrated_plane_cost(8)
+                d.close()
+                z0, nzl = RK3DDistributed.partition(dom, world, plane_cost=cost)[rank]
+                rR, rB = c5_densities(dom[z0:z0 + nzl], z0, nz)
+                m0_local = float((rR + rB).sum())
+                d = RK3DDistributed(dom, dict(relax=args.relax), device=local_rank, plane_cost=cost)
+                d.slab.set_density(rR, rB)
+                del rR, rB
+                partition = "equal measured cost per rank (8 timed steps on the equal-fluid-cells cuts, then re-cut)"
             d.step(warmup)
             d.sync(); barrier()
             t0 = time.perf_counter()
@@ -410,6 +424,7 @@ def main():
                                                   "no collective on the data path") if dist.get_backend() == "nccl" else
                                                  "REHEARSAL on the %s backend (host-staged copies): not an RCCL measurement" % dist.get_backend(),
                                     "boundary_depth_planes": int(os.environ.get("LBMPM_RK3D_BOUNDARY", "2")),
+                                    "partition": partition,
                                     "per_rank": per_rank}
             if world == 1 and not args.no_secondary:
                 sec = []

@@ -251,10 +251,12 @@ class RK3DCluster:
 class RK3DDistributed:
     """One slab per process/GPU; halos over torch.distributed P2P (RCCL over xGMI)."""
 
-    def __init__(self, is_domain_global, params=None, device=0, group=None, balance=True):
+    def __init__(self, is_domain_global, params=None, device=0, group=None, balance=True, plane_cost=None):
+        """plane_cost: measured cost per lattice plane (`calibrated_plane_cost` of an earlier instance); the cuts then equalise it
+        instead of the fluid cells"""
         import torch.distributed as dist
         self.rank, self.world, self.group = dist.get_rank(group), dist.get_world_size(group), group
-        z0, n = self.partition(is_domain_global, self.world, balance)[self.rank]
+        z0, n = self.partition(is_domain_global, self.world, balance, plane_cost)[self.rank]
         self.z0, self.nzl = z0, n
         import torch
         self._torch = torch
@@ -263,12 +265,38 @@ class RK3DDistributed:
         self.slab.use_torch_stream(self.stream)
 
     @staticmethod
-    def partition(is_domain_global, world, balance=True):
-        """z-ranges of the ranks: equal fluid cells per rank (default) or equal planes"""
+    def partition(is_domain_global, world, balance=True, plane_cost=None):
+        """z-ranges of the ranks: equal fluid cells per rank (default), equal measured cost (plane_cost, one value per plane), or
+        equal planes (balance=False)"""
         if not balance or world == 1:
             return partition_z(is_domain_global.shape[0], world)
+        if plane_cost is not None:
+            c = np.asarray(plane_cost, dtype=np.float64)
+            if c.shape != (is_domain_global.shape[0],) or not np.all(np.isfinite(c)) or c.min() <= 0:
+                raise ValueError("plane_cost needs one positive value per plane")
+            return partition_z_balanced(np.maximum(1, np.round(c / c.max() * 1e6)).astype(np.int64), world)
         counts = (np.asarray(is_domain_global) == 1).reshape(is_domain_global.shape[0], -1).sum(axis=1)
         return partition_z_balanced(counts, world)
+
+    def calibrated_plane_cost(self, steps=8):
+        """Cost per lattice plane as THIS partition runs it: `steps` timed steps, every rank's kernel time per owned plane, gathered --
+        the argument `plane_cost` of the next instance.  The march step of rk3dq_fused costs the same at every fluid fraction but more
+        where both colours meet, so equal fluid cells leave the rank that holds the interface ~10 % behind the others (DESIGN.md
+        section 5); one measured re-cut evens that out for as long as the interface stays within its rank.  Collective; the state is
+        advanced by `steps` steps (call set_density again)."""
+        import torch.distributed as dist
+        self.step(int(steps), timed=True)
+        t = self.timing()
+        rate = (t["interior_ms"] + t["boundary_ms"]) / max(self.nzl, 1)
+        got = [None] * self.world
+        dist.all_gather_object(got, (int(self.z0), int(self.nzl), float(rate)), group=self.group)
+        nz = max(z0 + n for z0, n, _ in got)
+        cost = np.zeros(nz)
+        for z0, n, r in got:
+            cost[z0:z0 + n] = r
+        if not np.all(cost > 0):
+            raise RuntimeError("calibration gave a non-positive plane cost")
+        return cost
 
     def set_density(self, rhoR_global, rhoB_global):
         self.slab.set_density(rhoR_global[self.z0:self.z0 + self.nzl], rhoB_global[self.z0:self.z0 + self.nzl])

@@ -146,3 +146,20 @@ def test_record_guard_verdict_is_collective():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results == {0: "other", 1: "own", 2: "other"}
+
+
+def test_partition_by_measured_plane_cost():
+    """RK3DDistributed.partition(plane_cost=...): the cuts equalise the measured cost, not the fluid cells -- a rank whose planes cost
+    more gets fewer of them; bad cost arrays are refused"""
+    from openlbmpm_amd.rk3d import RK3DDistributed
+    dom = np.ones((64, 4, 4), dtype=np.uint8)
+    even = RK3DDistributed.partition(dom, 4)
+    assert [n for _, n in even] == [16, 16, 16, 16]
+    cost = np.ones(64); cost[48:] = 1.5                     # the last quarter is 50 % dearer per plane
+    parts = RK3DDistributed.partition(dom, 4, plane_cost=cost)
+    assert parts[0][0] == 0 and sum(n for _, n in parts) == 64 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(3))
+    per_rank = [cost[z0:z0 + n].sum() for z0, n in parts]
+    assert parts[-1][1] < 16 and max(per_rank) / min(per_rank) < 1.12
+    for bad in (np.ones(63), np.zeros(64), np.full(64, np.nan)):
+        with pytest.raises(ValueError):
+            RK3DDistributed.partition(dom, 4, plane_cost=bad)
