@@ -81,6 +81,13 @@ class RKColorGradient3D:
             import torch.distributed as dist
             sim = RK3DDistributed(self.isDomain, par, device=self.device)
             sim.set_density(self.fluidsRhoR, self.fluidsRhoB)
+            if getattr(self, "calibrate_partition", self.timeSteps >= 1000):
+                # long runs: one measured re-cut of the slabs (rk3d.RK3DDistributed.calibrated_plane_cost), then start over from the
+                # initial state -- the rank that holds the colour interface otherwise runs ~10 % behind the others
+                cost = sim.calibrated_plane_cost(8)
+                sim.close()
+                sim = RK3DDistributed(self.isDomain, par, device=self.device, plane_cost=cost)
+                sim.set_density(self.fluidsRhoR, self.fluidsRhoB)
             step, observe, slab = sim.step, sim.observe, sim.slab
             name += "_rank%d" % dist.get_rank()
             self.z0, self.nzl = sim.z0, sim.nzl

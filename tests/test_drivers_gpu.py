@@ -268,9 +268,11 @@ def test_cli_runs(tmp_path):
     assert main(["rk3d", str(tmp_path), "--out", str(tmp_path / "o3")]) == 0
 
 
-def test_rk3d_driver_under_two_processes_writes_the_same_records(tmp_path):
+@pytest.mark.parametrize("calibrate", [False, True], ids=["equal-fluid-cuts", "measured-re-cut"])
+def test_rk3d_driver_under_two_processes_writes_the_same_records(tmp_path, calibrate):
     """RKColorGradient3D under torchrun (two ranks sharing this GPU, gloo transport): every rank writes the
-    planes it owns; stacked, the records equal those of the single-process driver bit for bit."""
+    planes it owns; stacked, the records equal those of the single-process driver bit for bit -- also after the one measured re-cut of
+    the slabs a long run makes at its start (calibrate_partition; wherever the cuts land, the slab step equals the single domain)."""
     import os
     import subprocess
     import sys
@@ -288,9 +290,10 @@ from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D
 dist.init_process_group("gloo")
 torch.cuda.set_device(0)
 sim = RKColorGradient3D(%r, output_dir=%r, record_every=8, device=0)
+sim.calibrate_partition = %r
 sim.runRKColorGradient3D()
 dist.destroy_process_group()
-''' % (root, str(tmp_path), str(tmp_path / "out2")))
+''' % (root, str(tmp_path), str(tmp_path / "out2"), calibrate))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], env=dict(os.environ), timeout=300)
     single = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out1"), record_every=8)
