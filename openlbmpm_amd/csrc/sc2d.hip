@@ -526,6 +526,148 @@ __global__ __launch_bounds__(256) void sc2d_iso_collide(SCDev p)
     for (int j = 0; j < 9; ++j) store_pair(p.fout, p.plane, j, idx, f0[j], f1[j]);
 }
 
+// ---------------------------------------------------------------- schemes 8 / 10: one sweep per step
+// The same step as sc2d_iso_psi + sc2d_iso_collide in ONE launch: a workgroup owns a 64 x 8 tile and recomputes psi = rho of the
+// streamed, boundary-corrected lattice on tile + 2 (scheme 8) or tile + 3 (scheme 10) into LDS, every halo node by one thread beside
+// its own pull; the 24 / 36-point force stencil with its line-of-sight rules then reads psi and the fluid mask from LDS (constant
+// offsets: no index arrays, no scratch).  The arithmetic is sc_force_iso's, statement for statement: bit-equal to the two sweeps.
+template <bool S10, typename Psi0, typename Psi1, typename Fl>
+__device__ __forceinline__ void sc_force_iso_tile(const SCDev &p, const Psi0 &q0, const Psi1 &q1, const Fl &F, const double psi[2], double Fx[2], double Fy[2])
+{
+    constexpr int DX[36] = {1, 0, -1, 0, 1, -1, -1, 1, 2, 0, -2, 0, 2, -2, -2, 2, 2, 1, -1, -2, -2, -1, 1, 2,
+                            3, 0, -3, 0, 3, 1, -1, -3, -3, -1, 1, 3};
+    constexpr int DY[36] = {0, 1, 0, -1, 1, 1, -1, -1, 0, 2, 0, -2, 2, 2, -2, -2, 1, 2, 2, 1, -1, -2, -2, -1,
+                            0, 3, 0, -3, 1, 3, 3, 1, -1, -3, -3, -1};
+    constexpr int K2[8][2] = {{0, 4}, {1, 4}, {1, 5}, {2, 5}, {2, 6}, {3, 6}, {3, 7}, {0, 7}};
+    constexpr int K3[8][4] = {{4, 16, 0, 8}, {1, 9, 4, 17}, {1, 9, 5, 18}, {2, 10, 5, 19}, {2, 10, 6, 20}, {3, 11, 6, 21}, {3, 11, 7, 22}, {0, 8, 7, 23}};
+    constexpr int nn = S10 ? 36 : 24;
+    unsigned long long fl = 0;
+#pragma unroll
+    for (int m = 0; m < nn; ++m) if (F(DX[m], DY[m])) fl |= 1ull << m;
+    auto On = [&](int k) { return (fl >> k) & 1ull; };
+    double fx[2] = {0., 0.}, fy[2] = {0., 0.};
+#pragma unroll
+    for (int m = 0; m < nn; ++m) {
+        bool on = On(m);
+        if (on && m >= 8) {
+            if (m < 16) on = On(m - 8);
+            else if (m < 24) on = On(K2[m - 16][0]) || On(K2[m - 16][1]);
+            else if (m < 28) on = On(m - 24) && On(m - 16);
+            else on = (On(K3[m - 28][0]) && On(K3[m - 28][1])) || (On(K3[m - 28][2]) && On(K3[m - 28][3]));
+        }
+        const int dx = DX[m], dy = DY[m];
+        const double sx = dx > 0 ? 1. : -1., sy = dy > 0 ? 1. : -1.;
+        if (on) {
+            const double w = S10 ? (m < 4 ? 262. / 1785. : m < 8 ? 93. / 1190. : m < 12 ? 7. / 340. : m < 16 ? 9. / 9520. : m < 24 ? 6. / 595. : m < 28 ? 2. / 5355. : 1. / 7140.)
+                                 : (m < 4 ? 4. / 21. : m < 8 ? 4. / 45. : m < 12 ? 1. / 60. : m < 16 ? 1. / 5040. : 2. / 315.);
+            const double q[2] = {q0(dx, dy), q1(dx, dy)};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = 1 - i;                                   // G_ii = 0
+                const double d = S10 ? q[j] : q[j] - psi[j];
+                if (dx == 1 || dx == -1) fx[i] += -6.0 * w * p.G * psi[i] * (d) * (sx);
+                if (dx == 2 || dx == -2) fx[i] += -2. * 6.0 * w * p.G * psi[i] * (d) * (sx);
+                if (dx == 3 || dx == -3) fx[i] += -3. * 6.0 * w * p.G * psi[i] * (d) * (sx);
+                if (dy == 1 || dy == -1) fy[i] += -6.0 * w * p.G * psi[i] * (d) * (sy);
+                if (dy == 2 || dy == -2) fy[i] += -2. * 6.0 * w * p.G * psi[i] * (d) * (sy);
+                if (dy == 3 || dy == -3) fy[i] += -3. * 6.0 * w * p.G * psi[i] * (d) * (sy);
+            }
+        } else if (m < 8 && !On(m)) {
+            const double c = m < 4 ? -1. / 9. : -1. / 36.;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (dx != 0) fx[i] += c * p.Gs[i] * psi[i] * (sx);
+                if (dy != 0) fy[i] += c * p.Gs[i] * psi[i] * (sy);
+            }
+        }
+    }
+    Fx[0] = fx[0]; Fx[1] = fx[1]; Fy[0] = fy[0]; Fy[1] = fy[1];
+}
+
+template <bool MRT, bool S10>
+__global__ __launch_bounds__(512) void sc2d_iso_fused(SCDev p, int tiles_x)
+{
+    constexpr int IW = 64, IH = 8, H = S10 ? 3 : 2, QW = IW + 2 * H, QH = IH + 2 * H, NT = IW * IH;
+    __shared__ double s_psi0[QH * QW];
+    __shared__ double s_psi1[QH * QW];
+    __shared__ uint8_t s_fl[QH * QW];
+    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx0 = (t % tiles_x) * IW, ty0 = (t / tiles_x) * IH;
+    const int tid = threadIdx.x, lx = tid % IW, ly = tid / IW;
+    const int x = tx0 + lx, y = ty0 + ly;
+    const bool inside = (x < p.nx) && (y < p.ny);
+    const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);
+    const size_t idx = (size_t)yw * p.pitch + xw;
+    const bool fluid = p.flags[idx] & 1;
+    const bool act = inside && fluid;
+    const int ri = (H + ly) * QW + H + lx;
+    double f0[9], f1[9], rho[2] = {0., 0.};
+    constexpr int NHALO = 2 * H * QW + 2 * H * IH;
+    static_assert(NHALO <= NT, "one halo node per thread");
+    int hri = -1;
+    bool hfl = false;
+    double ha = 0., hb = 0.;
+    if (fluid) node_state<true>(p, xw, yw, f0, f1, rho[0], rho[1]);
+    if (tid < NHALO) {
+        int rx, ry, m = tid;
+        if (m < H * QW) { ry = m / QW; rx = m % QW; }
+        else if ((m -= H * QW) < H * QW) { ry = QH - H + m / QW; rx = m % QW; }
+        else { m -= H * QW; ry = H + m / (2 * H); const int c = m % (2 * H); rx = c < H ? c : IW + c; }
+        hri = ry * QW + rx;
+        const int hx = wrapm(tx0 - H + rx, p.nx), hy = wrapm(ty0 - H + ry, p.ny);
+        hfl = p.flags[(size_t)hy * p.pitch + hx] & 1;
+        if (hfl) {
+            double g0[9], g1[9];
+            node_state<true>(p, hx, hy, g0, g1, ha, hb);
+        }
+    }
+    s_fl[ri] = fluid;
+    if (fluid) { s_psi0[ri] = rho[0]; s_psi1[ri] = rho[1]; }
+    if (hri >= 0) { s_fl[hri] = hfl; if (hfl) { s_psi0[hri] = ha; s_psi1[hri] = hb; } }
+    __syncthreads();
+    const bool line = lbmpm_dev::line_has_active<8>(act, tid & 63) && inside;
+    if (!line) return;
+    if (!act) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { f0[j] = 0.; f1[j] = 0.; }
+    } else {
+        double Fpx[2] = {0., 0.}, Fpy[2] = {0., 0.};
+        if (p.keep_force) { Fpx[0] = p.F[idx]; Fpx[1] = p.F[p.plane + idx]; Fpy[0] = p.F[2 * p.plane + idx]; Fpy[1] = p.F[3 * p.plane + idx]; }
+        double Fx[2], Fy[2], ueqx, ueqy;
+        auto q0 = [&](int dx, int dy) { return s_psi0[ri + dy * QW + dx]; };
+        auto q1 = [&](int dx, int dy) { return s_psi1[ri + dy * QW + dx]; };
+        auto fl = [&](int dx, int dy) { return s_fl[ri + dy * QW + dx] != 0; };
+        sc_force_iso_tile<S10>(p, q0, q1, fl, rho, Fx, Fy);
+        if (p.diag) {
+            double tx = 0., ty = 0., tr = 0.;
+            tx += (mom_x(f0) + 1. / 2. * Fpx[0]); ty += (mom_y(f0) + 1. / 2. * Fpy[0]); tr += rho[0];
+            tx += (mom_x(f1) + 1. / 2. * Fpx[1]); ty += (mom_y(f1) + 1. / 2. * Fpy[1]); tr += rho[1];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { p.diag[j * p.plane + idx] = f0[j]; p.diag[(9 + j) * p.plane + idx] = f1[j]; }
+            p.diag[D_RHO * p.plane + idx] = rho[0]; p.diag[(D_RHO + 1) * p.plane + idx] = rho[1];
+            p.diag[D_VX * p.plane + idx] = tx / tr; p.diag[D_VY * p.plane + idx] = ty / tr;
+            p.diag[D_FX * p.plane + idx] = Fx[0]; p.diag[(D_FX + 1) * p.plane + idx] = Fx[1];
+            p.diag[D_FY * p.plane + idx] = Fy[0]; p.diag[(D_FY + 1) * p.plane + idx] = Fy[1];
+        }
+        if (p.keep_force || (p.outlet == LBMPM_OUTLET_CONVECTIVE && y == 3)) {
+            p.F[idx] = Fx[0]; p.F[p.plane + idx] = Fx[1];
+            p.F[2 * p.plane + idx] = Fy[0]; p.F[3 * p.plane + idx] = Fy[1];
+        }
+        if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2) {
+            const size_t o = (size_t)y * p.pitch + x;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                p.fold_out[(size_t)j * 3 * p.pitch + o] = f0[j];
+                p.fold_out[(size_t)(9 + j) * 3 * p.pitch + o] = f1[j];
+            }
+        }
+        chain_collide<MRT>(p, f0, f1, rho, Fx, Fy, ueqx, ueqy);
+        if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) store_pair(p.fout, p.plane, j, idx, f0[j], f1[j]);
+}
+
 // SC end-of-iteration view (D:1624-1629): streamed populations + outlet copies, rho, u with the
 // force of that iteration.
 template <bool INLET>
@@ -689,6 +831,7 @@ struct lbmpm_sc2d {
     std::vector<uint8_t> h_domain;
     bool streamed = false, initialised = false, diag_valid = false, keep_force = false;
     int scheme = 4;                  // [ForceScheme] ExplicitScheme
+    int iso_sweeps = 1;              // schemes 8 / 10: 1 = sc2d_iso_fused, 2 = sc2d_iso_psi + sc2d_iso_collide (LBMPM_SC2D_ISO_SWEEPS, the cross-check)
     double *psi = nullptr;           // [2][plane], schemes 8 / 10 only
     int64_t steps = 0, bytes = 0;
     hipGraphExec_t graph_exec = nullptr;              // GRAPH_STEPS captured time steps, valid while fA is where it was at capture
@@ -773,7 +916,12 @@ int launch_step(lbmpm_sc2d *c, bool diag, bool timed)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool ev = timed && c->pool.take(&e0, &e1);
     if (ev) { LBMPM_HIP_TRY(hipEventRecord(e0, c->stream)); c->timed_steps += 1; }
-    if (c->scheme != 4) {
+    if (c->scheme != 4 && c->iso_sweeps == 1) {
+        const int tx8 = (c->nx + 63) / 64, ty8 = (c->ny + 7) / 8;
+        const dim3 g(tx8 * ty8), b(512);
+        if (c->scheme == 10) { if (p.mrt) sc2d_iso_fused<true, true><<<g, b, 0, c->stream>>>(p, tx8); else sc2d_iso_fused<false, true><<<g, b, 0, c->stream>>>(p, tx8); }
+        else { if (p.mrt) sc2d_iso_fused<true, false><<<g, b, 0, c->stream>>>(p, tx8); else sc2d_iso_fused<false, false><<<g, b, 0, c->stream>>>(p, tx8); }
+    } else if (c->scheme != 4) {
         const dim3 g((c->nx + 63) / 64, (c->ny + 3) / 4), b(64, 4);
         sc2d_iso_psi<<<g, b, 0, c->stream>>>(p);
         if (p.mrt) sc2d_iso_collide<true><<<g, b, 0, c->stream>>>(p);
@@ -926,6 +1074,7 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
     TRY_RC(dev_alloc(c, &c->fB, 18 * c->plane));
     TRY_RC(dev_alloc(c, &c->F, 4 * c->plane));
     c->scheme = cfg->force_scheme ? cfg->force_scheme : 4;
+    if (const char *e = getenv("LBMPM_SC2D_ISO_SWEEPS")) c->iso_sweeps = atoi(e) == 2 ? 2 : 1;
     if (c->scheme != 4) TRY_RC(dev_alloc(c, &c->psi, 2 * c->plane));
     TRY_RC(dev_alloc(c, &c->foldA, (size_t)18 * 3 * c->pitch));
     TRY_RC(dev_alloc(c, &c->foldB, (size_t)18 * 3 * c->pitch));
