@@ -186,8 +186,10 @@ typedef struct lbmpm_tracer_config {
 /* [SurfaceTension] SurfaceTensionType = 'Perturbation': the loop of RKColorGradientLBM.runRKColorGradient2DPerturbation
  * (RKCG2D/RKD2Q9.py:978-1223; kernels AcceleratedRKGPU2D.py:1125-1343 + the per-colour Zou-He rows :657-695, :1008-1039) as one
  * fused launch per time step instead of the CSF step the context was created for.  Uses tau_r, tau_b, beta, relaxation of the
- * create-time config; the step streams FIRST (set_pdf gives the state before the first streaming).  Velocity inlet and pressure
- * outlet only, rows 0, 1, ny-2, ny-1 free of solid: anything else is LBMPM_ERR_UNSUPPORTED (the kernel-level entry points run it).
+ * create-time config (its inlet_type / outlet_type pick the loop's boundary kernels: velocity :657-695 or pressure :925-962 inlet per
+ * colour from inlet_rho_r / inlet_rho_b, pressure outlet per colour :1008-1039 or convective outlet :700-784); the step streams FIRST
+ * (set_pdf gives the state before the first streaming).  The rows 0, 1 (convective outlet: 0 .. 3), ny-2 and ny-1 must hold no solid
+ * node, else LBMPM_ERR_UNSUPPORTED (the kernel-level entry points run such a lattice).
  * Fields: LBMPM_RK_PDF_R/B = the stored (recoloured) populations; RHO_R/B, VX, VY, PHI, GX, GY = those of the last step (needs
  * diagnostics); REC_* = what the next step records after streaming + boundary kernels. */
 typedef struct lbmpm_rk2d_perturbation {

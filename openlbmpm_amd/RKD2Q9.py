@@ -156,9 +156,9 @@ class RKColorGradientLBM:
         Also left out: the loop's last launch, calRecoloringProcess (:1206), reads gradient and collision arrays nothing ever
         writes -- it adds zeros where device_array_like happens to return zeros, garbage otherwise.
         Schedule (`self.perturbation_schedule`): "fused" = one launch per time step (rk2dp_fused behind lbmpm_rk2d_set_perturbation:
-        velocity inlet + pressure outlet, no solid node in the four boundary rows); "kernels" = the loop kernel by kernel, ~16
-        launches per step on the kernel-level entry points (include/lbmpm_kernels.h), arrays in the reference's sparse layout --
-        every boundary type of the loop; "auto" (default) = fused where it applies, else kernels.
+        every boundary type of the loop, no solid node in the boundary rows); "kernels" = the loop kernel by kernel, ~16
+        launches per step on the kernel-level entry points (include/lbmpm_kernels.h), arrays in the reference's sparse layout;
+        "auto" (default) = fused where it applies, else kernels.
         `initial_pdf` = (fR, fB) dense [ny][nx][9] replaces the rest-state start (tests)."""
         import sys
         drop = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")

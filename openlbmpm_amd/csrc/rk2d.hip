@@ -772,9 +772,13 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // post-streaming, post-boundary-rows state of node (x, y): both colour lattices and their densities
 __device__ __forceinline__ void pert_node_state(const RKDev &p, const PertDev &q, int x, int y, double fR[9], double fB[9], double &rhoR, double &rhoB)
 {
-    const int ys = y == p.ny - 1 ? p.ny - 2 : (y == 0 ? 1 : y);      // the ghost rows copy their neighbour row's state
+    // the ghost rows copy their neighbour row's state; the convective outlet (convectiveOutletGPU / Ghost2GPU / Ghost3GPU, A:700-784)
+    // hands row 3's streamed state down to the rows 2, 1, 0
+    int ys = y == p.ny - 1 ? p.ny - 2 : y;
+    if (p.outlet == LBMPM_OUTLET_PRESSURE) { if (y == 0) ys = 1; }
+    else if (y <= 2) ys = 3;
     pull_node(p, x, ys, fR, fB);
-    if (ys == 1) {                        // A:1008-1039 (blue first, then red)
+    if (p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1) {       // A:1008-1039 (blue first, then red)
         {
             double *b = fB;
             const double pL = q.pOutB;
@@ -792,7 +796,12 @@ __device__ __forceinline__ void pert_node_state(const RKDev &p, const PertDev &q
             r[6] = r[8] + 0.5 * (r[1] - r[3]) + 1. / 6. * pL * v;
         }
     }
-    if (ys == p.ny - 2) {                 // A:657-695
+    if (ys == p.ny - 2 && p.inlet != LBMPM_INLET_VELOCITY) {      // calConstPressureInletGPU A:925-962, per colour
+        double d;
+        bc_inlet_pressure_one(p.pInB, fB, d);
+        bc_inlet_pressure_one(p.pInR, fR, d);
+    }
+    if (ys == p.ny - 2 && p.inlet == LBMPM_INLET_VELOCITY) {      // constantVelocityZHBoundaryHigherRK A:657-695
         {
             double *r = fR;
             const double rho = (r[0] + r[1] + r[3] + 2. * (r[2] + r[5] + r[6])) / (1. + q.vyInR);
@@ -1545,20 +1554,20 @@ extern "C" int lbmpm_rk2d_set_perturbation(lbmpm_rk2d *c, const lbmpm_rk2d_pertu
     LBMPM_REQUIRE(std::isfinite(par->ak_r) && std::isfinite(par->ak_b) && std::isfinite(par->solid_phi) && par->outlet_rho_r > 0. &&
                   par->outlet_rho_b > 0. && par->inlet_velocity_y_r > -1. && par->inlet_velocity_y_b > -1.,
                   "lbmpm_rk2d_set_perturbation: A_k, solidPhi finite, outlet densities > 0, inlet velocities > -1");
-    if (c->cfg.inlet_type != LBMPM_INLET_VELOCITY || c->cfg.outlet_type != LBMPM_OUTLET_PRESSURE) {
-        set_error("the fused perturbation step has the velocity inlet ('Neumann') and the pressure outlet ('Dirichlet') built in; the other "
-                  "boundary kernels of the loop run on the kernel-level entry points (openlbmpm_amd/RKD2Q9.py)");
-        return LBMPM_ERR_UNSUPPORTED;
-    }
-    // the reference addresses the outlet rows by COMPACT index (n < nx, nx <= n < 2 nx: A:1008-1081) and the ghost rows copy their
-    // neighbour row through the neighbour table: both mean grid rows only when the two rows at either end hold no solid node
-    for (int y : {0, 1, c->ny - 2, c->ny - 1})
+    LBMPM_REQUIRE(c->cfg.inlet_type == LBMPM_INLET_VELOCITY || (c->cfg.inlet_rho_r > 0. && c->cfg.inlet_rho_b > 0.),
+                  "lbmpm_rk2d_set_perturbation: the pressure inlet needs inlet_rho_r, inlet_rho_b > 0");
+    // the reference addresses the pressure outlet's rows by COMPACT index (n < nx, nx <= n < 2 nx: A:1008-1081) and every ghost / copied
+    // row takes its neighbour row through the neighbour table: both mean grid rows only when the rows at either end hold no solid node
+    const int low = c->cfg.outlet_type == LBMPM_OUTLET_PRESSURE ? 2 : 4;
+    for (int y = 0; y < c->ny; ++y) {
+        if (y >= low && y < c->ny - 2) continue;
         for (int x = 0; x < c->nx; ++x)
             if (c->h_domain[(size_t)y * c->nx + x] != 1) {
-                set_error("the fused perturbation step needs rows 0, 1, ny-2 and ny-1 free of solid nodes (node (%d, %d) is not fluid): the "
-                          "reference's outlet kernels index those rows by compact node number", x, y);
+                set_error("the fused perturbation step needs the rows 0 .. %d, ny-2 and ny-1 free of solid nodes (node (%d, %d) is not fluid): the "
+                          "reference's boundary kernels reach those rows by compact node number / through the neighbour table", low - 1, x, y);
                 return LBMPM_ERR_UNSUPPORTED;
             }
+    }
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     c->pert = *par;
     c->model = 1;

@@ -27,9 +27,9 @@ def _f64(a):
 class RK2DSolver:
     def __init__(self, is_domain, params=None, device=0, variant=0, diagnostics=False, perturbation=None):
         """perturbation = dict(AkR=, AkB=, solidPhi=): the step of SurfaceTensionType 'Perturbation' (RKD2Q9.py:978-1223) as one fused
-        launch instead of the CSF step (lbmpm_rk2d_set_perturbation): per-colour velocity inlet vyR / vyB, per-colour pressure outlet
-        rhoRL / rhoBL, tauR, tauB, beta, relax of `params`; raises LbmpmError (unsupported) for other boundary types or solid nodes in
-        the four boundary rows."""
+        launch instead of the CSF step (lbmpm_rk2d_set_perturbation): inlet 'Neumann' (vyR / vyB per colour) or 'Dirichlet' (rhoRH /
+        rhoBH), outlet 'Dirichlet' (rhoRL / rhoBL per colour) or 'Convective', tauR, tauB, beta, relax of `params`; raises LbmpmError
+        (unsupported) for solid nodes in the boundary rows."""
         L = _lib.lib()
         p = dict(DEFAULT_PARAMS)
         p.update(params or {})

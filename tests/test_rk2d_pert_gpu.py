@@ -72,30 +72,40 @@ def test_what_the_fused_step_does_not_cover_is_refused():
     from openlbmpm_amd.rk2d import RK2DSolver
     dom = np.ones((24, 40), dtype=np.uint8)
     pert = dict(AkR=0.007, AkB=0.009, solidPhi=0.5)
-    for bad in (dict(outlet="Convective"), dict(inlet="Dirichlet")):
-        with pytest.raises(LbmpmError, match="kernel-level entry points"):
-            RK2DSolver(dom, dict(dict(inlet="Neumann", outlet="Dirichlet"), **bad), perturbation=pert)
     dom[1, 7] = 0
     with pytest.raises(LbmpmError, match=r"node \(7, 1\)"):
         RK2DSolver(dom, dict(inlet="Neumann", outlet="Dirichlet"), perturbation=pert)
+    dom[1, 7] = 1; dom[3, 5] = 0                   # row 3 matters to the convective outlet only (rows 2, 1, 0 copy it)
+    RK2DSolver(dom, dict(inlet="Neumann", outlet="Dirichlet"), perturbation=pert).close()
+    with pytest.raises(LbmpmError, match=r"rows 0 \.\. 3.*node \(5, 3\)"):
+        RK2DSolver(dom, dict(inlet="Neumann", outlet="Convective"), perturbation=pert)
     with pytest.raises(LbmpmError, match="fused schedule"):
         RK2DSolver(np.ones((24, 40), dtype=np.uint8), dict(inlet="Neumann", outlet="Dirichlet"), variant=1, perturbation=pert)
     with pytest.raises(KeyError):
         RK2DSolver(np.ones((24, 40), dtype=np.uint8), perturbation=dict(pert, sigma=1.0))
 
 
-def test_fused_step_at_a_ragged_size_equals_the_kernel_by_kernel_loop(tmp_path):
-    """150 x 97 porous lattice (partial tiles in both directions): the fused solver against the same loop on the kernel-level entry
-    points (16 launches per step, arrays in the reference's sparse layout) through the driver"""
+@pytest.mark.parametrize("inlet,outlet,relax", [("Neumann", "Dirichlet", "SRT"), ("Dirichlet", "Dirichlet", "MRT"), ("Neumann", "Convective", "MRT"),
+                                                ("Dirichlet", "Convective", "SRT")])
+def test_fused_step_at_a_ragged_size_equals_the_kernel_by_kernel_loop(tmp_path, inlet, outlet, relax):
+    """150 x 97 lattice (partial tiles in both directions), every pair of the loop's boundary kernels (velocity / pressure inlet per
+    colour, pressure / convective outlet): the fused solver against the same loop on the kernel-level entry points (16 launches per
+    step, arrays in the reference's sparse layout, each kernel pinned to the reference's by rkpert_kernels.npz) through the driver"""
+    import re
     from openlbmpm_amd.RKD2Q9 import RKColorGradientLBM
     from ini_fixtures import write_rk
-    write_rk(str(tmp_path), nx=150, ny=97, steps=40, interval=20, relax="SRT")
+    write_rk(str(tmp_path), nx=150, ny=97, steps=40, interval=20, relax=relax)
     ini = tmp_path / "RKtwophasesetup2D.ini"
-    ini.write_text(ini.read_text().replace("SurfaceTensionType = 'CSF'", "SurfaceTensionType = 'Perturbation'"))
+    text = ini.read_text().replace("SurfaceTensionType = 'CSF'", "SurfaceTensionType = 'Perturbation'")
+    text, n1 = re.subn(r"(?m)^(\s*BoundaryTypeInlet\s*=).*$", r"\1 '%s'" % inlet, text)
+    text, n2 = re.subn(r"(?m)^(\s*BoundaryTypeOutlet\s*=).*$", r"\1 '%s'" % outlet, text)
+    assert n1 == 1 and n2 == 1
+    ini.write_text(text)
     out = {}
     for mode in ("kernels", "fused"):
         sim = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / mode))
         sim.perturbation_schedule = mode
+        assert sim.par["inlet"] == inlet and sim.par["outlet"] == outlet
         sim.runRKColorGradient2D()
         out[mode] = {f: getattr(sim, f) for f in ("fluidsRhoR", "fluidsRhoB", "physicalVX", "physicalVY", "fluidPDFR", "fluidPDFB")}
         assert sim.records == 2
