@@ -585,7 +585,7 @@ __device__ __forceinline__ void sc_force_iso_tile(const SCDev &p, const Psi0 &q0
 }
 
 template <bool MRT, bool S10>
-__global__ __launch_bounds__(512) void sc2d_iso_fused(SCDev p, int tiles_x)
+__global__ __launch_bounds__(512, 4) void sc2d_iso_fused(SCDev p, int tiles_x)
 {
     constexpr int IW = 64, IH = 8, H = S10 ? 3 : 2, QW = IW + 2 * H, QH = IH + 2 * H, NT = IW * IH;
     __shared__ double s_psi0[QH * QW];
