@@ -1581,6 +1581,7 @@ extern "C" int lbmpm_rk2d_tracer_configure(lbmpm_rk2d *c, const lbmpm_tracer_con
     LBMPM_REQUIRE(c && t, "lbmpm_rk2d_tracer_configure: null argument");
     LBMPM_REQUIRE(t->num_tracers >= 1 && t->num_tracers <= 4, "NumberTracers must be 1..4 (got %d)", t->num_tracers);
     LBMPM_REQUIRE(c->cfg.variant == 0, "tracer transport is fused into the default (fused) schedule only");
+    LBMPM_REQUIRE(c->model == 0, "tracer transport rides on the CSF step (Transport2DRK.py); the perturbation operator has no tracer loop in the reference");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     // D2Q5 moment matrix and collision matrix -M^-1 S^-1 (Transport2DRK.py:316-347)
     const double M[25] = {1, 1, 1, 1, 1,   0, 1, -1, 0, 0,   0, 0, 0, 1, -1,   4, -1, -1, -1, -1,   0, 1, 1, -1, -1};

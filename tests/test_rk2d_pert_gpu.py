@@ -83,6 +83,10 @@ def test_what_the_fused_step_does_not_cover_is_refused():
         RK2DSolver(np.ones((24, 40), dtype=np.uint8), dict(inlet="Neumann", outlet="Dirichlet"), variant=1, perturbation=pert)
     with pytest.raises(KeyError):
         RK2DSolver(np.ones((24, 40), dtype=np.uint8), perturbation=dict(pert, sigma=1.0))
+    s = RK2DSolver(np.ones((24, 40), dtype=np.uint8), dict(inlet="Neumann", outlet="Dirichlet"), perturbation=pert)
+    with pytest.raises(LbmpmError, match="no tracer loop"):
+        s.configure_tracers()
+    s.close()
 
 
 @pytest.mark.parametrize("inlet,outlet,relax", [("Neumann", "Dirichlet", "SRT"), ("Dirichlet", "Dirichlet", "MRT"), ("Neumann", "Convective", "MRT"),
