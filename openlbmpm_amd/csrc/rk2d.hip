@@ -549,8 +549,12 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
     }
 }
 
-template <bool MRT, bool TRACER, typename SH>
-__global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rk2d_fused(RKDev p, int tiles_x)
+// TR (tracer variant): the order of the density sums on the rows a boundary kernel touches (node_finish).  Rows without a boundary
+// rule come out the same for TR = 0 and 1, so the tracer step runs as TWO launches: TR = 0 -- round 2's kernel, which fits its 128
+// registers with 12 B of spills -- on the tile rows whose region (tile + 3) stays clear of the lattice rows 0, 1, ny-2, ny-1, and
+// TR = 1 (the re-summing variant: 44 B of spills) on the first and last tile row only.  `tile0`: first tile of this launch.
+template <bool MRT, bool TRACER, typename SH, int TR = (TRACER ? 1 : 0)>
+__global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rk2d_fused(RKDev p, int tiles_x, int tile0 = 0)
 {
     constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
     constexpr int RW = SH::RW, RH = SH::RH;
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 
     // XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch order);
     // give every XCD a contiguous band of tiles so halo rows are shared inside one L2.
-    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    const int t = tile0 + xcd_tile(blockIdx.x, gridDim.x);
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
 
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             sn[m] = p.solidnbr[idx];
             Fpx[m] = p.F[idx];
             Fpy[m] = p.F[p.plane + idx];
-            node_state<true, TRACER ? 1 : 0>(p, xw, yw, fR, fB, rR[m], rB[m]);
+            node_state<true, TR>(p, xw, yw, fR, fB, rR[m], rB[m]);
 #pragma unroll
             for (int i = 0; i < 9; ++i) fT[m][i] = fR[i] + fB[i];
             s_phi[ri] = (rR[m] - rB[m]) / (rR[m] + rB[m]);
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     }
     if (hdo) {
         double a, c;
-        node_finish<true, TRACER ? 1 : 0>(p, hy, hys, hR, hB, a, c);
+        node_finish<true, TR>(p, hy, hys, hR, hB, a, c);
         s_phi[hry * RW + hrx] = (a - c) / (a + c);
     }
     for (int n = tid + THREADS; n < NHALO; n += THREADS) {          // shapes whose halo outnumbers the threads
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         if (!need3 && (rx == 0 || rx == RW - 1 || ry == 0 || ry == RH - 1)) continue;
         const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
         double fR[9], fB[9], a, c;
-        node_state<true, TRACER ? 1 : 0>(p, x, y, fR, fB, a, c);
+        node_state<true, TR>(p, x, y, fR, fB, a, c);
         s_phi[ri] = (a - c) / (a + c);
     }
     __syncthreads();
@@ -1138,8 +1142,24 @@ void launch_fused_tracer(lbmpm_rk2d *c, const RKDev &p)
 {
     const int tiles_x = (c->nx + SH::TW - 1) / SH::TW, tiles_y = (c->ny + SH::TH - 1) / SH::TH;
     const dim3 g(tiles_x * tiles_y), b(SH::THREADS);
-    if (c->cfg.relaxation == LBMPM_RELAX_MRT) rk2d_fused<true, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
-    else rk2d_fused<false, true, SH><<<g, b, 0, c->stream>>>(p, tiles_x);
+    const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
+    // tile rows whose region (tile + 3 rows, periodic) holds one of the rows 0, 1, ny-2, ny-1: the first and the last one
+    // (a lattice of fewer than four tile rows runs as one launch of the re-summing variant)
+    if (tiles_y < 4 || SH::TH < 4) {
+        if (mrt) rk2d_fused<true, true, SH, 1><<<g, b, 0, c->stream>>>(p, tiles_x, 0);
+        else rk2d_fused<false, true, SH, 1><<<g, b, 0, c->stream>>>(p, tiles_x, 0);
+        return;
+    }
+    const dim3 gi(tiles_x * (tiles_y - 2)), ge(tiles_x);
+    if (mrt) {
+        rk2d_fused<true, true, SH, 0><<<gi, b, 0, c->stream>>>(p, tiles_x, tiles_x);
+        rk2d_fused<true, true, SH, 1><<<ge, b, 0, c->stream>>>(p, tiles_x, 0);
+        rk2d_fused<true, true, SH, 1><<<ge, b, 0, c->stream>>>(p, tiles_x, tiles_x * (tiles_y - 1));
+    } else {
+        rk2d_fused<false, true, SH, 0><<<gi, b, 0, c->stream>>>(p, tiles_x, tiles_x);
+        rk2d_fused<false, true, SH, 1><<<ge, b, 0, c->stream>>>(p, tiles_x, 0);
+        rk2d_fused<false, true, SH, 1><<<ge, b, 0, c->stream>>>(p, tiles_x, tiles_x * (tiles_y - 1));
+    }
 }
 
 int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
