@@ -16,11 +16,18 @@ WORKLOADS = {"rk3dq_fused": "c5 512x512x512", "rk3dc_fused": "c5 512x512x512", "
 
 
 def parse(path, counter):
-    out = {}
+    """{kernel name as printed: (launches, average per launch)}.  Instances whose printed (truncated) names coincide are one kernel
+    launched over parts of the lattice -- the tracer step: the tile rows at the lattice's ends and the rest -- and are folded into ONE
+    entry per time step: the sum over the instances of launches x average, divided by the smallest launch count (= the steps)."""
+    rows = {}
     for line in open(path):
         m = re.match(r"^(.*?)\s+%s\s+(\d+)\s+([0-9.]+)\s*$" % counter, line.rstrip())
         if m:
-            out[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
+            rows.setdefault(m.group(1).strip(), []).append((int(m.group(2)), float(m.group(3))))
+    out = {}
+    for name, inst in rows.items():
+        steps = min(n for n, _ in inst)
+        out[name] = (steps, sum(n * v for n, v in inst) / steps)
     return out
 
 
