@@ -147,6 +147,40 @@ def c5_densities(dom_slab, z0, nz_global, nbuf=10):
     return np.where(fluid & red, 1.0, 0.0), np.where(fluid & ~red, 1.0, 0.0)
 
 
+C5_STATES = {
+    "initial": "SURVEY 8d's initial state: red below the 10 blue buffer planes (most row segments hold one colour)",
+    "mixed": "both colours in every fluid cell (rho_R = rho_B = 0.5): no single-colour row segment anywhere -- every record moved, "
+             "every rim cell pulled; the kernel's worst case",
+    "graded": "red below, blue above, the middle 30 % of the planes a linear mixture of the two",
+}
+
+
+def c5_state(dom_slab, z0, nz_global, state="initial", nbuf=10):
+    """initial densities of the c5 legs (C5_STATES); `initial` is the state SURVEY.md 8d prescribes"""
+    if state == "initial":
+        return c5_densities(dom_slab, z0, nz_global, nbuf)
+    fluid = dom_slab == 1
+    if state == "mixed":
+        return np.where(fluid, 0.5, 0.0), np.where(fluid, 0.5, 0.0)
+    if state == "graded":
+        zz = (np.arange(dom_slab.shape[0]) + z0)[:, None, None]
+        w = np.clip((zz - 0.35 * nz_global) / (0.3 * nz_global), 0.0, 1.0) * np.ones(dom_slab.shape)
+        return np.where(fluid, 1.0 - w, 0.0), np.where(fluid, w, 0.0)
+    raise ValueError(state)
+
+
+def c5_bytes_moved(storage, per_launch_ms, traffic):
+    """what one launch moves: by the storage's own count at the end of the run (owned cells: populations + records of unflagged row
+    segments; rim / halo re-reads not included) and, when a committed profile matches the workload, by the hardware counters"""
+    rate = lambda b: round(b / (per_launch_ms * 1e-3) / 1e9, 1)
+    return {"doubles_stored_per_cell": storage["doubles_per_cell"],
+            "cells_in_single_colour_rows": storage["cells_in_flagged_rows"], "fluid_cells": storage["fluid_cells"],
+            "storage_bytes_per_launch": storage["bytes_per_step"], "storage_GBs": rate(storage["bytes_per_step"]),
+            "storage_frac": round(rate(storage["bytes_per_step"]) / HBM_PEAK_GBS, 4),
+            "counted_bytes_per_launch": traffic, "counted_GBs": rate(traffic) if traffic else None,
+            "counted_frac": round(rate(traffic) / HBM_PEAK_GBS, 4) if traffic else None}
+
+
 def time_solver_2d(solver, steps, warmup):
     solver.step(warmup)
     solver.sync()
@@ -227,6 +261,9 @@ def main():
     ap.add_argument("--size", type=int, nargs="+", default=None, help="c5: NX NY NZ; c2/c3: NX NY")
     ap.add_argument("--relax", default="MRT", choices=["MRT", "SRT"],
                     help="c5 relaxation: BASELINE.json names the MRT configuration; the shipped ini says 'SRT' with ';;MRT' beside it")
+    ap.add_argument("--c5-state", default="initial", choices=sorted(C5_STATES),
+                    help="c5 initial condition of the primary line (default: SURVEY 8d's); the other two run as secondary legs at N = 1")
+    ap.add_argument("--no-c5-legs", action="store_true", help="N = 1: skip the secondary c5 legs (other states / other relaxation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="N > 1: keep the equal-fluid-cells cuts (no measured re-cut of the slabs)")
@@ -280,13 +317,13 @@ def main():
         from openlbmpm_amd.rk3d import RK3DDistributed, RK3DSlab
         from openlbmpm_amd.slab import partition_z
         size = tuple(args.size) if args.size else (512, 512, 512)
-        steps = args.steps if args.steps is not None else 100       # (SURVEY.md 8d asks for 500: `--steps 500` sustains 13.2 ms/step
-        warmup = args.warmup if args.warmup is not None else max(1, steps // 10)      #  where the first 100 run at 12.7 - 12.9: clocks settle)
+        steps = args.steps if args.steps is not None else 100       # (SURVEY.md 8d asks for 500: profiles/rNN_bench_c5_steps500.json)
+        warmup = args.warmup if args.warmup is not None else max(1, steps // 10)
         dom = c5_domain(size)
         nz = size[2]
         nfluid_global = int(dom.sum())
         z0, nzl = RK3DDistributed.partition(dom, world)[rank]       # equal fluid cells per rank
-        rR, rB = c5_densities(dom[z0:z0 + nzl], z0, nz)
+        rR, rB = c5_state(dom[z0:z0 + nzl], z0, nz, args.c5_state)
         m0_local = float((rR + rB).sum())
         # the K timed steps run as (up to) five back-to-back windows: the line carries their median / min / max beside the whole-run value
         nwin = min(5, steps)
@@ -321,7 +358,7 @@ def main():
                 cost = d.calibrated_plane_cost(8)
                 d.close()
                 z0, nzl = RK3DDistributed.partition(dom, world, plane_cost=cost)[rank]
-                rR, rB = c5_densities(dom[z0:z0 + nzl], z0, nz)
+                rR, rB = c5_state(dom[z0:z0 + nzl], z0, nz, args.c5_state)
                 m0_local = float((rR + rB).sum())
                 d = RK3DDistributed(dom, dict(relax=args.relax), device=local_rank, plane_cost=cost)
                 d.slab.set_density(rR, rB)
@@ -362,22 +399,19 @@ def main():
             wall = float(t.item())
         if rank == 0:
             per_launch_ms = ms_dom / steps
-            achieved = B_ALG["c5"] * nfl_local / (per_launch_ms * 1e-3) / 1e9
+            by_balg = B_ALG["c5"] * nfl_local / (per_launch_ms * 1e-3) / 1e9
             win = sorted(nfluid_global * n / (ms * 1e-3) / 1e6 for n, ms in zip(win_steps, win_ms))
-            traffic = pmc_traffic(dom_kernel + ("[SRT]" if args.relax == "SRT" else ""), "c5 %dx%dx%d" % size) if world == 1 else None
-            moved = {"doubles_stored_per_cell": storage["doubles_per_cell"],
-                     "cells_in_single_colour_rows": storage["cells_in_flagged_rows"], "fluid_cells": storage["fluid_cells"],
-                     "storage_bytes_per_launch": storage["bytes_per_step"],
-                     "storage_GBs": round(storage["bytes_per_step"] / (per_launch_ms * 1e-3) / 1e9, 1),
-                     "storage_frac": round(storage["bytes_per_step"] / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "counted_GBs": round(traffic / (per_launch_ms * 1e-3) / 1e9, 1) if traffic else None,
-                     "counted_frac": round(traffic / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                     "note": "frac above is MLUPS x 608 B (SURVEY 8d: both colour lattices read and written once) / 8 TB/s and may exceed what "
-                             "the memory system moved: the compact storage keeps 19 colour-blind populations + k_R + the recolouring vector "
-                             "per cell (23 doubles, the recolouring AcceleratedRKGPU2D.py:1241-1267 makes the 38 an affine image of them) and "
-                             "no record at all for row segments of a single colour; storage_* = bytes of the owned cells by the storage's own "
-                             "count at the end of the run (rim / halo re-reads not included), counted_* = rocprofv3 FETCH/WRITE of "
-                             "profiles/pmc_traffic.json"}
+            ktag = dom_kernel + ("[SRT]" if args.relax == "SRT" else "") + ("" if args.c5_state == "initial" else "[%s]" % args.c5_state)
+            traffic = pmc_traffic(ktag, "c5 %dx%dx%d" % size) if world == 1 else None
+            moved = c5_bytes_moved(storage, per_launch_ms, traffic)
+            # roofline.achieved / frac: BYTES MOVED per launch / launch time (the counters' figure when a committed profile matches this
+            # workload, else the storage's own count); SURVEY 8d's formula (608 B per update: both colour lattices read and written
+            # once) is kept beside it -- it exceeds 1 because the storage moves 23 doubles per cell, not 38
+            achieved = moved["counted_GBs"] if traffic else moved["storage_GBs"]
+            moved["note"] = ("the compact storage keeps 19 colour-blind populations + k_R + the recolouring vector per cell (23 doubles; the "
+                             "recolouring AcceleratedRKGPU2D.py:1241-1267 makes the 38 an affine image of them) and no record at all for row "
+                             "segments of a single colour; storage_* = bytes of the owned cells by the storage's own count at the end of the "
+                             "run (rim / halo re-reads not included), counted_* = rocprofv3 2 x FETCH_SIZE + WRITE_SIZE per launch")
             out = {
                 "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid_global * steps / wall / 1e6, 2),
                 "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -388,7 +422,7 @@ def main():
                             "clock": "HIP events on the kernel's stream" if world == 1 else "host clock of rank 0 around each window"},
                 "config": {"workload": "c5: D3Q19 colour gradient (perturbation operator, %s; RKtwophasesetup3D.ini "
                                        "parameters), %dx%dx%d synthetic porous medium (spheres r 6-20, porosity 0.65, "
-                                       "10 buffer planes, side walls), seed %d" % ((args.relax,) + size + (SEED,)),
+                                       "10 buffer planes, side walls), seed %d; initial condition: %s" % ((args.relax,) + size + (SEED, C5_STATES[args.c5_state])),
                            "fluid_nodes": nfluid_global, "lattice_nodes": int(np.prod(size)),
                            "mlups_total_lattice": round(float(np.prod(size)) * steps / wall / 1e6, 2),
                            "parallelism": ("z-slabs x%d, RCCL p2p: one face message per cut and step (5 populations, the cell record, row flags and the "
@@ -407,7 +441,13 @@ def main():
                                      "38-value kernels 1e-11 (tests/test_rk3d_gpu.py)"},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
+                             "achieved_is": "bytes moved per launch / avg_launch_ms: " + (
+                                 "hardware counters (traffic)" if traffic else "the storage's own count (no committed counter profile matches this workload)"),
+                             "achieved_by_survey_balg": round(by_balg, 1), "frac_by_survey_balg": round(by_balg / HBM_PEAK_GBS, 4),
+                             "frac_by_survey_balg_note": "SURVEY 8d: MLUPS x 608 B / 8 TB/s; not a bandwidth fraction for this storage (may exceed 1)",
                              "traffic": traffic,
+                             "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh over this "
+                                                "command on an MI355X box (committed; NOT measured in this run)") if traffic else None,
                              "bytes_moved": moved,
                              "kernel": dom_kernel,
                              "measured_stream_ceiling": measured_hbm(local_rank) if world == 1 else None,
@@ -451,18 +491,32 @@ def main():
                                            "the nearest coupling at which it stays put, three radii over 10^4 steps give dp * R within +-5 % of each other on the "
                                            "CPU oracle and on this kernel (tests/test_c1_droplet_gpu.py); this line times the ini's own parameters")
                     s.close()
-                # the other relaxation of the same 3-D workload (the shipped ini says 'SRT', BASELINE.json names MRT)
-                other = "SRT" if args.relax == "MRT" else "MRT"
-                rR2, rB2 = c5_densities(dom, 0, nz)
-                s3 = RK3DSlab(dom, 0, nz, dict(relax=other), device=local_rank)
-                s3.set_density(rR2, rB2)
-                del rR2, rB2
-                s3.step_single(5); s3.sync()
-                t1 = time.perf_counter(); mt3, md3 = s3.step_timed(30); s3.sync(); w3 = time.perf_counter() - t1
-                sec.append({"workload": "c5 with %s relaxation" % other, "value": round(s3.num_fluid_nodes * 30 / w3 / 1e6, 2), "unit": "MLUPS",
-                            "ms_per_step": round(w3 * 1e3 / 30, 5), "fluid_nodes": s3.num_fluid_nodes, "kernel": s3.dominant_kernel,
-                            "roofline_frac": round(B_ALG["c5"] * s3.num_fluid_nodes / (md3 / 30 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-                s3.close()
+                # the same 3-D workload in its other states and with the other relaxation
+                def c5_leg(label, relax, state, nsteps):
+                    r2, b2 = c5_state(dom, 0, nz, state)
+                    s3 = RK3DSlab(dom, 0, nz, dict(relax=relax), device=local_rank)
+                    s3.set_density(r2, b2)
+                    del r2, b2
+                    s3.step_single(5); s3.sync()
+                    t1 = time.perf_counter(); mt3, md3 = s3.step_timed(nsteps); s3.sync(); w3 = time.perf_counter() - t1
+                    st3 = s3.storage_info()
+                    ktag3 = s3.dominant_kernel + ("[SRT]" if relax == "SRT" else "") + ("" if state == "initial" else "[%s]" % state)
+                    mv = c5_bytes_moved(st3, md3 / nsteps, pmc_traffic(ktag3, "c5 %dx%dx%d" % size))
+                    leg = {"workload": label, "value": round(s3.num_fluid_nodes * nsteps / w3 / 1e6, 2), "unit": "MLUPS",
+                           "ms_per_step": round(w3 * 1e3 / nsteps, 5), "steps": nsteps, "fluid_nodes": s3.num_fluid_nodes, "kernel": s3.dominant_kernel,
+                           "state": C5_STATES[state], "cells_in_single_colour_rows": mv["cells_in_single_colour_rows"],
+                           "roofline_frac": mv["counted_frac"] if mv["counted_frac"] is not None else mv["storage_frac"],
+                           "roofline_frac_by_survey_balg": round(B_ALG["c5"] * s3.num_fluid_nodes / (md3 / nsteps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "bytes_moved": mv}
+                    s3.close()
+                    return leg
+                if not args.no_c5_legs:
+                    for state in sorted(C5_STATES):
+                        if state != args.c5_state:
+                            sec.append(c5_leg("c5 %s (%s)" % ({"mixed": "two colours in every cell", "graded": "graded (30 % of the planes mixed)",
+                                                                  "initial": "initial state"}[state], args.relax), args.relax, state, 40))
+                    other = "SRT" if args.relax == "MRT" else "MRT"
+                    sec.append(c5_leg("c5 with %s relaxation" % other, other, args.c5_state, 30))
                 out["secondary"] = sec
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_c5(args.relax)
@@ -506,6 +560,7 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
                              "traffic": pmc_traffic(solver.dominant_kernel, "%s %dx%d" % ((wl,) + size)),
+                             "traffic_source": "profiles/pmc_traffic.json (rocprofv3 counter passes of tools/profile_round.sh, committed; not measured in this run)",
                              "measured_stream_ceiling": measured_hbm(local_rank),
                              "kernel": solver.dominant_kernel, "avg_launch_ms": round(per_launch_ms, 6),
                              "algorithmic_bytes_per_launch": B_ALG[wl] * nfluid},

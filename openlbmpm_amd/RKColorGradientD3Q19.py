@@ -100,7 +100,7 @@ class RKColorGradient3D:
         out = ResultFile(self.output_dir, name, (("FluidMacro", "MacroData"), ("FluidVelocity", "MacroVelocity")))
         self.result_path = out.path
         # distributed: every rank checks its own slab, the verdict is collective (all ranks raise together, none is left in an exchange)
-        self._guard = RecordGuard("rk3d", slab.num_fluid_nodes, getattr(self, "nan_guard", "raise"), collective=self._distributed())
+        self._guard = RecordGuard("rk3d", slab.num_fluid_nodes, getattr(self, "nan_guard", "raise"), collective=self._distributed(), device=self.device)
         done = 0
         while done < self.timeSteps:
             self._step_now = done

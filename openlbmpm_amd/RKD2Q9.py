@@ -256,7 +256,8 @@ class RKColorGradientLBM:
         try:
             solver = RK2DSolver(self.isDomain, par, perturbation=dict(AkR=p["AkR"], AkB=p["AkB"], solidPhi=p["solidPhi"]))
         except LbmpmError as e:
-            if required or "(status -5)" not in str(e):                  # LBMPM_ERR_UNSUPPORTED: the kernel-level loop covers it
+            from ._lib import ERR_UNSUPPORTED
+            if required or e.status != ERR_UNSUPPORTED:                  # LBMPM_ERR_UNSUPPORTED: the kernel-level loop covers it
                 raise
             return False
         ny, nx = self.isDomain.shape

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "liblbmpm_hip.so")
+# LBMPM_LIBRARY: another build of the same sources (tools/dev/devlib.py: the -DLBMPM_DEV build with time stamps and knock-outs)
+LIB_PATH = os.environ.get("LBMPM_LIBRARY") or os.path.join(_PKG, "liblbmpm_hip.so")
 
 F64P = C.POINTER(C.c_double)
 U8P = C.POINTER(C.c_uint8)
@@ -15,7 +16,15 @@ I64P = C.POINTER(C.c_int64)
 
 
 class LbmpmError(RuntimeError):
-    pass
+    """status: the C function's return value (LBMPM_ERR_* of include/lbmpm.h; None when no call was involved)"""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
+
+
+# status codes of include/lbmpm.h
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 
 class RK2DConfig(C.Structure):
@@ -181,4 +190,4 @@ def lib():
 def check(rc, what=""):
     if rc != 0:
         msg = lib().lbmpm_last_error().decode("utf-8", "replace")
-        raise LbmpmError("%s failed (status %d): %s" % (what or "lbmpm call", rc, msg))
+        raise LbmpmError("%s failed (status %d): %s" % (what or "lbmpm call", rc, msg), status=rc)

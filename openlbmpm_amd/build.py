@@ -36,14 +36,48 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile_and_link(out, extra, objdir, verbose):
+    """one object per source (compiled side by side, recompiled only when the source, a header or this recipe is newer), then one link"""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(PKG), "include", "*.h")) + [os.path.abspath(__file__)]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    compile_flags = [f for f in FLAGS if f != "-shared"] + extra
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            jobs.append([HIPCC] + compile_flags + ["-c", src, "-o", obj])
+    if verbose:
+        for j in jobs:
+            print("[openlbmpm_amd.build]", " ".join(j), flush=True)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(subprocess.check_call, jobs))
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+    if verbose:
+        print("[openlbmpm_amd.build]", " ".join(link), flush=True)
+    subprocess.check_call(link)
+    return out
+
+
+def build_dev(out, verbose=True):
+    """The development build (-DLBMPM_DEV): per-workgroup time stamps of rk3dq_fused (LBMPM_RK3D_TRACE) and the timing knock-outs of the
+    slab step (LBMPM_RK3D_DBG, LBMPM_RK3D_COMM_CUS).  Never the product: tools/dev/devlib.py builds it beside the tools and points
+    LBMPM_LIBRARY at it; `build()` below does not define LBMPM_DEV, and tests/test_codeobj.py checks that the product library holds
+    none of those switches."""
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    return _compile_and_link(out, ["-DLBMPM_DEV"], os.path.join(os.path.dirname(out), "obj"), verbose)
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB]
-    if verbose:
-        print("[openlbmpm_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return LIB
+    objdir = os.path.join(PKG, "_obj")
+    if force:
+        for o in glob.glob(os.path.join(objdir, "*.o")):
+            os.remove(o)
+    return _compile_and_link(LIB, [], objdir, verbose)
 
 
 if __name__ == "__main__":

@@ -1143,22 +1143,31 @@ void launch_fused_tracer(lbmpm_rk2d *c, const RKDev &p)
     const int tiles_x = (c->nx + SH::TW - 1) / SH::TW, tiles_y = (c->ny + SH::TH - 1) / SH::TH;
     const dim3 g(tiles_x * tiles_y), b(SH::THREADS);
     const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
-    // tile rows whose region (tile + 3 rows, periodic) holds one of the rows 0, 1, ny-2, ny-1: the first and the last one
-    // (a lattice of fewer than four tile rows runs as one launch of the re-summing variant)
-    if (tiles_y < 4 || SH::TH < 4) {
+    // The re-summing variant (TR = 1: the transport driver's order of boundary rows and density sums, Transport2DRK.py:1199-1287) goes to
+    // every tile row whose region -- its TH own rows + 3 rows of halo on either side, periodic -- holds one of the rows 0, 1, ny-2, ny-1:
+    // the n_lo tile rows from the bottom with ty TH - 3 <= 1 and the n_hi from the top with ty TH + TH + 2 >= ny - 2 (one for TH = 8 when
+    // ny is a multiple of 8, two otherwise: ny % 8 in 1..4 puts row ny-2 into the halo or among the own rows of tile row tiles_y - 2).
+    // The tile rows in between run the variant that sums once.
+    constexpr int H = 3;
+    int n_lo = 0, n_hi = 0;
+    for (int ty = 0; ty < tiles_y; ++ty) {
+        if (ty * SH::TH - H <= 1) n_lo = ty + 1;
+        if (ty * SH::TH + SH::TH - 1 + H >= c->ny - 2 && n_hi == 0) n_hi = tiles_y - ty;
+    }
+    if (n_lo + n_hi >= tiles_y) {
         if (mrt) rk2d_fused<true, true, SH, 1><<<g, b, 0, c->stream>>>(p, tiles_x, 0);
         else rk2d_fused<false, true, SH, 1><<<g, b, 0, c->stream>>>(p, tiles_x, 0);
         return;
     }
-    const dim3 gi(tiles_x * (tiles_y - 2)), ge(tiles_x);
+    const dim3 gi(tiles_x * (tiles_y - n_lo - n_hi)), glo(tiles_x * n_lo), ghi(tiles_x * n_hi);
     if (mrt) {
-        rk2d_fused<true, true, SH, 0><<<gi, b, 0, c->stream>>>(p, tiles_x, tiles_x);
-        rk2d_fused<true, true, SH, 1><<<ge, b, 0, c->stream>>>(p, tiles_x, 0);
-        rk2d_fused<true, true, SH, 1><<<ge, b, 0, c->stream>>>(p, tiles_x, tiles_x * (tiles_y - 1));
+        rk2d_fused<true, true, SH, 0><<<gi, b, 0, c->stream>>>(p, tiles_x, tiles_x * n_lo);
+        rk2d_fused<true, true, SH, 1><<<glo, b, 0, c->stream>>>(p, tiles_x, 0);
+        rk2d_fused<true, true, SH, 1><<<ghi, b, 0, c->stream>>>(p, tiles_x, tiles_x * (tiles_y - n_hi));
     } else {
-        rk2d_fused<false, true, SH, 0><<<gi, b, 0, c->stream>>>(p, tiles_x, tiles_x);
-        rk2d_fused<false, true, SH, 1><<<ge, b, 0, c->stream>>>(p, tiles_x, 0);
-        rk2d_fused<false, true, SH, 1><<<ge, b, 0, c->stream>>>(p, tiles_x, tiles_x * (tiles_y - 1));
+        rk2d_fused<false, true, SH, 0><<<gi, b, 0, c->stream>>>(p, tiles_x, tiles_x * n_lo);
+        rk2d_fused<false, true, SH, 1><<<glo, b, 0, c->stream>>>(p, tiles_x, 0);
+        rk2d_fused<false, true, SH, 1><<<ghi, b, 0, c->stream>>>(p, tiles_x, tiles_x * (tiles_y - n_hi));
     }
 }
 
@@ -1571,9 +1580,12 @@ extern "C" int lbmpm_rk2d_set_perturbation(lbmpm_rk2d *c, const lbmpm_rk2d_pertu
 {
     LBMPM_REQUIRE(c && par, "lbmpm_rk2d_set_perturbation: null argument");
     LBMPM_REQUIRE(c->cfg.variant == 0 && c->ntr == 0, "the perturbation operator runs as the fused schedule, without tracers");
-    LBMPM_REQUIRE(std::isfinite(par->ak_r) && std::isfinite(par->ak_b) && std::isfinite(par->solid_phi) && par->outlet_rho_r > 0. &&
-                  par->outlet_rho_b > 0. && par->inlet_velocity_y_r > -1. && par->inlet_velocity_y_b > -1.,
-                  "lbmpm_rk2d_set_perturbation: A_k, solidPhi finite, outlet densities > 0, inlet velocities > -1");
+    // only the parameters the configured inlet / outlet kernels use are checked (the kernel-level loop runs an ini whose unused ones are odd)
+    LBMPM_REQUIRE(std::isfinite(par->ak_r) && std::isfinite(par->ak_b) && std::isfinite(par->solid_phi), "lbmpm_rk2d_set_perturbation: A_k and solidPhi must be finite");
+    LBMPM_REQUIRE(c->cfg.outlet_type != LBMPM_OUTLET_PRESSURE || (par->outlet_rho_r > 0. && par->outlet_rho_b > 0.),
+                  "lbmpm_rk2d_set_perturbation: the pressure outlet needs outlet_rho_r, outlet_rho_b > 0");
+    LBMPM_REQUIRE(c->cfg.inlet_type != LBMPM_INLET_VELOCITY || (par->inlet_velocity_y_r > -1. && par->inlet_velocity_y_b > -1.),
+                  "lbmpm_rk2d_set_perturbation: the velocity inlet needs inlet velocities > -1");
     LBMPM_REQUIRE(c->cfg.inlet_type == LBMPM_INLET_VELOCITY || (c->cfg.inlet_rho_r > 0. && c->cfg.inlet_rho_b > 0.),
                   "lbmpm_rk2d_set_perturbation: the pressure inlet needs inlet_rho_r, inlet_rho_b > 0");
     // the reference addresses the pressure outlet's rows by COMPACT index (n < nx, nx <= n < 2 nx: A:1008-1081) and every ghost / copied

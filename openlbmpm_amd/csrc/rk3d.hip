@@ -73,8 +73,9 @@ struct RK3Dev {
     int nseg;
     const uint32_t *pur_in;           // [rows][nseg] row flags of the q23 storage (rk3dq.h), ping-pong with fin / fout
     uint32_t *pur_out;
+#ifdef LBMPM_DEV                       // development builds only (tools/dev/devlib.py); the product library has neither
     unsigned long long *trace;        // LBMPM_RK3D_TRACE: four words per workgroup of rk3dq_fused (start, prologue done, end, planes)
-    int dbg;                          // LBMPM_RK3D_DBG: timing knock-outs of rk3dq_fused (results wrong), 0 in production
+#endif
 };
 
 // ---- addressing.  Populations are stored plane-major, f[zl][colour][q][y][x]: everything a node
@@ -1085,8 +1086,9 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     p.first = c->streamed ? 0 : 1;
     p.fill = c->fill;
     p.mrt = c->cfg.relaxation;
-    p.dbg = c->dbg;
+#ifdef LBMPM_DEV
     p.trace = c->trace;
+#endif
     p.pur_in = c->purA; p.pur_out = c->purB;
     return p;
 }
@@ -1142,11 +1144,15 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_LAYOUT")) if (!strcmp(e, "dense")) c->compact = false;
     c->q23 = c->compact && c->tile == 0;
     if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
+#ifdef LBMPM_DEV      // timing knock-outs of the slab step (results wrong): development builds only
     if (const char *e = getenv("LBMPM_RK3D_DBG")) c->dbg = atoi(e);
+#endif
     // q23 storage: the chunk length is chosen per launch (chunk_planes below) unless LBMPM_RK3D_CHUNK fixes it
     c->chunk_auto = c->q23 && !getenv("LBMPM_RK3D_CHUNK");
     if (c->chunk_auto) { c->chunk_len = 64; (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, cfg->device); if (c->ncu <= 0) c->ncu = 256; }
+#ifdef LBMPM_DEV
     if (c->q23 && getenv("LBMPM_RK3D_TRACE")) { (void)hipMalloc(reinterpret_cast<void **>(&c->trace), (size_t)1 << 22); (void)hipMemset(c->trace, 0, (size_t)1 << 22); }
+#endif
     c->pitch = (c->nx + 31) / 32 * 32;
     c->plane2 = (size_t)c->pitch * c->ny;
     c->vol = c->plane2 * (size_t)(c->nzl + 2);
@@ -1486,6 +1492,7 @@ void finish_step(lbmpm_rk3d *c)
     std::swap(c->purA, c->purB);
     c->streamed = true;
     c->steps += 1;
+    c->halo_valid = false;      // the halo planes held the previous state's neighbours; the pipelined slab step sets it again after its unpack
 }
 }  // namespace
 
@@ -1600,6 +1607,7 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             if (rc != LBMPM_OK) return fail(rc);
         }
         if (!c->aux) {
+#ifdef LBMPM_DEV
             // rk3dq_fused holds a CU's whole register file and most of its LDS: while the interior launch runs, the kernels of the exchange
             // (pack, RCCL's send / recv, unpack) find room only where one of its workgroups retires, so on one GPU the pack .. unpack chain
             // ends with the interior launch (tools/slab_rank_cost.py).  LBMPM_RK3D_COMM_CUS = k (default 0 = off) runs the interior on a
@@ -1616,6 +1624,7 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
                 for (int i = 0; i < ncu - reserve; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
                 if (hipExtStreamCreateWithCUMask(&c->aux, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); c->aux = nullptr; }
             }
+#endif
             if (!c->aux) LBMPM_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
             LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
             LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
@@ -1637,7 +1646,11 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
             RK3Dev q = p;                                                     // the state this step writes
             q.fin = c->fB; q.pur_in = c->purB; q.first = 0;
+#ifdef LBMPM_DEV
             const int skip = c->dbg;        // timing knock-outs (LBMPM_RK3D_DBG: 1 no pack, 2 no exchange, 4 no unpack / halo phase field)
+#else
+            constexpr int skip = 0;         // (the knock-outs exist in development builds only)
+#endif
             if (!(skip & 1)) rk3dq_face_pack<<<fgrid, fblock, 0, c->stream>>>(q, c->send_up, c->send_dn, has_below, has_above);
             if (has_interior) {
                 // Order (per-workgroup time stamps, 512^3 on 8 ranks, tools/dev/k3trace_slab.py): rk3dq_fused fills every CU, so whatever
@@ -1664,6 +1677,7 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
             if (has_interior) LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
             finish_step(c);
+            c->halo_valid = !(skip & 6);       // the face message of the state just written has been exchanged and unpacked above
             if (ev[1]) LBMPM_HIP_TRY(hipEventRecord(ev[1], c->stream));
         }
         return LBMPM_OK;
@@ -1869,6 +1883,9 @@ extern "C" int lbmpm_rk3d_storage_info(lbmpm_rk3d *c, int64_t *out)
 // dev tool (LBMPM_RK3D_TRACE=1): the time stamps the workgroups of the LAST rk3dq_fused launch wrote, 4 x n words (100 MHz clock)
 extern "C" int lbmpm_rk3d_debug_trace(lbmpm_rk3d *c, unsigned long long *out, int64_t nblocks)
 {
+#ifndef LBMPM_DEV
+    LBMPM_REQUIRE(false, "lbmpm_rk3d_debug_trace: this library was built without -DLBMPM_DEV (per-workgroup time stamps exist in development builds only: tools/dev/devlib.py)");
+#endif
     LBMPM_REQUIRE(c && out && c->trace && nblocks * 32 <= (1 << 22), "lbmpm_rk3d_debug_trace: tracing is off (LBMPM_RK3D_TRACE) or too many workgroups");
     LBMPM_HIP_TRY(hipDeviceSynchronize());
     LBMPM_HIP_TRY(hipMemcpy(out, c->trace, (size_t)nblocks * 32, hipMemcpyDeviceToHost));

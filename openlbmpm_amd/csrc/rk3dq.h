@@ -348,13 +348,17 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     __syncthreads();
     const int xcd = sslot[0], slot = sslot[1];
     if (xcd < 0) return;
+#ifdef LBMPM_DEV
     const int bid = xcd + 8 * slot;                     // (the time-stamp trace is indexed by it)
+#endif
     const int tx = slot % tilesX, r = slot / tilesX, ty = xcd * rows_per_xcd + r % rows_per_xcd, chunk = r / rows_per_xcd;
     if (ty >= tilesY) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: branches on it are branches, not exec masks
+#ifdef LBMPM_DEV
     // LBMPM_RK3D_TRACE: per-workgroup time stamps (dev tool); launches of fewer than 8 planes (a slab's boundary ranges) leave no stamps
     unsigned long long *trace = p.trace && z_last - z_first >= 8 ? p.trace + (size_t)bid * 4 : nullptr;
     if (trace && tid == 0) trace[0] = wall_clock64();
+#endif
     // Everything a thread derives from its id -- tile coordinates, its rim cell (bottom row, top row: one wave each; then the two
     // columns, corners included), its second entry of the scalar-tile fill (waves 3..6 take the tile rows -2, -1, 8, 9, wave 7 the
     // 4 x 12 cells left and right) -- is RE-DERIVED at the top of every march step from an id the compiler cannot see through:
@@ -532,7 +536,9 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     __syncthreads();
     issue(za - 1);
     pulls_landed();
+#ifdef LBMPM_DEV
     if (trace && tid == 0) { trace[1] = wall_clock64(); trace[3] = ((unsigned long long)(unsigned)za << 32) | (unsigned)zb; }
+#endif
 
     for (int z = za - 2; z <= zb; ++z) {
         const int zn = z + 1;
@@ -641,7 +647,9 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         for (int i = 0; i < Q; ++i) asm volatile("" : "+v"(raw[i]));
         fluid = fluidn;
     }
+#ifdef LBMPM_DEV
     if (trace && tid == 0) trace[2] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- set-up and diagnostics

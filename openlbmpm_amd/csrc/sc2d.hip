@@ -30,8 +30,9 @@ struct SCDev {
     const double *fin;
     double *fout;
     double *F;               // [4][plane] Fx0, Fx1, Fy0, Fy1 of the last iteration
-    const double *fold_in;   // [18][3][pitch] pre-collision f-bar of rows 0..2 (EFS convective outlet)
-    double *fold_out;
+    const double *fold_in;   // [18][3][pitch] pre-collision f-bar of rows 0..2 (EFS convective outlet), then [2][pitch]: F_y of both components
+    double *fold_out;        // on row 3 as the last step left it -- ping-pong, so that the rows 0..2 (halo columns of x-adjacent tiles, the
+                             // wrap-around halo of the last tile row) never read what another workgroup of the same launch writes
     double *diag;            // [28][plane] or nullptr
     double *psi;             // [2][plane]   (initialisation only)
     double *scrA, *scrB;     // [18][plane]  (initialisation only): f_eq, F_i
@@ -124,11 +125,10 @@ __device__ __forceinline__ void node_finish(const SCDev &p, int x, int y, int ys
         if (p.model == LBMPM_SC_MODEL_EFS) {
             // O:1044-1120 convectiveOutletEach{,2,3}GPU: rows 2,1,0 in sequence,
             // f = (f_old + |vy(row 3)| f(row above)) / (1 + |vy(row 3)|)
-            const size_t i3 = (size_t)3 * p.pitch + x;
             const double q0 = sum9(f0), q1 = sum9(f1);
             double ty = 0., tr = 0.;
-            ty += (mom_y(f0) + 1. / 2. * p.F[2 * p.plane + i3]); tr += q0;
-            ty += (mom_y(f1) + 1. / 2. * p.F[3 * p.plane + i3]); tr += q1;
+            ty += (mom_y(f0) + 1. / 2. * p.fold_in[(size_t)54 * p.pitch + x]); tr += q0;
+            ty += (mom_y(f1) + 1. / 2. * p.fold_in[(size_t)55 * p.pitch + x]); tr += q1;
             const double v = fabs(ty / tr);
             for (int r = 2; r >= y; --r) {
                 const size_t o = (size_t)r * p.pitch + x;
@@ -454,6 +454,9 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
         p.F[idx] = Fx[0]; p.F[p.plane + idx] = Fx[1];
         p.F[2 * p.plane + idx] = Fy[0]; p.F[3 * p.plane + idx] = Fy[1];
     }
+    if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_CONVECTIVE && y == 3) {
+        p.fold_out[(size_t)54 * p.pitch + x] = Fy[0]; p.fold_out[(size_t)55 * p.pitch + x] = Fy[1];
+    }
     if (p.model == LBMPM_SC_MODEL_EFS && p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2) {
         const size_t o = (size_t)y * p.pitch + x;     // savePDFLastStep O:70-80, rows 0..2 only
 #pragma unroll
@@ -512,6 +515,7 @@ __global__ __launch_bounds__(256) void sc2d_iso_collide(SCDev p)
         p.F[idx] = Fx[0]; p.F[p.plane + idx] = Fx[1];
         p.F[2 * p.plane + idx] = Fy[0]; p.F[3 * p.plane + idx] = Fy[1];
     }
+    if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y == 3) { p.fold_out[(size_t)54 * p.pitch + x] = Fy[0]; p.fold_out[(size_t)55 * p.pitch + x] = Fy[1]; }
     if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2) {
         const size_t o = (size_t)y * p.pitch + x;
 #pragma unroll
@@ -653,6 +657,7 @@ __global__ __launch_bounds__(512, 4) void sc2d_iso_fused(SCDev p, int tiles_x)
             p.F[idx] = Fx[0]; p.F[p.plane + idx] = Fx[1];
             p.F[2 * p.plane + idx] = Fy[0]; p.F[3 * p.plane + idx] = Fy[1];
         }
+        if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y == 3) { p.fold_out[(size_t)54 * p.pitch + x] = Fy[0]; p.fold_out[(size_t)55 * p.pitch + x] = Fy[1]; }
         if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y <= 2) {
             const size_t o = (size_t)y * p.pitch + x;
 #pragma unroll
@@ -771,6 +776,9 @@ __global__ __launch_bounds__(256) void sc2d_init_collide(SCDev p)
             p.fold_out[(size_t)j * 3 * p.pitch + o] = f0[j];
             p.fold_out[(size_t)(9 + j) * 3 * p.pitch + o] = f1[j];
         }
+    }
+    if (p.outlet == LBMPM_OUTLET_CONVECTIVE && y == 3) {         // the pre-loop force of row 3 (sc2d_init_chain), read by the first pass's rows 0..2
+        p.fold_out[(size_t)54 * p.pitch + x] = p.F[2 * p.plane + idx]; p.fold_out[(size_t)55 * p.pitch + x] = p.F[3 * p.plane + idx];
     }
     double *f[2] = {f0, f1};
     for (int k = 0; k < 2; ++k) {
@@ -1076,8 +1084,8 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
     c->scheme = cfg->force_scheme ? cfg->force_scheme : 4;
     if (const char *e = getenv("LBMPM_SC2D_ISO_SWEEPS")) c->iso_sweeps = atoi(e) == 2 ? 2 : 1;
     if (c->scheme != 4) TRY_RC(dev_alloc(c, &c->psi, 2 * c->plane));
-    TRY_RC(dev_alloc(c, &c->foldA, (size_t)18 * 3 * c->pitch));
-    TRY_RC(dev_alloc(c, &c->foldB, (size_t)18 * 3 * c->pitch));
+    TRY_RC(dev_alloc(c, &c->foldA, (size_t)(18 * 3 + 2) * c->pitch));
+    TRY_RC(dev_alloc(c, &c->foldB, (size_t)(18 * 3 + 2) * c->pitch));
     TRY_RC(dev_alloc(c, &c->chgA, (size_t)6 * c->pitch));
     TRY_RC(dev_alloc(c, &c->chgB, (size_t)6 * c->pitch));
 #undef TRY_RC

@@ -125,7 +125,7 @@ class RecordGuard:
     (logger 'openlbmpm_amd', level INFO) with the record index, the step, lattice updates per second since the last
     record and the sums the caller passes (masses, saturation)."""
 
-    def __init__(self, name, fluid_nodes, nan_guard="raise", group=None, collective=False):
+    def __init__(self, name, fluid_nodes, nan_guard="raise", group=None, collective=False, device=None):
         """collective: the run is distributed (one slab per process) -- the verdict of a record is then agreed on by all ranks
         (one MAX all-reduce of a flag over `group`) before anyone raises: a rank that raised alone would leave its neighbours
         waiting in the next halo exchange until the transport's watchdog fires"""
@@ -138,6 +138,7 @@ class RecordGuard:
         self.log = logging.getLogger("openlbmpm_amd")
         self._clock, self._t, self._step = time.perf_counter, time.perf_counter(), 0
         self.group, self.collective = group, bool(collective)
+        self.device = device            # the slab's GPU: NCCL reduces on it, whatever the process's current device is
 
     def _anyone_bad(self, bad):
         """MAX over the ranks of this rank's 'a field is not finite' flag"""
@@ -147,7 +148,9 @@ class RecordGuard:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return bad
-        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        dev = "cpu"
+        if dist.get_backend(self.group) == "nccl":
+            dev = torch.device("cuda", self.device if self.device is not None else torch.cuda.current_device())
         t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return bool(int(t.item()))

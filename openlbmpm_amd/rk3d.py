@@ -260,6 +260,11 @@ class RK3DDistributed:
         self.z0, self.nzl = z0, n
         import torch
         self._torch = torch
+        # every collective of this class and of its callers (NaN verdict, calibration, all_gather_object) runs on the process's
+        # CURRENT device under NCCL: make that the slab's GPU, whoever constructed us
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device)
+        self.device = device
         self.slab = RK3DSlab(is_domain_global, z0, n, params, device)
         self.stream = torch.cuda.Stream(device)
         self.slab.use_torch_stream(self.stream)

@@ -46,3 +46,17 @@ def test_default_2d_kernels_do_not_spill(kernels):
     assert len(pert) == 2
     for m in plain + pert:
         assert m[".vgpr_count"] <= 128 and m[".private_segment_fixed_size"] == 0 and m[".vgpr_spill_count"] == 0
+
+
+def test_the_product_library_holds_no_knock_out_switches():
+    """LBMPM_RK3D_DBG (skips pack / exchange / unpack of the slab step: wrong results from an environment variable), LBMPM_RK3D_COMM_CUS
+    and LBMPM_RK3D_TRACE exist behind -DLBMPM_DEV only, which openlbmpm_amd/build.py::build never defines (tools/dev/devlib.py builds
+    its own copy); the strings must not occur in the shipped library."""
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    blob = open(LIB, "rb").read()
+    for name in (b"LBMPM_RK3D_DBG", b"LBMPM_RK3D_COMM_CUS", b"LBMPM_RK3D_TRACE"):
+        assert name not in blob, name.decode()
+    src = open(os.path.join(ROOT, "openlbmpm_amd", "build.py")).read()
+    assert src.count("LBMPM_DEV") >= 1 and '"-DLBMPM_DEV"' in src.split("def build(")[0] and "LBMPM_DEV" not in src.split("def build(")[1]

@@ -90,3 +90,36 @@ def test_tracer_mass_conserved_without_open_boundaries():
     c = s.get_tracer(0)
     assert np.isfinite(c).all() and abs(c.sum() - m0) / m0 < 1e-11
     s.close()
+
+
+@pytest.mark.parametrize("ny", [57, 58, 60, 61, 44])
+def test_tracer_step_on_lattices_whose_height_is_no_multiple_of_the_tile(ny):
+    """The tracer step runs as up to three launches: the variant that re-sums the densities after the boundary rows (the transport
+    driver's order, Transport2DRK.py:1199-1287) on every tile row whose region -- 8 own rows + 3 rows of halo -- holds one of the rows
+    0, 1, ny-2, ny-1, the plain variant in between.  With ny % 8 in 1..4 row ny-2 lies among the own rows or in the halo of the
+    last-but-one tile row (round 3 gave it the plain variant: the stored densities of the inlet row then depended on the tile that
+    computed them).  Stored densities (rec_*: the streamed, boundary-corrected state), phase field, velocity and concentration
+    against the coupled oracle after every step of a short run, pressure inlet (where the two orders differ) and pressure outlet."""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.geometry import simple_geometry
+    from oracle.tr import CoupledOracle
+    dom = simple_geometry(72, ny)
+    nyy, nx = dom.shape
+    ii, jj = np.mgrid[0:nyy, 0:nx]
+    fluid = dom == 1
+    top = ii >= nyy - 12
+    rR = np.where(fluid & top, 1.0, 0.0) * (1.0 + 0.01 * np.sin(jj / 5.0)); rB = np.where(fluid & ~top, 1.0, 0.0) * (1.0 + 0.01 * np.cos(jj / 7.0))
+    conc = np.where(fluid & ~top, 0.3 + 0.2 * np.sin(ii / 3.0), 0.0)[None]
+    flow = dict(theta=70.0, tauR=1.0, tauB=0.8, inlet="Dirichlet", rhoRH=1.02)
+    tr = dict(diffX=(1. / 6.,), diffY=(1. / 6.,), beta=(1.0,), crit=0.5, inlet_conc=(1.0,), free_outlet=True, dirichlet_inlet=True)
+    s = RK2DSolver(dom, flow, diagnostics=True)
+    s.set_macro(rR, rB)
+    s.configure_tracers(**tr)
+    s.set_tracer(0, conc[0])
+    o = CoupledOracle(dom, flow, rR, rB, conc, tr)
+    for n in range(12):
+        s.step(1); o.run(1)
+        assert rel_err(s.get_tracer(0, compact=True), o.C[0]) < 1e-9, (ny, n)
+        for f in ("rhoR", "rhoB", "vx", "vy", "phi"):
+            assert rel_err(s.get_compact(f), getattr(o.flow, f)) < 1e-9, (ny, n, f)
+    s.close()

@@ -1,6 +1,8 @@
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  -- the -DLBMPM_DEV build: the product library has no time stamps / knock-outs
 import numpy as np
 from openlbmpm_amd.rk3d import RK3DSlab
 from openlbmpm_amd.geometry import porous_spheres

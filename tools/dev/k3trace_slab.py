@@ -2,6 +2,8 @@
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import devlib  # noqa: F401  -- the -DLBMPM_DEV build: the product library has no time stamps / knock-outs
 os.environ["LBMPM_RK3D_TRACE"] = "1"
 import numpy as np, torch
 import bench

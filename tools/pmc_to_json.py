@@ -39,9 +39,24 @@ def short(name):
 def main():
     fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
     kernels = {}
+    collect(fetch, write, kernels, "")
+    # further passes of `bench.py --c5-state STATE --no-secondary`:  STATE fetch.txt write.txt  -> keys rk3dq_fused[STATE]
+    rest = sys.argv[3:]
+    while len(rest) >= 3:
+        collect(parse(rest[1], "FETCH_SIZE"), parse(rest[2], "WRITE_SIZE"), kernels, "[%s]" % rest[0], only="rk3dq_fused")
+        rest = rest[3:]
+    print(json.dumps({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+                                "`python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-c5-legs` (and `--c5-state S --no-secondary` for the "
+                                "[S] entries), MI355X (tools/profile_round.sh)",
+                      "correction": "traffic = 2*FETCH_SIZE + WRITE_SIZE (KB -> B); x2 = the guide's gfx950 FETCH_SIZE correction "
+                                    "(calibrated on 16-B lanes; exact for rk3dc_fused, upper estimate for the 8-B-lane 2-D kernels)",
+                      "kernels": kernels}, indent=1))
+
+
+def collect(fetch, write, kernels, suffix, only=None):
     for name, (n, f) in fetch.items():
         k = short(name)
-        if k not in WORKLOADS:
+        if k not in WORKLOADS or (only and k != only):
             continue
         w = write.get(name, (0, 0.0))[1]
         rec = {"launches_profiled": n, "fetch_size_kb": f, "write_size_kb": w,
@@ -59,14 +74,10 @@ def main():
                 continue
             if targs[-1] == "false":
                 k += "[SRT]"
+        k += suffix
         if k in kernels and kernels[k]["launches_profiled"] >= n:
             continue                      # e.g. the first-step instantiation of the 3-D kernel: one launch only
         kernels[k] = rec
-    print(json.dumps({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
-                                "`python bench.py --steps 10 --warmup 2 --no-cpu-baseline`, MI355X (tools/profile_round.sh)",
-                      "correction": "traffic = 2*FETCH_SIZE + WRITE_SIZE (KB -> B); x2 = the guide's gfx950 FETCH_SIZE correction "
-                                    "(calibrated on 16-B lanes; exact for rk3dc_fused, upper estimate for the 8-B-lane 2-D kernels)",
-                      "kernels": kernels}, indent=1))
 
 
 if __name__ == "__main__":
