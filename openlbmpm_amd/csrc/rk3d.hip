@@ -408,19 +408,46 @@ __device__ __forceinline__ constexpr double mrt_piww(int i)
     constexpr int CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
     return (3. * mrt_c2(i) - 5.) * (double)(CY[i] * CY[i] - CZ[i] * CZ[i]);
 }
+// 1 / x and 1 / sqrt(x) for the collision: the hardware estimate + two Newton steps (5 / 8 instructions; the IEEE sequences hipcc
+// emits for `1. / x` and `sqrt(x)` take 11 and ~15 with their scaling and fix-ups).  Arguments here are densities and squared
+// gradients of O(1e-36 .. 1e2): no denormals, no infinities.  The result is within an ulp or two of the correctly rounded one; the
+// oracle keeps the reference's divisions, the tests bound the difference (1e-10).
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.), r, r);
+    return r;
+}
+__device__ __forceinline__ double rsq_nr(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = __builtin_fma(__builtin_fma(-0.5 * x * r, r, 0.5), r, r);
+    r = __builtin_fma(__builtin_fma(-0.5 * x * r, r, 0.5), r, r);
+    return r;
+}
+
+// pair classes of the D3Q19 directions in this file's numbering (i odd, i + 1 opposite): 1 x, 3 y, 5 z, 7 9 xy, 11 13 xz, 15 17 yz.
+// Rows of the moment basis of d'Humieres et al. 2002 that relax at their own rates, on the pair sums:
+//   e: rest -30, axis -11, diagonal 8;  eps: 12, -4, 1;  pi_xx: x -4, y z 2, xy xz 1, yz -2;  pi_ww: x 0, y -2, z 2, xy 1, xz -1, yz 0
+// (tests/test_lattice.py checks these against the closed forms 19 c^2 - 30 etc.)
+__device__ __forceinline__ constexpr int pair_class(int i) { return i < 7 ? (i - 1) / 2 : (i < 11 ? 3 : (i < 15 ? 4 : 5)); }   // 0 x, 1 y, 2 z, 3 xy, 4 xz, 5 yz
+
 // BGK + perturbation + recolouring of one node from the colour-blind populations ft = fR + fB,
 // the colour densities and the colour gradient; stores the post-collision populations of plane zl.
 // Lanes of non-fluid cells whose 128-byte line holds fluid store zeros: partially written
 // lines cost the memory system a read-modify-write (measured: +35 % kernel time at porosity 0.65).
 // STORE: 0 dense (two 8-byte stores per direction), 1 compact {red, blue} pairs (16 bytes per node and direction), 2 the
-// colour-blind population alone + one record {k_R, A} per node (rk3dq.h); MRT: [RelaxationType] Type
+// colour-blind population alone + one record {k_R, A} per node (rk3dq.h; every calling lane is a fluid cell there: the lanes that
+// write line padding go through pad_store_q); MRT: [RelaxationType] Type
 template <int STORE, bool MRT>
-__device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsigned stride, unsigned own, bool fluid,
+__device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsigned stride, unsigned own, bool fluid_in,
                                               const double ft_in[Q], double rR, double rB, double gx, double gy, double gz,
                                               uint32_t *rowflag = nullptr)
 {
 #pragma clang fp contract(fast)      // fused multiply-adds here (the 2-D kernels stay uncontracted for bit parity with the reference)
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+    const bool fluid = STORE == 2 ? true : fluid_in;
     double mx = 0., my = 0., mz = 0.;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -428,15 +455,16 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
         mx += (double)CX[i] * t; my += (double)CY[i] * t; mz += (double)CZ[i] * t;
     }
     // Arithmetic organised for the hardware, not after the reference's statement order (the oracle
-    // keeps that; the tests bound the rounding difference): five divisions per node, and the
+    // keeps that; the tests bound the rounding difference): reciprocals by Newton steps, and the
     // directions in opposite pairs, whose equilibrium, perturbation and recolouring terms differ
     // in sign only.
-    const double rho = rR + rB, irho = 1. / rho;
+    const double rho = rR + rB, irho = rcp_nr(rho);
     const double ux = mx * irho, uy = my * irho, uz = mz * irho, usq = ux * ux + uy * uy + uz * uz;
     const double phi = (rR - rB) * irho;
-    const double omega = 1. / (0.5 + 1. / ((1. + phi) * p.cR + (1. - phi) * p.cB));
-    const double g2 = gx * gx + gy * gy + gz * gz, gn = sqrt(g2);
-    const double ig2 = g2 != 0. ? 1. / g2 : 0., ign = gn * ig2;
+    const double omega = rcp_nr(0.5 + rcp_nr((1. + phi) * p.cR + (1. - phi) * p.cB));
+    const double g2 = gx * gx + gy * gy + gz * gz;
+    const double ign = g2 != 0. ? rsq_nr(g2) : 0.;          // 1 / |G|
+    const double gn = g2 * ign, ig2 = ign * ign;
     // STORE 2 keeps k_R alone (k_B = 1 - k_R): exactly 1 / 0 where the other colour is absent, so that a single-colour region
     // stays exactly single-colour (x * (1 / x) may be 1 - ulp)
     const double kR = STORE == 2 ? (rB == 0. ? 1. : (rR == 0. ? 0. : rR * irho)) : rR * irho;
@@ -450,26 +478,41 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     //   even part: Delta = omega d + sum_k (s_k - omega) M_k (M_k . d) / |M_k|^2 over k = e, eps, pi_xx, pi_ww
     //              (the moments see only the sums of opposite pairs),
     //   odd part:  everything that is not momentum relaxes at 1.2, i.e. the pair differences do.
-    double kev[4] = {0., 0., 0., 0.};
+    // The four projections by pair class (the rows are constant on a class): sums over the axis and the diagonal pairs for e and
+    // eps, signed sums for pi_xx and pi_ww; back: six distinct corrections, one per class.
+    double evc[6] = {0., 0., 0., 0., 0., 0.}, ev0 = 0.;
     const double hodd = MRT ? 0.5 * (1.2 - omega) : 0.;
     if (MRT) {
         // private copies of u: the equilibrium terms of this pass must not be kept (18 registers) for the next
         double vx = ux, vy = uy, vz = uz, v0 = c0;
         asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz), "+v"(v0));
         const double d0 = ft_in[0] - (rho * wq(0)) * v0;
-        kev[0] = -30. * d0; kev[1] = 12. * d0;
+        double sc[6] = {0., 0., 0., 0., 0., 0.};        // sum of the pair sums of f - feq, per class
 #pragma unroll
         for (int i = 1; i < Q; i += 2) {
             const double eu = (double)CX[i] * vx + (double)CY[i] * vy + (double)CZ[i] * vz;
             const double sp = (ft_in[i] + ft_in[i + 1]) - 2. * ((rho * wq(i)) * (v0 + 4.5 * eu * eu));
-            kev[0] += mrt_e(i) * sp; kev[1] += mrt_eps(i) * sp; kev[2] += mrt_pixx(i) * sp; kev[3] += mrt_piww(i) * sp;
+            constexpr int dummy = 0; (void)dummy;
+            sc[pair_class(i)] += sp;
         }
-        kev[0] *= (1.19 - omega) * (1. / 2394.); kev[1] *= (1.4 - omega) * (1. / 252.);
-        kev[2] *= (1.4 - omega) * (1. / 72.);    kev[3] *= (1.4 - omega) * (1. / 24.);
+        const double Sa = (sc[0] + sc[1]) + sc[2], Sd = (sc[3] + sc[4]) + sc[5];
+        double k0 = (-30. * d0 - 11. * Sa) + 8. * Sd, k1 = (12. * d0 - 4. * Sa) + Sd;
+        double k2 = ((-4. * sc[0] + 2. * (sc[1] + sc[2])) + (sc[3] + sc[4])) - 2. * sc[5];
+        double k3 = (2. * (sc[2] - sc[1]) + sc[3]) - sc[4];
+        k0 *= (1.19 - omega) * (1. / 2394.); k1 *= (1.4 - omega) * (1. / 252.);
+        k2 *= (1.4 - omega) * (1. / 72.);    k3 *= (1.4 - omega) * (1. / 24.);
+        const double ea = -11. * k0 - 4. * k1, ed = 8. * k0 + k1;
+        ev0 = -30. * k0 + 12. * k1;
+        evc[0] = ea - 4. * k2;
+        evc[1] = (ea + 2. * k2) - 2. * k3;
+        evc[2] = (ea + 2. * k2) + 2. * k3;
+        evc[3] = (ed + k2) + k3;
+        evc[4] = (ed + k2) - k3;
+        evc[5] = ed - 2. * k2;
     }
     char *blue = red + (size_t)Q * stride;       // red = population 0 of the node's plane, stride = bytes between populations
     auto put = [&](int i, double g, double a) {
-        if (STORE == 2) stg(red + (size_t)i * stride, own, fluid ? g : 0.);
+        if (STORE == 2) stg(red + (size_t)i * stride, own, g);
         else if (STORE == 1) {
             double2 v;
             v.x = fluid ? kR * g + a : 0.; v.y = fluid ? kB * g - a : 0.;
@@ -483,7 +526,7 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     // here on stores are outstanding, and a later wait for the pulls would wait for the stores too (vmcnt retires in order)
     if (STORE == 2) __builtin_amdgcn_s_waitcnt(0x0F70);
     // relaxation as f - (f - feq) omega: a node at equilibrium stays there bit for bit
-    put(0, ((ft_in[0] - (ft_in[0] - (rho * wq(0)) * c0) * omega) - (MRT ? -30. * kev[0] + 12. * kev[1] : 0.)) - akgn * bq(0), 0.);
+    put(0, ((ft_in[0] - (ft_in[0] - (rho * wq(0)) * c0) * omega) - (MRT ? ev0 : 0.)) - akgn * bq(0), 0.);
 #pragma unroll
     for (int i = 1; i < Q; i += 2) {             // i and i + 1 are opposite
         const double w = wq(i);
@@ -494,7 +537,7 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
         const double a = (i < 7 ? arcA : arcD) * eg;
         double ev = 0., od = 0.;
         if (MRT) {
-            ev = mrt_e(i) * kev[0] + mrt_eps(i) * kev[1] + mrt_pixx(i) * kev[2] + mrt_piww(i) * kev[3];
+            ev = evc[pair_class(i)];
             od = hodd * ((ft_in[i] - ft_in[i + 1]) - 2. * odd);
         }
         put(i, ((ft_in[i] - (ft_in[i] - (sym + odd)) * omega) - (ev + od)) + pert, a);
@@ -504,10 +547,10 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     if (STORE == 2) {                            // the record the next step's pulls rebuild the colours from: f_R,i = k_R g_i + c_i e_i.A
         const double ai = arc * ign;
         double2 v, w;
-        v.x = fluid ? kR : 0.; v.y = fluid ? ai * gx : 0.; w.x = fluid ? ai * gy : 0.; w.y = fluid ? ai * gz : 0.;
+        v.x = kR; v.y = ai * gx; w.x = ai * gy; w.y = ai * gz;
         // row flag (rk3dq.h): every fluid cell of this wave's row segment pure red / pure blue -> the records are not written
         const bool noA = v.y == 0. && w.x == 0. && w.y == 0.;
-        const bool notred = fluid && !(v.x == 1. && noA), notblue = fluid && !(v.x == 0. && noA);
+        const bool notred = !(v.x == 1. && noA), notblue = !(v.x == 0. && noA);
         const unsigned code = (__ballot(notred) == 0ull ? 1u : 0u) | (__ballot(notblue) == 0ull ? 2u : 0u);
         *rowflag = code;
         if (code == 0u) {

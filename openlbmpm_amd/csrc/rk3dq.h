@@ -626,10 +626,15 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         else { fl_raw = false; pad_raw = false; }
         staged = fetch_rows(z + 6);
         __syncthreads();
-        // ---- plane z: collide
-        const bool active = z >= za && !is_ghost(z) && ((fluid && own) || padzz);
-        if (__ballot(active) == 0ull) pulls_landed();       // a wave without a collision: its pulls still have to land before raw moves on
-        else if (active) {
+        // ---- plane z: collide.  Fluid cells only go through the collision (no zero selects in it); the idle lanes that complete the
+        //      last line of the tile's run (padzz) store zeros afterwards
+        const bool live = z >= za && !is_ghost(z);
+        const bool active = live && fluid && own;
+        if (__ballot(active) == 0ull) {
+            pulls_landed();       // a wave without a collision: its pulls still have to land before raw moves on
+            // a row segment without a fluid cell: flag 3 ("nothing here"), so that its neighbours' rows can still be taken as single-colour
+            if (live && own && lx == 0) p.pur_out[row_index(p, z, y, tx)] = 3u;
+        } else if (active) {
             double gx = 0., gy = 0., gz = 0.;
 #pragma unroll
             for (int i = 1; i < Q; ++i) {
@@ -638,10 +643,14 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
                 if (CY[i] != 0) gy += 3. * wq(i) * (double)CY[i] * ph;
                 if (CZ[i] != 0) gz += 3. * wq(i) * (double)CZ[i] * ph;
             }
-            const unsigned long long p0 = pz0;
-            const unsigned cnt = (unsigned)(pz1 - pz0);
-            collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * CELLB, cnt * 8u, jzz * 8u, fluid, ft, rRz, rhoz - rRz, gx, gy, gz,
-                                  p.pur_out + row_index(p, z, y, tx));
+            collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)pz0 * CELLB, (unsigned)(pz1 - pz0) * 8u, jzz * 8u, true, ft, rRz, rhoz - rRz,
+                                  gx, gy, gz, p.pur_out + row_index(p, z, y, tx));
+        }
+        if (live && padzz) {
+            char *pl = reinterpret_cast<char *>(p.fout) + (size_t)pz0 * CELLB;
+            const unsigned stride = (unsigned)(pz1 - pz0) * 8u;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) stg(pl + (size_t)i * stride, jzz * 8u, 0.);
         }
 #pragma unroll
         for (int i = 0; i < Q; ++i) asm volatile("" : "+v"(raw[i]));
