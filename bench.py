@@ -460,9 +460,14 @@ def main():
                 # what the transport really was, and where a step's time went on every rank (HIP events inside
                 # lbmpm_rk3d_step_slab): exchange_exposed_ms = step - max(interior, boundary)
                 out["multi_gpu"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                                    "transport": ("torch.distributed batch_isend_irecv (ncclSend/ncclRecv pairs, RCCL) per face; "
-                                                  "no collective on the data path") if dist.get_backend() == "nccl" else
-                                                 "REHEARSAL on the %s backend (host-staged copies): not an RCCL measurement" % dist.get_backend(),
+                                    "transport": per_rank[0].get("transport", "?") + {
+                                        True: " -- the library moves the face messages itself (include/lbmpm.h: LBMPM_TRANSPORT_*); torch.distributed "
+                                              "(%s) serves set-up and the timing reduction only" % dist.get_backend(),
+                                        False: " -- torch.distributed batch_isend_irecv per face and step (%s)" % (
+                                            "ncclSend / ncclRecv pairs, RCCL" if dist.get_backend() == "nccl" else
+                                            "REHEARSAL on the %s backend, host-staged copies: not an RCCL measurement" % dist.get_backend())}[
+                                        "callback" not in per_rank[0].get("transport", "callback")],
+                                    "host_enqueue_us_per_step": [r.get("host_enqueue_us_per_step") for r in per_rank],
                                     "boundary_depth_planes": int(os.environ.get("LBMPM_RK3D_BOUNDARY", "2")),
                                     "partition": partition,
                                     "per_rank": per_rank}

@@ -362,10 +362,56 @@ int lbmpm_rk3d_collide_boundary(lbmpm_rk3d *ctx);
  * timed != 0: HIP events around the step, the interior launch, the exchange chain and the boundary launches of
  * (up to 256) steps; read the averages with lbmpm_rk3d_slab_timing (out[5]: step, interior, pack..phi exchange,
  * boundary [ms], steps averaged). */
+/* (exchange == NULL on a slab with neighbours: the transport connected to the context -- see below -- moves the messages) */
 typedef int (*lbmpm_rk3d_exchange_fn)(void *user, int what);
 int lbmpm_rk3d_step_slab(lbmpm_rk3d *ctx, int64_t nsteps, int has_below, int has_above, lbmpm_rk3d_exchange_fn exchange,
                          void *user, int timed);
 int lbmpm_rk3d_slab_timing(lbmpm_rk3d *ctx, double *out);
+
+/* ---- Transport of the slab exchange INSIDE the library ("ncclGroupStart; ncclSend / ncclRecv ...; ncclGroupEnd on a
+ * communication stream").  With a transport connected, lbmpm_rk3d_step_slab(ctx, n, has_below, has_above, NULL, NULL, timed) and
+ * lbmpm_rk3d_halo_exchange drive the face messages themselves: no callback, no host work per step beyond the enqueues.  The compact
+ * 23-value storage only (one face message per cut and step).  Two transports:
+ *
+ * LBMPM_TRANSPORT_IPC (one node): every rank owns a landing area (two slots per face, by the parity of the message's sequence number,
+ *   plus one 64-bit flag per slot in fine-grained memory) that its neighbours map with hipIpcOpenMemHandle.  A message is ONE
+ *   hipMemcpyAsync from the sender's packed face into the receiver's slot -- a copy-engine (SDMA) transfer over xGMI that needs no
+ *   CU while the interior launch holds them all -- followed by hipStreamWriteValue64(flag, seq); the receiver's stream waits with
+ *   hipStreamWaitValue64(flag >= seq) before it unpacks.  (Where the device cannot do stream value operations, one-lane kernels write
+ *   and poll the flag instead.)  Two slots suffice without an acknowledgement: a rank sends message s + 2 only after it has received
+ *   its neighbour's message s + 1, which that neighbour sent after unpacking message s.
+ *     1. lbmpm_rk3d_ipc_init(ctx, blob): allocates the landing area, writes LBMPM_IPC_BLOB_BYTES describing it,
+ *     2. the caller moves every rank's blob to its two neighbours by any byte transport (torch.distributed, MPI, a file),
+ *     3. lbmpm_rk3d_ipc_connect(ctx, blob_of_the_rank_below | NULL, blob_of_the_rank_above | NULL).
+ *   Blobs of the calling process itself (several slabs in one process) connect by plain pointers.
+ *
+ * LBMPM_TRANSPORT_RCCL: ncclSend / ncclRecv to the ranks rank - 1 and rank + 1 in one group per message, on the context's stream;
+ *   librccl is opened at run time (dlopen: `librccl_path` or "librccl.so.1" / "librccl.so"), so the library does not link against it.
+ *     1. rank 0: lbmpm_rccl_unique_id(id, path), 2. the caller broadcasts the LBMPM_RCCL_ID_BYTES, 3. every rank:
+ *     lbmpm_rk3d_rccl_connect(ctx, id, rank, nranks, path)  (collective: ncclCommInitRank).
+ *
+ * Every rank of a run must make the same sequence of exchanging calls (step_slab with the same step counts, halo_exchange). */
+enum { LBMPM_TRANSPORT_NONE = 0, LBMPM_TRANSPORT_IPC = 1, LBMPM_TRANSPORT_RCCL = 2 };
+#define LBMPM_IPC_BLOB_BYTES 256
+#define LBMPM_RCCL_ID_BYTES 128
+int lbmpm_rk3d_ipc_init(lbmpm_rk3d *ctx, void *blob_out);
+int lbmpm_rk3d_ipc_connect(lbmpm_rk3d *ctx, const void *blob_below, const void *blob_above);
+int lbmpm_rccl_unique_id(void *id_out, const char *librccl_path);
+int lbmpm_rk3d_rccl_connect(lbmpm_rk3d *ctx, const void *id, int rank, int nranks, const char *librccl_path);
+/* drop the connected transport (closes the mapped handles / destroys the communicator); the callback path applies again */
+int lbmpm_rk3d_transport_disconnect(lbmpm_rk3d *ctx);
+/* LBMPM_TRANSPORT_* of the context; *value_ops (may be NULL): 1 when the IPC flags go through hipStreamWriteValue64 / WaitValue64 */
+int lbmpm_rk3d_transport_kind(lbmpm_rk3d *ctx, int *value_ops);
+/* pack -> exchange over the connected transport -> unpack of the CURRENT state's face planes, enqueued on the context's stream (what
+ * step_slab does before its first step; also used before diagnostics of a distributed run) */
+int lbmpm_rk3d_halo_exchange(lbmpm_rk3d *ctx);
+/* IPC only, for a set-up self-test with a deadline: makes every wait of this context's stream on an incoming message return
+ * (the host writes the largest sequence number into the context's own flags).  The transport is unusable afterwards: disconnect. */
+int lbmpm_rk3d_ipc_release_waits(lbmpm_rk3d *ctx);
+/* Transport-level self-test on ONE GPU: three messages of `bytes` bytes sent "up" and "down" to the caller itself through the given
+ * transport -- IPC: the landing area connected to itself (by pointer: same process), both slot parities, copies + flag operations as
+ * in a run; RCCL: a one-rank communicator, ncclSend / ncclRecv to rank 0 in one group -- and compared with what was sent. */
+int lbmpm_transport_selftest(int kind, int device, int64_t bytes, const char *librccl_path);
 int lbmpm_rk3d_step(lbmpm_rk3d *ctx, int64_t nsteps);
 int lbmpm_rk3d_step_timed(lbmpm_rk3d *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
 int lbmpm_rk3d_sync(lbmpm_rk3d *ctx);

@@ -75,6 +75,8 @@ class RK3DConfig(C.Structure):
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # lbmpm_rk3d_exchange_fn
+IPC_BLOB_BYTES, RCCL_ID_BYTES = 256, 128                     # LBMPM_IPC_BLOB_BYTES, LBMPM_RCCL_ID_BYTES
+TRANSPORT_NONE, TRANSPORT_IPC, TRANSPORT_RCCL = 0, 1, 2
 
 _lib = None
 
@@ -127,6 +129,15 @@ _SIGNATURES = {
     "lbmpm_rk3d_collide_boundary": (C.c_int, [C.c_void_p]),
     "lbmpm_rk3d_step_slab": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "lbmpm_rk3d_slab_timing": (C.c_int, [C.c_void_p, F64P]),
+    "lbmpm_rk3d_ipc_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lbmpm_rk3d_ipc_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lbmpm_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "lbmpm_rk3d_rccl_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "lbmpm_rk3d_transport_disconnect": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3d_transport_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "lbmpm_rk3d_halo_exchange": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3d_ipc_release_waits": (C.c_int, [C.c_void_p]),
+    "lbmpm_transport_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_char_p]),
     "lbmpm_rk3d_step": (C.c_int, [C.c_void_p, C.c_int64]),
     "lbmpm_rk3d_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),
     "lbmpm_rk3d_sync": (C.c_int, [C.c_void_p]),

@@ -1064,6 +1064,8 @@ __global__ void rk3d_setup_solidnbr(RK3Dev p, uint32_t *solidnbr)
 }  // namespace
 
 // ====================================================================== host side
+#include "rk3d_transport.h"
+
 struct lbmpm_rk3d {
     lbmpm_rk3d_config cfg;
     int nx, ny, nzl, pitch;
@@ -1085,6 +1087,7 @@ struct lbmpm_rk3d {
     unsigned long long *trace = nullptr;      // dev tool, see RK3Dev
     unsigned *slotq = nullptr;                // tile counters of the rk3dq_fused launches (launch_q23); null: tiles by block index
     unsigned slot_launches = 0;
+    slabtx::Transport tx;            // the exchange's transport when the library drives it itself (lbmpm_rk3d_ipc_* / lbmpm_rk3d_rccl_connect)
     bool halo_valid = false;         // q23 slabs: the halo planes (populations, records, flags, phase field) belong to the current state
     int dbg = 0;
     int nseg = 0;
@@ -1310,6 +1313,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
 
 extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
 {
+    if (c) c->tx.disconnect();
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1373,6 +1377,13 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
     c->steps = 0;
     c->observed_at = -1;
     return LBMPM_OK;
+}
+
+// bytes of the face message that describes plane zl (compact storages move the fluid cells of the plane only)
+static int64_t face_bytes(const lbmpm_rk3d *c, int zl)
+{
+    if (c->q23) return (int64_t)(((c->h_pstart[zl + 1] - c->h_pstart[zl]) * FACE_DOUBLES + ((size_t)c->ny * c->nseg + 1) / 2) * sizeof(double));
+    return c->compact ? (int64_t)((c->h_pstart[zl + 1] - c->h_pstart[zl]) * 10 * sizeof(double)) : (int64_t)(10 * c->plane2 * sizeof(double));
 }
 
 extern "C" int lbmpm_rk3d_pack_halo(lbmpm_rk3d *c)
@@ -1610,6 +1621,183 @@ static int collide_boundary_ev(lbmpm_rk3d *c, hipEvent_t e0, hipEvent_t e1)
     return LBMPM_OK;
 }
 
+// ---- transports of the slab exchange inside the library (include/lbmpm.h; rk3d_transport.h)
+static int tx_shape(lbmpm_rk3d *c)
+{
+    LBMPM_REQUIRE(c->q23, "the in-library transports move the one-exchange face message of the compact 23-value storage (nx a multiple of 64, LBMPM_RK3D_STORAGE unset)");
+    const bool below = c->cfg.z_offset > 0, above = c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global;
+    return c->tx.set_shape(c->cfg.device, below, above, (size_t)face_bytes(c, c->nzl), (size_t)face_bytes(c, 1), (size_t)face_bytes(c, 0),
+                           (size_t)face_bytes(c, c->nzl + 1));
+}
+
+extern "C" int lbmpm_rk3d_ipc_init(lbmpm_rk3d *c, void *blob_out)
+{
+    LBMPM_REQUIRE(c && blob_out, "lbmpm_rk3d_ipc_init: null argument");
+    int rc = tx_shape(c);
+    slabtx::IpcBlob b;
+    if (rc == LBMPM_OK) rc = c->tx.ipc_alloc(&b);
+    if (rc != LBMPM_OK) { c->tx.disconnect(); return rc; }
+    memset(blob_out, 0, LBMPM_IPC_BLOB_BYTES);
+    memcpy(blob_out, &b, sizeof b);
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3d_ipc_connect(lbmpm_rk3d *c, const void *blob_below, const void *blob_above)
+{
+    LBMPM_REQUIRE(c && c->tx.kind == LBMPM_TRANSPORT_IPC && !c->tx.connected, "lbmpm_rk3d_ipc_connect: call lbmpm_rk3d_ipc_init first (once)");
+    LBMPM_REQUIRE((blob_below != nullptr) == c->tx.has_below && (blob_above != nullptr) == c->tx.has_above,
+                  "lbmpm_rk3d_ipc_connect: a blob for exactly the neighbours this slab has (below: %d, above: %d)", (int)c->tx.has_below, (int)c->tx.has_above);
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    slabtx::IpcBlob b;
+    int rc = LBMPM_OK;
+    if (blob_below) { memcpy(&b, blob_below, sizeof b); rc = c->tx.ipc_open(0, &b, c->tx.bytes_dn); }
+    if (rc == LBMPM_OK && blob_above) { memcpy(&b, blob_above, sizeof b); rc = c->tx.ipc_open(1, &b, c->tx.bytes_up); }
+    if (rc != LBMPM_OK) return rc;
+    c->tx.connected = true;
+    c->halo_valid = false;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rccl_unique_id(void *id_out, const char *librccl_path)
+{
+    LBMPM_REQUIRE(id_out, "lbmpm_rccl_unique_id: null argument");
+    slabtx::Rccl r;
+    int rc = r.open(librccl_path);
+    if (rc != LBMPM_OK) return rc;
+    slabtx::Rccl::UniqueId id;
+    const int e = r.GetUniqueId(&id);
+    if (e != 0) { set_error("ncclGetUniqueId: %s", r.GetErrorString(e)); r.close(); return LBMPM_ERR_HIP; }
+    memcpy(id_out, &id, LBMPM_RCCL_ID_BYTES);
+    // (the handle stays open: unloading librccl here would unload what the id refers to in some builds)
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3d_rccl_connect(lbmpm_rk3d *c, const void *id, int rank, int nranks, const char *librccl_path)
+{
+    LBMPM_REQUIRE(c && id && nranks >= 1 && rank >= 0 && rank < nranks, "lbmpm_rk3d_rccl_connect: bad argument");
+    int rc = tx_shape(c);
+    if (rc != LBMPM_OK) return rc;
+    LBMPM_REQUIRE((c->tx.has_below ? rank > 0 : true) && (c->tx.has_above ? rank + 1 < nranks : true),
+                  "lbmpm_rk3d_rccl_connect: rank %d of %d has no rank %s it, but the slab has a neighbour there", rank, nranks, c->tx.has_below && rank == 0 ? "below" : "above");
+    rc = c->tx.rccl.open(librccl_path);
+    if (rc != LBMPM_OK) { c->tx.disconnect(); return rc; }
+    slabtx::Rccl::UniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    const int e = c->tx.rccl.CommInitRank(&c->tx.comm, nranks, uid, rank);
+    if (e != 0) { set_error("ncclCommInitRank(rank %d of %d): %s", rank, nranks, c->tx.rccl.GetErrorString(e)); c->tx.disconnect(); return LBMPM_ERR_HIP; }
+    c->tx.rank = rank; c->tx.nranks = nranks; c->tx.peer_up = rank + 1; c->tx.peer_dn = rank - 1;
+    c->tx.kind = LBMPM_TRANSPORT_RCCL; c->tx.connected = true; c->tx.seq = 0;
+    c->halo_valid = false;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3d_transport_disconnect(lbmpm_rk3d *c)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
+    c->tx.disconnect();
+    c->halo_valid = false;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3d_transport_kind(lbmpm_rk3d *c, int *value_ops)
+{
+    if (!c) return LBMPM_TRANSPORT_NONE;
+    if (value_ops) *value_ops = c->tx.kind == LBMPM_TRANSPORT_IPC && c->tx.value_ops ? 1 : 0;
+    return c->tx.connected ? c->tx.kind : LBMPM_TRANSPORT_NONE;
+}
+
+extern "C" int lbmpm_rk3d_ipc_release_waits(lbmpm_rk3d *c)
+{
+    LBMPM_REQUIRE(c && c->tx.kind == LBMPM_TRANSPORT_IPC && c->tx.flags, "lbmpm_rk3d_ipc_release_waits: no IPC transport");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    const unsigned long long big[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    LBMPM_HIP_TRY(hipMemcpy(c->tx.flags, big, sizeof big, hipMemcpyHostToDevice));
+    return LBMPM_OK;
+}
+
+namespace { __global__ void tx_fill(double *p, size_t n, double v) { const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) p[i] = v + (double)i; } }
+
+extern "C" int lbmpm_transport_selftest(int kind, int device, int64_t bytes, const char *librccl_path)
+{
+    LBMPM_REQUIRE((kind == LBMPM_TRANSPORT_IPC || kind == LBMPM_TRANSPORT_RCCL) && bytes >= 8 && bytes % 8 == 0, "lbmpm_transport_selftest: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(device));
+    slabtx::Transport t;
+    const size_t n = (size_t)bytes / 8;
+    double *up = nullptr, *dn = nullptr;
+    hipStream_t st = nullptr;
+    int rc = t.set_shape(device, true, true, (size_t)bytes, (size_t)bytes, (size_t)bytes, (size_t)bytes);
+    auto done = [&](int code) { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } t.disconnect(); (void)hipFree(up); (void)hipFree(dn); return code; };
+    if (rc != LBMPM_OK) return done(rc);
+    if (hipMalloc(reinterpret_cast<void **>(&up), (size_t)bytes) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&dn), (size_t)bytes) != hipSuccess ||
+        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("lbmpm_transport_selftest: allocation failed"); return done(LBMPM_ERR_NOMEM); }
+    if (kind == LBMPM_TRANSPORT_IPC) {
+        slabtx::IpcBlob b;
+        rc = t.ipc_alloc(&b);
+        if (rc == LBMPM_OK) rc = t.ipc_open(0, &b, (size_t)bytes);       // both neighbours are this very landing area (same process: by pointer)
+        if (rc == LBMPM_OK) rc = t.ipc_open(1, &b, (size_t)bytes);
+        if (rc != LBMPM_OK) return done(rc);
+        t.connected = true;
+    } else {
+        rc = t.rccl.open(librccl_path);
+        if (rc != LBMPM_OK) return done(rc);
+        slabtx::Rccl::UniqueId id;
+        int e = t.rccl.GetUniqueId(&id);
+        if (e == 0) e = t.rccl.CommInitRank(&t.comm, 1, id, 0);
+        if (e != 0) { set_error("RCCL self-test: %s", t.rccl.GetErrorString(e)); return done(LBMPM_ERR_HIP); }
+        t.kind = LBMPM_TRANSPORT_RCCL; t.rank = 0; t.nranks = 1; t.peer_up = 0; t.peer_dn = 0; t.connected = true;
+    }
+    std::vector<double> got(n);
+    for (int round = 1; round <= 3; ++round) {          // three messages: both parities of the IPC slots, and the first one again
+        tx_fill<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(up, n, 1000. * round);
+        tx_fill<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(dn, n, -1000. * round);
+        const double *fb = nullptr, *fa = nullptr;
+        rc = t.exchange(st, up, dn, &fb, &fa);
+        if (rc != LBMPM_OK) return done(rc);
+        // IPC: "up" lands in the upper neighbour's from-below slot = our own; RCCL to oneself: sends and receives match in order,
+        // the first receive posted is the from-above slot
+        const double *exp_up = kind == LBMPM_TRANSPORT_IPC ? fb : fa, *exp_dn = kind == LBMPM_TRANSPORT_IPC ? fa : fb;
+        for (int w = 0; w < 2; ++w) {
+            if (hipMemcpyAsync(got.data(), w == 0 ? exp_up : exp_dn, (size_t)bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                set_error("lbmpm_transport_selftest: reading the landed message failed: %s", hipGetErrorString(hipGetLastError())); return done(LBMPM_ERR_HIP);
+            }
+            const double v = (w == 0 ? 1000. : -1000.) * round;
+            for (size_t i = 0; i < n; ++i)
+                if (got[i] != v + (double)i) { set_error("lbmpm_transport_selftest: message %d (%s) differs at double %zu", round, w == 0 ? "up" : "down", i); return done(LBMPM_ERR_STATE); }
+        }
+    }
+    return done(LBMPM_OK);
+}
+
+// the face message of the state (f, pur) over the connected transport, enqueued on the context's stream: pack is the caller's
+static int tx_exchange_unpack(lbmpm_rk3d *c, const RK3Dev &q, double *f, uint32_t *pur, bool unpack)
+{
+    const double *fb = nullptr, *fa = nullptr;
+    const int rc = c->tx.exchange(c->stream, c->send_up, c->send_dn, &fb, &fa);
+    if (rc != LBMPM_OK) return rc;
+    if (unpack) {
+        const dim3 grid(c->nseg, (c->ny + BY3 - 1) / BY3, 2), block(BX3, BY3);
+        rk3dq_face_unpack<<<grid, block, 0, c->stream>>>(q, f, pur, fb, fa, c->tx.has_below, c->tx.has_above);
+        rk3dq_halo_phi<<<grid, block, 0, c->stream>>>(q, fb, fa, c->tx.has_below, c->tx.has_above);
+        LBMPM_HIP_TRY(hipGetLastError());
+    }
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3d_halo_exchange(lbmpm_rk3d *c)
+{
+    LBMPM_REQUIRE(c && c->tx.connected, "lbmpm_rk3d_halo_exchange: no transport connected (lbmpm_rk3d_ipc_connect / lbmpm_rk3d_rccl_connect)");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->tx.has_below && !c->tx.has_above) return LBMPM_OK;
+    int rc = lbmpm_rk3d_pack_halo(c);
+    if (rc == LBMPM_OK) rc = tx_exchange_unpack(c, make_dev(c), c->fA, c->purA, true);
+    if (rc == LBMPM_OK) c->halo_valid = true;
+    return rc;
+}
+
 // The whole time step of a slab behind ONE call: interior planes on the second stream, then on the context's
 // stream pack -> exchange(populations) -> unpack -> phase field of the face planes -> exchange(phase field) ->
 // boundary planes -> join.  `exchange(user, what)` (what = 0 populations, 1 phase field) is the caller's transport:
@@ -1621,7 +1809,9 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
 {
     LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_rk3d_step_slab: bad argument");
     const bool nb = has_below || has_above;
-    LBMPM_REQUIRE(!nb || exchange, "lbmpm_rk3d_step_slab: a slab with neighbours needs an exchange callback");
+    const bool own_tx = nb && !exchange && c->tx.connected;
+    LBMPM_REQUIRE(!nb || exchange || own_tx, "lbmpm_rk3d_step_slab: a slab with neighbours needs an exchange callback or a connected transport");
+    LBMPM_REQUIRE(!own_tx || c->q23, "the in-library transports serve the compact 23-value storage");
     LBMPM_REQUIRE((has_below != 0) == (c->cfg.z_offset > 0) && (has_above != 0) == (c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global),
                   "lbmpm_rk3d_step_slab: has_below / has_above contradict the slab's position in the lattice");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
@@ -1644,9 +1834,13 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             return code;
         };
         if (!c->halo_valid) {
-            int rc = lbmpm_rk3d_pack_halo(c);
-            if (rc == LBMPM_OK && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (priming the halo planes)"); rc = LBMPM_ERR_STATE; }
-            if (rc == LBMPM_OK) rc = lbmpm_rk3d_unpack_halo(c, has_below, has_above);
+            int rc;
+            if (own_tx) rc = lbmpm_rk3d_halo_exchange(c);
+            else {
+                rc = lbmpm_rk3d_pack_halo(c);
+                if (rc == LBMPM_OK && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (priming the halo planes)"); rc = LBMPM_ERR_STATE; }
+                if (rc == LBMPM_OK) rc = lbmpm_rk3d_unpack_halo(c, has_below, has_above);
+            }
             if (rc != LBMPM_OK) return fail(rc);
         }
         if (!c->aux) {
@@ -1704,7 +1898,11 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
                 LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
                 LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));
             }
-            if (!(skip & 2) && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
+            const double *from_below = c->recv_below, *from_above = c->recv_above;
+            if (own_tx) {          // copies / ncclSend + ncclRecv and the waits for the neighbours' messages, enqueued here
+                if (!(skip & 2)) { const int rc = c->tx.exchange(c->stream, c->send_up, c->send_dn, &from_below, &from_above); if (rc != LBMPM_OK) return fail(rc); }
+            }
+            else if (!(skip & 2) && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
             if (has_interior) {
                 hipStream_t ist = (skip & 8) ? c->stream : c->aux;       // (knock-out 8: the interior on the context's own stream)
                 if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], ist));
@@ -1713,8 +1911,8 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
                 LBMPM_HIP_TRY(hipEventRecord(c->ev_done, ist));
             }
             if (!(skip & 4)) {
-                rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, c->recv_below, c->recv_above, has_below, has_above);
-                rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, c->recv_below, c->recv_above, has_below, has_above);
+                rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, from_below, from_above, has_below, has_above);
+                rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, from_below, from_above, has_below, has_above);
             }
             if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: face kernel launch failed"); return fail(LBMPM_ERR_HIP); }
             if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
@@ -1845,10 +2043,7 @@ extern "C" int lbmpm_rk3d_buffer(lbmpm_rk3d *c, int which, void **ptr, int64_t *
     LBMPM_REQUIRE(c && ptr && bytes, "lbmpm_rk3d_buffer: null argument");
     const int64_t pb = (int64_t)(c->plane2 * sizeof(double));
     // compact storage moves the fluid cells of the plane only (the two sides of a cut hold the same plane)
-    auto fb = [&](int zl) {
-        if (c->q23) return (int64_t)(((c->h_pstart[zl + 1] - c->h_pstart[zl]) * FACE_DOUBLES + ((size_t)c->ny * c->nseg + 1) / 2) * sizeof(double));
-        return c->compact ? (int64_t)((c->h_pstart[zl + 1] - c->h_pstart[zl]) * 10 * sizeof(double)) : (int64_t)(10 * c->plane2 * sizeof(double));
-    };
+    auto fb = [&](int zl) { return face_bytes(c, zl); };
     if (c->q23 && which >= LBMPM_RK3D_BUF_PHI_SEND_UP && which <= LBMPM_RK3D_BUF_PHI_RECV_FROM_ABOVE) {
         *ptr = c->phi; *bytes = 0;          // one exchange per step: the phase field of the halo planes travels as class sums
         return LBMPM_OK;

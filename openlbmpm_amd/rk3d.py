@@ -126,6 +126,46 @@ class RK3DSlab:
             raise err[0]
         check(rc, "lbmpm_rk3d_step_slab")
 
+    # ---- the exchange's transport inside the library (include/lbmpm.h: LBMPM_TRANSPORT_*)
+    def ipc_init(self):
+        """allocate this slab's landing area; returns the bytes its neighbours need (lbmpm_rk3d_ipc_init)"""
+        blob = C.create_string_buffer(_lib.IPC_BLOB_BYTES)
+        check(self._L.lbmpm_rk3d_ipc_init(self._h, blob), "lbmpm_rk3d_ipc_init")
+        return blob.raw
+
+    def ipc_connect(self, blob_below, blob_above):
+        """map the neighbours' landing areas (their ipc_init bytes; None where the slab has no neighbour)"""
+        keep = [C.create_string_buffer(b, _lib.IPC_BLOB_BYTES) if b is not None else None for b in (blob_below, blob_above)]
+        check(self._L.lbmpm_rk3d_ipc_connect(self._h, keep[0], keep[1]), "lbmpm_rk3d_ipc_connect")
+
+    @staticmethod
+    def rccl_unique_id(librccl_path=None):
+        idb = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+        check(_lib.lib().lbmpm_rccl_unique_id(idb, librccl_path.encode() if librccl_path else None), "lbmpm_rccl_unique_id")
+        return idb.raw
+
+    def rccl_connect(self, unique_id, rank, nranks, librccl_path=None):
+        """collective over the ranks of the run: ncclCommInitRank inside the library"""
+        idb = C.create_string_buffer(unique_id, _lib.RCCL_ID_BYTES)
+        check(self._L.lbmpm_rk3d_rccl_connect(self._h, idb, int(rank), int(nranks), librccl_path.encode() if librccl_path else None),
+              "lbmpm_rk3d_rccl_connect")
+
+    def transport_disconnect(self):
+        check(self._L.lbmpm_rk3d_transport_disconnect(self._h), "lbmpm_rk3d_transport_disconnect")
+
+    @property
+    def transport(self):
+        """'callback' (none connected: the caller's exchange function), 'ipc' or 'rccl'; with ipc also how the flags travel"""
+        v = C.c_int(0)
+        k = self._L.lbmpm_rk3d_transport_kind(self._h, C.byref(v))
+        return {0: "callback", 1: "ipc (copy engine + %s)" % ("stream value operations" if v.value else "one-lane flag kernels"), 2: "rccl"}[k]
+
+    def halo_exchange(self):
+        check(self._L.lbmpm_rk3d_halo_exchange(self._h), "lbmpm_rk3d_halo_exchange")
+
+    def ipc_release_waits(self):
+        check(self._L.lbmpm_rk3d_ipc_release_waits(self._h), "lbmpm_rk3d_ipc_release_waits")
+
     def slab_timing(self):
         """dict of average ms over the timed steps of the last step_slab(..., timed=True)"""
         out = (C.c_double * 5)()
@@ -184,6 +224,17 @@ class RK3DSlab:
         """True for the q23 storage: one face message per step carries populations, records, row flags and the class sums the
         neighbour needs for the phase field of its halo plane (csrc/rk3dq.h); it is needed before the first step too"""
         return self.dominant_kernel == "rk3dq_fused"
+
+
+def _torch_librccl():
+    """the librccl that ships inside the torch wheel (the one torch.distributed's nccl backend uses), or None: the system's"""
+    import os
+    try:
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return p if os.path.exists(p) else None
+    except ImportError:
+        return None
 
 
 class RK3DCluster:
@@ -249,11 +300,16 @@ class RK3DCluster:
 
 
 class RK3DDistributed:
-    """One slab per process/GPU; halos over torch.distributed P2P (RCCL over xGMI)."""
+    """One slab per process/GPU.  The face messages travel over a transport INSIDE the library where one connects -- 'ipc' (landing
+    areas mapped with hipIpcOpenMemHandle, one copy-engine transfer + a stream value operation per message: no CU, no host work per
+    step) or 'rccl' (ncclSend / ncclRecv of a communicator the library makes itself) -- else through the 'callback': torch.distributed
+    P2P enqueued from Python once per step.  torch.distributed is used for set-up (handles, unique id, agreement) either way."""
 
-    def __init__(self, is_domain_global, params=None, device=0, group=None, balance=True, plane_cost=None):
+    def __init__(self, is_domain_global, params=None, device=0, group=None, balance=True, plane_cost=None, transport=None):
         """plane_cost: measured cost per lattice plane (`calibrated_plane_cost` of an earlier instance); the cuts then equalise it
-        instead of the fluid cells"""
+        instead of the fluid cells.
+        transport: 'auto' (default; environment LBMPM_TRANSPORT overrides) | 'ipc' | 'rccl' | 'callback'.  auto = ipc where every
+        rank's set-up self-test passes within its deadline, else the callback; a named transport that fails raises on every rank."""
         import torch.distributed as dist
         self.rank, self.world, self.group = dist.get_rank(group), dist.get_world_size(group), group
         z0, n = self.partition(is_domain_global, self.world, balance, plane_cost)[self.rank]
@@ -268,6 +324,71 @@ class RK3DDistributed:
         self.slab = RK3DSlab(is_domain_global, z0, n, params, device)
         self.stream = torch.cuda.Stream(device)
         self.slab.use_torch_stream(self.stream)
+        import os
+        want = transport or os.environ.get("LBMPM_TRANSPORT", "auto")
+        if want not in ("auto", "ipc", "rccl", "callback"):
+            raise ValueError("transport must be 'auto', 'ipc', 'rccl' or 'callback'")
+        self.transport_note, self.host_us_per_step = "", 0.0
+        if self.world > 1 and want != "callback" and self.slab.one_exchange:
+            self._connect(want)
+
+    def _agree(self, ok):
+        """True when every rank says ok (MIN over the group; a collective on host objects: works on every backend)"""
+        import torch.distributed as dist
+        got = [None] * self.world
+        dist.all_gather_object(got, bool(ok), group=self.group)
+        return all(got)
+
+    def _connect(self, want):
+        """Connect the in-library transport; every rank takes the same decision (a transport that works on some ranks only is dropped
+        by all).  IPC is tried with a self-test under a deadline: one face message each way, released by the host if it does not
+        arrive -- a stuck wait must not hang the job before it has begun."""
+        import time
+        import torch.distributed as dist
+        s, err = self.slab, None
+        for kind in (("ipc", "rccl") if want == "auto" and dist.get_backend(self.group) == "nccl" else (("ipc",) if want in ("auto", "ipc") else ("rccl",))):
+            ok = True
+            try:
+                if kind == "ipc":
+                    blobs = [None] * self.world
+                    dist.all_gather_object(blobs, s.ipc_init(), group=self.group)
+                    s.ipc_connect(blobs[self.rank - 1] if self.rank > 0 else None, blobs[self.rank + 1] if self.rank + 1 < self.world else None)
+                else:
+                    box = [s.rccl_unique_id(_torch_librccl()) if self.rank == 0 else None]
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                    s.rccl_connect(box[0], self.rank, self.world, _torch_librccl())
+            except Exception as e:          # noqa: BLE001 -- whatever it was, the ranks must still agree
+                ok, err = False, e
+            if self._agree(ok) and self._self_test(kind):
+                self.transport_note = "in-library "
+                return
+            try:
+                s.transport_disconnect()
+            except Exception:               # noqa: BLE001
+                pass
+            self.transport_note = "%s did not connect on every rank%s; " % (kind, " (%s)" % err if err else "")
+            if want != "auto":
+                raise RuntimeError("transport %r could not be connected on every rank%s" % (kind, ": %s" % err if err else ""))
+
+    def _self_test(self, kind, deadline_s=20.0):
+        """one halo exchange of the (zero) initial state through the new transport; IPC: under a deadline"""
+        import time
+        s = self.slab
+        with self._torch.cuda.stream(self.stream):
+            s.halo_exchange()
+        done = self.stream.query()
+        t0 = time.perf_counter()
+        while not done and (kind != "ipc" or time.perf_counter() - t0 < deadline_s):
+            time.sleep(0.002)
+            done = self.stream.query()
+        if not done:
+            s.ipc_release_waits()
+            self.stream.synchronize()
+        return self._agree(done)
+
+    @property
+    def transport(self):
+        return self.slab.transport
 
     @staticmethod
     def partition(is_domain_global, world, balance=True, plane_cost=None):
@@ -317,6 +438,9 @@ class RK3DDistributed:
     def _halo_f(self):
         s = self.slab
         if (s.steps_done > 0 or s.one_exchange) and self.world > 1:
+            if s.transport != "callback":
+                s.halo_exchange()
+                return
             s.pack()
             self._exchange("f")
             s.unpack(self.rank > 0, self.rank + 1 < self.world)
@@ -325,10 +449,15 @@ class RK3DDistributed:
         """n time steps: ONE call into the library (lbmpm_rk3d_step_slab), which runs the interior planes on the slab's
         second stream and calls back twice per step for the two neighbour exchanges (torch.distributed P2P = RCCL
         over xGMI, enqueued on the slab's stream).  timed: per-phase HIP events, read with timing()."""
+        import time
         s = self.slab
+        own = s.transport != "callback"
+        t0 = time.perf_counter()
         with self._torch.cuda.stream(self.stream):
             s.step_slab(n, self.rank > 0, self.rank + 1 < self.world,
-                        (lambda what: self._exchange("phi" if what else "f")) if self.world > 1 else None, timed)
+                        (lambda what: self._exchange("phi" if what else "f")) if self.world > 1 and not own else None, timed)
+        # what the HOST spent enqueueing (the call returns before the GPU has done the work): per step, launches + exchange enqueues
+        self.host_us_per_step = (time.perf_counter() - t0) * 1e6 / max(int(n), 1)
 
     def timing(self):
         t = self.slab.slab_timing()
@@ -345,6 +474,8 @@ class RK3DDistributed:
                 faces[side] = int(f.numel() * f.element_size() + (ph.numel() * ph.element_size() if ph is not None else 0))
         t["bytes_sent_per_step"] = faces                    # populations (5 x 2 colours, fluid cells of the face plane) + phi plane
         t["bytes_per_face"] = max(faces.values()) if faces else 0
+        t["transport"] = (self.transport_note + self.slab.transport) if self.world > 1 else "none (one slab)"
+        t["host_enqueue_us_per_step"] = round(getattr(self, "host_us_per_step", 0.0), 1)
         return t
 
     def observe(self):

@@ -300,7 +300,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _two_rank_run(tmp_path, backend, same_gpu, nx=33):
+def _two_rank_run(tmp_path, backend, same_gpu, nx=33, transport="callback", extra_env=None):
     """two OS processes through RK3DDistributed (one lbmpm_rk3d_step_slab call for all steps, the exchanges as
     callbacks); returns the gathered fields and the per-rank timing dicts"""
     import json
@@ -323,7 +323,7 @@ if %r == "nccl":
 else:
     dist.init_process_group("gloo")
 dom, rR, rB = _case(nx=int(os.environ["LBMPM_TEST_NX"]), ny=18, nz=41, seed=9)
-d = RK3DDistributed(dom, device=dev)
+d = RK3DDistributed(dom, device=dev, transport=os.environ["LBMPM_TEST_TRANSPORT"])
 d.set_density(rR, rB)
 d.step(9); d.step(6, timed=True)
 t = d.timing()
@@ -335,7 +335,7 @@ d.close(); dist.destroy_process_group()
 ''' % (root, root, same_gpu, backend, str(tmp_path), str(tmp_path), str(tmp_path)))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
-                          env=dict(os.environ, LBMPM_TEST_NX=str(nx)), timeout=300)
+                          env=dict(os.environ, LBMPM_TEST_NX=str(nx), LBMPM_TEST_TRANSPORT=transport, **(extra_env or {})), timeout=300)
     fields = {f: np.concatenate([np.load(tmp_path / ("%s_%d.npy" % (f, r))) for r in range(2)], axis=0) for f in ("phi", "vz")}
     return fields, [json.load(open(tmp_path / ("t_%d.json" % r))) for r in range(2)]
 
@@ -351,19 +351,75 @@ def _single_process_reference(nx=33):
     return ref
 
 
-@pytest.mark.parametrize("nx", [33, 64], ids=["dense-two-exchanges", "q23-one-exchange"])
-def test_two_process_slab_run_equals_single_process(tmp_path, nx):
-    """The N>1 orchestration of bench.py / RK3DDistributed with two OS processes sharing this one
-    GPU (gloo transport staged through the host, because RCCL refuses duplicate devices): the
-    gathered result must equal the single-process run bit for bit; the per-phase timing is filled in.
-    nx = 64: the bench's storage -- boundary planes first, ONE face exchange beside the interior planes (lbmpm_rk3d_step_slab)."""
-    got, timing = _two_rank_run(tmp_path, "gloo", same_gpu=True, nx=nx)
+@pytest.mark.parametrize("nx,transport,env", [(33, "callback", None), (64, "callback", None), (64, "ipc", None), (64, "ipc", {"LBMPM_IPC_FLAG_KERNELS": "1"})],
+                         ids=["dense-two-exchanges-callback", "q23-one-exchange-callback", "q23-ipc-stream-value-ops", "q23-ipc-flag-kernels"])
+def test_two_process_slab_run_equals_single_process(tmp_path, nx, transport, env):
+    """The N>1 orchestration of bench.py / RK3DDistributed with two OS processes sharing this one GPU: the gathered result must
+    equal the single-process run bit for bit; the per-phase timing is filled in.
+    callback: the exchange as a Python callback per step over the gloo transport staged through the host (RCCL refuses duplicate
+    devices).  nx = 64: the bench's storage -- boundary planes first, ONE face exchange beside the interior planes.
+    ipc: the transport INSIDE the library (include/lbmpm.h LBMPM_TRANSPORT_IPC) -- each process maps the other's landing area with
+    hipIpcOpenMemHandle, a message is one hipMemcpyAsync + hipStreamWriteValue64, the receiver's stream waits with
+    hipStreamWaitValue64; no callback, torch.distributed only carries the handles at set-up.  flag-kernels: the same with the
+    one-lane kernels that devices without stream value operations fall back on."""
+    got, timing = _two_rank_run(tmp_path, "gloo", same_gpu=True, nx=nx, transport=transport, extra_env=env)
     ref = _single_process_reference(nx)
     for f in ref:
         assert np.array_equal(got[f], ref[f]), f
     for t in timing:
         assert t["world"] == 2 and t["steps"] == 6 and t["step_ms"] > 0 and t["interior_ms"] > 0 and t["boundary_ms"] > 0
         assert t["bytes_per_face"] > 0 and t["step_ms"] >= t["boundary_ms"]
+        if transport == "ipc":
+            assert "in-library ipc" in t["transport"] and ("one-lane flag kernels" if env else "stream value operations") in t["transport"]
+        else:
+            assert t["transport"] == "callback"
+
+
+@pytest.mark.parametrize("kind", ["ipc", "rccl"])
+def test_transport_selftest_on_one_gpu(kind):
+    """The transports of the slab exchange at transport level, on the one GPU of this box (lbmpm_transport_selftest): three messages
+    up and down to the caller itself.  ipc: the landing area connected to itself, hipMemcpyAsync + stream value operations, both slot
+    parities.  rccl: librccl opened with dlopen, a one-rank communicator (ncclCommInitRank), ncclSend / ncclRecv to rank 0 in one
+    group on a stream -- the RCCL branch of the library executing on hardware (with two ranks it needs two GPUs: the test below)."""
+    from openlbmpm_amd import _lib
+    from openlbmpm_amd.rk3d import _torch_librccl
+    import torch  # noqa: F401  (its HIP runtime first, as everywhere)
+    L = _lib.lib()
+    path = _torch_librccl()
+    _lib.check(L.lbmpm_transport_selftest(_lib.TRANSPORT_IPC if kind == "ipc" else _lib.TRANSPORT_RCCL, 0, 3 * 1024 * 1024 + 8,
+                                          path.encode() if path else None), "lbmpm_transport_selftest(%s)" % kind)
+
+
+def test_a_transport_needs_the_compact_storage_and_matching_neighbours():
+    """error paths of the connect calls: the dense storage has no in-library transport; a blob for a neighbour the slab lacks, a
+    blob that is none and a neighbour that expects another message size are refused with a status, nothing hangs"""
+    from openlbmpm_amd import _lib
+    from openlbmpm_amd._lib import LbmpmError
+    from openlbmpm_amd.rk3d import RK3DSlab
+    dom, rR, rB = _case(nx=64, ny=18, nz=41, seed=9)
+    lo, hi = RK3DSlab(dom, 0, 20), RK3DSlab(dom, 20, 21)
+    b_lo, b_hi = lo.ipc_init(), hi.ipc_init()
+    with pytest.raises(LbmpmError) as e:
+        lo.ipc_connect(b_hi, None)                 # the bottom slab has no rank below
+    assert e.value.status == _lib.ERR_INVALID
+    with pytest.raises(LbmpmError) as e:
+        lo.ipc_connect(None, b"\0" * 256)
+    assert e.value.status == _lib.ERR_INVALID and "not a blob" in str(e.value)
+    other = RK3DSlab(dom, 21, 20)                  # another cut: its bottom plane is not the plane above `lo`
+    with pytest.raises(LbmpmError) as e:
+        lo.ipc_connect(None, other.ipc_init())
+    assert e.value.status == _lib.ERR_INVALID and "different cuts" in str(e.value)
+    lo.ipc_connect(None, b_hi); hi.ipc_connect(b_lo, None)          # same process: connected by pointer
+    assert lo.transport.startswith("ipc") and hi.transport.startswith("ipc")
+    lo.transport_disconnect()
+    assert lo.transport == "callback"
+    dense_dom, _, _ = _case(nx=33, ny=18, nz=41, seed=9)
+    d = RK3DSlab(dense_dom, 0, 20)
+    with pytest.raises(LbmpmError) as e:
+        d.ipc_init()
+    assert e.value.status == _lib.ERR_INVALID
+    for s in (lo, hi, other, d):
+        s.close()
 
 
 def test_two_gpu_rccl_slab_run_equals_single_process(tmp_path):
@@ -371,11 +427,14 @@ def test_two_gpu_rccl_slab_run_equals_single_process(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("RCCL refuses two ranks on one device: needs >= 2 GPUs")
-    got, timing = _two_rank_run(tmp_path, "nccl", same_gpu=False, nx=64)
-    ref = _single_process_reference(64)
-    for f in ref:
-        assert np.array_equal(got[f], ref[f]), f
-    assert all(t["backend"] == "nccl" and t["world"] == 2 for t in timing)
+    for transport in ("rccl", "ipc", "callback"):
+        d = tmp_path / transport
+        d.mkdir()
+        got, timing = _two_rank_run(d, "nccl", same_gpu=False, nx=64, transport=transport)
+        ref = _single_process_reference(64)
+        for f in ref:
+            assert np.array_equal(got[f], ref[f]), (transport, f)
+        assert all(t["backend"] == "nccl" and t["world"] == 2 and transport in t["transport"] for t in timing)
 
 
 def test_bench_line_of_a_two_rank_run(tmp_path):
@@ -395,7 +454,9 @@ def test_bench_line_of_a_two_rank_run(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "MLUPS"
     m = d["multi_gpu"]
-    assert m["backend"] == "gloo" and m["world_size"] == 2 and m["boundary_depth_planes"] == 2 and "REHEARSAL" in m["transport"]
+    # two processes on one GPU: the in-library IPC transport connects (auto), gloo carries the handles
+    assert m["backend"] == "gloo" and m["world_size"] == 2 and m["boundary_depth_planes"] == 2 and "in-library ipc" in m["transport"]
+    assert len(m["host_enqueue_us_per_step"]) == 2 and all(v > 0 for v in m["host_enqueue_us_per_step"])
     assert [r["rank"] for r in m["per_rank"]] == [0, 1]
     for r in m["per_rank"]:
         assert r["steps"] == 6 and r["step_ms"] > 0 and r["interior_ms"] > 0 and r["boundary_ms"] > 0 and r["bytes_per_face"] > 0
