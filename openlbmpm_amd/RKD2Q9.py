@@ -173,6 +173,16 @@ class RKColorGradientLBM:
         schedule = getattr(self, "perturbation_schedule", "auto")
         if schedule not in ("auto", "fused", "kernels"):
             raise ValueError("perturbation_schedule must be 'auto', 'fused' or 'kernels'")
+        # `self.perturbation_order = "literal"` (opt-in; default "repaired"): the loop WITHOUT repair R3 -- calTotalFluidPDF where
+        # RKD2Q9.py:1065 has it, right after streaming, so that calRKCollision23GPUNew recolours from the pre-boundary, pre-relaxation
+        # sum.  Kernel by kernel only; tests/golden/rkpert_*_literal.npz are captures of the reference in that order.
+        order = getattr(self, "perturbation_order", "repaired")
+        if order not in ("repaired", "literal"):
+            raise ValueError("perturbation_order must be 'repaired' or 'literal'")
+        if order == "literal":
+            if schedule == "fused":
+                raise ValueError("the fused perturbation step implements the repaired order; the literal order runs kernel by kernel")
+            schedule = "kernels"
         if schedule != "kernels":
             done = self._run_perturbation_fused(progress, initial_pdf, required=schedule == "fused")
             if done:
@@ -213,10 +223,14 @@ class RKColorGradientLBM:
                   else [("calConstPressureLowerGPU", {}), ("ghostPointsConstPressureLowerRK", {})])                      # :1064-1088
         inlet = ([("constantVelocityZHBoundaryHigherRK", {}), ("ghostPointsConstantVelocityRK", {})] if p["inlet"] == "Neumann"
                  else [("calConstPressureInletGPU", {}), ("ghostPointsConstPressureInletRK", {})])                       # :1089-1110
-        head = [("calStreaming1GPU", R), ("calStreaming1GPU", Bq), ("calStreaming2GPU", R), ("calStreaming2GPU", Bq)] + outlet + inlet + \
+        literal = [("calTotalFluidPDF", {})] if order == "literal" else []       # RKD2Q9.py:1065
+        head = [("calStreaming1GPU", R), ("calStreaming1GPU", Bq), ("calStreaming2GPU", R), ("calStreaming2GPU", Bq)] + literal + outlet + inlet + \
                [("calMacroDensityRKGPU2D", {}), ("calPhysicalVelocityRKGPU2D", {})]
-        tail = [("calPhaseFieldPhi", {})] + ([("calTotalFluidPDF", {}), ("calRKCollision1GPU2DMRTNew", {})] if mrt
-                                             else [("calRKCollision1GPU2DSRTNew", {}), ("calTotalFluidPDF", {})]) + [("calRKCollision23GPUNew", {})]
+        if order == "literal":
+            tail = [("calPhaseFieldPhi", {}), ("calRKCollision1GPU2DMRTNew" if mrt else "calRKCollision1GPU2DSRTNew", {}), ("calRKCollision23GPUNew", {})]
+        else:
+            tail = [("calPhaseFieldPhi", {})] + ([("calTotalFluidPDF", {}), ("calRKCollision1GPU2DMRTNew", {})] if mrt
+                                                 else [("calRKCollision1GPU2DSRTNew", {}), ("calTotalFluidPDF", {})]) + [("calRKCollision23GPUNew", {})]
         out = ResultFile(self.output_dir, "SimulationResultsRK",
                          (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity")))
         self.result_path = out.path

@@ -465,10 +465,22 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     const double g2 = gx * gx + gy * gy + gz * gz;
     const double ign = g2 != 0. ? rsq_nr(g2) : 0.;          // 1 / |G|
     const double gn = g2 * ign, ig2 = ign * ign;
-    // STORE 2 keeps k_R alone (k_B = 1 - k_R): exactly 1 / 0 where the other colour is absent, so that a single-colour region
-    // stays exactly single-colour (x * (1 / x) may be 1 - ulp)
-    const double kR = STORE == 2 ? (rB == 0. ? 1. : (rR == 0. ? 0. : rR * irho)) : rR * irho;
-    const double kB = rB * irho, arc = rR * rB * irho * irho, akgn = p.ak * gn;
+    // STORE 2 keeps k_R alone (k_B = 1 - k_R).  The rule that makes "single colour" a crisp property of a cell (the row flags of
+    // rk3dq.h rest on it): a colour whose density is within 2 ulp of the total's rounding (|rho_c| <= 2^-51 rho: absent, or the
+    // residue of rho - rho_R at the far end of the other colour's tail) is absent -- k_R exactly 1 / 0 and no recolouring vector;
+    // a colour that is present keeps k_R off the end point even where the product with the Newton reciprocal rounds onto it.
+    // (Negative densities beyond rounding -- the scheme's undershoot next to a sharp front, 1e-8 -- stay what they are.)
+    double kR = rR * irho, arc = rR * rB * irho * irho;
+    if (STORE == 2) {
+        constexpr double below_one = 1. - 0x1p-53, above_one = 1. + 0x1p-52;
+        const double tiny = 0x1p-51 * rho;
+        const bool noB = fabs(rB) <= tiny, noR = fabs(rR) <= tiny;
+        if (kR == 1.) kR = rB > 0. ? below_one : above_one;
+        if (kR == 0.) kR = rR > 0. ? 0x1p-1022 : -0x1p-1022;
+        kR = noB ? 1. : (noR ? 0. : kR);
+        arc = (noB || noR) ? 0. : arc;
+    }
+    const double kB = rB * irho, akgn = p.ak * gn;
     const double arcA = (arc * p.rcA) * ign, arcD = (arc * p.rcD) * ign;
     const double c0 = 1. - 1.5 * usq;
     // MRT ([RelaxationType] Type = 'MRT'): f -= M^-1 S M (f - feq) in the D3Q19 basis of d'Humieres et al. 2002

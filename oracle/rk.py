@@ -248,8 +248,9 @@ class RKPertOracle:
             setattr(s, name, _p(getattr(self, name), F64P))
         self._s, self._L = s, L
 
-    def run(self, nsteps):
-        self._L.rk_pert_run(C.byref(self._s), C.c_int64(int(nsteps)))
+    def run(self, nsteps, order="repaired"):
+        """order: 'repaired' (R3: f_tot summed where the collision kernels need it) or 'literal' (RKD2Q9.py:1065: right after streaming)"""
+        (self._L.rk_pert_run if order == "repaired" else self._L.rk_pert_run_literal)(C.byref(self._s), C.c_int64(int(nsteps)))
         return self
 
     def dense(self, name):

@@ -236,3 +236,33 @@ void rk_pert_run(rk_pert_sim *s, i64 nsteps)
 {
     for (i64 k = 0; k < nsteps; ++k) rk_pert_step(s);
 }
+
+/* The same time step in the LITERAL order of RKD2Q9.py:1046-1223, i.e. without repair R3: fluidPDFTotal = fR + fB is summed right
+ * after streaming (RKD2Q9.py:1065), before the boundary kernels and before collision 1, and calRKCollision23GPUNew recolours from
+ * that sum -- the inlet / outlet rows and (SRT) the BGK relaxation of the two colours never reach the populations the next step
+ * streams.  Kept so that the effect of R3 is a number (tests/test_oracle_rk_pert.py), not an argument. */
+void rk_pert_step_literal(rk_pert_sim *s)
+{
+    i64 N = s->N;
+    rk_stream1(N, s->nbr, s->fR, s->fRn);
+    rk_stream1(N, s->nbr, s->fB, s->fBn);
+    rk_stream2(N, s->fRn, s->fR);
+    rk_stream2(N, s->fBn, s->fB);
+    rk_total_pdf(N, s->fR, s->fB, s->fT);                                    /* RKD2Q9.py:1065 */
+    rk_pert_outlet_pressure(N, s->nx, s->pLB, s->pLR, s->rhoB, s->rhoR, s->fB, s->fR);
+    rk_ghost_outlet_pressure(N, s->nx, s->nbr, s->rhoR, s->rhoB, s->fR, s->fB);
+    rk_pert_inlet_velocity(N, s->nx, s->ny, s->vyR, s->vyB, s->fluidNodes, s->rhoR, s->rhoB, s->fR, s->fB);
+    rk_ghost_inlet_velocity(N, s->nx, s->ny, s->fluidNodes, s->nbr, s->rhoR, s->rhoB, s->fR, s->fB);
+    rk_macro_density(N, s->fR, s->fB, s->rhoR, s->rhoB);
+    rk_pert_velocity(N, s->fR, s->fB, s->rhoR, s->rhoB, s->vx, s->vy);
+    rk_phase_field(N, s->rhoR, s->rhoB, s->phi);
+    if (s->mrt) rk_pert_collide1_mrt(N, s->tauR, s->tauB, 0., 0., s->vx, s->vy, s->rhoR, s->rhoB, s->phi, s->fT, s->M, s->Minv, s->S);
+    else rk_pert_collide1_srt(N, s->tauR, s->tauB, s->vx, s->vy, s->rhoR, s->rhoB, s->phi, s->fR, s->fB);
+    rk_pert_collide23(N, s->beta, s->AkR, s->AkB, s->solidPhi, s->nbr, s->Bc, s->rhoR, s->rhoB, s->fR, s->fB, s->fT, s->Gx, s->Gy,
+                      s->rw);
+}
+
+void rk_pert_run_literal(rk_pert_sim *s, i64 nsteps)
+{
+    for (i64 k = 0; k < nsteps; ++k) rk_pert_step_literal(s);
+}

@@ -337,6 +337,44 @@ def test_records_are_checked_for_nan_and_logged(tmp_path, caplog):
 
 
 @pytest.mark.parametrize("name", ["srt_capillary", "mrt_capillary"])
+def test_perturbation_driver_in_the_literal_order_of_the_reference_loop(tmp_path, name):
+    """`perturbation_order = "literal"` (opt-in): the loop WITHOUT repair R3 -- calTotalFluidPDF right after streaming, RKD2Q9.py:1065 --
+    kernel by kernel on the kernel-level layer, against tests/golden/rkpert_*_literal.npz (the real driver run with R1, R2, R4
+    only).  What R3 changes is measured in tests/test_oracle_rk_pert.py: |phi_literal - phi_repaired| = 0.63 after 80 steps."""
+    from openlbmpm_amd.RKD2Q9 import RKColorGradientLBM
+    d = np.load([f for f in golden_files("rkpert_") if f.endswith("rkpert_%s_literal.npz" % name)][0])
+    assert not any(str(r).startswith("R3") for r in d["repairs"])
+    par = load_params(d)
+    write_rk(str(tmp_path), nx=par["nx"], ny=par["ny"], steps=par["steps"], interval=25, relax=par["relax"])
+    ini = tmp_path / "RKtwophasesetup2D.ini"
+    ini.write_text(ini.read_text().replace("SurfaceTensionType = 'CSF'", "SurfaceTensionType = 'Perturbation'"))
+    sim = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "out"))
+    sim.perturbation_order = "literal"
+    sim.nan_guard = "off"
+    sim.par.update({k: par[k] for k in ("beta", "delta", "tauR", "tauB", "vyR", "vyB", "rhoBL", "rhoRL", "nbuf")},
+                   AkR=float(d["AkR"]), AkB=float(d["AkB"]), solidPhi=0.5)
+    dom = d["isDomain"]
+    dense = lambda c: (lambda a: (a.__setitem__(d["fluidNodes"], c), a.reshape(dom.shape + c.shape[1:]))[1])(np.zeros((dom.size,) + c.shape[1:]))
+    snaps = [int(k) for k in d["snaps"]]
+    seen = {}
+
+    def at(step):
+        if step in snaps:
+            T = sim._pert_table
+            seen[step] = {k: T[v].copy_to_host() for k, v in dict(fR="fluidPDFR", fB="fluidPDFB", fTot="fluidPDFTotal", rhoR="fluidRhoR",
+                                                                   rhoB="fluidRhoB", phi="phiValue", vx="physicalVX", vy="physicalVY").items()}
+    sim.runRKColorGradient2DPerturbation(progress=at, initial_pdf=(dense(d["init_fR"]), dense(d["init_fB"])))
+    assert sorted(seen) == snaps
+    for k in snaps:
+        for f, got in seen[k].items():
+            assert rel_err(got, d["s%d_%s" % (k, f)]) < 1e-12, (k, f)
+    fused = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "out2"))
+    fused.perturbation_order, fused.perturbation_schedule = "literal", "fused"
+    with pytest.raises(ValueError, match="repaired order"):
+        fused.runRKColorGradient2DPerturbation()
+
+
+@pytest.mark.parametrize("name", ["srt_capillary", "mrt_capillary"])
 def test_perturbation_driver_reproduces_the_repaired_reference_driver(tmp_path, name):
     """[SurfaceTension] SurfaceTensionType = 'Perturbation' through the driver (kernel by kernel on the kernel-level layer):
     the state at the end of the captured time steps of the real runRKColorGradient2DPerturbation (repairs R1-R4), and the

@@ -24,6 +24,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="th
     ("make_golden_tr.py", [], "tr_kernels.npz"),
     ("make_golden_rk_pert.py", ["kernels"], "rkpert_kernels.npz"),
     ("make_golden_rk_pert.py", ["srt_porous"], "rkpert_srt_porous.npz"),
+    ("make_golden_rk_pert.py", ["mrt_capillary_literal"], "rkpert_mrt_capillary_literal.npz"),
     ("make_golden_rkb.py", [], "rkb_kernels.npz"),
     ("make_golden_dense.py", [], "dense_kernels.npz"),
     ("make_golden_tr_coupled.py", ["capillary"], "trc_capillary.npz"),

@@ -511,3 +511,84 @@ def test_bench_with_eight_ranks_on_a_wide_lattice():
     planes = [r["planes"] for r in m["per_rank"]]
     assert planes[0][0] == 0 and planes[-1][1] == 128 and all(planes[i][1] == planes[i + 1][0] for i in range(7))
     assert sum(r["fluid_nodes"] for r in m["per_rank"]) == d["config"]["fluid_nodes"]
+
+
+@pytest.mark.parametrize("medium", ["porous, red-wetting grains", "open duct, neutral walls"])
+def test_row_flags_while_a_front_sweeps_the_lattice(monkeypatch, medium):
+    """The row flags of the 23-value storage under a moving interface.  Blue is driven in at 2e-2 lattice units through a porous
+    lattice of two row segments per row; over 1600 steps the front crosses more than 40 planes, i.e. row segments go single-colour ->
+    mixed -> single-colour of the other colour (the minority colour's tail is exactly zero some 30 planes away from the interface:
+    below 1e-16 of the density it does not survive the sums), and with marching chunks of 8 planes (LBMPM_RK3D_CHUNK) it crosses
+    chunk borders all the way.  At five
+    checkpoints: (a) densities and phase field equal the 38-value kernels' (both colour lattices stored, no flags) within 1e-9;
+    (b) the stored flag of every row segment equals "every fluid cell of the segment holds one colour", recomputed on the host from
+    the densities the step collided with -- a flagged segment holds one colour only (the other's density is within 2^-51 of the total's
+    in every cell: zero, or a rounding residue of rho - rho_R, which the collision treats as absent), an unflagged one holds a cell with both; (c) three slabs (one face message per cut and step, flags travelling with it) give the single domain's bits."""
+    from openlbmpm_amd.rk3d import RK3DCluster
+    from openlbmpm_amd.geometry import porous_spheres, initial_densities_rk3d
+    dom = porous_spheres(128, 24, 192, porosity=0.7, rmin=3.0, rmax=7.0, seed=31, nbuf=5)
+    par = dict(relax="MRT", tauR=1.0, tauB=1.0, velocityZB=-2.0e-2)
+    if medium.startswith("open"):           # nothing holds the displaced colour back: the segments behind the front that do not touch
+        dom = np.ones((192, 24, 256), dtype=np.uint8)      # a side wall (the middle two of four) turn single-colour again
+        dom[:, :, 0] = 0; dom[:, :, -1] = 0
+        par.update(SolidRhoR=0.5, SolidRhoB=0.5)
+    rR, rB = initial_densities_rk3d(dom, 5)
+    monkeypatch.setenv("LBMPM_RK3D_CHUNK", "8")
+    runs = {}
+    for name, storage, k in (("q23", "23", 1), ("q23 x3", "23", 3), ("both lattices", "38", 1)):
+        monkeypatch.setenv("LBMPM_RK3D_STORAGE", storage)
+        c = RK3DCluster(dom, k, par)
+        assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if storage == "23" else "rk3dc_fused")
+        c.set_density(rR, rB)
+        runs[name] = c
+    nz, ny, nx = dom.shape
+    fluid = dom == 1
+    seg_has_fluid = fluid.reshape(nz, ny, nx // 64, 64).any(axis=3)
+    front_planes = []
+    done = 0
+    for target in (200, 500, 800, 1200, 1600):
+        for c in runs.values():
+            c.step(target - 1 - done)
+            c.observe()                      # the streamed, boundary-corrected state: the densities step `target` collides with
+        obs = {name: {f: c.get(f) for f in ("rhoR", "rhoB", "phi")} for name, c in runs.items()}
+        for c in runs.values():
+            c.step(1)
+        done = target
+        a, b = obs["q23"], obs["both lattices"]
+        for f in ("rhoR", "rhoB", "phi"):
+            assert np.isfinite(a[f]).all()
+            assert rel_err(a[f], b[f]) < 1e-9, (target, f, rel_err(a[f], b[f]))
+            assert np.array_equal(a[f], obs["q23 x3"][f]), (target, f)
+        # (b) flags written by step `target` (planes next to the ghost planes included; the ghost planes themselves are never collided)
+        s = runs["q23"].slabs[0]
+        # (the collision's rule, collide_store in csrc/rk3d.hip: a colour with |rho_c| <= 2^-51 rho -- absent, or a rounding residue of
+        #  rho - rho_R -- is absent)
+        tiny = 2.0 ** -51 * (a["rhoR"] + a["rhoB"])
+        only_red = np.where(fluid, np.abs(a["rhoB"]) <= tiny, True).reshape(nz, ny, nx // 64, 64).all(axis=3)
+        only_blue = np.where(fluid, np.abs(a["rhoR"]) <= tiny, True).reshape(nz, ny, nx // 64, 64).all(axis=3)
+        want = only_red.astype(np.int64) + 2 * only_blue.astype(np.int64)
+        mixed_planes = 0
+        for z in range(1, nz - 1):
+            got = s.debug_plane(24, z + 1).astype(np.int64)           # local plane index = z + 1 (plane 0 is the halo plane)
+            sel = seg_has_fluid[z]
+            assert np.array_equal(got[sel], want[z][sel]), (target, z, got[sel][:8], want[z][sel][:8])
+            mixed_planes += int((got[sel] == 0).any())
+        # where the front is: the highest plane whose segments are all still pure red (the outlet plane pair at the bottom imposes
+        # blue, so the lowest planes are mixed from the start; the red bulk lies between the two)
+        red_planes = np.flatnonzero((only_red | ~seg_has_fluid).all(axis=(1, 2)))
+        front_planes.append(int(red_planes.max()) if red_planes.size else -1)
+
+        assert mixed_planes >= 1
+    if medium.startswith("porous"):
+        assert front_planes[-1] >= 0 and front_planes[0] - front_planes[-1] >= 40, front_planes       # the front came down by more than 40 planes
+    else:
+        assert front_planes[0] > front_planes[1], front_planes
+    # ... and left single-colour segments of the OTHER colour behind: row segments that started pure red and are flagged pure blue
+    # now, i.e. went red -> mixed -> blue
+    red_at_start = np.where(fluid, rB == 0.0, True).reshape(nz, ny, nx // 64, 64).all(axis=3)
+    turned = int((red_at_start & (want == 2) & seg_has_fluid).sum())
+    if medium.startswith("open"):
+        assert turned >= 50, turned
+    # (in the porous medium the grains are red-wetting: a red film stays on them, no segment behind the front turns pure blue)
+    for c in runs.values():
+        c.close()
