@@ -408,6 +408,12 @@ int lbmpm_rk3d_halo_exchange(lbmpm_rk3d *ctx);
 /* IPC only, for a set-up self-test with a deadline: makes every wait of this context's stream on an incoming message return
  * (the host writes the largest sequence number into the context's own flags).  The transport is unusable afterwards: disconnect. */
 int lbmpm_rk3d_ipc_release_waits(lbmpm_rk3d *ctx);
+/* Probe of the connected transport between the real neighbours (set-up, before set_density): `rounds` patterned messages each way
+ * through the send buffers and landing slots -- every slot several times, so that a stale cached line would show -- enqueued on the
+ * context's stream with a comparing kernel behind the transport's waits.  The caller waits for the stream under a deadline (IPC:
+ * lbmpm_rk3d_ipc_release_waits frees a stuck wait), then reads the number of doubles that arrived wrong. */
+int lbmpm_rk3d_transport_probe(lbmpm_rk3d *ctx, int rounds);
+int lbmpm_rk3d_transport_probe_result(lbmpm_rk3d *ctx, int64_t *mismatches);
 /* Transport-level self-test on ONE GPU: three messages of `bytes` bytes sent "up" and "down" to the caller itself through the given
  * transport -- IPC: the landing area connected to itself (by pointer: same process), both slot parities, copies + flag operations as
  * in a run; RCCL: a one-rank communicator, ncclSend / ncclRecv to rank 0 in one group -- and compared with what was sent. */

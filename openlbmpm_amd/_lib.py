@@ -137,6 +137,8 @@ _SIGNATURES = {
     "lbmpm_rk3d_transport_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "lbmpm_rk3d_halo_exchange": (C.c_int, [C.c_void_p]),
     "lbmpm_rk3d_ipc_release_waits": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3d_transport_probe": (C.c_int, [C.c_void_p, C.c_int]),
+    "lbmpm_rk3d_transport_probe_result": (C.c_int, [C.c_void_p, I64P]),
     "lbmpm_transport_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_char_p]),
     "lbmpm_rk3d_step": (C.c_int, [C.c_void_p, C.c_int64]),
     "lbmpm_rk3d_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),

@@ -1099,6 +1099,7 @@ struct lbmpm_rk3d {
     unsigned long long *trace = nullptr;      // dev tool, see RK3Dev
     unsigned *slotq = nullptr;                // tile counters of the rk3dq_fused launches (launch_q23); null: tiles by block index
     unsigned slot_launches = 0;
+    unsigned long long *probe_bad = nullptr;    // mismatch counter of lbmpm_rk3d_transport_probe
     slabtx::Transport tx;            // the exchange's transport when the library drives it itself (lbmpm_rk3d_ipc_* / lbmpm_rk3d_rccl_connect)
     bool halo_valid = false;         // q23 slabs: the halo planes (populations, records, flags, phase field) belong to the current state
     int dbg = 0;
@@ -1325,7 +1326,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
 
 extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
 {
-    if (c) c->tx.disconnect();
+    if (c) { c->tx.disconnect(); if (c->probe_bad) (void)hipFree(c->probe_bad); }
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1732,6 +1733,50 @@ extern "C" int lbmpm_rk3d_ipc_release_waits(lbmpm_rk3d *c)
 }
 
 namespace { __global__ void tx_fill(double *p, size_t n, double v) { const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) p[i] = v + (double)i; } }
+namespace { __global__ void tx_check(const double *p, size_t n, double v, unsigned long long *bad)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n && p[i] != v + (double)i) atomicAdd(bad, 1ull);
+} }
+
+// Probe of the CONNECTED transport between the real neighbours, enqueued on the context's stream (the caller polls the stream under a
+// deadline, then reads the verdict): `rounds` patterned messages each way -- both slot parities several times over, so that a reader
+// that served a landing slot from a stale cache line would be caught -- written into the (still unused) send buffers, exchanged,
+// and compared on the receiving side by a kernel launched behind the transport's waits.  Call before set_density.
+extern "C" int lbmpm_rk3d_transport_probe(lbmpm_rk3d *c, int rounds)
+{
+    LBMPM_REQUIRE(c && c->tx.connected && rounds >= 1, "lbmpm_rk3d_transport_probe: no transport connected");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->probe_bad) LBMPM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->probe_bad), sizeof(unsigned long long)));
+    LBMPM_HIP_TRY(hipMemsetAsync(c->probe_bad, 0, sizeof(unsigned long long), c->stream));
+    const size_t nu = c->tx.bytes_up / 8, nd = c->tx.bytes_dn / 8, nb = c->tx.bytes_from_below / 8, na = c->tx.bytes_from_above / 8;
+    auto grid = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    for (int r = 1; r <= rounds; ++r) {
+        const double up = 1000. * r + 1., dn = -(1000. * r + 1.);
+        if (c->tx.has_above) tx_fill<<<grid(nu), dim3(256), 0, c->stream>>>(c->send_up, nu, up);
+        if (c->tx.has_below) tx_fill<<<grid(nd), dim3(256), 0, c->stream>>>(c->send_dn, nd, dn);
+        const double *fb = nullptr, *fa = nullptr;
+        const int rc = c->tx.exchange(c->stream, c->send_up, c->send_dn, &fb, &fa);
+        if (rc != LBMPM_OK) return rc;
+        if (c->tx.has_below) tx_check<<<grid(nb), dim3(256), 0, c->stream>>>(fb, nb, up, c->probe_bad);       // what the rank below sent up
+        if (c->tx.has_above) tx_check<<<grid(na), dim3(256), 0, c->stream>>>(fa, na, dn, c->probe_bad);       // what the rank above sent down
+        LBMPM_HIP_TRY(hipGetLastError());
+    }
+    c->halo_valid = false;
+    return LBMPM_OK;
+}
+
+// verdict of the last probe: doubles that arrived different from what the neighbour sent (synchronises the context's stream)
+extern "C" int lbmpm_rk3d_transport_probe_result(lbmpm_rk3d *c, int64_t *mismatches)
+{
+    LBMPM_REQUIRE(c && mismatches && c->probe_bad, "lbmpm_rk3d_transport_probe_result: no probe was run");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    unsigned long long v = 0;
+    LBMPM_HIP_TRY(hipMemcpyAsync(&v, c->probe_bad, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    *mismatches = (int64_t)v;
+    return LBMPM_OK;
+}
 
 extern "C" int lbmpm_transport_selftest(int kind, int device, int64_t bytes, const char *librccl_path)
 {

@@ -163,6 +163,14 @@ class RK3DSlab:
     def halo_exchange(self):
         check(self._L.lbmpm_rk3d_halo_exchange(self._h), "lbmpm_rk3d_halo_exchange")
 
+    def transport_probe(self, rounds=6):
+        check(self._L.lbmpm_rk3d_transport_probe(self._h, int(rounds)), "lbmpm_rk3d_transport_probe")
+
+    def transport_probe_result(self):
+        v = C.c_int64(-1)
+        check(self._L.lbmpm_rk3d_transport_probe_result(self._h, C.byref(v)), "lbmpm_rk3d_transport_probe_result")
+        return int(v.value)
+
     def ipc_release_waits(self):
         check(self._L.lbmpm_rk3d_ipc_release_waits(self._h), "lbmpm_rk3d_ipc_release_waits")
 
@@ -371,11 +379,12 @@ class RK3DDistributed:
                 raise RuntimeError("transport %r could not be connected on every rank%s" % (kind, ": %s" % err if err else ""))
 
     def _self_test(self, kind, deadline_s=20.0):
-        """one halo exchange of the (zero) initial state through the new transport; IPC: under a deadline"""
+        """six patterned messages each way between the real neighbours through the new transport (lbmpm_rk3d_transport_probe: every
+        landing slot three times, compared on the receiving GPU); IPC: under a deadline, a stuck wait is released by the host"""
         import time
         s = self.slab
         with self._torch.cuda.stream(self.stream):
-            s.halo_exchange()
+            s.transport_probe(6)
         done = self.stream.query()
         t0 = time.perf_counter()
         while not done and (kind != "ipc" or time.perf_counter() - t0 < deadline_s):
@@ -384,7 +393,7 @@ class RK3DDistributed:
         if not done:
             s.ipc_release_waits()
             self.stream.synchronize()
-        return self._agree(done)
+        return self._agree(done and s.transport_probe_result() == 0)
 
     @property
     def transport(self):
