@@ -61,13 +61,13 @@ def _compile_and_link(out, extra, objdir, verbose):
     return out
 
 
-def build_dev(out, verbose=True):
+def build_dev(out, verbose=True, extra=()):
     """The development build (-DLBMPM_DEV): per-workgroup time stamps of rk3dq_fused (LBMPM_RK3D_TRACE) and the timing knock-outs of the
     slab step (LBMPM_RK3D_DBG, LBMPM_RK3D_COMM_CUS).  Never the product: tools/dev/devlib.py builds it beside the tools and points
     LBMPM_LIBRARY at it; `build()` below does not define LBMPM_DEV, and tests/test_codeobj.py checks that the product library holds
     none of those switches."""
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    return _compile_and_link(out, ["-DLBMPM_DEV"], os.path.join(os.path.dirname(out), "obj"), verbose)
+    return _compile_and_link(out, ["-DLBMPM_DEV"] + list(extra), os.path.join(os.path.dirname(out), "obj" + "".join(e.replace("-D", "_") for e in extra)), verbose)
 
 
 def build(force=False, verbose=True):

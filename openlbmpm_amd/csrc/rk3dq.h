@@ -540,8 +540,18 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     if (trace && tid == 0) { trace[1] = wall_clock64(); trace[3] = ((unsigned long long)(unsigned)za << 32) | (unsigned)zb; }
 #endif
 
+    // -DLBMPM_DEV -DLBMPM_PHASES (tools/dev/phases.py): cycle counter at six marks of the march step, summed per wave
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES)
+    unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_t = 0;
+#define PH_MARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); if (z >= za) ph_acc[k] += now_ - ph_t; ph_t = now_; }
+#else
+#define PH_MARK(k)
+#endif
     for (int z = za - 2; z <= zb; ++z) {
         const int zn = z + 1;
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES)
+        ph_t = __builtin_readcyclecounter();
+#endif
         {
             int t = tid;
             asm volatile("" : "+v"(t));
@@ -591,6 +601,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
                 if (fill_gb) sphi[(zn - 1) & (M::RING - 1)][hly][hlx] = ph;
             }
         }
+        PH_MARK(0)
         // ---- plane z + 1, own cell (pulled during the previous march step): class sums from the LDS records, boundary
         //      rules, phase field into the ring; the plane that waited (z) moves on to its collision
         double ft[Q];
@@ -619,13 +630,17 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         }
         const bool padzz = padz;
         padz = pad_raw;
+        PH_MARK(1)
         // ---- pulls of plane z + 2 into flight
         put_s(z + 3, e0, e1);
         __builtin_amdgcn_s_waitcnt(LBMPM_WAIT_VMCNT0);
+        PH_MARK(2)
         if (z + 2 <= zb + 1) issue(z + 2);
         else { fl_raw = false; pad_raw = false; }
         staged = fetch_rows(z + 6);
+        PH_MARK(3)
         __syncthreads();
+        PH_MARK(4)
         // ---- plane z: collide.  Fluid cells only go through the collision (no zero selects in it); the idle lanes that complete the
         //      last line of the tile's run (padzz) store zeros afterwards
         const bool live = z >= za && !is_ghost(z);
@@ -655,7 +670,16 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
 #pragma unroll
         for (int i = 0; i < Q; ++i) asm volatile("" : "+v"(raw[i]));
         fluid = fluidn;
+        PH_MARK(5)
     }
+#undef PH_MARK
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES)
+    if (p.trace && (tid & 63) == 0 && bid < 4096) {          // second half of the 4 MB trace area: [workgroup][wave][8]
+        unsigned long long *o = p.trace + (1u << 18) + ((size_t)bid * 8 + (size_t)wave) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = ph_acc[k];
+        o[6] = (unsigned long long)(zb - za + 1);
+    }
+#endif
 #ifdef LBMPM_DEV
     if (trace && tid == 0) trace[2] = wall_clock64();
 #endif

@@ -3,6 +3,12 @@ import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["LBMPM_RK3D_TRACE"] = "1"
+if not os.environ.get("LBMPM_LIBRARY"):          # build the -DLBMPM_DEV -DLBMPM_PHASES flavour beside the tools (hipcc needed) and load it
+    from openlbmpm_amd import build
+    out = os.path.join(ROOT, "tools", "dev", "_build", "liblbmpm_hip_phases.so")
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in build.sources()):
+        build.build_dev(out, extra=("-DLBMPM_PHASES",))
+    os.environ["LBMPM_LIBRARY"] = out
 import numpy as np
 from openlbmpm_amd.rk3d import RK3DSlab
 import bench
