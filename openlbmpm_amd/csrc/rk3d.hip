@@ -440,7 +440,7 @@ __device__ __forceinline__ constexpr int pair_class(int i) { return i < 7 ? (i -
 // STORE: 0 dense (two 8-byte stores per direction), 1 compact {red, blue} pairs (16 bytes per node and direction), 2 the
 // colour-blind population alone + one record {k_R, A} per node (rk3dq.h; every calling lane is a fluid cell there: the lanes that
 // write line padding go through pad_store_q); MRT: [RelaxationType] Type
-template <int STORE, bool MRT>
+template <int STORE, bool MRT, bool NT = false>
 __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsigned stride, unsigned own, bool fluid_in,
                                               const double ft_in[Q], double rR, double rB, double gx, double gy, double gz,
                                               uint32_t *rowflag = nullptr)
@@ -524,7 +524,12 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
     }
     char *blue = red + (size_t)Q * stride;       // red = population 0 of the node's plane, stride = bytes between populations
     auto put = [&](int i, double g, double a) {
-        if (STORE == 2) stg(red + (size_t)i * stride, own, g);
+        if (STORE == 2) {
+            // NT (rk3dq_fused, rows where both colours meet): streaming stores, so that the written lines do not push the rim cells'
+            // and halo records' lines -- which neighbouring workgroups read within a march step or two -- out of the XCD's L2
+            if (NT) __builtin_nontemporal_store(g, reinterpret_cast<double *>(red + (size_t)i * stride + own));
+            else stg(red + (size_t)i * stride, own, g);
+        }
         else if (STORE == 1) {
             double2 v;
             v.x = fluid ? kR * g + a : 0.; v.y = fluid ? kB * g - a : 0.;
@@ -567,8 +572,14 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
         *rowflag = code;
         if (code == 0u) {
             char *s = red + (size_t)Q * stride + (size_t)own * 4u;
-            *reinterpret_cast<double2 *>(s) = v;
-            *reinterpret_cast<double2 *>(s + 16) = w;
+            if (NT) {
+                double *sd = reinterpret_cast<double *>(s);
+                __builtin_nontemporal_store(v.x, sd); __builtin_nontemporal_store(v.y, sd + 1);
+                __builtin_nontemporal_store(w.x, sd + 2); __builtin_nontemporal_store(w.y, sd + 3);
+            } else {
+                *reinterpret_cast<double2 *>(s) = v;
+                *reinterpret_cast<double2 *>(s + 16) = w;
+            }
         }
     }
 }

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     bool padz = false, pad_raw = false;         // idle lane that writes line padding for that plane
     unsigned jz = 0, j_raw = 0;                 // their j
     double rR = 1., rho = 2.;                   // densities of the waiting plane
+    bool mixed_w = false, mixed_n = false;      // the waiting / landed plane's row took the general class sums (wave-uniform)
     double raw[Q], cur[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) { raw[i] = 0.; cur[i] = 0.; }
@@ -607,6 +608,8 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         double ft[Q];
         const double rRz = rR, rhoz = rho;
         const unsigned jzz = jz;
+        const bool mixed_z = mixed_w;
+        mixed_n = false;
         const bool fluidn = fl_raw && !halo_n && !ghost_n;
         {
             double rRn = 1., rhon = 2., ph = p.solidPhi;
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             else if (fl_raw) {
                 Sums S;
                 const int pc = purity(zn, ly, ly);
+                mixed_n = pc == 0;
                 if (pc != 0) class_sums_pure(raw, (pc & 1) != 0, S);
                 else class_sums<FIRST, true>(p, rows_own, lds_scal(zn, ly, lx), zn, (unsigned)lx, raw, S);
                 bc_q<true>(p, zn, S, raw, rRn, rhon);
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             }
 #pragma unroll
             for (int i = 0; i < Q; ++i) { ft[i] = cur[i]; cur[i] = raw[i]; }
-            rR = rRn; rho = rhon; jz = j_raw;
+            rR = rRn; rho = rhon; jz = j_raw; mixed_w = mixed_n;
         }
         const bool padzz = padz;
         padz = pad_raw;
@@ -658,8 +662,12 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
                 if (CY[i] != 0) gy += 3. * wq(i) * (double)CY[i] * ph;
                 if (CZ[i] != 0) gz += 3. * wq(i) * (double)CZ[i] * ph;
             }
-            collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)pz0 * CELLB, (unsigned)(pz1 - pz0) * 8u, jzz * 8u, true, ft, rRz, rhoz - rRz,
-                                  gx, gy, gz, p.pur_out + row_index(p, z, y, tx));
+            if (__builtin_amdgcn_readfirstlane((int)mixed_z))
+                collide_store<2, MRT, true>(p, reinterpret_cast<char *>(p.fout) + (size_t)pz0 * CELLB, (unsigned)(pz1 - pz0) * 8u, jzz * 8u, true, ft, rRz,
+                                            rhoz - rRz, gx, gy, gz, p.pur_out + row_index(p, z, y, tx));
+            else
+                collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)pz0 * CELLB, (unsigned)(pz1 - pz0) * 8u, jzz * 8u, true, ft, rRz, rhoz - rRz,
+                                      gx, gy, gz, p.pur_out + row_index(p, z, y, tx));
         }
         if (live && padzz) {
             char *pl = reinterpret_cast<char *>(p.fout) + (size_t)pz0 * CELLB;
