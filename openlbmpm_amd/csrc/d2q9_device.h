@@ -22,6 +22,27 @@ __device__ __forceinline__ void store_pair(double *f, size_t plane, int q, size_
     reinterpret_cast<double2 *>(f)[(size_t)q * plane + node] = v;
 }
 
+// The nine population pairs of a node.  stream: non-temporal stores -- what a step writes is read a whole lattice later, while the lines
+// it READS twice (the halo nodes neighbouring tiles share) profit from every line of the XCD's L2 the stores leave alone: measured
+// on 2048^2 lattices c3 0.254 -> 0.245 ms, c4 0.431 -> 0.413, c2 0.292 -> 0.284 (1024^2: 0.087 -> 0.085).  Off for lattices small
+// enough to live in the caches from one step to the next (configs[0]).
+// (STREAM is a template argument: behind a run-time flag hipcc merges the two store sequences and the non-temporal bit is lost.)
+template <bool STREAM>
+__device__ __forceinline__ void store_pairs(double *f, size_t plane, size_t node, const double a[9], const double b[9])
+{
+    if (STREAM) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            double *d = f + ((size_t)q * plane + node) * 2;
+            __builtin_nontemporal_store(a[q], d);
+            __builtin_nontemporal_store(b[q], d + 1);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) store_pair(f, plane, q, node, a[q], b[q]);
+    }
+}
+
 // Pull-streaming of the two lattices.
 // Equivalent to the reference's push + in-place half-way bounce-back
 // (AcceleratedRKGPU2D.py:340-417, OptimizedD2Q9GPU.py:452-550).  P needs the members

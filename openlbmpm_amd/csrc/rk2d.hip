@@ -439,8 +439,7 @@ __global__ __launch_bounds__(BX *BY) void rk2d_collide_stream(RKDev p)
     if (p.diag) { p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K; }
     collide<MRT>(p, fT, rR, rB, phi, vx, vy, Fx, Fy);
     recolor(p.beta, fT, rR, rB, gx, gy, fR, fB);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) lbmpm_dev::store_pair(p.fout, p.plane, i, idx, fR[i], fB[i]);
+    lbmpm_dev::store_pairs<true>(p.fout, p.plane, idx, fR, fB);
 }
 
 // ---------------------------------------------------------------- fused schedule
@@ -755,8 +754,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         p.F[idx] = Fx;
         p.F[p.plane + idx] = Fy;
         if (line8) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) lbmpm_dev::store_pair(p.fout, p.plane, i, idx, fR[i], fB[i]);
+            lbmpm_dev::store_pairs<true>(p.fout, p.plane, idx, fR, fB);
         }
     }
 }
@@ -942,8 +940,7 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, PertDev q, int tiles
             p.phi[idx] = phi; p.G[idx] = gx; p.G[p.plane + idx] = gy;
         }
     }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) lbmpm_dev::store_pair(p.fout, p.plane, i, idx, oR[i], oB[i]);
+    lbmpm_dev::store_pairs<true>(p.fout, p.plane, idx, oR, oB);
 }
 
 // what the perturbation loop would record at the start of the next step (RKD2Q9.py:1121-1131: after streaming, boundary kernels,

@@ -366,7 +366,7 @@ __device__ __forceinline__ void chain_collide(const SCDev &p, double f0[9], doub
 // ---------------------------------------------------------------- fused step kernel
 constexpr int TW = 64, TH = 4, HALO = 1, RW = TW + 2 * HALO, RH = TH + 2 * HALO, THREADS = TW * TH;
 
-template <bool MRT>
+template <bool MRT, bool STREAM>      // STREAM: non-temporal population stores (d2q9_device.h::store_pairs)
 __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
 {
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
@@ -469,8 +469,7 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
     if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
     }
     // non-fluid lanes of a line that holds fluid write zeros into their dead slots (full-line stores)
-#pragma unroll
-    for (int j = 0; j < 9; ++j) store_pair(p.fout, p.plane, j, idx, f0[j], f1[j]);
+    store_pairs<STREAM>(p.fout, p.plane, idx, f0, f1);
 }
 
 // ---------------------------------------------------------------- schemes 8 / 10: two sweeps per step
@@ -526,8 +525,7 @@ __global__ __launch_bounds__(256) void sc2d_iso_collide(SCDev p)
     }
     chain_collide<MRT>(p, f0, f1, rho, Fx, Fy, ueqx, ueqy);
     if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) store_pair(p.fout, p.plane, j, idx, f0[j], f1[j]);
+    store_pairs<false>(p.fout, p.plane, idx, f0, f1);
 }
 
 // ---------------------------------------------------------------- schemes 8 / 10: one sweep per step
@@ -669,8 +667,7 @@ __global__ __launch_bounds__(512, 4) void sc2d_iso_fused(SCDev p, int tiles_x)
         chain_collide<MRT>(p, f0, f1, rho, Fx, Fy, ueqx, ueqy);
         if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
     }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) store_pair(p.fout, p.plane, j, idx, f0[j], f1[j]);
+    store_pairs<true>(p.fout, p.plane, idx, f0, f1);
 }
 
 // SC end-of-iteration view (D:1624-1629): streamed populations + outlet copies, rho, u with the
@@ -865,6 +862,7 @@ SCDev make_dev(const lbmpm_sc2d *c)
     p.scheme = c->scheme; p.sh = c->scheme == 8 ? 1 : 0; p.nobc = (c->scheme == 10 || c->cfg.outlet_type == LBMPM_OUTLET_NONE) ? 1 : 0;
     p.psi = c->psi;
     p.chang = c->cfg.inlet_method == LBMPM_INLET_CHANG ? 1 : 0;
+
     p.chg_in = c->chgA; p.chg_out = c->chgB;
     return p;
 }
@@ -934,8 +932,12 @@ int launch_step(lbmpm_sc2d *c, bool diag, bool timed)
         sc2d_iso_psi<<<g, b, 0, c->stream>>>(p);
         if (p.mrt) sc2d_iso_collide<true><<<g, b, 0, c->stream>>>(p);
         else sc2d_iso_collide<false><<<g, b, 0, c->stream>>>(p);
-    } else if (p.mrt) sc2d_fused<true><<<dim3(tiles_x * tiles_y), dim3(THREADS), 0, c->stream>>>(p, tiles_x);
-    else sc2d_fused<false><<<dim3(tiles_x * tiles_y), dim3(THREADS), 0, c->stream>>>(p, tiles_x);
+    } else {
+        // lattices small enough to live in the caches from step to step (configs[0]: 128^2) keep ordinary stores
+        const dim3 g(tiles_x * tiles_y), b(THREADS);
+        if (c->plane > ((size_t)1 << 18)) { if (p.mrt) sc2d_fused<true, true><<<g, b, 0, c->stream>>>(p, tiles_x); else sc2d_fused<false, true><<<g, b, 0, c->stream>>>(p, tiles_x); }
+        else { if (p.mrt) sc2d_fused<true, false><<<g, b, 0, c->stream>>>(p, tiles_x); else sc2d_fused<false, false><<<g, b, 0, c->stream>>>(p, tiles_x); }
+    }
     if (p.outlet == LBMPM_OUTLET_FREEFLOW) sc2d_freeflow_rows<<<dim3((c->nx + 63) / 64, 3), dim3(64), 0, c->stream>>>(p, p.fout);
     if (ev) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     LBMPM_HIP_TRY(hipGetLastError());

@@ -64,7 +64,7 @@ def collect(fetch, write, kernels, suffix, only=None):
         if k == "rk2d_fused":             # c2 (no tracer) and c4 (tracer) are different template instances
             rec["workload"] = "c4 2048x2048" if re.search(r"rk2d_fused<(true|false), true", name) else "c2 1024x1024"
             k = "rk2d_fused" if rec["workload"].startswith("c2") else "rk2d_fused[tracer]"
-        if k == "sc2d_fused" and "sc2d_fused<false>" in name:      # SRT instance = the 128 x 128 droplet of configs[0]
+        if k == "sc2d_fused" and re.search(r"sc2d_fused<false[,>]", name):      # SRT instance = the 128 x 128 droplet of configs[0]
             rec["workload"] = "c1 128x128"
             k = "sc2d_fused[c1]"
         m3 = re.search(r"rk3d[cq]?_fused<([^>]*)>", name)
