@@ -536,14 +536,14 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
         double *go = p.gout + (size_t)t * 5 * p.plane;
         const double S = (p.trRate != 0.) ? (t == 2 ? src : -src) : 0.;        // tracers 0, 1 consumed, 2 produced
         const double J0 = p.trJ[t], J1 = (1. - p.trJ[t]) / 4.;
-        if (p.trRate != 0.) go[idx] = (g[0] + d[0]) + J0 * S;
-        else go[idx] = g[0] + d[0];
+        // (streaming stores like the populations': read again a whole lattice later)
+        __builtin_nontemporal_store(p.trRate != 0. ? (g[0] + d[0]) + J0 * S : g[0] + d[0], go + idx);
 #pragma unroll
         for (int j = 1; j < 5; ++j) {
             double c = 0.;
             if (un > 1.0e-8) c = ((double)VX5[j] * ux + (double)VY5[j] * uy) / (1. * un);
             const double v = (g[j] + d[j]) + p.trBeta[t] * ind * (W5[j] * C) * c;
-            go[j * p.plane + idx] = (p.trRate != 0.) ? v + J1 * S : v;
+            __builtin_nontemporal_store((p.trRate != 0.) ? v + J1 * S : v, go + j * p.plane + idx);
         }
     }
 }
@@ -751,8 +751,8 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         collide<MRT>(p, f, rR[m], rB[m], phi, vx, vy, Fx, Fy);
         recolor(p.beta, f, rR[m], rB[m], gx[m], gy[m], fR, fB);
         }
-        p.F[idx] = Fx;
-        p.F[p.plane + idx] = Fy;
+        __builtin_nontemporal_store(Fx, p.F + idx);
+        __builtin_nontemporal_store(Fy, p.F + p.plane + idx);
         if (line8) {
             lbmpm_dev::store_pairs<true>(p.fout, p.plane, idx, fR, fB);
         }
