@@ -1,7 +1,7 @@
 # utilisation counters of the c5 kernel (run on the GPU box from the repo root):  bash tools/pmc_busy_c5.sh [initial|mixed|graded] [outfile]
 state=${1:-initial}
 R=$(pwd)
-outf=${2:-$R/gpurun_out/pmc_busy_c5_$state.txt}
+outf=${2:-$R/gpurun_out/pmc_busy_c5_$state.txt}; case $outf in /*) ;; *) outf=$R/$outf;; esac
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 6 --warmup 2 --no-secondary --no-cpu-baseline --c5-state $state"
 : > $outf
