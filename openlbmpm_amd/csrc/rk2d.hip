@@ -621,8 +621,8 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         if (fluid) {
             double fR[9], fB[9];
             sn[m] = p.solidnbr[idx];
-            Fpx[m] = p.F[idx];
-            Fpy[m] = p.F[p.plane + idx];
+            Fpx[m] = __builtin_nontemporal_load(p.F + idx);          // read once, by its own node
+            Fpy[m] = __builtin_nontemporal_load(p.F + p.plane + idx);
             node_state<true, TR>(p, xw, yw, fR, fB, rR[m], rB[m]);
 #pragma unroll
             for (int i = 0; i < 9; ++i) fT[m][i] = fR[i] + fB[i];
