@@ -355,18 +355,39 @@ class RK3DDistributed:
         import torch.distributed as dist
         s, err = self.slab, None
         for kind in (("ipc", "rccl") if want == "auto" and dist.get_backend(self.group) == "nccl" else (("ipc",) if want in ("auto", "ipc") else ("rccl",))):
-            ok = True
-            try:
-                if kind == "ipc":
-                    blobs = [None] * self.world
-                    dist.all_gather_object(blobs, s.ipc_init(), group=self.group)
-                    s.ipc_connect(blobs[self.rank - 1] if self.rank > 0 else None, blobs[self.rank + 1] if self.rank + 1 < self.world else None)
+            # every rank goes through the same collectives in the same order, whatever fails on it: a rank that skipped one would pair
+            # its next collective with its neighbours' current one
+            ok, err = True, None
+            if kind == "ipc":
+                try:
+                    mine = s.ipc_init()
+                except Exception as e:      # noqa: BLE001
+                    mine, ok, err = None, False, e
+                blobs = [None] * self.world
+                dist.all_gather_object(blobs, mine, group=self.group)
+                if ok and all(b is not None for b in blobs):
+                    try:
+                        s.ipc_connect(blobs[self.rank - 1] if self.rank > 0 else None, blobs[self.rank + 1] if self.rank + 1 < self.world else None)
+                    except Exception as e:  # noqa: BLE001
+                        ok, err = False, e
                 else:
-                    box = [s.rccl_unique_id(_torch_librccl()) if self.rank == 0 else None]
-                    dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-                    s.rccl_connect(box[0], self.rank, self.world, _torch_librccl())
-            except Exception as e:          # noqa: BLE001 -- whatever it was, the ranks must still agree
-                ok, err = False, e
+                    ok = False
+            else:
+                box = [None]
+                if self.rank == 0:
+                    try:
+                        box = [s.rccl_unique_id(_torch_librccl())]
+                    except Exception as e:  # noqa: BLE001
+                        err = e
+                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                ok = box[0] is not None
+                if self._agree(ok):         # ncclCommInitRank is a blocking collective: enter it only if every rank will
+                    try:
+                        s.rccl_connect(box[0], self.rank, self.world, _torch_librccl())
+                    except Exception as e:  # noqa: BLE001
+                        ok, err = False, e
+                else:
+                    ok = False
             if self._agree(ok) and self._self_test(kind):
                 self.transport_note = "in-library "
                 return
@@ -383,8 +404,11 @@ class RK3DDistributed:
         landing slot three times, compared on the receiving GPU); IPC: under a deadline, a stuck wait is released by the host"""
         import time
         s = self.slab
-        with self._torch.cuda.stream(self.stream):
-            s.transport_probe(6)
+        try:
+            with self._torch.cuda.stream(self.stream):
+                s.transport_probe(6)
+        except Exception:                   # noqa: BLE001 -- this rank could not even enqueue: tell the others (same collective)
+            return self._agree(False)
         done = self.stream.query()
         t0 = time.perf_counter()
         while not done and (kind != "ipc" or time.perf_counter() - t0 < deadline_s):

@@ -163,3 +163,126 @@ def test_partition_by_measured_plane_cost():
     for bad in (np.ones(63), np.zeros(64), np.full(64, np.nan)):
         with pytest.raises(ValueError):
             RK3DDistributed.partition(dom, 4, plane_cost=bad)
+
+
+# ---- host logic of the transport selection (openlbmpm_amd/rk3d.py::RK3DDistributed._connect), world size 2 over gloo, no GPU: the
+# slab is a stand-in that records the calls and fails where the scenario says so
+class _FakeStream:
+    def query(self):
+        return True
+
+    def synchronize(self):
+        pass
+
+
+class _FakeTorch:
+    class cuda:
+        @staticmethod
+        def stream(_s):
+            import contextlib
+            return contextlib.nullcontext()
+
+
+class _FakeSlab:
+    one_exchange = True
+
+    def __init__(self, rank, fail):
+        self.rank, self.fail, self.kind, self.calls = rank, fail, "callback", []
+
+    def _maybe(self, what):
+        self.calls.append(what)
+        if self.fail.get(what) == self.rank or self.fail.get(what) == "all":
+            raise RuntimeError("%s fails on rank %d" % (what, self.rank))
+
+    def ipc_init(self):
+        self._maybe("ipc_init")
+        return b"blob-of-rank-%d" % self.rank
+
+    def ipc_connect(self, below, above):
+        self._maybe("ipc_connect")
+        assert (below, above) == ((None, b"blob-of-rank-1") if self.rank == 0 else (b"blob-of-rank-0", None))
+        self.kind = "ipc (copy engine + stream value operations)"
+
+    @staticmethod
+    def rccl_unique_id(_path=None):
+        return b"U" * 128
+
+    def rccl_connect(self, uid, rank, nranks, _path=None):
+        self._maybe("rccl_connect")
+        assert uid == b"U" * 128 and rank == self.rank and nranks == 2
+        self.kind = "rccl"
+
+    def transport_probe(self, rounds):
+        self._maybe("probe")
+
+    def transport_probe_result(self):
+        return 3 if self.fail.get("mismatch") in (self.rank, "all") and self.kind.startswith("ipc") else 0
+
+    def transport_disconnect(self):
+        self.calls.append("disconnect")
+        self.kind = "callback"
+
+    def ipc_release_waits(self):
+        self.calls.append("release")
+
+    @property
+    def transport(self):
+        return self.kind
+
+
+def _connect_worker(rank, world, port, q, want, fail, backend_name):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openlbmpm_amd.rk3d import RK3DDistributed
+        d = RK3DDistributed.__new__(RK3DDistributed)
+        d.rank, d.world, d.group, d.slab, d.stream, d._torch = rank, world, None, _FakeSlab(rank, fail), _FakeStream(), _FakeTorch
+        d.transport_note = ""
+        real = dist.get_backend
+        dist.get_backend = lambda group=None: backend_name          # 'nccl': auto may go on to rccl
+        err = None
+        try:
+            d._connect(want)
+        except RuntimeError as e:
+            err = str(e)
+        finally:
+            dist.get_backend = real
+        q.put((rank, d.slab.transport, d.transport_note, d.slab.calls, err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("want,fail,backend,expect", [
+    ("auto", {}, "gloo", "ipc"),                                   # everything works: IPC
+    ("auto", {"ipc_connect": 1}, "gloo", "callback"),              # one rank cannot map its neighbour: every rank drops IPC
+    ("auto", {"mismatch": 0}, "nccl", "rccl"),                     # the probe finds wrong data on one rank: on to RCCL (nccl backend)
+    ("auto", {"mismatch": "all", "rccl_connect": 1}, "nccl", "callback"),
+    ("auto", {"probe": 1}, "gloo", "callback"),                    # one rank cannot even enqueue the probe
+    ("auto", {"ipc_init": 0}, "gloo", "callback"),                 # one rank cannot allocate its landing area
+    ("ipc", {"ipc_init": 0}, "gloo", "raises"),                    # a named transport that fails raises on EVERY rank
+    ("rccl", {}, "nccl", "rccl"),
+])
+def test_transport_selection_is_agreed_on_by_all_ranks(want, fail, backend, expect):
+    """RK3DDistributed._connect with a stand-in slab, two ranks over gloo: whatever happens on one rank, both end on the same
+    transport (a rank that kept IPC while its neighbour fell back would wait for messages that never come)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_connect_worker, args=(r, world, port, q, want, fail, backend)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kinds = [g[1].split(" ")[0] for g in got]
+    if expect == "raises":
+        assert all(g[4] and "could not be connected on every rank" in g[4] for g in got) and kinds == ["callback", "callback"]
+    else:
+        assert kinds == [expect, expect], got
+        assert all(g[4] is None for g in got)
+        if expect != "callback":
+            assert all(g[2] == "in-library " for g in got)
+        if fail:
+            assert all("disconnect" in g[3] for g in got)           # the dropped transport was disconnected on both ranks
