@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""K OS processes sharing ONE GPU step the bench lattice through RK3DDistributed (gloo staged through the host: RCCL refuses two ranks
-on one device) and rank 0 compares the gathered phase field with the single domain's, bit for bit.
+"""K OS processes sharing ONE GPU step the bench lattice through RK3DDistributed -- the in-library IPC transport by default (gloo only
+carries the handles at set-up; LBMPM_TRANSPORT=callback: every message staged through the host, RCCL refuses two ranks on one device) --
+and rank 0 compares the gathered phase field with the single domain's, bit for bit.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node K --master-addr 127.0.0.1 --master-port P tools/dev/slab_procs.py [n=256] [steps=6]
 """
@@ -26,6 +27,7 @@ warm = int(os.environ.get("SLAB_WARM", "3"))
 if warm: d.step(warm)
 d.step(steps)
 d.observe()
+transport = d.timing()["transport"]
 phi = d.slab.get("phi")
 out = os.environ.get("SLAB_OUT", "/tmp")
 np.save(os.path.join(out, "slabprocs_phi_%d.npy" % rank), phi)
@@ -36,7 +38,7 @@ if rank == 0:
     ref = RK3DSlab(dom, 0, n, par); ref.set_density(rR, rB); ref.step_single(steps + warm); ref.phase_field(diagnostics=True)
     rphi = ref.get("phi"); ref.close()
     same = bool(np.array_equal(got, rphi))
-    print("%d processes, %d^3, %d steps: phase field equals the single domain's bit for bit: %s" % (world, n, steps + warm, same))
+    print("%d processes, %d^3, %d steps, transport %s: phase field equals the single domain's bit for bit: %s" % (world, n, steps + warm, transport, same))
     if not same:
         bad = ~np.isfinite(got)
         per = bad.reshape(n, -1).sum(axis=1)
