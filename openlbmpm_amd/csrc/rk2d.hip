@@ -552,6 +552,13 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
 // rule come out the same for TR = 0 and 1, so the tracer step runs as TWO launches: TR = 0 -- round 2's kernel, which fits its 128
 // registers with 12 B of spills -- on the tile rows whose region (tile + 3) stays clear of the lattice rows 0, 1, ny-2, ny-1, and
 // TR = 1 (the re-summing variant: 44 B of spills) on the first and last tile row only.  `tile0`: first tile of this launch.
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES2D)
+// tools/dev/phases2d.py: cycle counter at the phase borders of rk2d_fused, kept per wave and added to one of 256 slots at the end
+__device__ unsigned long long rk2d_ph[256 * 16];
+#define PH2(k) { const unsigned long long now_ = __builtin_readcyclecounter(); ph_acc[k] = now_ - ph_t; ph_t = now_; }
+#else
+#define PH2(k)
+#endif
 template <bool MRT, bool TRACER, typename SH, int TR = (TRACER ? 1 : 0)>
 __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rk2d_fused(RKDev p, int tiles_x, int tile0 = 0)
 {
@@ -570,6 +577,10 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
 
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES2D)
+    unsigned long long ph_acc[8] = {};
+    unsigned long long ph_t = __builtin_readcyclecounter();
+#endif
     // fluid mask of the region (issued first so that the wait for it leaves the population
     // loads below in flight)
     bool any_solid = false;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 
     // ---- phase A: the node's own pull and the pull of "its" halo node are issued back to back -- one memory round trip, not two
     const bool need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
+    PH2(0)
     constexpr int NHALO = 2 * H * RW + 2 * H * TH;
     auto halo_cell = [&](int n, int &rx, int &ry) {
         int mloc = n;
@@ -645,7 +657,9 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         node_state<true, TR>(p, x, y, fR, fB, a, c);
         s_phi[ri] = (a - c) / (a + c);
     }
+    PH2(1)
     __syncthreads();
+    PH2(2)
 
     // ---- phase B: colour value on wetting solids (calColorValueOnSolid A:1560-1581)
     if (need3) {
@@ -663,6 +677,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         }
         __syncthreads();
     }
+    PH2(3)
 
     // ---- phase C: colour gradient, wetting correction, unit normal
     auto gradient_at = [&](int ri, int x, int y, double &gx, double &gy) {
@@ -707,7 +722,9 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         double a, c;
         gradient_at(ri, x, y, a, c);
     }
+    PH2(4)
     __syncthreads();
+    PH2(5)
 
     // ---- phase D: force, velocity, collision, recolouring, store
 #pragma unroll
@@ -757,7 +774,18 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             lbmpm_dev::store_pairs<true>(p.fout, p.plane, idx, fR, fB);
         }
     }
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES2D)
+    PH2(6)
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): until the stores are acknowledged
+    PH2(7)
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long *slot = rk2d_ph + (blockIdx.x & 255) * 16;
+        for (int k = 0; k < 8; ++k) atomicAdd(slot + k, ph_acc[k]);
+        atomicAdd(slot + 15, 1ull);
+    }
+#endif
 }
+#undef PH2
 
 // ---------------------------------------------------------------- perturbation operator, fused
 // [SurfaceTension] SurfaceTensionType = 'Perturbation': the loop of RKColorGradientLBM.runRKColorGradient2DPerturbation
@@ -1675,6 +1703,18 @@ extern "C" int lbmpm_rk2d_tracer_get_concentration(lbmpm_rk2d *c, int tracer, do
     return copy_plane(c, c->obs, out, 1);
 }
 
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES2D)
+extern "C" int lbmpm_dev_rk2d_phases(unsigned long long *out16)
+{
+    static unsigned long long h[256 * 16];
+    LBMPM_HIP_TRY(hipDeviceSynchronize());
+    LBMPM_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(rk2d_ph), sizeof(h)));
+    for (int k = 0; k < 16; ++k) { out16[k] = 0; for (int b = 0; b < 256; ++b) out16[k] += h[b * 16 + k]; }
+    memset(h, 0, sizeof(h));
+    LBMPM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rk2d_ph), h, sizeof(h)));
+    return LBMPM_OK;
+}
+#endif
 extern "C" int64_t lbmpm_rk2d_num_fluid_nodes(const lbmpm_rk2d *c) { return c ? c->nfluid : 0; }
 extern "C" int64_t lbmpm_rk2d_steps_done(const lbmpm_rk2d *c) { return c ? c->steps : 0; }
 extern "C" int64_t lbmpm_rk2d_device_bytes(const lbmpm_rk2d *c) { return c ? c->bytes : 0; }
