@@ -74,6 +74,7 @@ struct Transport {
     // ---- IPC
     char *land = nullptr;                     // own landing area, 4 slots
     size_t slot = 0;
+    bool land_fine = false;                   // the landing area is fine-grained memory
     unsigned long long *flags = nullptr;      // own, fine-grained: [face 0 from below | 1 from above][parity]
     char *peer_land[2] = {nullptr, nullptr};  // [0] landing area of the rank below (we fill its "from above" slots), [1] of the rank above
     unsigned long long *peer_flags[2] = {nullptr, nullptr};
@@ -97,7 +98,17 @@ struct Transport {
         const size_t m = from_below > from_above ? from_below : from_above;
         slot = (m + 4095) / 4096 * 4096;
         LBMPM_HIP_TRY(hipSetDevice(dev));
-        LBMPM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&land), 4 * slot));
+        // The landing area is FINE-GRAINED memory where the device offers it: with the IPC transport a neighbour GPU's copy engine writes it
+        // over xGMI, past this GPU's L2, and ordinary (coarse-grained) memory is coherent at kernel boundaries only -- a slot is reused
+        // every second step, and a line of it left in L2 by the previous unpack would be served stale.  (The probe at set-up would catch
+        // that and the selection would fall back to RCCL; this keeps the copy-engine path.  LBMPM_IPC_LAND=coarse: ordinary memory.)
+        const char *lk = getenv("LBMPM_IPC_LAND");
+        land_fine = !(lk && !strcmp(lk, "coarse")) &&
+                    hipExtMallocWithFlags(reinterpret_cast<void **>(&land), 4 * slot, hipDeviceMallocFinegrained) == hipSuccess;
+        if (!land_fine) {
+            (void)hipGetLastError();
+            LBMPM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&land), 4 * slot));
+        }
         return LBMPM_OK;
     }
 

@@ -6,7 +6,7 @@ for t in callback ipc callback ipc; do
 import json, sys
 t = sys.argv[1]
 try:
-    d = json.load(open("gpurun_out/r4c/n8_%s.json" % t))
+    d = json.loads([l for l in open("gpurun_out/r4c/n8_%s.json" % t) if l.startswith("{")][-1])
     m = d["multi_gpu"]
     print(t, d["value"], d["ms_per_step"], m["transport"][:50], m["host_enqueue_us_per_step"], [round(r["step_ms"], 3) for r in m["per_rank"]])
 except Exception as e:
