@@ -549,9 +549,8 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
 }
 
 // TR (tracer variant): the order of the density sums on the rows a boundary kernel touches (node_finish).  Rows without a boundary
-// rule come out the same for TR = 0 and 1, so the tracer step runs as TWO launches: TR = 0 -- round 2's kernel, which fits its 128
-// registers with 12 B of spills -- on the tile rows whose region (tile + 3) stays clear of the lattice rows 0, 1, ny-2, ny-1, and
-// TR = 1 (the re-summing variant: 44 B of spills) on the first and last tile row only.  `tile0`: first tile of this launch.
+// rule come out the same for TR = 0 and 1, so the tracer step takes TR = 1 (the re-summing variant) only on the tile rows whose
+// region (tile + 3) holds one of the lattice rows 0, 1, ny-2, ny-1 and TR = 0 on the rest: rk2d_fused_tracer below.
 #if defined(LBMPM_DEV) && defined(LBMPM_PHASES2D)
 // tools/dev/phases2d.py: cycle counter at the phase borders of rk2d_fused, kept per wave and added to one of 256 slots at the end
 __device__ unsigned long long rk2d_ph[256 * 16];
@@ -559,21 +558,14 @@ __device__ unsigned long long rk2d_ph[256 * 16];
 #else
 #define PH2(k)
 #endif
-template <bool MRT, bool TRACER, typename SH, int TR = (TRACER ? 1 : 0)>
-__global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rk2d_fused(RKDev p, int tiles_x, int tile0 = 0)
+// the step of tile t; s_*: the workgroup's LDS arrays of RH x RW entries each
+template <bool MRT, bool TRACER, typename SH, int TR>
+__device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int t, double *s_phi, double *s_ux, double *s_uy, uint8_t *s_fluid)
 {
     constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
     constexpr int RW = SH::RW, RH = SH::RH;
     constexpr double W[9] = LBMPM_D2Q9_W;
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
-    __shared__ double s_phi[RH * RW];
-    __shared__ double s_ux[RH * RW];
-    __shared__ double s_uy[RH * RW];
-    __shared__ uint8_t s_fluid[RH * RW];
-
-    // XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch order);
-    // give every XCD a contiguous band of tiles so halo rows are shared inside one L2.
-    const int t = tile0 + xcd_tile(blockIdx.x, gridDim.x);
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
 
@@ -786,6 +778,34 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 #endif
 }
 #undef PH2
+
+template <bool MRT, bool TRACER, typename SH, int TR = (TRACER ? 1 : 0)>
+__global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rk2d_fused(RKDev p, int tiles_x, int tile0 = 0)
+{
+    __shared__ double s_phi[SH::RH * SH::RW];
+    __shared__ double s_ux[SH::RH * SH::RW];
+    __shared__ double s_uy[SH::RH * SH::RW];
+    __shared__ uint8_t s_fluid[SH::RH * SH::RW];
+    // XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch order);
+    // give every XCD a contiguous band of tiles so halo rows are shared inside one L2.
+    rk2d_fused_tile<MRT, TRACER, SH, TR>(p, tiles_x, tile0 + xcd_tile(blockIdx.x, gridDim.x), s_phi, s_ux, s_uy, s_fluid);
+}
+
+// The tracer step as ONE launch: tiles below lo_end and from hi_begin on (the tile rows whose region holds a lattice row a boundary rule
+// touches, see launch_fused_tracer) take the re-summing variant TR = 1, the others TR = 0 -- a workgroup-uniform branch over two copies of
+// the step.  As three launches the two boundary ones, a few dozen tiles each, cost a whole tile's latency chain apiece (2 x 16 us of c4's
+// 0.42 ms) behind the interior launch.
+template <bool MRT, typename SH>
+__global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rk2d_fused_tracer(RKDev p, int tiles_x, int lo_end, int hi_begin)
+{
+    __shared__ double s_phi[SH::RH * SH::RW];
+    __shared__ double s_ux[SH::RH * SH::RW];
+    __shared__ double s_uy[SH::RH * SH::RW];
+    __shared__ uint8_t s_fluid[SH::RH * SH::RW];
+    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    if (t < lo_end || t >= hi_begin) rk2d_fused_tile<MRT, true, SH, 1>(p, tiles_x, t, s_phi, s_ux, s_uy, s_fluid);
+    else rk2d_fused_tile<MRT, true, SH, 0>(p, tiles_x, t, s_phi, s_ux, s_uy, s_fluid);
+}
 
 // ---------------------------------------------------------------- perturbation operator, fused
 // [SurfaceTension] SurfaceTensionType = 'Perturbation': the loop of RKColorGradientLBM.runRKColorGradient2DPerturbation
@@ -1184,16 +1204,8 @@ void launch_fused_tracer(lbmpm_rk2d *c, const RKDev &p)
         else rk2d_fused<false, true, SH, 1><<<g, b, 0, c->stream>>>(p, tiles_x, 0);
         return;
     }
-    const dim3 gi(tiles_x * (tiles_y - n_lo - n_hi)), glo(tiles_x * n_lo), ghi(tiles_x * n_hi);
-    if (mrt) {
-        rk2d_fused<true, true, SH, 0><<<gi, b, 0, c->stream>>>(p, tiles_x, tiles_x * n_lo);
-        rk2d_fused<true, true, SH, 1><<<glo, b, 0, c->stream>>>(p, tiles_x, 0);
-        rk2d_fused<true, true, SH, 1><<<ghi, b, 0, c->stream>>>(p, tiles_x, tiles_x * (tiles_y - n_hi));
-    } else {
-        rk2d_fused<false, true, SH, 0><<<gi, b, 0, c->stream>>>(p, tiles_x, tiles_x * n_lo);
-        rk2d_fused<false, true, SH, 1><<<glo, b, 0, c->stream>>>(p, tiles_x, 0);
-        rk2d_fused<false, true, SH, 1><<<ghi, b, 0, c->stream>>>(p, tiles_x, tiles_x * (tiles_y - n_hi));
-    }
+    if (mrt) rk2d_fused_tracer<true, SH><<<g, b, 0, c->stream>>>(p, tiles_x, tiles_x * n_lo, tiles_x * (tiles_y - n_hi));
+    else rk2d_fused_tracer<false, SH><<<g, b, 0, c->stream>>>(p, tiles_x, tiles_x * n_lo, tiles_x * (tiles_y - n_hi));
 }
 
 int launch_step(lbmpm_rk2d *c, bool diag, bool timed)

@@ -12,7 +12,7 @@ import re
 import sys
 
 WORKLOADS = {"rk3dq_fused": "c5 512x512x512", "rk3dc_fused": "c5 512x512x512", "rk3d_fused": "c5 512x512x512", "rk3d_collide": "c5 512x512x512",
-             "rk3d_phase_field": "c5 512x512x512", "rk2d_fused": None, "sc2d_fused": "c3 2048x2048"}
+             "rk3d_phase_field": "c5 512x512x512", "rk2d_fused": None, "rk2d_fused_tracer": None, "sc2d_fused": "c3 2048x2048"}
 
 
 def parse(path, counter):
@@ -61,6 +61,9 @@ def collect(fetch, write, kernels, suffix, only=None):
         w = write.get(name, (0, 0.0))[1]
         rec = {"launches_profiled": n, "fetch_size_kb": f, "write_size_kb": w,
                "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0, "workload": WORKLOADS[k]}
+        if k == "rk2d_fused_tracer":      # the tracer step of c4 (one launch since round 4; earlier: three of rk2d_fused<.., true, ..>)
+            k = "rk2d_fused"
+            name = name.replace("rk2d_fused_tracer<", "rk2d_fused<true, true, ")
         if k == "rk2d_fused":             # c2 (no tracer) and c4 (tracer) are different template instances
             rec["workload"] = "c4 2048x2048" if re.search(r"rk2d_fused<(true|false), true", name) else "c2 1024x1024"
             k = "rk2d_fused" if rec["workload"].startswith("c2") else "rk2d_fused[tracer]"
