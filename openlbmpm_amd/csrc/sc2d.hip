@@ -469,7 +469,11 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
     if (p.diag) { p.diag[D_UEQ * p.plane + idx] = ueqx; p.diag[(D_UEQ + 1) * p.plane + idx] = ueqy; }
     }
     // non-fluid lanes of a line that holds fluid write zeros into their dead slots (full-line stores)
-    store_pairs<STREAM>(p.fout, p.plane, idx, f0, f1);
+    // (the node index is rebuilt from an opaque copy of the thread id: kept across the collision it was the one value sc2d_fused<MRT>
+    // spilled under its 128-register cap; `line` implies the node lies inside the lattice)
+    unsigned tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));
+    store_pairs<STREAM>(p.fout, p.plane, (size_t)(ty0 + (int)(tq / TW)) * p.pitch + (tx0 + (int)(tq % TW)), f0, f1);
 }
 
 // ---------------------------------------------------------------- schemes 8 / 10: two sweeps per step

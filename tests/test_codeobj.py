@@ -46,6 +46,12 @@ def test_default_2d_kernels_do_not_spill(kernels):
     assert len(pert) == 2
     for m in plain + pert:
         assert m[".vgpr_count"] <= 128 and m[".private_segment_fixed_size"] == 0 and m[".vgpr_spill_count"] == 0
+    # the bench kernels of c3 (sc2d_fused, all four instances) and c4 (the MRT tracer step of the default shape): no scratch either
+    sc = [m for n, m in kernels.items() if "sc2d_fusedIL" in n]
+    tr = [m for n, m in kernels.items() if "rk2d_fused_tracerILb1E" in n and "FusedShapeILi8ELi1" in n]
+    assert len(sc) == 4 and len(tr) == 1
+    for m in sc + tr:
+        assert m[".vgpr_count"] <= 128 and m[".private_segment_fixed_size"] == 0 and m[".vgpr_spill_count"] == 0
 
 
 def test_the_product_library_holds_no_knock_out_switches():
