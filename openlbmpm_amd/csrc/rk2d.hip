@@ -560,7 +560,8 @@ __device__ unsigned long long rk2d_ph[256 * 16];
 #endif
 // the step of tile t; s_*: the workgroup's LDS arrays of RH x RW entries each
 template <bool MRT, bool TRACER, typename SH, int TR>
-__device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int t, double *s_phi, double *s_ux, double *s_uy, uint8_t *s_fluid)
+__device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int t, double *s_phi, double *s_ux, double *s_uy, double *s_gx, double *s_gy,
+                                                uint16_t *s_list, int *s_cnt, uint8_t *s_fluid)
 {
     constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
     constexpr int RW = SH::RW, RH = SH::RH;
@@ -573,6 +574,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
     unsigned long long ph_acc[8] = {};
     unsigned long long ph_t = __builtin_readcyclecounter();
 #endif
+    if (tid == 0) *s_cnt = 0;                  // the queue of phase C (three barriers from here)
     // fluid mask of the region (issued first so that the wait for it leaves the population
     // loads below in flight)
     bool any_solid = false;
@@ -672,7 +674,12 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
     PH2(3)
 
     // ---- phase C: colour gradient, wetting correction, unit normal
-    auto gradient_at = [&](int ri, int x, int y, double &gx, double &gy) {
+    // C1: every fluid node of tile + 1 gets its gradient; a node without solid neighbours gets its unit normal at once, one with is
+    //     queued (raw gradient in s_gx / s_gy, its region index in s_list).
+    // C2: the queue is worked off by as many lanes as it has entries.  The wetting correction is some 450 fp64 instructions (acos, sin,
+    //     cos + four square roots); done in place it is paid by every wave that holds ONE node next to a solid -- in a porous medium all
+    //     of them, with a third of their lanes.  Same arithmetic per node, bit for bit.
+    auto raw_gradient = [&](int ri, double &gx, double &gy) -> bool {
         double ax = 0., ay = 0.;
         bool solid_nb = false;
 #pragma unroll
@@ -685,22 +692,22 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         }
         gx = 3. * ax; gy = 3. * ay;
         if (solid_nb) {
-            const size_t idx = (size_t)y * p.pitch + x;
-            wetting_fix(p, p.ns[idx], p.ns[p.plane + idx], gx, gy);
+            s_gx[ri] = gx; s_gy[ri] = gy;
+            s_list[atomicAdd(s_cnt, 1)] = (uint16_t)ri;
+        } else {
+            double ux, uy;
+            unit_normal(p.wetting, gx, gy, ux, uy);
+            s_ux[ri] = ux; s_uy[ri] = uy;
         }
-        double ux, uy;
-        unit_normal(p.wetting, gx, gy, ux, uy);
-        s_ux[ri] = ux; s_uy[ri] = uy;
+        return solid_nb;
     };
     double gx[NT], gy[NT];
+    bool wet[NT];
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
         const int ri = (H + ly + m * TY) * RW + H + lx;
-        gx[m] = 0.; gy[m] = 0.;
-        if (s_fluid[ri]) {
-            const int x = wrapm(tx0 + lx, p.nx), y = wrapm(ty0 + ly + m * TY, p.ny);
-            gradient_at(ri, x, y, gx[m], gy[m]);
-        }
+        gx[m] = 0.; gy[m] = 0.; wet[m] = false;
+        if (s_fluid[ri]) wet[m] = raw_gradient(ri, gx[m], gy[m]);
     }
     constexpr int NRING = 2 * (TW + 2) + 2 * TH;
     for (int n = tid; n < NRING; n += THREADS) {
@@ -710,9 +717,19 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         else { mloc -= TW + 2; ry = H + mloc / 2; rx = (mloc & 1) ? H + TW : H - 1; }
         const int ri = ry * RW + rx;
         if (!s_fluid[ri]) continue;
-        const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
         double a, c;
-        gradient_at(ri, x, y, a, c);
+        raw_gradient(ri, a, c);
+    }
+    if (need3) __syncthreads();            // (a region without solids queues nothing: no barrier, an empty loop)
+    for (int k = tid, nq = need3 ? *s_cnt : 0; k < nq; k += THREADS) {
+        const int ri = s_list[k];
+        const int x = wrapm(tx0 - H + ri % RW, p.nx), y = wrapm(ty0 - H + ri / RW, p.ny);
+        const size_t idx = (size_t)y * p.pitch + x;
+        double a = s_gx[ri], c = s_gy[ri], ux, uy;
+        wetting_fix(p, p.ns[idx], p.ns[p.plane + idx], a, c);
+        unit_normal(p.wetting, a, c, ux, uy);
+        s_ux[ri] = ux; s_uy[ri] = uy;
+        s_gx[ri] = a; s_gy[ri] = c;
     }
     PH2(4)
     __syncthreads();
@@ -732,6 +749,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         for (int i = 0; i < 9; ++i) { fR[i] = 0.; fB[i] = 0.; }
         if (act[m]) {
         const int ri = (H + ly + m * TY) * RW + H + lx;
+        if (wet[m]) { gx[m] = s_gx[ri]; gy[m] = s_gy[ri]; }
         const double ux = s_ux[ri], uy = s_uy[ri];
         double pyx = 0., pxy = 0., px = 0., py = 0.;
 #pragma unroll
@@ -785,10 +803,14 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     __shared__ double s_phi[SH::RH * SH::RW];
     __shared__ double s_ux[SH::RH * SH::RW];
     __shared__ double s_uy[SH::RH * SH::RW];
+    __shared__ double s_gx[SH::RH * SH::RW];
+    __shared__ double s_gy[SH::RH * SH::RW];
+    __shared__ uint16_t s_list[(SH::TW + 2) * (SH::TH + 2)];
+    __shared__ int s_cnt;
     __shared__ uint8_t s_fluid[SH::RH * SH::RW];
     // XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch order);
     // give every XCD a contiguous band of tiles so halo rows are shared inside one L2.
-    rk2d_fused_tile<MRT, TRACER, SH, TR>(p, tiles_x, tile0 + xcd_tile(blockIdx.x, gridDim.x), s_phi, s_ux, s_uy, s_fluid);
+    rk2d_fused_tile<MRT, TRACER, SH, TR>(p, tiles_x, tile0 + xcd_tile(blockIdx.x, gridDim.x), s_phi, s_ux, s_uy, s_gx, s_gy, s_list, &s_cnt, s_fluid);
 }
 
 // The tracer step as ONE launch: tiles below lo_end and from hi_begin on (the tile rows whose region holds a lattice row a boundary rule
@@ -801,10 +823,14 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     __shared__ double s_phi[SH::RH * SH::RW];
     __shared__ double s_ux[SH::RH * SH::RW];
     __shared__ double s_uy[SH::RH * SH::RW];
+    __shared__ double s_gx[SH::RH * SH::RW];
+    __shared__ double s_gy[SH::RH * SH::RW];
+    __shared__ uint16_t s_list[(SH::TW + 2) * (SH::TH + 2)];
+    __shared__ int s_cnt;
     __shared__ uint8_t s_fluid[SH::RH * SH::RW];
     const int t = xcd_tile(blockIdx.x, gridDim.x);
-    if (t < lo_end || t >= hi_begin) rk2d_fused_tile<MRT, true, SH, 1>(p, tiles_x, t, s_phi, s_ux, s_uy, s_fluid);
-    else rk2d_fused_tile<MRT, true, SH, 0>(p, tiles_x, t, s_phi, s_ux, s_uy, s_fluid);
+    if (t < lo_end || t >= hi_begin) rk2d_fused_tile<MRT, true, SH, 1>(p, tiles_x, t, s_phi, s_ux, s_uy, s_gx, s_gy, s_list, &s_cnt, s_fluid);
+    else rk2d_fused_tile<MRT, true, SH, 0>(p, tiles_x, t, s_phi, s_ux, s_uy, s_gx, s_gy, s_list, &s_cnt, s_fluid);
 }
 
 // ---------------------------------------------------------------- perturbation operator, fused
