@@ -571,7 +571,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
 
 #if defined(LBMPM_DEV) && defined(LBMPM_PHASES2D)
-    unsigned long long ph_acc[8] = {};
+    unsigned long long ph_acc[12] = {};
     unsigned long long ph_t = __builtin_readcyclecounter();
 #endif
     if (tid == 0) *s_cnt = 0;                  // the queue of phase C (three barriers from here)
@@ -774,7 +774,13 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
             p.diag[idx] = vx; p.diag[p.plane + idx] = vy; p.diag[2 * p.plane + idx] = K;
             p.phi[idx] = phi; p.G[idx] = gx[m]; p.G[p.plane + idx] = gy[m];
         }
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES2D)
+        unsigned long long tr_t0 = __builtin_readcyclecounter();
+#endif
         if (TRACER) tracer_substep(p, x, y, sn[m], rR[m], vx, vy, gx[m], gy[m]);
+#if defined(LBMPM_DEV) && defined(LBMPM_PHASES2D)
+        ph_acc[8] += __builtin_readcyclecounter() - tr_t0;
+#endif
         collide<MRT>(p, f, rR[m], rB[m], phi, vx, vy, Fx, Fy);
         recolor(p.beta, f, rR[m], rB[m], gx[m], gy[m], fR, fB);
         }
@@ -790,7 +796,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
     PH2(7)
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *slot = rk2d_ph + (blockIdx.x & 255) * 16;
-        for (int k = 0; k < 8; ++k) atomicAdd(slot + k, ph_acc[k]);
+        for (int k = 0; k < 12; ++k) atomicAdd(slot + k, ph_acc[k]);
         atomicAdd(slot + 15, 1ull);
     }
 #endif

@@ -26,4 +26,5 @@ for name, build, size in (("c2", bench.build_c2, 1024), ("c2@2048", bench.build_
     for k, nm in enumerate(names):
         print("   %-36s %8.0f" % (nm, a[k] / n))
     print("   %-36s %8.0f" % ("sum", a[:8].sum() / n))
+    print("   %-36s %8.0f" % ("(of D: the tracer sub-step)", a[8] / n))
     s.close()
