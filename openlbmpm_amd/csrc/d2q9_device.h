@@ -78,6 +78,48 @@ __device__ __forceinline__ void pull_node(const P &p, int x, int y, double f0[9]
     }
 }
 
+// Loads as asm statements: absent from hipcc's s_waitcnt bookkeeping, and not split up or consumed one by one by its scheduler; the
+// caller counts them and waits itself (LBMPM_VMCNT(n): at most n younger loads still in flight), then fences the registers.
+typedef double lbmpm_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lbmpm_d2 asm_ld16(const void *a) { lbmpm_d2 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(a)); return v; }
+__device__ __forceinline__ double asm_ld8_nt(const void *a) { double v; asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(a)); return v; }
+__device__ __forceinline__ unsigned asm_ldu8(const void *a) { unsigned v; asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(a)); return v; }
+// s_waitcnt simm16 of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]; the other two counters left alone
+#define LBMPM_VMCNT(n) (((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+template <typename P>
+__device__ __forceinline__ void pull_issue_asm(const P &p, int x, int y, lbmpm_d2 q[9])
+{
+    constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
+    const size_t idx = (size_t)y * p.pitch + x;
+    const lbmpm_d2 *f2 = reinterpret_cast<const lbmpm_d2 *>(p.fin);
+    const bool first = p.first != 0;          // the state is already "post-streaming" (initial condition): read in place
+    q[0] = asm_ld16(f2 + idx);
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int xs = wrapi(x - EX[i], p.nx), ys = wrapi(y - EY[i], p.ny);
+        const size_t s = first ? idx : (size_t)ys * p.pitch + xs;
+        q[i] = asm_ld16(f2 + i * p.plane + s);
+    }
+}
+// the bounce-back links of a node whose nine pairs pull_issue_asm fetched (sn: its solid-neighbour byte, 0 in the first step)
+template <typename P>
+__device__ __forceinline__ void pull_patch(const P &p, int x, int y, unsigned sn, double f0[9], double f1[9])
+{
+    constexpr int OPP[9] = LBMPM_D2Q9_OPP;
+    if (sn != 0) {
+        const size_t idx = (size_t)y * p.pitch + x;
+        const double2 *f2 = reinterpret_cast<const double2 *>(p.fin);
+#pragma unroll
+        for (int i = 1; i < 9; ++i) {
+            const int o = OPP[i];
+            if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
+                const double2 v = f2[o * p.plane + idx];
+                f0[i] = v.x; f1[i] = v.y;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ double sum9(const double f[9])
 {   // accumulation order of calMacroDensityRKGPU2D / calFluidRhoGPU and of the ghost kernels
     double r = 0.;

@@ -565,6 +565,11 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
 {
     constexpr int TW = SH::TW, TH = SH::TH, NT = SH::NT, H = SH::H, TY = SH::TY, THREADS = SH::THREADS;
     constexpr int RW = SH::RW, RH = SH::RH;
+#ifdef RK2D_NO_EAGER
+    constexpr bool EAGER = false;
+#else
+    constexpr bool EAGER = (NT == 1);
+#endif
     constexpr double W[9] = LBMPM_D2Q9_W;
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
@@ -575,6 +580,113 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
     unsigned long long ph_t = __builtin_readcyclecounter();
 #endif
     if (tid == 0) *s_cnt = 0;                  // the queue of phase C (three barriers from here)
+    constexpr int NHALO = 2 * H * RW + 2 * H * TH;
+    auto halo_cell = [&](int n, int &rx, int &ry) {
+        int mloc = n;
+        if (mloc < H * RW) { ry = mloc / RW; rx = mloc % RW; }
+        else if ((mloc -= H * RW) < H * RW) { ry = RH - H + mloc / RW; rx = mloc % RW; }
+        else { mloc -= H * RW; ry = H + mloc / (2 * H); const int c = mloc % (2 * H); rx = c < H ? c : RW - 2 * H + c; }
+    };
+    double fT[NT][9], rR[NT], rB[NT], Fpx[NT], Fpy[NT];
+    unsigned sn[NT];
+    bool act[NT];
+    int hrx = 0, hry = 0, hx = 0, hy = 0, hys = 0;          // the first halo node of this thread (all of them when NHALO <= THREADS)
+    bool hdo = false;
+    double hR[9], hB[9];
+    bool need3;
+    if constexpr (EAGER) {
+        // ---- phase A, own node first: the loads of the region's fluid mask and, with no flag known yet, the own node's solid-neighbour
+        // byte, lagged force and nine population pairs go out together (a lane on a solid node reads finite junk it never uses), so the
+        // volume of the own pulls moves through the CU's address path while the mask is on its way -- the halo pulls, which need the mask,
+        // follow the barrier as before, with half the burst.  asm loads + hand-counted waits: written in C++ hipcc consumes the early pulls
+        // one by one as they arrive to save registers (13 % slower than not hoisting them at all).
+        using namespace lbmpm_dev;
+        constexpr int NFL = (RH * RW + THREADS - 1) / THREADS;
+        static_assert(NT == 1, "one own node per lane");
+        unsigned flr[NFL];
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int n = min(tid + k * THREADS, RH * RW - 1);
+            const int rx = n % RW, ry = n / RW;
+            const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
+            flr[k] = asm_ldu8(p.flags + (size_t)y * p.pitch + x);
+        }
+        lbmpm_d2 q[9], hq[9];
+        unsigned hsn = 0;
+        const int x = tx0 + lx, y = ty0 + ly;
+        const bool inside = (x < p.nx) && (y < p.ny);
+        // nodes beyond the lattice edge of a partial tile are periodic images of real nodes and serve as halo for the valid part of the tile
+        const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);
+        const int ys = node_source_row<true>(p, yw);
+        {
+            const size_t idx = (size_t)yw * p.pitch + xw;
+            sn[0] = asm_ldu8(p.solidnbr + idx);
+            Fpx[0] = asm_ld8_nt(p.F + idx);                  // read once, by its own node
+            Fpy[0] = asm_ld8_nt(p.F + p.plane + idx);
+            pull_issue_asm(p, xw, ys, q);
+        }
+        __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(12));          // the mask has landed; the own node's 12 loads may still be out
+        bool any_solid = false;
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            asm volatile("" : "+v"(flr[k]));
+            const int n = tid + k * THREADS;
+            if (n < RH * RW) {
+                const int rx = n % RW, ry = n / RW;
+                const uint8_t fl = flr[k] & 1;
+                s_fluid[n] = fl;
+                if (!fl && rx >= 1 && rx < RW - 1 && ry >= 1 && ry < RH - 1) any_solid = true;
+            }
+        }
+        need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
+        PH2(0)
+        const bool first = p.first != 0;
+        if (tid < NHALO) {
+            halo_cell(tid, hrx, hry);
+            hdo = s_fluid[hry * RW + hrx] && (need3 || !(hrx == 0 || hrx == RW - 1 || hry == 0 || hry == RH - 1));
+        }
+        if (__ballot(hdo) != 0ull) {               // wave-uniform: the count of loads in flight must be known
+            if (hdo) {
+                hx = wrapm(tx0 - H + hrx, p.nx); hy = wrapm(ty0 - H + hry, p.ny);
+                hys = node_source_row<true>(p, hy);
+                hsn = asm_ldu8(p.solidnbr + (size_t)hys * p.pitch + hx);
+                pull_issue_asm(p, hx, hys, hq);
+            }
+            __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(10));      // the own node's loads have landed, the halo node's 10 are out
+        } else __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(0));
+        asm volatile("" : "+v"(sn[0]), "+v"(Fpx[0]), "+v"(Fpy[0]));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(q[i]));
+        {
+            const int ri = (H + ly) * RW + H + lx;
+            const bool fluid = s_fluid[ri];
+            act[0] = inside && fluid;
+            if (!fluid) { sn[0] = 0; Fpx[0] = 0.; Fpy[0] = 0.; }
+            if (fluid) {
+                double fR[9], fB[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { fR[i] = q[i].x; fB[i] = q[i].y; }
+                const unsigned psn = first ? 0u : (ys == yw ? sn[0] : (unsigned)p.solidnbr[(size_t)ys * p.pitch + xw]);
+                pull_patch(p, xw, ys, psn, fR, fB);
+                node_finish<true, TR>(p, yw, ys, fR, fB, rR[0], rB[0]);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) fT[0][i] = fR[i] + fB[i];
+                s_phi[ri] = (rR[0] - rB[0]) / (rR[0] + rB[0]);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(0));
+        asm volatile("" : "+v"(hsn));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(hq[i]));
+        if (hdo) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { hR[i] = hq[i].x; hB[i] = hq[i].y; }
+            pull_patch(p, hx, hys, first ? 0u : hsn, hR, hB);
+            double a, c;
+            node_finish<true, TR>(p, hy, hys, hR, hB, a, c);
+            s_phi[hry * RW + hrx] = (a - c) / (a + c);
+        }
+    } else {
     // fluid mask of the region (issued first so that the wait for it leaves the population
     // loads below in flight)
     bool any_solid = false;
@@ -587,22 +699,9 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
     }
 
     // ---- phase A: the node's own pull and the pull of "its" halo node are issued back to back -- one memory round trip, not two
-    const bool need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
+    need3 = __syncthreads_or(any_solid);   // also publishes s_fluid
     PH2(0)
-    constexpr int NHALO = 2 * H * RW + 2 * H * TH;
-    auto halo_cell = [&](int n, int &rx, int &ry) {
-        int mloc = n;
-        if (mloc < H * RW) { ry = mloc / RW; rx = mloc % RW; }
-        else if ((mloc -= H * RW) < H * RW) { ry = RH - H + mloc / RW; rx = mloc % RW; }
-        else { mloc -= H * RW; ry = H + mloc / (2 * H); const int c = mloc % (2 * H); rx = c < H ? c : RW - 2 * H + c; }
-    };
-    double fT[NT][9], rR[NT], rB[NT], Fpx[NT], Fpy[NT];
-    unsigned sn[NT];
-    bool act[NT];
     // the first halo node of this thread (all of them when NHALO <= THREADS)
-    int hrx = 0, hry = 0, hx = 0, hy = 0, hys = 0;
-    bool hdo = false;
-    double hR[9], hB[9];
     if (tid < NHALO) {
         halo_cell(tid, hrx, hry);
         hdo = s_fluid[hry * RW + hrx] && (need3 || !(hrx == 0 || hrx == RW - 1 || hry == 0 || hry == RH - 1));
@@ -639,6 +738,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         double a, c;
         node_finish<true, TR>(p, hy, hys, hR, hB, a, c);
         s_phi[hry * RW + hrx] = (a - c) / (a + c);
+    }
     }
     for (int n = tid + THREADS; n < NHALO; n += THREADS) {          // shapes whose halo outnumbers the threads
         int rx, ry;
