@@ -952,14 +952,25 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // for SRT, before it for MRT).  A workgroup owns a 64 x 8 tile and recomputes the phase field on tile + 1.
 
 // post-streaming, post-boundary-rows state of node (x, y): both colour lattices and their densities
-__device__ __forceinline__ void pert_node_state(const RKDev &p, const PertDev &q, int x, int y, double fR[9], double fB[9], double &rhoR, double &rhoB)
+// in two halves (source row -- pull -- boundary rows and densities), so that a thread can have the pulls of two nodes in flight
+__device__ __forceinline__ int pert_source_row(const RKDev &p, int y)
 {
     // the ghost rows copy their neighbour row's state; the convective outlet (convectiveOutletGPU / Ghost2GPU / Ghost3GPU, A:700-784)
     // hands row 3's streamed state down to the rows 2, 1, 0
     int ys = y == p.ny - 1 ? p.ny - 2 : y;
     if (p.outlet == LBMPM_OUTLET_PRESSURE) { if (y == 0) ys = 1; }
     else if (y <= 2) ys = 3;
+    return ys;
+}
+__device__ __forceinline__ void pert_node_finish(const RKDev &p, const PertDev &q, int ys, double fR[9], double fB[9], double &rhoR, double &rhoB);
+__device__ __forceinline__ void pert_node_state(const RKDev &p, const PertDev &q, int x, int y, double fR[9], double fB[9], double &rhoR, double &rhoB)
+{
+    const int ys = pert_source_row(p, y);
     pull_node(p, x, ys, fR, fB);
+    pert_node_finish(p, q, ys, fR, fB, rhoR, rhoB);
+}
+__device__ __forceinline__ void pert_node_finish(const RKDev &p, const PertDev &q, int ys, double fR[9], double fB[9], double &rhoR, double &rhoB)
+{
     if (p.outlet == LBMPM_OUTLET_PRESSURE && ys == 1) {       // A:1008-1039 (blue first, then red)
         {
             double *b = fB;
@@ -1024,34 +1035,82 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, PertDev q, int tiles
     const int t = xcd_tile(blockIdx.x, gridDim.x);
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
-    for (int n = tid; n < RH * RW; n += THREADS) {
-        const int x = wrapm(tx0 - 1 + n % RW, p.nx), y = wrapm(ty0 - 1 + n / RW, p.ny);
-        s_fluid[n] = p.flags[(size_t)y * p.pitch + x] & 1;
-    }
-    // own node and "its" rim node: both pulls back to back
+    // All flags (the region's mask, the own node's, the rim node's) and -- before any of them is known -- the own node's solid-neighbour
+    // byte and nine population pairs go out together; the rim node's pulls follow when the flags are in (rk2d_fused, phase A: the volume
+    // of the own pulls moves while the flags are on their way; asm loads, hand-counted waits).
+    using namespace lbmpm_dev;
+    constexpr int NFL = (RH * RW + THREADS - 1) / THREADS;
+    constexpr int NRIM = 2 * RW + 2 * TH;
     const int x = tx0 + lx, y = ty0 + ly;
     const bool inside = x < p.nx && y < p.ny;
     const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);       // (partial tiles: periodic images serve as rim)
     const size_t idx = (size_t)yw * p.pitch + xw;
-    const bool fluid = p.flags[idx] & 1, act = inside && fluid;
-    double fR[9], fB[9], rR = 1., rB = 1.;
-    if (fluid) pert_node_state(p, q, xw, yw, fR, fB, rR, rB);
-    constexpr int NRIM = 2 * RW + 2 * TH;
-    int hr = -1;
-    double hphi = 0.;
+    int hr = -1, hx = 0, hy = 0;
     if (tid < NRIM) {
         int rx, ry;
         if (tid < RW) { ry = 0; rx = tid; }
         else if (tid < 2 * RW) { ry = RH - 1; rx = tid - RW; }
         else { const int k = tid - 2 * RW; ry = 1 + k / 2; rx = (k & 1) ? RW - 1 : 0; }
-        const int hx = wrapm(tx0 - 1 + rx, p.nx), hy = wrapm(ty0 - 1 + ry, p.ny);
-        if (p.flags[(size_t)hy * p.pitch + hx] & 1) {
-            double a[9], b[9], ra, rb;
-            pert_node_state(p, q, hx, hy, a, b, ra, rb);
-            hr = ry * RW + rx;
-            hphi = (ra - rb) / (ra + rb);
-        }
+        hx = wrapm(tx0 - 1 + rx, p.nx); hy = wrapm(ty0 - 1 + ry, p.ny);
+        hr = ry * RW + rx;
     }
+    unsigned flr[NFL];
+#pragma unroll
+    for (int k = 0; k < NFL; ++k) {
+        const int n = min(tid + k * THREADS, RH * RW - 1);
+        const int xx = wrapm(tx0 - 1 + n % RW, p.nx), yy = wrapm(ty0 - 1 + n / RW, p.ny);
+        flr[k] = asm_ldu8(p.flags + (size_t)yy * p.pitch + xx);
+    }
+    unsigned ofl = asm_ldu8(p.flags + idx);
+    unsigned hfl = asm_ldu8(p.flags + (size_t)hy * p.pitch + hx);          // (lanes without a rim node: node (0, 0), ignored)
+    const int ys = pert_source_row(p, yw);
+    unsigned osn = asm_ldu8(p.solidnbr + (size_t)ys * p.pitch + xw);
+    lbmpm_d2 pq[9], hq[9];
+    pull_issue_asm(p, xw, ys, pq);
+    __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(10));              // the flags are in; the own node's 10 loads may still be out
+    asm volatile("" : "+v"(ofl), "+v"(hfl));
+#pragma unroll
+    for (int k = 0; k < NFL; ++k) {
+        asm volatile("" : "+v"(flr[k]));
+        const int n = tid + k * THREADS;
+        if (n < RH * RW) s_fluid[n] = flr[k] & 1;
+    }
+    const bool fluid = ofl & 1, act = inside && fluid;
+    const bool hdo = hr >= 0 && (hfl & 1);
+    const bool first = p.first != 0;
+    int hys = 0;
+    unsigned hsn = 0;
+    if (__ballot(hdo) != 0ull) {                               // wave-uniform: the count of loads in flight must be known
+        if (hdo) {
+            hys = pert_source_row(p, hy);
+            hsn = asm_ldu8(p.solidnbr + (size_t)hys * p.pitch + hx);
+            pull_issue_asm(p, hx, hys, hq);
+        }
+        __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(10));          // the own node's loads have landed, the rim node's 10 are out
+    } else __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(0));
+    asm volatile("" : "+v"(osn));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(pq[i]));
+    double fR[9], fB[9], rR = 1., rB = 1.;
+    if (fluid) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { fR[i] = pq[i].x; fB[i] = pq[i].y; }
+        pull_patch(p, xw, ys, first ? 0u : osn, fR, fB);
+        pert_node_finish(p, q, ys, fR, fB, rR, rB);
+    }
+    __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(0));
+    asm volatile("" : "+v"(hsn));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(hq[i]));
+    double hphi = 0.;
+    if (hdo) {
+        double a[9], b[9], ra, rb;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { a[i] = hq[i].x; b[i] = hq[i].y; }
+        pull_patch(p, hx, hys, first ? 0u : hsn, a, b);
+        pert_node_finish(p, q, hys, a, b, ra, rb);
+        hphi = (ra - rb) / (ra + rb);
+    } else hr = -1;
     const int ri = (1 + ly) * RW + 1 + lx;
     if (fluid) s_phi[ri] = (rR - rB) / (rR + rB);
     if (hr >= 0) s_phi[hr] = hphi;
