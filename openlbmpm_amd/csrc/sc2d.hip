@@ -269,30 +269,31 @@ __device__ __forceinline__ void sc_force_iso(const SCDev &p, int x, int y, const
 // M from SimpleD2Q9.py:107-124 (rows mutually orthogonal => M^-1 = M^T diag(1/|row|^2)).
 __device__ __forceinline__ void mrt_relax(const double d[9], double itau, double out[9])
 {
-    constexpr int M[9][9] = {{1, 1, 1, 1, 1, 1, 1, 1, 1},      {-4, -1, -1, -1, -1, 2, 2, 2, 2},
-                             {4, -2, -2, -2, -2, 1, 1, 1, 1},  {0, 1, 0, -1, 0, 1, -1, -1, 1},
-                             {0, -2, 0, 2, 0, 1, -1, -1, 1},   {0, 0, 1, 0, -1, 1, 1, -1, -1},
-                             {0, 0, -2, 0, 2, 1, 1, -1, -1},   {0, 1, -1, 1, -1, 0, 0, 0, 0},
-                             {0, 0, 0, 0, 0, 1, -1, 1, -1}};
-    constexpr double INV_N2[9] = {1. / 9., 1. / 36., 1. / 36., 1. / 6., 1. / 12., 1. / 6., 1. / 12., 1. / 4., 1. / 4.};
-    const double S[9] = {1., 0.6, 1.5, 1., 1.2, 1., 1.2, itau, itau};
-    double m[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        double t = 0.;
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            if (M[i][j] != 0) t += (double)M[i][j] * d[j];
-        m[i] = t * (S[i] * INV_N2[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        double t = 0.;
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            if (M[j][i] != 0) t += (double)M[j][i] * m[j];
-        out[i] = t;
-    }
+    // The two products by M and M^T with the sums every row shares formed once (the matrix entries are 0, +-1, +-2, +-4: 118
+    // multiply-adds as written out row by row, 60 additions and 12 scalings this way).  Same algebra, another order of the additions.
+    const double a = (d[1] + d[2]) + (d[3] + d[4]), b = (d[5] + d[6]) + (d[7] + d[8]);
+    const double px = d[1] - d[3], py = d[2] - d[4];
+    const double qx = (d[5] - d[6]) - (d[7] - d[8]), qy = (d[5] + d[6]) - (d[7] + d[8]);
+    const double m0 = ((d[0] + a) + b) * (1. / 9.);
+    const double m1 = ((2. * b - a) - 4. * d[0]) * (0.6 / 36.);
+    const double m2 = ((4. * d[0] - 2. * a) + b) * (1.5 / 36.);
+    const double m3 = (px + qx) * (1. / 6.);
+    const double m4 = (qx - 2. * px) * (1.2 / 12.);
+    const double m5 = (py + qy) * (1. / 6.);
+    const double m6 = (qy - 2. * py) * (1.2 / 12.);
+    const double m7 = ((d[1] - d[2]) + (d[3] - d[4])) * (itau * (1. / 4.));
+    const double m8 = ((d[5] - d[6]) + (d[7] - d[8])) * (itau * (1. / 4.));
+    const double A = (m0 - m1) - 2. * m2, B = (m0 + 2. * m1) + m2;
+    const double X = m3 - 2. * m4, Y = m5 - 2. * m6, U = m3 + m4, V = m5 + m6;
+    out[0] = (m0 - 4. * m1) + 4. * m2;
+    out[1] = (A + X) + m7;
+    out[2] = (A + Y) - m7;
+    out[3] = (A - X) + m7;
+    out[4] = (A - Y) - m7;
+    out[5] = (B + (U + V)) + m8;
+    out[6] = (B - (U - V)) - m8;
+    out[7] = (B - (U + V)) + m8;
+    out[8] = (B + (U - V)) - m8;
 }
 
 // Force chain + collision of one node, both components; f0/f1 updated in place.
