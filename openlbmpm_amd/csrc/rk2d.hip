@@ -520,9 +520,13 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
             double ve = 0., vp = 0.;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
+                // (the D2Q5 moment matrix of lbmpm_rk2d_tracer_configure as constants: the products by 0 and 1 fold away -- adding
+                // 0 * x to a finite sum changes nothing -- and 25 doubles leave the scalar registers)
+                constexpr double M5[25] = {1, 1, 1, 1, 1,   0, 1, -1, 0, 0,   0, 0, 0, 1, -1,   4, -1, -1, -1, -1,   0, 1, 1, -1, -1};
+                if (M5[5 * j + k] == 0.) continue;
                 const double eq = C * W5[k] * (1. + 3. * ((double)VX5[k] * vx + (double)VY5[k] * vy));
-                ve += p.trM[5 * j + k] * eq;
-                vp += g[k] * p.trM[5 * j + k];
+                ve += M5[5 * j + k] * eq;
+                vp += g[k] * M5[5 * j + k];
             }
             diff[j] = vp - ve;
         }
