@@ -86,6 +86,10 @@ __device__ __forceinline__ double asm_ld8_nt(const void *a) { double v; asm vola
 __device__ __forceinline__ unsigned asm_ldu8(const void *a) { unsigned v; asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(a)); return v; }
 // s_waitcnt simm16 of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]; the other two counters left alone
 #define LBMPM_VMCNT(n) (((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+// Head of a region guarded by `if (__ballot(c) != 0) { if (c) {` : states that some lane of the wave always enters.  hipcc still emits an
+// s_cbranch_execz around the region; openlbmpm_amd/inflight.py (the static check of the asm loads in flight, tests/test_codeobj.py)
+// drops that infeasible edge where it finds this comment in the assembly.
+#define LBMPM_TAKEN asm volatile("; lbmpm-taken")
 template <typename P>
 __device__ __forceinline__ void pull_issue_asm(const P &p, int x, int y, lbmpm_d2 q[9])
 {

@@ -651,6 +651,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         }
         if (__ballot(hdo) != 0ull) {               // wave-uniform: the count of loads in flight must be known
             if (hdo) {
+                LBMPM_TAKEN;                       // (a lane of this wave is here: openlbmpm_amd/inflight.py drops hipcc's all-lanes-off branch)
                 hx = wrapm(tx0 - H + hrx, p.nx); hy = wrapm(ty0 - H + hry, p.ny);
                 hys = node_source_row<true>(p, hy);
                 hsn = asm_ldu8(p.solidnbr + (size_t)hys * p.pitch + hx);
@@ -1086,6 +1087,7 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, PertDev q, int tiles
     unsigned hsn = 0;
     if (__ballot(hdo) != 0ull) {                               // wave-uniform: the count of loads in flight must be known
         if (hdo) {
+            LBMPM_TAKEN;
             hys = pert_source_row(p, hy);
             hsn = asm_ldu8(p.solidnbr + (size_t)hys * p.pitch + hx);
             pull_issue_asm(p, hx, hys, hq);

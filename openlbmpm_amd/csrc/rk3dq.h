@@ -654,6 +654,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             // a row segment without a fluid cell: flag 3 ("nothing here"), so that its neighbours' rows can still be taken as single-colour
             if (live && own && lx == 0) p.pur_out[row_index(p, z, y, tx)] = 3u;
         } else if (active) {
+            LBMPM_TAKEN;          // (the ballot above: a lane of this wave is here -- every path of the step passes a wait for the pulls)
             double gx = 0., gy = 0., gz = 0.;
 #pragma unroll
             for (int i = 1; i < Q; ++i) {

@@ -66,3 +66,52 @@ def test_the_product_library_holds_no_knock_out_switches():
         assert name not in blob, name.decode()
     src = open(os.path.join(ROOT, "openlbmpm_amd", "build.py")).read()
     assert src.count("LBMPM_DEV") >= 1 and '"-DLBMPM_DEV"' in src.split("def build(")[0] and "LBMPM_DEV" not in src.split("def build(")[1]
+
+
+# ---- the asm loads that the kernels wait for by hand (openlbmpm_amd/inflight.py)
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    """hipcc -S of rk2d.hip and rk3d.hip with the product's flags (side by side; ~1 min)"""
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from openlbmpm_amd import build
+    if not (shutil.which(build.HIPCC) or os.path.exists(build.HIPCC)):
+        pytest.skip("no hipcc here")
+    out = tmp_path_factory.mktemp("asm")
+    flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+
+    def one(name):
+        dst = str(out / (name + ".s"))
+        subprocess.check_call([build.HIPCC] + flags + ["-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
+                                                       os.path.join(build.CSRC, name + ".hip"), "-o", dst], stderr=subprocess.DEVNULL)
+        return open(dst).read()
+    with ThreadPoolExecutor(2) as ex:
+        a, b = ex.map(one, ("rk2d", "rk3d"))
+    return {"rk2d": a, "rk3d": b}
+
+
+def test_nothing_touches_a_register_an_asm_load_has_in_flight(device_asm, kernels):
+    """rk2d_fused / rk2d_fused_tracer / rk2dp_fused (every tile shape with one node per lane) and rk3dq_fused issue their own-node pulls
+    as asm statements outside hipcc's s_waitcnt bookkeeping and wait by hand.  Between issue and wait the compiler may not read, copy,
+    spill or re-use a destination register -- nothing in the language says so (advisor, round 4: "safe by register-allocator luck"),
+    hence this look at the assembly: openlbmpm_amd/inflight.py walks every kernel's control-flow graph and must find no such
+    instruction.  The instances that keep a value in scratch (the SRT tracer step: one double, spilled and reloaded inside the
+    collision) are held to the same: a spill of a register in flight would be a finding."""
+    from openlbmpm_amd import inflight
+    rep = inflight.check(device_asm["rk2d"])
+    names = list(rep)
+    assert sum("rk2d_fusedI" in n for n in names) == 10 and sum("rk2d_fused_tracerI" in n for n in names) == 4 and sum("rk2dp_fusedI" in n for n in names) == 2, names
+    for n, (nloads, bad, _harmless) in rep.items():
+        assert nloads >= 22 and not bad, (n, bad[:4])
+    # kernels of the 2-D file that use scratch at all: none of them may be an instance with asm loads, except the SRT tracer step
+    scratch = [n for n, m in kernels.items() if ("rk2d_fused" in n or "rk2dp_fused" in n) and m[".private_segment_fixed_size"]]
+    assert all(n not in rep or "rk2d_fused_tracerILb0E" in n for n in scratch), scratch
+    rep3 = inflight.check(device_asm["rk3d"], "rk3dq_fused")
+    assert len(rep3) == 4
+    for n, (nloads, bad, _h) in rep3.items():
+        assert nloads == 38
+        if "rk3dq_fusedILb1E" in n:                 # the first step's instances: walked to the end
+            assert not bad, (n, bad[:4])
+        else:                                       # the walk of the steady-state instances exceeds its state budget (19 per-direction
+            assert all(k < 0 and t == inflight.GAVE_UP for k, t in bad), (n, bad[:4])      # branches x lanes-off variants): no finding either
