@@ -383,7 +383,7 @@ def main():
             storage = d.slab.storage_info()
             ms_dom = tm["step_ms"] * steps
             ms_total = wall * 1e3
-            mine = dict(rank=rank, planes=[int(z0), int(z0 + nzl)], fluid_nodes=int(d.slab.num_fluid_nodes),
+            mine = dict(rank=rank, planes=[int(z0), int(z0 + nzl)], fluid_nodes=int(d.slab.num_fluid_nodes), device="cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank)),
                         **{k: (round(v, 5) if isinstance(v, float) else v) for k, v in tm.items()})
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
@@ -467,6 +467,12 @@ def main():
                                             "ncclSend / ncclRecv pairs, RCCL" if dist.get_backend() == "nccl" else
                                             "REHEARSAL on the %s backend, host-staged copies: not an RCCL measurement" % dist.get_backend())}[
                                         "callback" not in per_rank[0].get("transport", "callback")],
+                                    # which transport every rank ended on, and what set-up tried before it with the verdict of each candidate
+                                    # (RK3DDistributed.transport_log: connect errors, the probe's mismatch count, the watchdog's message) --
+                                    # enough to diagnose a run that fell back without a second lease on the node
+                                    "transport_per_rank": [r.get("transport", "?") for r in per_rank],
+                                    "transport_candidates": [{"rank": r.get("rank"), "tried": r.get("transport_log", [])} for r in per_rank
+                                                             if r.get("rank") == 0 or r.get("transport_log") != per_rank[0].get("transport_log")],
                                     "host_enqueue_us_per_step": [r.get("host_enqueue_us_per_step") for r in per_rank],
                                     "boundary_depth_planes": int(os.environ.get("LBMPM_RK3D_BOUNDARY", "2")),
                                     "partition": partition,

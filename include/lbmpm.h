@@ -37,7 +37,8 @@ typedef enum lbmpm_status {
     LBMPM_ERR_HIP = -2,         /* a HIP runtime call failed                   */
     LBMPM_ERR_NOMEM = -3,       /* device or host allocation failed            */
     LBMPM_ERR_STATE = -4,       /* call not valid in the context's state       */
-    LBMPM_ERR_UNSUPPORTED = -5  /* option exists in the reference but not here */
+    LBMPM_ERR_UNSUPPORTED = -5, /* option exists in the reference but not here */
+    LBMPM_ERR_TIMEOUT = -6      /* a neighbour rank's face message did not arrive in time (lbmpm_rk3d_sync_deadline) */
 } lbmpm_status;
 
 const char *lbmpm_last_error(void);
@@ -421,6 +422,14 @@ int lbmpm_transport_selftest(int kind, int device, int64_t bytes, const char *li
 int lbmpm_rk3d_step(lbmpm_rk3d *ctx, int64_t nsteps);
 int lbmpm_rk3d_step_timed(lbmpm_rk3d *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
 int lbmpm_rk3d_sync(lbmpm_rk3d *ctx);
+/* The steady-state watchdog of a slab run.  Like lbmpm_rk3d_sync, but the host polls the context's streams and gives up after
+ * `seconds`: the stream then sits in a wait for a neighbour's face message that will not come (the neighbour died, or hangs itself).
+ * IPC transport: the host releases the waits (lbmpm_rk3d_ipc_release_waits), drains the streams and returns LBMPM_ERR_TIMEOUT;
+ * RCCL transport: the communicator is aborted (ncclCommAbort) first.  The context's lattice state is garbage afterwards and the
+ * transport is marked dead (every later exchange returns LBMPM_ERR_TIMEOUT): the caller reports and ends the run, or sets it up
+ * again from a record.  Every rank of a run whose neighbour chain is broken reaches its own deadline: call it on all of them.
+ * (The reference has no multi-GPU path; this belongs to the slab decomposition of SURVEY section 8e.) */
+int lbmpm_rk3d_sync_deadline(lbmpm_rk3d *ctx, double seconds);
 /* device pointer + size of a halo buffer (LBMPM_RK3D_BUF_*) for the caller's transport */
 int lbmpm_rk3d_buffer(lbmpm_rk3d *ctx, int which, void **device_ptr, int64_t *bytes);
 /* owned planes [nz_local][ny][nx] */

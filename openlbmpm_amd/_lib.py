@@ -24,7 +24,7 @@ class LbmpmError(RuntimeError):
 
 
 # status codes of include/lbmpm.h
-OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6
 
 
 class RK2DConfig(C.Structure):
@@ -143,6 +143,7 @@ _SIGNATURES = {
     "lbmpm_rk3d_step": (C.c_int, [C.c_void_p, C.c_int64]),
     "lbmpm_rk3d_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),
     "lbmpm_rk3d_sync": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3d_sync_deadline": (C.c_int, [C.c_void_p, C.c_double]),
     "lbmpm_rk3d_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), I64P]),
     "lbmpm_rk3d_get_field": (C.c_int, [C.c_void_p, C.c_int, F64P]),
     "lbmpm_rk3d_num_fluid_nodes": (C.c_int64, [C.c_void_p]),

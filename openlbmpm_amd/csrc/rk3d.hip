@@ -1337,16 +1337,19 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
 
 extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
 {
-    if (c) { c->tx.disconnect(); if (c->probe_bad) (void)hipFree(c->probe_bad); }
     if (!c) return;
+    // first the device and the streams (unpack kernels or peer copies may still be queued on them), then the transport's memory
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
+    c->tx.disconnect();
+    if (c->probe_bad) (void)hipFree(c->probe_bad);
     for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->purA, (void *)c->purB, (void *)c->trace, (void *)c->slotq, (void *)c->phi, (void *)c->diag,
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
     c->pool.destroy();
     c->slab_pool.destroy();
-    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); (void)hipEventDestroy(c->ev_dep); (void)hipEventDestroy(c->ev_done); }
+    if (c->aux) { (void)hipStreamDestroy(c->aux); (void)hipEventDestroy(c->ev_dep); (void)hipEventDestroy(c->ev_done); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1700,14 +1703,17 @@ extern "C" int lbmpm_rk3d_rccl_connect(lbmpm_rk3d *c, const void *id, int rank, 
 {
     LBMPM_REQUIRE(c && id && nranks >= 1 && rank >= 0 && rank < nranks, "lbmpm_rk3d_rccl_connect: bad argument");
     int rc = tx_shape(c);
-    if (rc != LBMPM_OK) return rc;
-    LBMPM_REQUIRE((c->tx.has_below ? rank > 0 : true) && (c->tx.has_above ? rank + 1 < nranks : true),
-                  "lbmpm_rk3d_rccl_connect: rank %d of %d has no rank %s it, but the slab has a neighbour there", rank, nranks, c->tx.has_below && rank == 0 ? "below" : "above");
+    if (rc != LBMPM_OK) { c->tx.disconnect(); return rc; }
+    if (!((c->tx.has_below ? rank > 0 : true) && (c->tx.has_above ? rank + 1 < nranks : true))) {
+        set_error("lbmpm_rk3d_rccl_connect: rank %d of %d has no rank %s it, but the slab has a neighbour there", rank, nranks, c->tx.has_below && rank == 0 ? "below" : "above");
+        c->tx.disconnect();           // (the landing area of tx_shape: every error path behind it gives it back)
+        return LBMPM_ERR_INVALID;
+    }
     rc = c->tx.rccl.open(librccl_path);
     if (rc != LBMPM_OK) { c->tx.disconnect(); return rc; }
     slabtx::Rccl::UniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (hipSetDevice(c->cfg.device) != hipSuccess) { set_error("hipSetDevice(%d) failed", c->cfg.device); c->tx.disconnect(); return LBMPM_ERR_HIP; }
     const int e = c->tx.rccl.CommInitRank(&c->tx.comm, nranks, uid, rank);
     if (e != 0) { set_error("ncclCommInitRank(rank %d of %d): %s", rank, nranks, c->tx.rccl.GetErrorString(e)); c->tx.disconnect(); return LBMPM_ERR_HIP; }
     c->tx.rank = rank; c->tx.nranks = nranks; c->tx.peer_up = rank + 1; c->tx.peer_dn = rank - 1;
@@ -2104,6 +2110,54 @@ extern "C" int lbmpm_rk3d_sync(lbmpm_rk3d *c)
     LBMPM_REQUIRE(c, "null context");
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     return LBMPM_OK;
+}
+
+// The steady-state watchdog (include/lbmpm.h): host-side polling, so that a stream stuck in hipStreamWaitValue64 / flag_wait / an
+// ncclRecv on a neighbour that died does not hang this process for good.
+extern "C" int lbmpm_rk3d_sync_deadline(lbmpm_rk3d *c, double seconds)
+{
+    LBMPM_REQUIRE(c && seconds > 0., "lbmpm_rk3d_sync_deadline: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    struct timespec t0, t;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    auto idle = [&]() -> int {          // 1 idle, 0 busy, -1 error
+        hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess && c->aux) e = hipStreamQuery(c->aux);
+        if (e == hipSuccess) return 1;
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+        set_error("lbmpm_rk3d_sync_deadline: %s", hipGetErrorString(e));
+        return -1;
+    };
+    unsigned spins = 0;
+    for (;;) {
+        const int s = idle();
+        if (s == 1) return LBMPM_OK;
+        if (s < 0) return LBMPM_ERR_HIP;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > seconds) break;
+        if (++spins > 2000) { struct timespec nap = {0, 200000}; nanosleep(&nap, nullptr); }       // busy for the first moments, then 0.2 ms naps
+    }
+    const int kind = c->tx.connected ? c->tx.kind : LBMPM_TRANSPORT_NONE;
+    if (kind == LBMPM_TRANSPORT_IPC) {
+        const unsigned long long big[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        (void)hipMemcpy(c->tx.flags, big, sizeof big, hipMemcpyHostToDevice);       // every wait of this context returns
+        c->tx.dead = true;
+        (void)hipStreamSynchronize(c->stream);
+        if (c->aux) (void)hipStreamSynchronize(c->aux);
+    } else if (kind == LBMPM_TRANSPORT_RCCL) {
+        c->tx.dead = true;
+        if (c->tx.comm && c->tx.rccl.CommAbort) { (void)c->tx.rccl.CommAbort(c->tx.comm); c->tx.comm = nullptr; }
+        (void)hipStreamSynchronize(c->stream);
+        if (c->aux) (void)hipStreamSynchronize(c->aux);
+    }
+    c->halo_valid = false;
+    c->interior_pending = false;
+    set_error("lbmpm_rk3d_sync_deadline: the slab's streams were still busy after %.1f s -- %s (rank with planes %d..%d of %d)", seconds,
+              kind == LBMPM_TRANSPORT_IPC ? "a neighbour's face message did not arrive; the waits were released, the lattice state is void" :
+              kind == LBMPM_TRANSPORT_RCCL ? "a neighbour did not answer; the communicator was aborted, the lattice state is void" :
+                                             "no in-library transport is connected: nothing was released",
+              c->cfg.z_offset, c->cfg.z_offset + c->cfg.nz_local - 1, c->cfg.nz_global);
+    return LBMPM_ERR_TIMEOUT;
 }
 
 extern "C" int lbmpm_rk3d_buffer(lbmpm_rk3d *c, int which, void **ptr, int64_t *bytes)

@@ -3,6 +3,8 @@
 // time.  Included by rk3d.hip (host code only; the two one-lane kernels are the fallback of devices without stream value operations).
 #include <dlfcn.h>
 #include <unistd.h>
+#include <time.h>
+#include <stdio.h>
 
 namespace slabtx {
 
@@ -22,9 +24,28 @@ struct IpcBlob {
     uint64_t bytes_from_below, bytes_from_above;      // message sizes this rank expects (0: no neighbour there)
     uint64_t land_ptr, flags_ptr;         // addresses in the owner's process (used by slabs of the same process)
     hipIpcMemHandle_t land, flags;
+    uint64_t nonce;                       // drawn once per process: "same pid" alone does not mean "same process" (ranks in separate
+                                          // containers or pid namespaces of one node commonly share a pid, e.g. 1)
 };
 static_assert(sizeof(IpcBlob) <= LBMPM_IPC_BLOB_BYTES, "blob size is part of the ABI");
 constexpr uint32_t BLOB_MAGIC = 0x4c424d50u;     // "LBMP"
+constexpr uint32_t BLOB_VERSION = 2;
+
+// one random 64-bit value per process (from /dev/urandom; pid, clock and an address as the fallback)
+inline uint64_t process_nonce()
+{
+    static uint64_t n = 0;
+    if (n) return n;
+    uint64_t v = 0;
+    if (FILE *f = fopen("/dev/urandom", "rb")) { if (fread(&v, sizeof v, 1, f) != 1) v = 0; fclose(f); }
+    if (!v) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        v = ((uint64_t)getpid() << 32) ^ (uint64_t)ts.tv_nsec ^ ((uint64_t)ts.tv_sec << 20) ^ reinterpret_cast<uint64_t>(&n);
+    }
+    n = v | 1ull;
+    return n;
+}
 
 // the part of librccl this file calls (types as in rccl.h: opaque communicator, 128-byte id, int enums)
 struct Rccl {
@@ -33,6 +54,7 @@ struct Rccl {
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;          // optional (present in every RCCL since 2.4): tears a communicator down without its peers
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -58,6 +80,7 @@ struct Rccl {
         Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
         Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(dl, "ncclCommAbort"));
         if (!ok) { set_error("RCCL transport: librccl lacks ncclSend / ncclRecv / ncclCommInitRank"); close(); return LBMPM_ERR_UNSUPPORTED; }
         return LBMPM_OK;
     }
@@ -82,6 +105,7 @@ struct Transport {
     bool mapped[2] = {false, false};          // peer_* came from hipIpcOpenMemHandle (to be closed)
     bool value_ops = false;
     bool connected = false;
+    bool dead = false;                        // the steady-state watchdog gave up on a neighbour (lbmpm_rk3d_sync_deadline)
     // ---- RCCL
     Rccl rccl;
     void *comm = nullptr;
@@ -98,6 +122,7 @@ struct Transport {
         const size_t m = from_below > from_above ? from_below : from_above;
         slot = (m + 4095) / 4096 * 4096;
         LBMPM_HIP_TRY(hipSetDevice(dev));
+        if (land) { (void)hipFree(land); land = nullptr; }          // (a connect that failed half way and is tried again)
         // The landing area is FINE-GRAINED memory where the device offers it: with the IPC transport a neighbour GPU's copy engine writes it
         // over xGMI, past this GPU's L2, and ordinary (coarse-grained) memory is coherent at kernel boundaries only -- a slot is reused
         // every second step, and a line of it left in L2 by the previous unpack would be served stale.  (The probe at set-up would catch
@@ -126,7 +151,8 @@ struct Transport {
         (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev);
         value_ops = can != 0 && !getenv("LBMPM_IPC_FLAG_KERNELS");      // (the variable forces the one-lane kernels: test coverage of the fallback)
         memset(blob, 0, sizeof *blob);
-        blob->magic = BLOB_MAGIC; blob->version = 1; blob->pid = (int32_t)getpid(); blob->device = dev;
+        blob->magic = BLOB_MAGIC; blob->version = BLOB_VERSION; blob->pid = (int32_t)getpid(); blob->device = dev;
+        blob->nonce = process_nonce();
         blob->slot_bytes = slot; blob->bytes_from_below = below ? bytes_from_below : 0; blob->bytes_from_above = above ? bytes_from_above : 0;
         blob->land_ptr = reinterpret_cast<uint64_t>(land); blob->flags_ptr = reinterpret_cast<uint64_t>(flags);
         LBMPM_HIP_TRY(hipIpcGetMemHandle(&blob->land, land));
@@ -137,7 +163,7 @@ struct Transport {
 
     int ipc_open(int side, const IpcBlob *b, size_t my_bytes)
     {
-        if (b->magic != BLOB_MAGIC || b->version != 1) { set_error("lbmpm_rk3d_ipc_connect: not a blob of lbmpm_rk3d_ipc_init"); return LBMPM_ERR_INVALID; }
+        if (b->magic != BLOB_MAGIC || b->version != BLOB_VERSION) { set_error("lbmpm_rk3d_ipc_connect: not a blob of lbmpm_rk3d_ipc_init"); return LBMPM_ERR_INVALID; }
         const uint64_t theirs = side == 0 ? b->bytes_from_above : b->bytes_from_below;     // the rank below receives "from above"
         if (theirs != my_bytes) {
             set_error("lbmpm_rk3d_ipc_connect: the rank %s expects %llu bytes per message, this rank sends %llu (different cuts or lattices)",
@@ -146,7 +172,7 @@ struct Transport {
         }
         if (b->slot_bytes < my_bytes) { set_error("lbmpm_rk3d_ipc_connect: the neighbour's slots are smaller than the message"); return LBMPM_ERR_INVALID; }
         peer_slot[side] = (size_t)b->slot_bytes;
-        if (b->pid == (int32_t)getpid()) {          // a slab of this very process: plain pointers (peer access if it lives on another GPU)
+        if (b->pid == (int32_t)getpid() && b->nonce == process_nonce()) {      // a slab of this very process: plain pointers (peer access if it lives on another GPU)
             if (b->device != device) {
                 const hipError_t e = hipDeviceEnablePeerAccess(b->device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("hipDeviceEnablePeerAccess(%d): %s", b->device, hipGetErrorString(e)); return LBMPM_ERR_HIP; }
@@ -175,6 +201,7 @@ struct Transport {
     int exchange(hipStream_t st, const double *send_up, const double *send_dn, const double **from_below, const double **from_above)
     {
         if (!connected) { set_error("the slab's transport is not connected"); return LBMPM_ERR_STATE; }
+        if (dead) { set_error("the slab's transport was given up by the watchdog (a neighbour did not answer): disconnect and set up the run again"); return LBMPM_ERR_TIMEOUT; }
         seq += 1;
         const unsigned par = (unsigned)(seq & 1ull);
         if (kind == LBMPM_TRANSPORT_IPC) {
@@ -221,12 +248,15 @@ struct Transport {
             if (mapped[s]) { (void)hipIpcCloseMemHandle(peer_land[s]); (void)hipIpcCloseMemHandle(peer_flags[s]); }
             peer_land[s] = nullptr; peer_flags[s] = nullptr; mapped[s] = false;
         }
-        if (comm) { (void)rccl.CommDestroy(comm); comm = nullptr; }
+        if (comm) {         // dead: a peer is known not to answer (the watchdog fired) -- ncclCommDestroy would wait for it
+            if (dead && rccl.CommAbort) (void)rccl.CommAbort(comm); else if (!dead) (void)rccl.CommDestroy(comm);
+            comm = nullptr;
+        }
         rccl.close();
         if (land) (void)hipFree(land);
         if (flags) (void)hipFree(flags);
         land = nullptr; flags = nullptr;
-        kind = LBMPM_TRANSPORT_NONE; connected = false; seq = 0;
+        kind = LBMPM_TRANSPORT_NONE; connected = false; seq = 0; dead = false;
         (void)hipGetLastError();
     }
 };

@@ -1136,6 +1136,10 @@ extern "C" int lbmpm_sc2d_set_pdf(lbmpm_sc2d *c, const double *pdf0, const doubl
         }
     LBMPM_HIP_TRY(hipMemcpyAsync(c->fA, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     LBMPM_HIP_TRY(hipMemsetAsync(c->F, 0, 4 * c->plane * sizeof(double), c->stream));
+    // the fold buffers too: rows 54, 55 carry the outlet's F_y of lattice row 3, which the step writes for fluid nodes only -- a column
+    // whose row-3 node is solid would keep the previous run's value on a re-initialised context (before round 4 it read the zeroed F)
+    LBMPM_HIP_TRY(hipMemsetAsync(c->foldA, 0, (size_t)(18 * 3 + 2) * c->pitch * sizeof(double), c->stream));
+    LBMPM_HIP_TRY(hipMemsetAsync(c->foldB, 0, (size_t)(18 * 3 + 2) * c->pitch * sizeof(double), c->stream));
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     c->streamed = false; c->initialised = false; c->diag_valid = false; c->steps = 0;
     return LBMPM_OK;

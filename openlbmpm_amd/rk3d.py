@@ -188,8 +188,13 @@ class RK3DSlab:
         check(self._L.lbmpm_rk3d_step_timed(self._h, int(n), C.byref(a), C.byref(b)), "step_timed")
         return a.value, b.value
 
-    def sync(self):
-        check(self._L.lbmpm_rk3d_sync(self._h), "sync")
+    def sync(self, deadline_s=None):
+        """wait for the slab's streams; with deadline_s the library's watchdog (lbmpm_rk3d_sync_deadline): LbmpmError with status
+        LBMPM_ERR_TIMEOUT (-6) when a neighbour's face message does not arrive in time -- the waits are released, the state is void"""
+        if deadline_s is None:
+            check(self._L.lbmpm_rk3d_sync(self._h), "sync")
+        else:
+            check(self._L.lbmpm_rk3d_sync_deadline(self._h, float(deadline_s)), "lbmpm_rk3d_sync_deadline")
 
     def get(self, name):
         out = np.empty((self.nzl, self.ny, self.nx), dtype=np.float64)
@@ -322,6 +327,7 @@ class RK3DDistributed:
         self.rank, self.world, self.group = dist.get_rank(group), dist.get_world_size(group), group
         z0, n = self.partition(is_domain_global, self.world, balance, plane_cost)[self.rank]
         self.z0, self.nzl = z0, n
+        import os
         import torch
         self._torch = torch
         # every collective of this class and of its callers (NaN verdict, calibration, all_gather_object) runs on the process's
@@ -332,13 +338,24 @@ class RK3DDistributed:
         self.slab = RK3DSlab(is_domain_global, z0, n, params, device)
         self.stream = torch.cuda.Stream(device)
         self.slab.use_torch_stream(self.stream)
-        import os
         want = transport or os.environ.get("LBMPM_TRANSPORT", "auto")
         if want not in ("auto", "ipc", "rccl", "callback"):
             raise ValueError("transport must be 'auto', 'ipc', 'rccl' or 'callback'")
         self.transport_note, self.host_us_per_step = "", 0.0
-        if self.world > 1 and want != "callback" and self.slab.one_exchange:
-            self._connect(want)
+        # what set-up tried, in order: [{"transport": kind, "ok": bool, "why": text}] -- the diagnosis of a run that ended on another
+        # transport than expected (bench.py --gpus N prints it per rank)
+        self.transport_log = []
+        self.deadline_s = float(os.environ.get("LBMPM_SLAB_DEADLINE_S", "120"))      # steady-state watchdog of sync() / observe()
+        if self.world > 1 and want != "callback":
+            if not self.slab.one_exchange:
+                # (decided by the lattice and the environment, i.e. alike on every rank: no collective needed to agree on it)
+                why = "the %s storage has two exchanges per step; the in-library transports carry the one-exchange face message of the 23-value storage" % self.slab.dominant_kernel
+                self.transport_log.append(dict(transport=want, ok=False, why=why))
+                if want != "auto":
+                    raise RuntimeError("transport %r was asked for, but %s" % (want, why))
+                self.transport_note = "callback (%s); " % why
+            else:
+                self._connect(want)
 
     def _agree(self, ok):
         """True when every rank says ok (MIN over the group; a collective on host objects: works on every backend)"""
@@ -349,9 +366,9 @@ class RK3DDistributed:
 
     def _connect(self, want):
         """Connect the in-library transport; every rank takes the same decision (a transport that works on some ranks only is dropped
-        by all).  IPC is tried with a self-test under a deadline: one face message each way, released by the host if it does not
-        arrive -- a stuck wait must not hang the job before it has begun."""
-        import time
+        by all).  Each candidate is tried with a self-test under a deadline: patterned face messages each way; a stuck wait (IPC) is
+        released by the host, a stuck communicator (RCCL) aborted -- a hang must not stop the job before it has begun.  Every candidate's
+        verdict goes to self.transport_log."""
         import torch.distributed as dist
         s, err = self.slab, None
         for kind in (("ipc", "rccl") if want == "auto" and dist.get_backend(self.group) == "nccl" else (("ipc",) if want in ("auto", "ipc") else ("rccl",))):
@@ -370,8 +387,8 @@ class RK3DDistributed:
                         s.ipc_connect(blobs[self.rank - 1] if self.rank > 0 else None, blobs[self.rank + 1] if self.rank + 1 < self.world else None)
                     except Exception as e:  # noqa: BLE001
                         ok, err = False, e
-                else:
-                    ok = False
+                elif ok:
+                    ok, err = False, "ipc_init failed on rank(s) %s" % [r for r, b in enumerate(blobs) if b is None]
             else:
                 box = [None]
                 if self.rank == 0:
@@ -381,6 +398,15 @@ class RK3DDistributed:
                         err = e
                 dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
                 ok = box[0] is not None
+                if not ok and err is None:
+                    err = "rank 0 could not make a unique id"
+                # ipc_open compares the neighbours' message sizes; ncclSend / ncclRecv would silently pair messages of different
+                # lengths (different cuts or lattices on two ranks): compare them here, before the blocking collective
+                sizes = [None] * self.world
+                dist.all_gather_object(sizes, self._face_bytes(), group=self.group)
+                for r in range(self.world - 1):
+                    if sizes[r]["up"] != sizes[r + 1]["from_below"] or sizes[r + 1]["down"] != sizes[r]["from_above"]:
+                        ok, err = False, "ranks %d and %d disagree on the size of the face message across their cut (%s vs %s)" % (r, r + 1, sizes[r], sizes[r + 1])
                 if self._agree(ok):         # ncclCommInitRank is a blocking collective: enter it only if every rank will
                     try:
                         s.rccl_connect(box[0], self.rank, self.world, _torch_librccl())
@@ -388,36 +414,53 @@ class RK3DDistributed:
                         ok, err = False, e
                 else:
                     ok = False
-            if self._agree(ok) and self._self_test(kind):
+            connected = self._agree(ok)
+            tested, why = (self._self_test(kind) if connected else (False, "not tried"))
+            if connected and tested:
+                self.transport_log.append(dict(transport=kind, ok=True, why="connected; probe of 6 patterned messages each way compared equal on every rank"))
                 self.transport_note = "in-library "
                 return
             try:
                 s.transport_disconnect()
             except Exception:               # noqa: BLE001
                 pass
-            self.transport_note = "%s did not connect on every rank%s; " % (kind, " (%s)" % err if err else "")
+            reason = ("connect: %s" % err) if err else ("another rank could not connect" if not connected else "self-test: %s" % why)
+            self.transport_log.append(dict(transport=kind, ok=False, why=str(reason)))
+            self.transport_note = "%s did not connect on every rank (%s); " % (kind, reason)
             if want != "auto":
-                raise RuntimeError("transport %r could not be connected on every rank%s" % (kind, ": %s" % err if err else ""))
+                raise RuntimeError("transport %r could not be connected on every rank: %s" % (kind, reason))
+
+    def _face_bytes(self):
+        """sizes of this rank's four face messages (bytes; 0 where it has no neighbour), from its halo buffers"""
+        out = {}
+        for key, name, there in (("up", "f_send_up", self.rank + 1 < self.world), ("down", "f_send_down", self.rank > 0),
+                                 ("from_below", "f_recv_below", self.rank > 0), ("from_above", "f_recv_above", self.rank + 1 < self.world)):
+            b = self.slab.buffer(name) if there else None
+            out[key] = int(b.numel() * b.element_size()) if b is not None else 0
+        return out
 
     def _self_test(self, kind, deadline_s=20.0):
         """six patterned messages each way between the real neighbours through the new transport (lbmpm_rk3d_transport_probe: every
-        landing slot three times, compared on the receiving GPU); IPC: under a deadline, a stuck wait is released by the host"""
-        import time
+        landing slot three times, compared on the receiving GPU), under a deadline for EITHER transport: the library's watchdog
+        releases a stuck IPC wait / aborts a stuck communicator.  -> (every rank passed, this rank's verdict as text)"""
         s = self.slab
         try:
             with self._torch.cuda.stream(self.stream):
                 s.transport_probe(6)
-        except Exception:                   # noqa: BLE001 -- this rank could not even enqueue: tell the others (same collective)
-            return self._agree(False)
-        done = self.stream.query()
-        t0 = time.perf_counter()
-        while not done and (kind != "ipc" or time.perf_counter() - t0 < deadline_s):
-            time.sleep(0.002)
-            done = self.stream.query()
-        if not done:
-            s.ipc_release_waits()
-            self.stream.synchronize()
-        return self._agree(done and s.transport_probe_result() == 0)
+        except Exception as e:              # noqa: BLE001 -- this rank could not even enqueue: tell the others (same collective)
+            self._agree(False)
+            return False, "could not enqueue the probe: %s" % e
+        why = "ok"
+        try:
+            s.sync(deadline_s=deadline_s)
+            bad = s.transport_probe_result()
+            mine = bad == 0
+            if not mine:
+                why = "%d doubles arrived wrong" % bad
+        except Exception as e:              # noqa: BLE001 -- the watchdog fired (or the stream failed)
+            mine, why = False, str(e)
+        every = self._agree(mine)
+        return every, (why if not mine else ("ok here, failed on another rank" if not every else "ok"))
 
     @property
     def transport(self):
@@ -508,6 +551,7 @@ class RK3DDistributed:
         t["bytes_sent_per_step"] = faces                    # populations (5 x 2 colours, fluid cells of the face plane) + phi plane
         t["bytes_per_face"] = max(faces.values()) if faces else 0
         t["transport"] = (self.transport_note + self.slab.transport) if self.world > 1 else "none (one slab)"
+        t["transport_log"] = list(self.transport_log)
         t["host_enqueue_us_per_step"] = round(getattr(self, "host_us_per_step", 0.0), 1)
         return t
 
@@ -515,10 +559,17 @@ class RK3DDistributed:
         with self._torch.cuda.stream(self.stream):
             self._halo_f()
             self.slab.phase_field(diagnostics=True)
-        self.stream.synchronize()
+        self.sync()
 
-    def sync(self):
-        self.stream.synchronize()
+    def sync(self, deadline_s=None):
+        """Wait for this rank's work.  With an in-library transport the wait is the library's watchdog (lbmpm_rk3d_sync_deadline,
+        `deadline_s` or self.deadline_s = LBMPM_SLAB_DEADLINE_S, default 120 s): a rank whose neighbour died mid-run raises
+        LbmpmError (status -6) after the deadline instead of hanging in hipStreamWaitValue64 for good -- and so does every other
+        rank of the broken chain, each at its own deadline."""
+        if self.world > 1 and self.slab.transport != "callback":
+            self.slab.sync(deadline_s=self.deadline_s if deadline_s is None else deadline_s)
+        else:
+            self.stream.synchronize()
 
     def close(self):
         self.slab.close()

@@ -375,6 +375,96 @@ def test_two_process_slab_run_equals_single_process(tmp_path, nx, transport, env
             assert t["transport"] == "callback"
 
 
+def test_a_rank_whose_neighbour_dies_mid_run_raises_at_its_deadline(tmp_path):
+    """The steady-state watchdog of the IPC transport (lbmpm_rk3d_sync_deadline; round 4 had a deadline at set-up only: a rank that
+    died mid-run left its neighbour's stream in hipStreamWaitValue64 for good).  Two OS processes on this GPU over the in-library IPC
+    transport; rank 1 leaves without a word (os._exit) after 5 steps, rank 0 goes on stepping: its stream blocks in the wait for a
+    message that never comes, sync() gives up after its 3 s deadline with status LBMPM_ERR_TIMEOUT, the released context refuses
+    further exchanges with the same status and can be closed.  The same with the one-lane flag kernels."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "k.py"
+    script.write_text('''
+import json, os, sys, time
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from test_rk3d_gpu import _case
+from openlbmpm_amd import _lib
+from openlbmpm_amd.rk3d import RK3DDistributed
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+dom, rR, rB = _case(nx=64, ny=18, nz=41, seed=9)
+d = RK3DDistributed(dom, device=0, transport="ipc")
+d.deadline_s = 3.0
+d.set_density(rR, rB)
+d.step(5); d.sync()
+if rank == 1:
+    os._exit(0)                      # dies without closing anything
+out = dict(transport=d.transport)
+t0 = time.perf_counter()
+try:
+    d.step(40)                       # enqueues 40 steps: the second one waits for rank 1's message
+    d.sync()
+    out["raised"] = None
+except _lib.LbmpmError as e:
+    out["raised"], out["status"], out["seconds"] = str(e), e.status, time.perf_counter() - t0
+try:
+    d.step(1)
+    out["after"] = None
+except _lib.LbmpmError as e:
+    out["after"] = e.status
+d.close()
+json.dump(out, open(os.path.join(%r, "rank0.json"), "w"))
+os._exit(0)                          # (no destroy_process_group: the peer is gone)
+''' % (root, root, str(tmp_path)))
+    for env in (None, {"LBMPM_IPC_FLAG_KERNELS": "1"}):
+        if os.path.exists(tmp_path / "rank0.json"):
+            os.remove(tmp_path / "rank0.json")
+        subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), str(script)], env=dict(os.environ, **(env or {})), timeout=240)
+        out = json.load(open(tmp_path / "rank0.json"))
+        assert out["transport"].startswith("ipc"), out
+        assert out["raised"] and out["status"] == -6 and "did not arrive" in out["raised"], out
+        assert 2.5 < out["seconds"] < 30., out
+        assert out["after"] == -6, out
+
+
+def test_a_named_transport_on_the_two_exchange_storage_raises(tmp_path):
+    """advisor, round 4: transport='ipc' on a lattice that runs the 38-value storage (nx not a multiple of 64: two exchanges per step)
+    was silently served by the callback; a named transport that cannot be had raises (on every rank alike: the decision depends on
+    the lattice only), and 'auto' says in its log why it fell back"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "n.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch, torch.distributed as dist
+from test_rk3d_gpu import _case
+from openlbmpm_amd.rk3d import RK3DDistributed
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+dom, rR, rB = _case(nx=33, ny=18, nz=41, seed=9)
+try:
+    RK3DDistributed(dom, device=0, transport="ipc")
+    raise SystemExit("no error")
+except RuntimeError as e:
+    assert "two exchanges per step" in str(e), e
+d = RK3DDistributed(dom, device=0, transport="auto")
+assert d.transport == "callback" and d.transport_log and not d.transport_log[0]["ok"] and "two exchanges" in d.transport_log[0]["why"]
+d.set_density(rR, rB); d.step(2); d.sync(); d.close()
+dist.destroy_process_group()
+''' % (root, root))
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(_free_port()), str(script)], timeout=240)
+
+
 @pytest.mark.parametrize("kind", ["ipc", "rccl"])
 def test_transport_selftest_on_one_gpu(kind):
     """The transports of the slab exchange at transport level, on the one GPU of this box (lbmpm_transport_selftest): three messages

@@ -222,8 +222,24 @@ class _FakeSlab:
         self.calls.append("disconnect")
         self.kind = "callback"
 
-    def ipc_release_waits(self):
-        self.calls.append("release")
+    def sync(self, deadline_s=None):
+        self.calls.append("sync(%s)" % ("deadline" if deadline_s else "no deadline"))
+        if self.fail.get("hang") in (self.rank, "all") and self.kind.startswith(tuple(self.fail.get("hang_kinds", ("ipc", "rccl")))):
+            raise RuntimeError("lbmpm_rk3d_sync_deadline: the slab's streams were still busy after %.1f s" % deadline_s)
+
+    class _Buf:
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+
+        def element_size(self):
+            return 8
+
+    def buffer(self, name):
+        # the two sides of the cut hold the same message sizes unless the scenario says the ranks disagree
+        return self._Buf(1000 + (7 if self.fail.get("sizes") == self.rank and name == "f_send_up" else 0))
 
     @property
     def transport(self):
@@ -238,7 +254,7 @@ def _connect_worker(rank, world, port, q, want, fail, backend_name):
         from openlbmpm_amd.rk3d import RK3DDistributed
         d = RK3DDistributed.__new__(RK3DDistributed)
         d.rank, d.world, d.group, d.slab, d.stream, d._torch = rank, world, None, _FakeSlab(rank, fail), _FakeStream(), _FakeTorch
-        d.transport_note = ""
+        d.transport_note, d.transport_log = "", []
         real = dist.get_backend
         dist.get_backend = lambda group=None: backend_name          # 'nccl': auto may go on to rccl
         err = None
@@ -248,7 +264,7 @@ def _connect_worker(rank, world, port, q, want, fail, backend_name):
             err = str(e)
         finally:
             dist.get_backend = real
-        q.put((rank, d.slab.transport, d.transport_note, d.slab.calls, err))
+        q.put((rank, d.slab.transport, d.transport_note, d.slab.calls, err, d.transport_log))
     finally:
         dist.destroy_process_group()
 
@@ -262,6 +278,9 @@ def _connect_worker(rank, world, port, q, want, fail, backend_name):
     ("auto", {"ipc_init": 0}, "gloo", "callback"),                 # one rank cannot allocate its landing area
     ("ipc", {"ipc_init": 0}, "gloo", "raises"),                    # a named transport that fails raises on EVERY rank
     ("rccl", {}, "nccl", "rccl"),
+    ("auto", {"hang": 1, "hang_kinds": ("ipc",)}, "nccl", "rccl"),  # the probe hangs on one rank over IPC: its watchdog fires, all go on to RCCL
+    ("rccl", {"hang": 0}, "nccl", "raises"),                       # the deadline serves the RCCL probe too (advisor, round 4)
+    ("rccl", {"sizes": 0}, "nccl", "raises"),                      # ranks that disagree on the face message's size never enter ncclCommInitRank
 ])
 def test_transport_selection_is_agreed_on_by_all_ranks(want, fail, backend, expect):
     """RK3DDistributed._connect with a stand-in slab, two ranks over gloo: whatever happens on one rank, both end on the same
@@ -286,3 +305,13 @@ def test_transport_selection_is_agreed_on_by_all_ranks(want, fail, backend, expe
             assert all(g[2] == "in-library " for g in got)
         if fail:
             assert all("disconnect" in g[3] for g in got)           # the dropped transport was disconnected on both ranks
+    # every candidate left its verdict in the log, the last one the transport the ranks ended on (or why there is none)
+    for g in got:
+        log = g[5]
+        assert log and all(set(e) == {"transport", "ok", "why"} for e in log)
+        assert [e["ok"] for e in log].count(True) == (0 if expect in ("callback", "raises") else 1)
+        if expect not in ("callback", "raises"):
+            assert log[-1]["ok"] and log[-1]["transport"] == expect
+        assert all("sync(deadline)" in c for c in g[3] if c.startswith("sync"))        # no probe is waited for without a deadline
+    if fail.get("sizes") is not None:
+        assert all("disagree on the size" in g[4] for g in got) and all("rccl_connect" not in g[3] for g in got)
