@@ -411,7 +411,8 @@ def main():
             moved["note"] = ("the compact storage keeps 19 colour-blind populations + k_R + the recolouring vector per cell (23 doubles; the "
                              "recolouring AcceleratedRKGPU2D.py:1241-1267 makes the 38 an affine image of them) and no record at all for row "
                              "segments of a single colour; storage_* = bytes of the owned cells by the storage's own count at the end of the "
-                             "run (rim / halo re-reads not included), counted_* = rocprofv3 2 x FETCH_SIZE + WRITE_SIZE per launch")
+                             "run (rim / halo re-reads not included), counted_* = rocprofv3 FETCH_SIZE / WRITE_SIZE per launch, each times the factor measured in the same counter passes on a calibration "
+                             "kernel of this kernel's access width (profiles/pmc_traffic.json: calibration, fetch_factor; x 2 / x 1 where a profile has none)")
             out = {
                 "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid_global * steps / wall / 1e6, 2),
                 "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,

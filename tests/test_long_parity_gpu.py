@@ -1,0 +1,121 @@
+"""Longer and larger comparisons with the CPU oracles than the rest of the GPU suite runs ("nothing larger than
+64 x 20 x 28 meets an oracle, full-size checks stay at 3 steps").  Sizes are chosen so that the oracles -- OpenMP C, every usable core --
+finish within a minute or two each; tolerances are the suite's (field-relative; the north star asks 1e-6 on rho, u, phi).
+
+  * D3Q19 (the c5 model, MRT): 192 x 192 x 256 porous lattice (6.3 M fluid cells), 200 steps of `rk3dq_fused` against
+    oracle/rk3d_oracle.c, with a displacement front that crosses a chunk border of the single-domain run AND a slab cut of a three-slab
+    run (both at plane 171) on its way: rho_R, rho_B, phi <= 1e-9, u <= 1e-9 of its maximum.
+  * c3 (explicit-forcing Shan-Chen, MRT, convective outlet) and c4 (colour gradient + D2Q5 tracer) at 512 x 512 porous for 200 steps
+    against oracle/sc_oracle.c and the coupled oracle (oracle/tr.py + rk_oracle.c / tr_oracle.c).
+"""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _front_case(nx, ny, nz, z_front, seed=11):
+    """porous lattice with blue above plane z_front and red below (the bench's initial state has the front at the top buffer)"""
+    from openlbmpm_amd.geometry import porous_spheres
+    dom = porous_spheres(nx, ny, nz, porosity=0.68, rmin=5.0, rmax=14.0, seed=seed, nbuf=8)
+    zz = np.arange(nz)[:, None, None]
+    fluid = dom == 1
+    rB = np.where(fluid & (zz >= z_front), 1.0, 0.0)
+    rR = np.where(fluid & (zz < z_front), 1.0, 0.0)
+    return dom, rR, rB
+
+
+def test_c5_model_200_steps_against_the_oracle_with_the_front_crossing_a_chunk_border_and_a_slab_cut(monkeypatch):
+    """rk3dq_fused (23 stored values per cell, row flags, chunked marching) and the three-slab run of the same lattice against the
+    oracle after 100 and 200 steps.  Inlet 2e-2 (200 x the ini's): the front, started at plane 174, moves ~4 planes -- its diffuse
+    band (+- 6 planes of mixed rows) sweeps over plane 171, which is a chunk border of the single-domain run (chunks of 57 planes) and
+    the upper cut of the three-slab run (86 + 85 + 85 planes): row segments there go blue -> mixed, records appear in the halo
+    messages, the face message carries class sums of mixed cells."""
+    from openlbmpm_amd.rk3d import RK3DCluster
+    from oracle.rk3d import RK3DOracle
+    nx, ny, nz = 192, 192, 256
+    dom, rR, rB = _front_case(nx, ny, nz, 174)
+    par = dict(relax="MRT", velocityZB=-2.0e-2, tauR=1.0, tauB=0.8)
+    o = RK3DOracle(dom, rR, rB, par)
+    monkeypatch.setenv("LBMPM_RK3D_CHUNK", "57")
+    single = RK3DCluster(dom, 1, par)
+    monkeypatch.delenv("LBMPM_RK3D_CHUNK")
+    slabs = RK3DCluster(dom, 3, par)
+    assert single.slabs[0].dominant_kernel == "rk3dq_fused" and [n for _, n in slabs.parts] == [86, 85, 85]
+    for c in (single, slabs):
+        c.set_density(rR, rB)
+    phi0 = None
+    for n in (100, 100):
+        o.run(n); o.macro()
+        umax = max(float(np.max(np.abs(o.field(f)))) for f in ("vx", "vy", "vz"))
+        got = []
+        for c in (single, slabs):
+            c.step(n); c.observe()
+            got.append({f: c.get(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz")})
+        steps = single.slabs[0].steps_done
+        for f in got[0]:
+            assert np.array_equal(got[0][f], got[1][f]), "three slabs != single domain in %s after %d steps" % (f, steps)
+            e = rel_err(got[0][f], o.field(f), scale=umax if f[0] == "v" else None)
+            assert e < 1e-9, "field %s rel err %.3e after %d steps" % (f, e, steps)
+        if phi0 is None:
+            phi0 = got[0]["phi"]
+    # the front did move across plane 171: mixed cells (|phi| < 0.9) on both sides of it, and the mean phase field of the planes
+    # 168 .. 171 changed since step 100
+    phi, fluid = got[0]["phi"], dom == 1
+    for z in (169, 173):
+        assert np.count_nonzero(fluid[z] & (np.abs(phi[z]) < 0.9)) > 100, z
+    assert abs(float(phi[168:172][fluid[168:172]].mean()) - float(phi0[168:172][fluid[168:172]].mean())) > 1e-3
+    single.close(); slabs.close()
+
+
+def test_c3_model_512_squared_200_steps_against_the_oracle():
+    """explicit-forcing Shan-Chen, MRT, convective outlet (the c3 configuration of bench.py) on a 512 x 512 porous image: f, rho, u,
+    F, u_eq of `sc2d_fused` against oracle/sc_oracle.c after 100 and 200 steps"""
+    from openlbmpm_amd.sc2d import SC2DSolver
+    from openlbmpm_amd.geometry import porous_disks, image_domain
+    from oracle.sc import SCOracle, initial_densities
+    from test_sc2d_gpu import _compare
+    dom = image_domain(porous_disks(512, 492, porosity=0.68, rmin=5.0, rmax=16.0, seed=7), 20, 0.5)
+    par = dict(inter="EFS", relax="MRT", outlet="Convective", tau0=1.0, tau1=0.8)
+    dens = dict(rho0=1.0, rho1=1.0, bg0=0.15, bg1=0.15)
+    o = SCOracle(dom, dict(par, **dens), image=True)
+    rho = initial_densities(dom, True, dict(par, **dens))
+    s = SC2DSolver(dom, par, diagnostics=True)
+    s.set_density(rho[0], rho[1])
+    alias = dict(ueqx="ux", ueqy="uy")
+    for n in (100, 100):
+        s.step(n); o.run(n)
+        _compare(s, True, lambda name: getattr(o, alias.get(name, name)), "after %d steps" % s.steps_done)
+    s.close()
+
+
+def test_c4_model_512_squared_200_steps_against_the_coupled_oracle():
+    """colour gradient (CSF, MRT, wetting) + one D2Q5 tracer with interface blocking (the c4 configuration) on a 512 x 512 porous
+    image: `rk2d_fused_tracer` against the coupled oracle after 100 and 200 steps.  Densities, phi, concentration 1e-9; u 1e-8 of its
+    maximum (the lagged CSF force enters u: one wall node's wetting-corrected gradient differs at 5e-9 on the small captures too)."""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.geometry import porous_disks, image_domain
+    from oracle.tr import CoupledOracle
+    dom = image_domain(porous_disks(512, 492, porosity=0.68, rmin=5.0, rmax=16.0, seed=7), 10, 0.5)
+    ny, nx = dom.shape
+    ii = np.mgrid[0:ny, 0:nx][0]
+    fluid = dom == 1
+    top = ii >= ny - 14
+    rR = np.where(fluid & top, 1.0, 0.0); rB = np.where(fluid & ~top, 1.0, 0.0)
+    conc = np.where(fluid & ~top, 0.3 + 0.2 * np.sin(ii / 7.0), 0.0)[None]
+    flow = dict(theta=60.0, tauR=1.0, tauB=0.8, relax="MRT")
+    tr = dict(diffX=(1. / 6.,), diffY=(1. / 6.,), dXY=0.0, dYX=0.0, beta=(1.0,), crit=0.5, inlet_conc=(1.0,), free_outlet=True, dirichlet_inlet=True)
+    s = RK2DSolver(dom, flow, diagnostics=True)
+    s.set_macro(rR, rB)
+    s.configure_tracers(**tr)
+    s.set_tracer(0, conc[0])
+    o = CoupledOracle(dom, flow, rR, rB, conc, tr)
+    for n in (100, 100):
+        s.step(n); o.run(n)
+        assert rel_err(s.get_tracer(0, compact=True), o.C[0]) < 1e-9, "tracer after %d steps" % s.steps_done
+        for f, tol in (("rhoR", 1e-9), ("rhoB", 1e-9), ("phi", 1e-9), ("vx", 1e-8), ("vy", 1e-8)):
+            e = rel_err(s.get_compact(f), getattr(o.flow, f))
+            assert e < tol, "%s rel err %.3e after %d steps" % (f, e, s.steps_done)
+    s.close()

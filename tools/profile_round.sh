@@ -33,10 +33,22 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/prof_mixed_$set -o x -- $CMDX > /dev/null 2> $out/pmc_mixed_$set.log
   python $R/tools/rocprof_summary.py $(find $R/gpurun_out/prof_mixed_$set -name x_results.db | head -1) --pmc > $out/${tag}_pmc_mixed_$set.txt
 done
+# the graded state and the SRT relaxation: their legs of the bench line get counted bytes too (no `counted_frac: null`)
+CMDG="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --c5-state graded"
+CMDS="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --relax SRT"
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf $R/gpurun_out/prof_graded_$set $R/gpurun_out/prof_srt_$set
+  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/prof_graded_$set -o x -- $CMDG > /dev/null 2> $out/pmc_graded_$set.log
+  python $R/tools/rocprof_summary.py $(find $R/gpurun_out/prof_graded_$set -name x_results.db | head -1) --pmc > $out/${tag}_pmc_graded_$set.txt
+  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/prof_srt_$set -o x -- $CMDS > /dev/null 2> $out/pmc_srt_$set.log
+  python $R/tools/rocprof_summary.py $(find $R/gpurun_out/prof_srt_$set -name x_results.db | head -1) --pmc > $out/${tag}_pmc_srt_$set.txt
+done
 unset LBMPM_BENCH_SECONDARY_STEPS LBMPM_NO_GRAPH
 cd $R
 python tools/pmc_to_json.py $out/${tag}_pmc_FETCH_SIZE.txt $out/${tag}_pmc_WRITE_SIZE.txt \
-       mixed $out/${tag}_pmc_mixed_FETCH_SIZE.txt $out/${tag}_pmc_mixed_WRITE_SIZE.txt > $out/pmc_traffic.json
+       mixed $out/${tag}_pmc_mixed_FETCH_SIZE.txt $out/${tag}_pmc_mixed_WRITE_SIZE.txt \
+       graded $out/${tag}_pmc_graded_FETCH_SIZE.txt $out/${tag}_pmc_graded_WRITE_SIZE.txt \
+       - $out/${tag}_pmc_srt_FETCH_SIZE.txt $out/${tag}_pmc_srt_WRITE_SIZE.txt > $out/pmc_traffic.json
 cp $out/pmc_traffic.json profiles/pmc_traffic.json      # (on the box: the bench runs below read it; copy it back by hand as well)
 python bench.py > $out/${tag}_bench_c5_n1.json 2> $out/bench.log
 if [ -z "$SKIP_LONG" ]; then
