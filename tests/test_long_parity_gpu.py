@@ -29,14 +29,14 @@ def _front_case(nx, ny, nz, z_front, seed=11):
 
 def test_c5_model_200_steps_against_the_oracle_with_the_front_crossing_a_chunk_border_and_a_slab_cut(monkeypatch):
     """rk3dq_fused (23 stored values per cell, row flags, chunked marching) and the three-slab run of the same lattice against the
-    oracle after 100 and 200 steps.  Inlet 2e-2 (200 x the ini's): the front, started at plane 174, moves ~4 planes -- its diffuse
-    band (+- 6 planes of mixed rows) sweeps over plane 171, which is a chunk border of the single-domain run (chunks of 57 planes) and
-    the upper cut of the three-slab run (86 + 85 + 85 planes): row segments there go blue -> mixed, records appear in the halo
-    messages, the face message carries class sums of mixed cells."""
+    oracle after 100 and 200 steps.  Inlet 2e-2 (200 x the ini's): the front, started between the planes 171 and 172, moves ~4 planes
+    down -- across the border 170 | 171, which is a chunk border of the single-domain run (chunks of 57 planes) and the upper cut of
+    the three-slab run (86 + 85 + 85 planes): row segments on both sides go blue / red -> mixed, records appear in the halo planes,
+    the face message carries class sums of mixed cells."""
     from openlbmpm_amd.rk3d import RK3DCluster
     from oracle.rk3d import RK3DOracle
     nx, ny, nz = 192, 192, 256
-    dom, rR, rB = _front_case(nx, ny, nz, 174)
+    dom, rR, rB = _front_case(nx, ny, nz, 172)
     par = dict(relax="MRT", velocityZB=-2.0e-2, tauR=1.0, tauB=0.8)
     o = RK3DOracle(dom, rR, rB, par)
     monkeypatch.setenv("LBMPM_RK3D_CHUNK", "57")
@@ -61,12 +61,11 @@ def test_c5_model_200_steps_against_the_oracle_with_the_front_crossing_a_chunk_b
             assert e < 1e-9, "field %s rel err %.3e after %d steps" % (f, e, steps)
         if phi0 is None:
             phi0 = got[0]["phi"]
-    # the front did move across plane 171: mixed cells (|phi| < 0.9) on both sides of it, and the mean phase field of the planes
-    # 168 .. 171 changed since step 100
+    # the front did cross the border 170 | 171: at the start every plane below 172 was pure red; now cells of both colours (|phi| < 0.9)
+    # sit below the border, and the phase field of the planes 167 .. 170 has changed since step 100
     phi, fluid = got[0]["phi"], dom == 1
-    for z in (169, 173):
-        assert np.count_nonzero(fluid[z] & (np.abs(phi[z]) < 0.9)) > 100, z
-    assert abs(float(phi[168:172][fluid[168:172]].mean()) - float(phi0[168:172][fluid[168:172]].mean())) > 1e-3
+    assert np.count_nonzero(fluid[160:171] & (np.abs(phi[160:171]) < 0.9)) > 100
+    assert abs(float(phi[167:171][fluid[167:171]].mean()) - float(phi0[167:171][fluid[167:171]].mean())) > 1e-3
     single.close(); slabs.close()
 
 

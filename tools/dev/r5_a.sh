@@ -16,4 +16,4 @@ done
 cd $R
 python tools/pmc_to_json.py $out/r05a_pmc_FETCH_SIZE.txt $out/r05a_pmc_WRITE_SIZE.txt > $out/pmc_traffic.json 2> $out/pmc_json.log
 rm -rf $R/gpurun_out/prof_FETCH_SIZE $R/gpurun_out/prof_WRITE_SIZE
-tail -5 $out/pytest_transport.log $out/pytest_long.log $out/pytest_2d.log; head -c 900 $out/bench.json; grep -A8 calibration $out/pmc_traffic.json | head -60
+tail -n 5 $out/pytest_transport.log $out/pytest_long.log $out/pytest_2d.log; head -c 900 $out/bench.json; grep -A8 calibration $out/pmc_traffic.json | head -60
