@@ -440,6 +440,17 @@ __device__ __forceinline__ constexpr int pair_class(int i) { return i < 7 ? (i -
 // STORE: 0 dense (two 8-byte stores per direction), 1 compact {red, blue} pairs (16 bytes per node and direction), 2 the
 // colour-blind population alone + one record {k_R, A} per node (rk3dq.h; every calling lane is a fluid cell there: the lanes that
 // write line padding go through pad_store_q); MRT: [RelaxationType] Type
+// e_i . v for a lattice direction whose components are 0 or +-1 (they fold in the unrolled loops): the non-zero terms only
+__device__ __forceinline__ double edot(int cx, int cy, int cz, double x, double y, double z)
+{
+    double r = 0.;
+    bool any = false;
+    if (cx != 0) { r = cx > 0 ? x : -x; any = true; }
+    if (cy != 0) { r = any ? (cy > 0 ? r + y : r - y) : (cy > 0 ? y : -y); any = true; }
+    if (cz != 0) { r = any ? (cz > 0 ? r + z : r - z) : (cz > 0 ? z : -z); }
+    return r;
+}
+
 template <int STORE, bool MRT, bool NT = false>
 __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsigned stride, unsigned own, bool fluid_in,
                                               const double ft_in[Q], double rR, double rB, double gx, double gy, double gz,
@@ -448,11 +459,25 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
 #pragma clang fp contract(fast)      // fused multiply-adds here (the 2-D kernels stay uncontracted for bit parity with the reference)
     constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
     const bool fluid = STORE == 2 ? true : fluid_in;
+    // momentum from the differences of opposite pairs (i odd, i + 1 opposite): 9 subtractions + 12 additions, no products by the
+    // zero components of e_i (hipcc may not drop `0. * t`: no fast-math here)
     double mx = 0., my = 0., mz = 0.;
+    // momentum: the populations that move along +e and along -e summed separately, no products by the zero components of e_i
+    // (hipcc may not drop `0. * t`: no fast-math here).  (Not via the differences of opposite pairs: hipcc then keeps all nine alive
+    // for the odd part of the MRT relaxation further down, and the kernel spills.)
+    {
+        double px = 0., py = 0., pz = 0., nx = 0., ny = 0., nz = 0.;
 #pragma unroll
-    for (int i = 0; i < Q; ++i) {
-        const double t = ft_in[i];
-        mx += (double)CX[i] * t; my += (double)CY[i] * t; mz += (double)CZ[i] * t;
+        for (int i = 1; i < Q; ++i) {
+            const double t = ft_in[i];
+            if (CX[i] > 0) px += t;
+            if (CX[i] < 0) nx += t;
+            if (CY[i] > 0) py += t;
+            if (CY[i] < 0) ny += t;
+            if (CZ[i] > 0) pz += t;
+            if (CZ[i] < 0) nz += t;
+        }
+        mx = px - nx; my = py - ny; mz = pz - nz;
     }
     // Arithmetic organised for the hardware, not after the reference's statement order (the oracle
     // keeps that; the tests bound the rounding difference): reciprocals by Newton steps, and the
@@ -502,7 +527,7 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
         double sc[6] = {0., 0., 0., 0., 0., 0.};        // sum of the pair sums of f - feq, per class
 #pragma unroll
         for (int i = 1; i < Q; i += 2) {
-            const double eu = (double)CX[i] * vx + (double)CY[i] * vy + (double)CZ[i] * vz;
+            const double eu = edot(CX[i], CY[i], CZ[i], vx, vy, vz);
             const double sp = (ft_in[i] + ft_in[i + 1]) - 2. * ((rho * wq(i)) * (v0 + 4.5 * eu * eu));
             constexpr int dummy = 0; (void)dummy;
             sc[pair_class(i)] += sp;
@@ -547,8 +572,8 @@ __device__ __forceinline__ void collide_store(const RK3Dev &p, char *red, unsign
 #pragma unroll
     for (int i = 1; i < Q; i += 2) {             // i and i + 1 are opposite
         const double w = wq(i);
-        const double eu = (double)CX[i] * ux + (double)CY[i] * uy + (double)CZ[i] * uz;
-        const double eg = (double)CX[i] * gx + (double)CY[i] * gy + (double)CZ[i] * gz;
+        const double eu = edot(CX[i], CY[i], CZ[i], ux, uy, uz);
+        const double eg = edot(CX[i], CY[i], CZ[i], gx, gy, gz);
         const double sym = (rho * w) * (c0 + 4.5 * eu * eu), odd = (3. * rho * w) * eu;
         const double pert = (akgn * w * ig2) * (eg * eg) - akgn * bq(i);
         const double a = (i < 7 ? arcA : arcD) * eg;

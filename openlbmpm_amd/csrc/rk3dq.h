@@ -655,14 +655,23 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             if (live && own && lx == 0) p.pur_out[row_index(p, z, y, tx)] = 3u;
         } else if (active) {
             LBMPM_TAKEN;          // (the ballot above: a lane of this wave is here -- every path of the step passes a wait for the pulls)
-            double gx = 0., gy = 0., gz = 0.;
+            // colour gradient 3 sum_i w_i e_i phi(x + e_i): the axis and the diagonal neighbours summed separately (signed), one
+            // product per weight class and component
+            double ax = 0., ay = 0., az = 0., dx = 0., dy = 0., dz = 0.;
 #pragma unroll
             for (int i = 1; i < Q; ++i) {
                 const double ph = sphi[(z + CZ[i]) & (M::RING - 1)][ly + 1 + CY[i]][lx + 1 + CX[i]];
-                if (CX[i] != 0) gx += 3. * wq(i) * (double)CX[i] * ph;
-                if (CY[i] != 0) gy += 3. * wq(i) * (double)CY[i] * ph;
-                if (CZ[i] != 0) gz += 3. * wq(i) * (double)CZ[i] * ph;
+                if (i < 7) {
+                    if (CX[i] != 0) ax = CX[i] > 0 ? ax + ph : ax - ph;
+                    if (CY[i] != 0) ay = CY[i] > 0 ? ay + ph : ay - ph;
+                    if (CZ[i] != 0) az = CZ[i] > 0 ? az + ph : az - ph;
+                } else {
+                    if (CX[i] != 0) dx = CX[i] > 0 ? dx + ph : dx - ph;
+                    if (CY[i] != 0) dy = CY[i] > 0 ? dy + ph : dy - ph;
+                    if (CZ[i] != 0) dz = CZ[i] > 0 ? dz + ph : dz - ph;
+                }
             }
+            const double gx = 3. * wq(1) * ax + 3. * wq(7) * dx, gy = 3. * wq(1) * ay + 3. * wq(7) * dy, gz = 3. * wq(1) * az + 3. * wq(7) * dz;
             if (__builtin_amdgcn_readfirstlane((int)mixed_z))
                 collide_store<2, MRT, true>(p, reinterpret_cast<char *>(p.fout) + (size_t)pz0 * CELLB, (unsigned)(pz1 - pz0) * 8u, jzz * 8u, true, ft, rRz,
                                             rhoz - rRz, gx, gy, gz, p.pur_out + row_index(p, z, y, tx));
