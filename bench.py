@@ -353,17 +353,20 @@ def main():
             del rR, rB
             partition = "equal fluid cells per rank"
             if not args.no_calibration:
-                # one measured re-cut (untimed set-up): equal fluid cells leave the rank that holds the colour interface ~10 % behind
-                d.step(2)
-                cost = d.calibrated_plane_cost(8)
-                d.close()
-                z0, nzl = RK3DDistributed.partition(dom, world, plane_cost=cost)[rank]
-                rR, rB = c5_state(dom[z0:z0 + nzl], z0, nz, args.c5_state)
-                m0_local = float((rR + rB).sum())
-                d = RK3DDistributed(dom, dict(relax=args.relax), device=local_rank, plane_cost=cost)
-                d.slab.set_density(rR, rB)
-                del rR, rB
-                partition = "equal measured cost per rank (8 timed steps on the equal-fluid-cells cuts, then re-cut)"
+                # two measured re-cuts (untimed set-up): equal fluid cells leave the rank that holds the colour interface ~10 % behind, and
+                # the end ranks (one boundary range instead of two) ahead; the second re-cut corrects what the first one's uniform cost per
+                # rank could not see
+                for _recut in range(2):
+                    d.step(2)
+                    cost = d.calibrated_plane_cost(8)
+                    d.close()
+                    z0, nzl = RK3DDistributed.partition(dom, world, plane_cost=cost)[rank]
+                    rR, rB = c5_state(dom[z0:z0 + nzl], z0, nz, args.c5_state)
+                    m0_local = float((rR + rB).sum())
+                    d = RK3DDistributed(dom, dict(relax=args.relax), device=local_rank, plane_cost=cost)
+                    d.slab.set_density(rR, rB)
+                    del rR, rB
+                partition = "equal measured step time per rank (8 timed steps on the equal-fluid-cells cuts, re-cut, 8 timed steps, re-cut)"
             d.step(warmup)
             d.sync(); barrier()
             t0 = time.perf_counter()

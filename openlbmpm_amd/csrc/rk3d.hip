@@ -1968,6 +1968,58 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
         const int cb = c->boundary;
         const bool has_interior = c->nzl >= 2 * cb + 1;
         const dim3 fgrid(c->nseg, (c->ny + BY3 - 1) / BY3, 2), fblock(BX3, BY3);
+        // Two schedules.  "lattice in one stream" (default; LBMPM_RK3D_SLAB_SCHEDULE=split for the other): boundary launch -> pack ->
+        // interior launch back to back on the SECOND stream, the chain  wait(pack) -> exchange -> unpack -> halo phase field  on the
+        // context's stream beside the interior launch; the next step's boundary launch waits for the chain -- which has long finished.
+        // No cross-stream event sits between two lattice launches.  The split schedule (rounds 3 - 4: boundary + pack on the context's
+        // stream, the interior behind an event on the second, the step ends with the context's stream waiting for it) pays two such
+        // waits per step on the critical path (~ 10 - 15 us each) but enqueues the exchange ahead of the interior launch: it stays the
+        // choice for the RCCL transport, whose send / recv kernels need CUs that the interior launch would otherwise take first.
+        const char *sched = getenv("LBMPM_RK3D_SLAB_SCHEDULE");
+        const bool one_stream = has_interior && !(sched && !strcmp(sched, "split")) && ((sched && !strcmp(sched, "one")) || !own_tx || c->tx.kind != LBMPM_TRANSPORT_RCCL);
+        if (one_stream) {
+            LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // everything enqueued so far (the primed halo planes included)
+            for (int64_t k = 0; k < nsteps; ++k) {
+                hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                if (k < tsteps) for (int i = 0; i < 4; ++i) c->slab_pool.take(&ev[2 * i], &ev[2 * i + 1]);
+                const RK3Dev p = make_dev(c);
+                if (ev[0]) LBMPM_HIP_TRY(hipEventRecord(ev[0], c->aux));     // (before the wait: a chain that ended late counts into this step)
+                LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));     // the previous step's chain: its halo planes
+                if (ev[6]) LBMPM_HIP_TRY(hipEventRecord(ev[6], c->aux));
+                const int zi0 = has_below ? cb + 1 : 1, zi1 = has_above ? c->nzl - cb : c->nzl;
+                if (has_below && has_above) launch_q23(c, p, c->aux, 1, cb, c->nzl - cb + 1, c->nzl);
+                else if (has_below) launch_q23(c, p, c->aux, 1, cb, 1, 0);
+                else launch_q23(c, p, c->aux, c->nzl - cb + 1, c->nzl, 1, 0);
+                if (ev[7]) LBMPM_HIP_TRY(hipEventRecord(ev[7], c->aux));
+                RK3Dev q = p;                                                 // the state this step writes
+                q.fin = c->fB; q.pur_in = c->purB; q.first = 0;
+                rk3dq_face_pack<<<fgrid, fblock, 0, c->aux>>>(q, c->send_up, c->send_dn, has_below, has_above);
+                LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));           // (here: "the face message is packed")
+                if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
+                // the chain, enqueued ahead of the interior launch
+                LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+                if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
+                const double *from_below = c->recv_below, *from_above = c->recv_above;
+                if (own_tx) { const int rc = c->tx.exchange(c->stream, c->send_up, c->send_dn, &from_below, &from_above); if (rc != LBMPM_OK) return fail(rc); }
+                else if (exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
+                rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, from_below, from_above, has_below, has_above);
+                rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, from_below, from_above, has_below, has_above);
+                if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
+                LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
+                // the interior planes, straight behind the pack in the lattice stream
+                if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], c->aux));
+                launch_step_range(c, p, c->aux, zi0, zi1);
+                if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], c->aux));
+                if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
+                finish_step(c);
+                c->halo_valid = true;
+                if (ev[1]) LBMPM_HIP_TRY(hipEventRecord(ev[1], c->aux));
+            }
+            // join: whoever uses the context's stream next finds the lattice launches done
+            LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));
+            LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+            return LBMPM_OK;
+        }
         for (int64_t k = 0; k < nsteps; ++k) {
             hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (k < tsteps) for (int i = 0; i < 4; ++i) c->slab_pool.take(&ev[2 * i], &ev[2 * i + 1]);
@@ -1975,7 +2027,14 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             const RK3Dev p = make_dev(c);
             LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // the previous step, its unpack included
             if (ev[6]) LBMPM_HIP_TRY(hipEventRecord(ev[6], c->stream));
-            if (has_interior) launch_q23(c, p, c->stream, 1, cb, c->nzl - cb + 1, c->nzl);      // both boundary ranges, one launch
+            // the boundary ranges that feed a face message, in one launch; a face without a neighbour (the lattice's inlet / outlet end)
+            // has no message to hurry for: its planes march with the interior (one range, one prologue and two fill steps less on the end ranks)
+            const int zi0 = has_below ? cb + 1 : 1, zi1 = has_above ? c->nzl - cb : c->nzl;
+            if (has_interior) {
+                if (has_below && has_above) launch_q23(c, p, c->stream, 1, cb, c->nzl - cb + 1, c->nzl);
+                else if (has_below) launch_q23(c, p, c->stream, 1, cb, 1, 0);
+                else launch_q23(c, p, c->stream, c->nzl - cb + 1, c->nzl, 1, 0);
+            }
             else launch_step_range(c, p, c->stream, 1, c->nzl);
             if (ev[7]) LBMPM_HIP_TRY(hipEventRecord(ev[7], c->stream));
             if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
@@ -2005,7 +2064,7 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             if (has_interior) {
                 hipStream_t ist = (skip & 8) ? c->stream : c->aux;       // (knock-out 8: the interior on the context's own stream)
                 if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], ist));
-                launch_step_range(c, p, ist, cb + 1, c->nzl - cb);
+                launch_step_range(c, p, ist, zi0, zi1);
                 if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], ist));
                 LBMPM_HIP_TRY(hipEventRecord(c->ev_done, ist));
             }

@@ -489,7 +489,7 @@ class RK3DDistributed:
         import torch.distributed as dist
         self.step(int(steps), timed=True)
         t = self.timing()
-        rate = (t["interior_ms"] + t["boundary_ms"]) / max(self.nzl, 1)
+        rate = t["step_ms"] / max(self.nzl, 1)          # the whole step (fixed parts included: repeated re-cuts converge on equal step times)
         got = [None] * self.world
         dist.all_gather_object(got, (int(self.z0), int(self.nzl), float(rate)), group=self.group)
         nz = max(z0 + n for z0, n, _ in got)

@@ -93,12 +93,16 @@ def measure(parts):
 
 parts = RK3DDistributed.partition(dom, K)
 rows = measure(parts)
-if os.environ.get("SLAB_CALIBRATE"):
-    # what RK3DDistributed.calibrated_plane_cost + partition(plane_cost=...) do in a real run: kernel time per owned plane, re-cut
-    import numpy as np
-    cost = np.zeros(n)
+# what RK3DDistributed.calibrated_plane_cost + partition(plane_cost=...) do in a real run: a rank's step time per owned plane, re-cut;
+# SLAB_CALIBRATE = number of re-cuts (bench.py --gpus N does two)
+import numpy as np
+cost = None
+for it in range(int(os.environ.get("SLAB_CALIBRATE", "0"))):
+    new = np.zeros(n)
     for (z0, nz), t in zip(parts, rows):
-        cost[z0:z0 + nz] = (t["interior_ms"] + t["boundary_ms"]) / nz
+        new[z0:z0 + nz] = t["step_ms"] / nz
+    cost = new
     parts2 = RK3DDistributed.partition(dom, K, plane_cost=cost)
-    print("re-cut by measured cost per plane: planes per rank %s -> %s" % ([nz for _, nz in parts], [nz for _, nz in parts2]), flush=True)
-    measure(parts2)
+    print("re-cut %d by measured cost per plane: planes per rank %s -> %s" % (it + 1, [nz for _, nz in parts], [nz for _, nz in parts2]), flush=True)
+    parts = parts2
+    rows = measure(parts)
