@@ -969,6 +969,7 @@ static inline void launch_rk_inlet_velocity_red(hipStream_t st, i64 N, i64 nx, i
 #include "sparse_rest_rk.h"
 #include "sparse_rest_sc.h"
 #include "sparse_rest_tr.h"
+#include "dense_ef.h"
 
 #define sc_check_nf(nf) do { if ((nf) != 2) { set_error("numFluids must be 2 (got %lld)", (long long)(nf)); return LBMPM_ERR_UNSUPPORTED; } } while (0)
 #define tr_check_q5(q) do { if ((q) != 5) { set_error("numSchemes must be 5 (D2Q5); got %lld", (long long)(q)); return LBMPM_ERR_UNSUPPORTED; } } while (0)

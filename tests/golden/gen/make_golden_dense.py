@@ -8,7 +8,8 @@ two-fluid case (solid side columns + a solid disc; periodic in y), chained the w
     -> calEffectiveVGPU (:2309) -> calEquilibriumFuncEFGPU (:2354) x 2 -> calForcingTermEFGPU (:2403) x 2
     -> calTransformedDistrFuncGPU (:2444) x 2 -> calCollisionEFGPU (:2487) x 2
     -> calHalfWallBounceBack (:2698) x 2 -> calStreamingStep1 / Step2 (:1336 / :1372) x 2
-    and calMacroDensityGPU1D (:54), calMacroVelocityGPU1D (:80) on the result.
+    and calMacroDensityGPU1D (:54), calMacroVelocityGPU1D (:80) on the result; beside the chain one launch each of
+    calExternalForceSolid (:2209) and calEffectiveVGPUMRT (:2332).
 
 Container-only.  Writes tests/golden/dense_kernels.npz.
 """
@@ -54,6 +55,10 @@ def main():
     out.update(Ff_0x=F[0].copy(), Ff_0y=F[1].copy(), Ff_1x=F[2].copy(), Ff_1y=F[3].copy())
     D.calExternalForceSolidEF[grid, block](nx, ny, Gs[0], Gs[1], psi[0], psi[1], F[0], F[1], F[2], F[3], isDomain, isSolid)
     out.update(F_0x=F[0].copy(), F_0y=F[1].copy(), F_1x=F[2].copy(), F_1y=F[3].copy())
+    # side answer (not part of the chain): the fluid-solid force of the original Shan-Chen weights, calExternalForceSolid (:2209), on a copy
+    Fs = [out["Ff_0x"].copy(), out["Ff_0y"].copy(), out["Ff_1x"].copy(), out["Ff_1y"].copy()]
+    D.calExternalForceSolid[grid, block](nx, ny, Gs[0], Gs[1], psi[0], psi[1], Fs[0], Fs[1], Fs[2], Fs[3], isSolid)
+    out.update(Fs_0x=Fs[0], Fs_0y=Fs[1], Fs_1x=Fs[2], Fs_1y=Fs[3])
     v = [np.zeros(n) for _ in range(4)]                       # v0x, v0y, v1x, v1y
     for k in range(2):
         D.calMacroVelocityEFGPU[grid, block](nx, ny, rho[k], F[2 * k], F[2 * k + 1], f[k], v[2 * k], v[2 * k + 1], isDomain)
@@ -61,6 +66,10 @@ def main():
     ux, uy = np.zeros(n), np.zeros(n)
     D.calEffectiveVGPU[grid, block](nx, ny, tau[0], tau[1], rho[0], rho[1], v[0], v[1], v[2], v[3], ux, uy, isDomain)
     out.update(ueff_x=ux.copy(), ueff_y=uy.copy())
+    # side answer: the MRT flavour of the effective velocity, calEffectiveVGPUMRT (:2332), conserveS = (1.0, 0.9)
+    uxm, uym = np.zeros(n), np.zeros(n)
+    D.calEffectiveVGPUMRT[grid, block](nx, ny, 1.0, 0.9, rho[0], rho[1], v[0], v[1], v[2], v[3], uxm, uym, isDomain)
+    out.update(ueffm_x=uxm, ueffm_y=uym)
     feq = [np.zeros((9, n)), np.zeros((9, n))]; ff = [np.zeros((9, n)), np.zeros((9, n))]
     for k in range(2):
         D.calEquilibriumFuncEFGPU[grid, block](nx, ny, rho[k], ux, uy, feq[k], isDomain)

@@ -64,3 +64,14 @@ def test_every_kernel_of_the_five_kernel_modules_has_an_entry_point():
                 assert KERNELS[(tag.strip(), name)][2] == params, (rel, name)
             total += 1
     assert total >= 155
+    # the legacy dense file (north_star names it; SURVEY 8 a16 scopes it to its explicit-forcing pipeline :1336-2487 + :2698): the 15 entry
+    # points of openlbmpm_amd/dropin/AccelerateGPU2D.py carry the reference kernels' own parameter lists
+    src = open(os.path.join("/root/reference", "ShanChen2D/AccelerateGPU2D.py")).read()
+    dense = {name: params for (tag, name), (_sym, _ct, params, _k) in KERNELS.items() if tag == "de"}
+    assert len(dense) == 15
+    found = 0
+    for m in re.finditer(r"@cuda\.jit\(([^@]*?)\)\s*\ndef (\w+)\(([^)]*)\)", src, re.S):
+        if m.group(2) in dense:
+            assert dense[m.group(2)] == tuple(p.strip() for p in m.group(3).replace("\\", " ").split(",") if p.strip()), m.group(2)
+            found += 1
+    assert found == 15

@@ -11,7 +11,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 A = "RKCG2D/AcceleratedRKGPU2D.py"; O = "ShanChen2D/OptimizedD2Q9GPU.py"; E = "ShanChen2D/ExplicitD2Q9GPU.py"
-T = "RKCG2D/AccelerateTransport2DRK.py"; B = "RKCG2D/RKGPU2DBoundary.py"
+T = "RKCG2D/AccelerateTransport2DRK.py"; B = "RKCG2D/RKGPU2DBoundary.py"; DE = "ShanChen2D/AccelerateGPU2D.py"
 
 # (module tag, reference kernel, file:line, "name:kind ...", launcher call)
 SPEC = [
@@ -345,6 +345,38 @@ SPEC = [
   "launch_tr9_interface(st, totalNodes, (int)numTracers, betaTracer, valueTransportDomain, gradientX, gradientY, weightsCoeff, tracerConc, tracerPDF)"),
  ("tr", "calCollisionTransportLinearEqlMRTGPUD2Q9", T + ":1053", "totalNodes:i xDim:i numTracers:i unitVX:D unitVY:D velocityVX:D velocityVY:D tracerConc:D tracerPDF:D transportM:D inverseRelaxationMS:D weightsCoeff:D",
   "launch_tr9_collide_mrt(st, totalNodes, (int)numTracers, velocityVX, velocityVY, tracerConc, tracerPDF, transportM, inverseRelaxationMS, weightsCoeff)"),
+ # ---------------- ShanChen2D/AccelerateGPU2D.py: the legacy DENSE explicit-forcing pipeline (:1336-2487, :2698) + the two macro kernels its
+ # driver chains in front (csrc/dense_ef.h); dense direction-major f[9][ny * nx], boolean masks, periodic wrap inside the kernels
+ ("de", "calMacroDensityGPU1D", DE + ":54", "nx:i ny:i fluidDensity:D fluidDistrC:D fluidDistrN:D isDomain:B",
+  "launch_de_macro_density(st, nx, ny, fluidDensity, fluidDistrC, fluidDistrN, isDomain)"),
+ ("de", "calMacroVelocityGPU1D", DE + ":80", "nx:i ny:i fluidVelocityX:D fluidVelocityY:D fluidDensity:D fluidDistr:D isDomain:B",
+  "launch_de_macro_velocity(st, nx, ny, fluidVelocityX, fluidVelocityY, fluidDensity, fluidDistr)"),
+ ("de", "calStreamingStep1", DE + ":1336", "nx:i ny:i fluidDistrOld:D fluidDistrMiddle:D",
+  "launch_de_stream1(st, nx, ny, fluidDistrOld, fluidDistrMiddle)"),
+ ("de", "calStreamingStep2", DE + ":1372", "nx:i ny:i fluidDistrNew:D fluidDistrMiddle:D",
+  "launch_de_stream2(st, nx, ny, fluidDistrNew, fluidDistrMiddle)"),
+ ("de", "calInteractionForceEFGPU", DE + ":1392", "nx:i ny:i constC:d interactionFluids:d potentialFluid0:D potentialFluid1:D externalForce0X:D externalForce0Y:D externalForce1X:D externalForce1Y:D isDomain1D:B isSolid:B",
+  "launch_de_force(st, nx, ny, constC, interactionFluids, potentialFluid0, potentialFluid1, externalForce0X, externalForce0Y, externalForce1X, externalForce1Y, isDomain1D)"),
+ ("de", "calExternalForceSolid", DE + ":2209", "nx:i ny:i interactionS0:d interactionS1:d potentialFluid0:D potentialFluid1:D externalForce0X:D externalForce0Y:D externalForce1X:D externalForce1Y:D isSolid:B",
+  "launch_de_force_solid<false>(st, nx, ny, interactionS0, interactionS1, potentialFluid0, potentialFluid1, externalForce0X, externalForce0Y, externalForce1X, externalForce1Y, nullptr, isSolid)"),
+ ("de", "calExternalForceSolidEF", DE + ":2257", "nx:i ny:i interactionS0:d interactionS1:d potentialFluid0:D potentialFluid1:D externalForce0X:D externalForce0Y:D externalForce1X:D externalForce1Y:D isDomain:B isSolid:B",
+  "launch_de_force_solid<true>(st, nx, ny, interactionS0, interactionS1, potentialFluid0, potentialFluid1, externalForce0X, externalForce0Y, externalForce1X, externalForce1Y, isDomain, isSolid)"),
+ ("de", "calEffectiveVGPU", DE + ":2309", "nx:i ny:i tau0:d tau1:d fluidDensity0:D fluidDensity1:D velocityX0:D velocityY0:D velocityX1:D velocityY1:D effectiveVX:D effectiveVY:D isDomain:B",
+  "launch_de_effective_v<false>(st, nx, ny, tau0, tau1, fluidDensity0, fluidDensity1, velocityX0, velocityY0, velocityX1, velocityY1, effectiveVX, effectiveVY, isDomain)"),
+ ("de", "calEffectiveVGPUMRT", DE + ":2332", "nx:i ny:i conserveS0:d conserveS1:d fluidDensity0:D fluidDensity1:D velocityX0:D velocityY0:D velocityX1:D velocityY1:D effectiveVX:D effectiveVY:D isDomain:B",
+  "launch_de_effective_v<true>(st, nx, ny, conserveS0, conserveS1, fluidDensity0, fluidDensity1, velocityX0, velocityY0, velocityX1, velocityY1, effectiveVX, effectiveVY, isDomain)"),
+ ("de", "calEquilibriumFuncEFGPU", DE + ":2354", "nx:i ny:i fluidDensity:D effectiveVX:D effectiveVY:D equilibriumFunc:D isDomain:B",
+  "launch_de_equilibrium(st, nx, ny, fluidDensity, effectiveVX, effectiveVY, equilibriumFunc, isDomain)"),
+ ("de", "calForcingTermEFGPU", DE + ":2403", "nx:i ny:i fluidDensity:D externalForceX:D externalForceY:D effectiveVX:D effectiveVY:D equilibriumFunc:D forcingTerm:D isDomain:B",
+  "launch_de_forcing_term(st, nx, ny, fluidDensity, externalForceX, externalForceY, effectiveVX, effectiveVY, equilibriumFunc, forcingTerm, isDomain)"),
+ ("de", "calTransformedDistrFuncGPU", DE + ":2444", "nx:i ny:i fluidDistr:D forcingTerm:D isDomain:B",
+  "launch_de_transform(st, nx, ny, fluidDistr, forcingTerm, isDomain)"),
+ ("de", "calMacroVelocityEFGPU", DE + ":2460", "nx:i ny:i fluidDensity:D externalFX:D externalFY:D distrFunc:D velocityX:D velocityY:D isDomain:B",
+  "launch_de_velocity_ef(st, nx, ny, fluidDensity, externalFX, externalFY, distrFunc, velocityX, velocityY, isDomain)"),
+ ("de", "calCollisionEFGPU", DE + ":2487", "nx:i ny:i tau:d fluidDistrOld:D equilibriumFunc:D forcingTerm:D isDomain:B",
+  "launch_de_collision(st, nx, ny, tau, fluidDistrOld, equilibriumFunc, forcingTerm, isDomain)"),
+ ("de", "calHalfWallBounceBack", DE + ":2698", "nx:i ny:i fluidDistr:D isDomain:B isSolid:B",
+  "launch_de_bounce_back(st, nx, ny, fluidDistr, isDomain, isSolid)"),
 ]
 
 CT = {"i": "int64_t", "d": "double", "I": "int64_t *", "D": "double *", "B": "uint8_t *"}
@@ -355,7 +387,9 @@ def main():
     hdr = ['''/*
  * lbmpm_kernels.h -- kernel-level (drop-in) C ABI of liblbmpm_hip.so: one entry point per @cuda.jit KERNEL of the
  * reference's five kernel modules (RKCG2D/AcceleratedRKGPU2D.py -> lbmpm_rk_*, RKCG2D/RKGPU2DBoundary.py -> lbmpm_rkb_*,
- * ShanChen2D/OptimizedD2Q9GPU.py and ExplicitD2Q9GPU.py -> lbmpm_sc_*, RKCG2D/AccelerateTransport2DRK.py -> lbmpm_tr_*),
+ * ShanChen2D/OptimizedD2Q9GPU.py and ExplicitD2Q9GPU.py -> lbmpm_sc_*, RKCG2D/AccelerateTransport2DRK.py -> lbmpm_tr_*), plus the
+ * explicit-forcing pipeline of the legacy dense file ShanChen2D/AccelerateGPU2D.py -> lbmpm_de_* (15 kernels on its own dense
+ * direction-major arrays f[9][ny * nx]; the rest of that file is unreachable dead code, see DESIGN.md section 7),
  * the ones its working loops launch and the ones nothing launches alike, on the reference's own sparse
  * arrays (AoS f[N][9] / f[nF][N][9] float64, int64 neighbour tables, boolean masks one byte per entry), same argument
  * order as the Numba signature minus the launch configuration `[grid, block]`; a list argument the reference kernel
