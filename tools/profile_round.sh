@@ -55,7 +55,7 @@ if [ -z "$SKIP_LONG" ]; then
 python bench.py --steps 500 --warmup 50 --no-secondary --no-cpu-baseline > $out/${tag}_bench_c5_steps500.json 2>> $out/bench.log
 python tools/dev/k3mixed.py 512 > $out/${tag}_k3mixed.log 2>&1
 python tools/slab_rank_cost.py 512 8 > $out/${tag}_slab_rank_cost_512_8.log 2>&1
-SLAB_CALIBRATE=1 python tools/slab_rank_cost.py 512 8 > $out/${tag}_slab_rank_cost_512_8_calibrated.log 2>&1
+SLAB_CALIBRATE=2 python tools/slab_rank_cost.py 512 8 > $out/${tag}_slab_rank_cost_512_8_calibrated.log 2>&1
 python tools/slabbench_pipelined.py 512 8 > $out/${tag}_slabbench_pipelined_512_8.log 2>&1
 python tools/slabbench_pipelined.py 512 2 > $out/${tag}_slabbench_pipelined_512_2.log 2>&1
 fi
