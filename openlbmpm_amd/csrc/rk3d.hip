@@ -1996,7 +1996,13 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
                 rk3dq_face_pack<<<fgrid, fblock, 0, c->aux>>>(q, c->send_up, c->send_dn, has_below, has_above);
                 LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));           // (here: "the face message is packed")
                 if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
-                // the chain, enqueued ahead of the interior launch
+                // the interior planes, straight behind the pack in the lattice stream
+                if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], c->aux));
+                launch_step_range(c, p, c->aux, zi0, zi1);
+                if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], c->aux));
+                // the chain.  (Enqueued BEHIND the interior launch: its dispatch is then in the lattice stream's queue when the pack retires, and the
+                // interior's workgroups take the CUs first -- with the chain first, a rank's copy / unpack kernels sometimes won that race and the
+                // interior started 0.05 ms late (one rank in eight on one GPU).  A copy engine needs no CU; RCCL keeps the split schedule.)
                 LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
                 if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
                 const double *from_below = c->recv_below, *from_above = c->recv_above;
@@ -2006,10 +2012,6 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
                 rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, from_below, from_above, has_below, has_above);
                 if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
                 LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
-                // the interior planes, straight behind the pack in the lattice stream
-                if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], c->aux));
-                launch_step_range(c, p, c->aux, zi0, zi1);
-                if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], c->aux));
                 if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
                 finish_step(c);
                 c->halo_valid = true;
