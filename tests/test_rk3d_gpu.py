@@ -555,6 +555,11 @@ def test_bench_line_of_a_two_rank_run(tmp_path):
     planes = [r["planes"] for r in m["per_rank"]]
     assert planes[0][0] == 0 and planes[0][1] == planes[1][0] and planes[1][1] == 128
     assert sum(r["fluid_nodes"] for r in m["per_rank"]) == d["config"]["fluid_nodes"]
+    # round 5: which transport every rank ended on, what set-up tried before it and why a candidate was rejected, the device of each rank
+    assert m["transport_per_rank"] == [r["transport"] for r in m["per_rank"]] and all("in-library ipc" in t for t in m["transport_per_rank"])
+    tried = m["transport_candidates"][0]["tried"]
+    assert m["transport_candidates"][0]["rank"] == 0 and tried[-1]["transport"] == "ipc" and tried[-1]["ok"] and "probe" in tried[-1]["why"]
+    assert all(r["device"].startswith("cuda:0") for r in m["per_rank"]) and "re-cut" in m["partition"]
 
 
 def test_bench_starts_its_own_ranks():
