@@ -542,10 +542,13 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
         const double J0 = p.trJ[t], J1 = (1. - p.trJ[t]) / 4.;
         // (streaming stores like the populations': read again a whole lattice later)
         __builtin_nontemporal_store(p.trRate != 0. ? (g[0] + d[0]) + J0 * S : g[0] + d[0], go + idx);
+        // cos of the angle between direction j and the interface normal, (e_j . u) / |u| (T:995-1008): e_j is a unit axis vector, so the four
+        // quotients are +-u_x / |u| and +-u_y / |u| -- two divisions instead of four, the same bits ((-a) / b == -(a / b); 1 * a + 0 * b == a)
+        double cax = 0., cay = 0.;
+        if (un > 1.0e-8) { cax = ux / (1. * un); cay = uy / (1. * un); }
 #pragma unroll
         for (int j = 1; j < 5; ++j) {
-            double c = 0.;
-            if (un > 1.0e-8) c = ((double)VX5[j] * ux + (double)VY5[j] * uy) / (1. * un);
+            const double c = VX5[j] != 0 ? (VX5[j] > 0 ? cax : -cax) : (VY5[j] > 0 ? cay : -cay);
             const double v = (g[j] + d[j]) + p.trBeta[t] * ind * (W5[j] * C) * c;
             __builtin_nontemporal_store((p.trRate != 0.) ? v + J1 * S : v, go + j * p.plane + idx);
         }
