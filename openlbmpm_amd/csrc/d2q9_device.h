@@ -144,6 +144,35 @@ __device__ __forceinline__ int xcd_tile(int b, int nb)
     return k * q + (k < r ? k : r) + j;
 }
 
+// The same for lattices at least 32 tiles wide (2048 nodes): there the rows a tile row shares with the next one (its halo) have left
+// the XCD's 4 MB L2 by the time the next tile row asks for them.  The whole tile rows of an XCD's share are walked in bands of four,
+// column by column -- vertically adjacent tiles run close in time -- and every XCD starts at another column: all eight walking the same
+// columns at once is 9 - 13 % SLOWER than whole rows (the same few channels from every XCD); staggered, c3 - 2 %, c4 - 3 % and 5 - 10 % fewer
+// bytes fetched (profiles/r05_walk2d.txt).  Narrower lattices keep whole rows (c2 1024^2: + 4 % with bands).  A permutation of the tiles;
+// results do not depend on it.
+__device__ __forceinline__ int xcd_tile(int b, int nb, int tiles_x)
+{
+#if defined(LBMPM_DEV) && defined(LBMPM_WALK_BAND)
+    constexpr int B = LBMPM_WALK_BAND;
+#else
+    constexpr int B = 4;
+#endif
+#if defined(LBMPM_DEV) && defined(LBMPM_WALK_ROWS)
+    return xcd_tile(b, nb);
+#endif
+    if (tiles_x < 32) return xcd_tile(b, nb);
+    const int q = nb >> 3, r = nb & 7, k = b & 7, j = b >> 3;
+    const int base = k * q + (k < r ? k : r), cnt = q + (k < r ? 1 : 0);
+    const int row0 = (base + tiles_x - 1) / tiles_x, row1 = (base + cnt) / tiles_x;      // the whole tile rows of this XCD's share
+    const int lead = row0 * tiles_x - base;
+    if (row1 <= row0 || j < lead || j >= lead + (row1 - row0) * tiles_x) return base + j;
+    const int jj = j - lead, per = tiles_x * B;
+    const int band = jj / per, w = jj - band * per;
+    const int rows = min(B, row1 - row0 - band * B);
+    const int col = (w / rows + k * tiles_x / 8) % tiles_x, row = w % rows;
+    return (row0 + band * B + row) * tiles_x + col;
+}
+
 // Full-line stores: true when the 128-byte line (16 consecutive lanes = 16 doubles of a row) this
 // lane would store into holds at least one active node.  Lanes of non-fluid cells of such a line
 // store zeros into their (dead) slots with the same instruction, so the line leaves L2 complete:

@@ -924,7 +924,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     __shared__ uint8_t s_fluid[SH::RH * SH::RW];
     // XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch order);
     // give every XCD a contiguous band of tiles so halo rows are shared inside one L2.
-    rk2d_fused_tile<MRT, TRACER, SH, TR>(p, tiles_x, tile0 + xcd_tile(blockIdx.x, gridDim.x), s_phi, s_ux, s_uy, s_gx, s_gy, s_list, &s_cnt, s_fluid);
+    rk2d_fused_tile<MRT, TRACER, SH, TR>(p, tiles_x, tile0 + xcd_tile(blockIdx.x, gridDim.x, tiles_x), s_phi, s_ux, s_uy, s_gx, s_gy, s_list, &s_cnt, s_fluid);
 }
 
 // The tracer step as ONE launch: tiles below lo_end and from hi_begin on (the tile rows whose region holds a lattice row a boundary rule
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(SH::THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     __shared__ uint16_t s_list[(SH::TW + 2) * (SH::TH + 2)];
     __shared__ int s_cnt;
     __shared__ uint8_t s_fluid[SH::RH * SH::RW];
-    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    const int t = xcd_tile(blockIdx.x, gridDim.x, tiles_x);
     if (t < lo_end || t >= hi_begin) rk2d_fused_tile<MRT, true, SH, 1>(p, tiles_x, t, s_phi, s_ux, s_uy, s_gx, s_gy, s_list, &s_cnt, s_fluid);
     else rk2d_fused_tile<MRT, true, SH, 0>(p, tiles_x, t, s_phi, s_ux, s_uy, s_gx, s_gy, s_list, &s_cnt, s_fluid);
 }
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(512) void rk2dp_fused(RKDev p, PertDev q, int tiles
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
     __shared__ double s_phi[RH * RW];
     __shared__ uint8_t s_fluid[RH * RW];
-    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    const int t = xcd_tile(blockIdx.x, gridDim.x, tiles_x);
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
     // All flags (the region's mask, the own node's, the rim node's) and -- before any of them is known -- the own node's solid-neighbour
@@ -1427,6 +1427,9 @@ int launch_step(lbmpm_rk2d *c, bool diag, bool timed)
         if (c->ntr > 0) {
             // registers are capped at 128 (amdgpu_waves_per_eu on the kernel): two 64 x 8 blocks share a CU
             if (c->shape == 3) launch_fused_tracer<FusedShape<4, 1>>(c, p);
+#if defined(LBMPM_DEV) && defined(LBMPM_TRACER_TALL)
+            else if (c->shape == 2) launch_fused_tracer<FusedShape<16, 1>>(c, p);      // tools/dev/walk2d.sh: one 1024-thread workgroup per CU
+#endif
             else launch_fused_tracer<FusedShape<8, 1>>(c, p);
         } else
         switch (c->shape) {

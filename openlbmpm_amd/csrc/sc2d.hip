@@ -373,7 +373,7 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
     __shared__ double s_psi0[RH * RW];
     __shared__ double s_psi1[RH * RW];
-    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    const int t = xcd_tile(blockIdx.x, gridDim.x, tiles_x);
     const int tx0 = (t % tiles_x) * TW, ty0 = (t / tiles_x) * TH;
     const int tid = threadIdx.x, lx = tid % TW, ly = tid / TW;
 
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512, 4) void sc2d_iso_fused(SCDev p, int tiles_x)
     __shared__ double s_psi0[QH * QW];
     __shared__ double s_psi1[QH * QW];
     __shared__ uint8_t s_fl[QH * QW];
-    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    const int t = xcd_tile(blockIdx.x, gridDim.x, tiles_x);
     const int tx0 = (t % tiles_x) * IW, ty0 = (t / tiles_x) * IH;
     const int tid = threadIdx.x, lx = tid % IW, ly = tid / IW;
     const int x = tx0 + lx, y = ty0 + ly;

@@ -92,8 +92,8 @@ def test_tracer_mass_conserved_without_open_boundaries():
     s.close()
 
 
-@pytest.mark.parametrize("ny", [57, 58, 60, 61, 44])
-def test_tracer_step_on_lattices_whose_height_is_no_multiple_of_the_tile(ny):
+@pytest.mark.parametrize("ny,nx", [(57, 72), (58, 72), (60, 72), (61, 72), (44, 72), (61, 2100)], ids=lambda v: str(v))
+def test_tracer_step_on_lattices_whose_height_is_no_multiple_of_the_tile(ny, nx):
     """The tracer step runs as up to three launches: the variant that re-sums the densities after the boundary rows (the transport
     driver's order, Transport2DRK.py:1199-1287) on every tile row whose region -- 8 own rows + 3 rows of halo -- holds one of the rows
     0, 1, ny-2, ny-1, the plain variant in between.  With ny % 8 in 1..4 row ny-2 lies among the own rows or in the halo of the
@@ -103,7 +103,8 @@ def test_tracer_step_on_lattices_whose_height_is_no_multiple_of_the_tile(ny):
     from openlbmpm_amd.rk2d import RK2DSolver
     from openlbmpm_amd.geometry import simple_geometry
     from oracle.tr import CoupledOracle
-    dom = simple_geometry(72, ny)
+    # (2100 wide: 33 tiles per row, where the tiles are walked in staggered bands -- xcd_tile, d2q9_device.h)
+    dom = simple_geometry(nx, ny)
     nyy, nx = dom.shape
     ii, jj = np.mgrid[0:nyy, 0:nx]
     fluid = dom == 1
