@@ -92,7 +92,7 @@ def test_tracer_mass_conserved_without_open_boundaries():
     s.close()
 
 
-@pytest.mark.parametrize("ny,nx", [(57, 72), (58, 72), (60, 72), (61, 72), (44, 72), (61, 2100)], ids=lambda v: str(v))
+@pytest.mark.parametrize("ny,nx", [(57, 72), (58, 72), (60, 72), (61, 72), (44, 72), (141, 2100)], ids=lambda v: str(v))
 def test_tracer_step_on_lattices_whose_height_is_no_multiple_of_the_tile(ny, nx):
     """The tracer step runs as up to three launches: the variant that re-sums the densities after the boundary rows (the transport
     driver's order, Transport2DRK.py:1199-1287) on every tile row whose region -- 8 own rows + 3 rows of halo -- holds one of the rows
