@@ -52,6 +52,65 @@ def pmc_traffic(kernel, workload_tag):
     return rec["traffic_bytes_per_launch"]
 
 
+def under_rocprof():
+    """this process is itself being profiled (tools/profile_round.sh, the driver's own rocprofv3 run): no nested profiler"""
+    return any(k.startswith("ROCPROF") or k == "ROCP_TOOL_LIBRARIES" for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_pmc_traffic(kernel, child_args, timeout=240):
+    """HBM bytes per launch of `kernel` counted IN THIS RUN: two short rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`, then
+    `--pmc WRITE_SIZE`: one counter group per pass and no other trace domain beside it, as the guide's HBM section prescribes) over a few
+    steps of this same workload in a child process.  FETCH_SIZE is scaled by the factor the SAME pass measures on the calibration kernel
+    of the lattice kernel's access width (calib_pull19_b64, 19 planes of 48 MiB pulled 8 bytes per lane: the child's stream test launches
+    it), WRITE_SIZE is taken as reported (measured factor 1.000 in every committed profile).  Returns a dict, or None with nothing
+    changed when rocprofv3 is absent, this process is already under a profiler, or a pass fails or runs over its time."""
+    import glob
+    import shutil
+    import signal
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or under_rocprof():
+        return None
+    tmp = tempfile.mkdtemp(prefix="lbmpm_pmc_", dir="/tmp")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "x", "--", sys.executable, os.path.abspath(__file__)] + child_args
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)        # the process group this call started, nothing else
+                p.wait()
+                return None
+            dbs = glob.glob(os.path.join(d, "**", "x_results.db"), recursive=True)
+            if rc != 0 or not dbs:
+                return None
+            rows = sqlite3.connect(dbs[0]).execute(
+                "select name, count(*), avg(v) from (select name, dispatch_id, sum(counter_value) as v from pmc_events "
+                "where counter_name = ? group by name, dispatch_id) group by name", (counter,)).fetchall()
+            lattice = [(n, a) for name, n, a in rows if kernel in name]
+            if not lattice:
+                return None
+            got[counter] = {"launches": sum(n for n, _ in lattice), "kb": sum(n * a for n, a in lattice) / sum(n for n, _ in lattice),
+                            "calib_kb": next((a for name, _n, a in rows if "calib_pull19_b64" in name), None)}
+    except (OSError, sqlite3.Error):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    true_calib = 19.0 * (48 << 20)
+    ck = got["FETCH_SIZE"]["calib_kb"]
+    factor = true_calib / (ck * 1024.0) if ck else 2.0
+    return {"traffic": factor * got["FETCH_SIZE"]["kb"] * 1024.0 + got["WRITE_SIZE"]["kb"] * 1024.0,
+            "fetch_size_kb": round(got["FETCH_SIZE"]["kb"], 1), "write_size_kb": round(got["WRITE_SIZE"]["kb"], 1),
+            "fetch_factor": round(factor, 4), "fetch_factor_from": "calib_pull19_b64 in the same pass" if ck else "the guide's gfx950 correction (no calibration row)",
+            "launches_counted": got["FETCH_SIZE"]["launches"]}
+
+
 def measured_hbm(device):
     """copy / read-only GB/s of this device over 2 x 4 GiB (context for roofline.frac, which is quoted
     against the 8 TB/s specification)"""
@@ -266,6 +325,8 @@ def main():
     ap.add_argument("--no-c5-legs", action="store_true", help="N = 1: skip the secondary c5 legs (other states / other relaxation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="N = 1, c5: skip the two short rocprofv3 counter passes that count this run's HBM bytes "
+                                                                   "(roofline.traffic then comes from the committed profile)")
     ap.add_argument("--no-calibration", action="store_true", help="N > 1: keep the equal-fluid-cells cuts (no measured re-cut of the slabs)")
     args = ap.parse_args()
 
@@ -405,7 +466,13 @@ def main():
             by_balg = B_ALG["c5"] * nfl_local / (per_launch_ms * 1e-3) / 1e9
             win = sorted(nfluid_global * n / (ms * 1e-3) / 1e6 for n, ms in zip(win_steps, win_ms))
             ktag = dom_kernel + ("[SRT]" if args.relax == "SRT" else "") + ("" if args.c5_state == "initial" else "[%s]" % args.c5_state)
-            traffic = pmc_traffic(ktag, "c5 %dx%dx%d" % size) if world == 1 else None
+            committed = pmc_traffic(ktag, "c5 %dx%dx%d" % size) if world == 1 else None
+            live = None
+            if world == 1 and not args.no_live_traffic and dom_kernel == "rk3dq_fused":
+                # the instance that runs every step but the first (template argument FIRST = false)
+                live = live_pmc_traffic("rk3dq_fused<false", ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic",
+                                                               "--relax", args.relax, "--c5-state", args.c5_state, "--size"] + [str(v) for v in size])
+            traffic = live["traffic"] if live else committed
             moved = c5_bytes_moved(storage, per_launch_ms, traffic)
             # roofline.achieved / frac: BYTES MOVED per launch / launch time (the counters' figure when a committed profile matches this
             # workload, else the storage's own count); SURVEY 8d's formula (608 B per update: both colour lattices read and written
@@ -450,8 +517,14 @@ def main():
                              "achieved_by_survey_balg": round(by_balg, 1), "frac_by_survey_balg": round(by_balg / HBM_PEAK_GBS, 4),
                              "frac_by_survey_balg_note": "SURVEY 8d: MLUPS x 608 B / 8 TB/s; not a bandwidth fraction for this storage (may exceed 1)",
                              "traffic": traffic,
-                             "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh over this "
-                                                "command on an MI355X box (committed; NOT measured in this run)") if traffic else None,
+                             "traffic_source": ("measured in THIS run, on this GPU: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE) over "
+                                                "8 steps of this workload in a child process of bench.py; FETCH_SIZE x the factor the same pass measures on "
+                                                "the calibration kernel of this kernel's access width") if live else
+                                               ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh over this "
+                                                "command on an MI355X box (committed; NOT measured in this run" + (
+                                                    ": this process is itself under a profiler" if under_rocprof() else
+                                                    ": --no-live-traffic" if args.no_live_traffic else ": the live counter passes did not complete") + ")") if traffic else None,
+                             "traffic_live": live, "traffic_committed_profile": committed,
                              "bytes_moved": moved,
                              "kernel": dom_kernel,
                              "measured_stream_ceiling": measured_hbm(local_rank) if world == 1 else None,
@@ -515,15 +588,21 @@ def main():
                     s3.step_single(5); s3.sync()
                     t1 = time.perf_counter(); mt3, md3 = s3.step_timed(nsteps); s3.sync(); w3 = time.perf_counter() - t1
                     st3 = s3.storage_info()
-                    ktag3 = s3.dominant_kernel + ("[SRT]" if relax == "SRT" else "") + ("" if state == "initial" else "[%s]" % state)
-                    mv = c5_bytes_moved(st3, md3 / nsteps, pmc_traffic(ktag3, "c5 %dx%dx%d" % size))
-                    leg = {"workload": label, "value": round(s3.num_fluid_nodes * nsteps / w3 / 1e6, 2), "unit": "MLUPS",
-                           "ms_per_step": round(w3 * 1e3 / nsteps, 5), "steps": nsteps, "fluid_nodes": s3.num_fluid_nodes, "kernel": s3.dominant_kernel,
+                    nf3, dk3 = s3.num_fluid_nodes, s3.dominant_kernel
+                    ktag3 = dk3 + ("[SRT]" if relax == "SRT" else "") + ("" if state == "initial" else "[%s]" % state)
+                    s3.close()
+                    live3 = None
+                    if not args.no_live_traffic and dk3 == "rk3dq_fused":
+                        live3 = live_pmc_traffic("rk3dq_fused<false", ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic",
+                                                                        "--relax", relax, "--c5-state", state, "--size"] + [str(v) for v in size])
+                    mv = c5_bytes_moved(st3, md3 / nsteps, live3["traffic"] if live3 else pmc_traffic(ktag3, "c5 %dx%dx%d" % size))
+                    mv["counted_in"] = "this run (rocprofv3 counter passes in a child process)" if live3 else "profiles/pmc_traffic.json (committed profile)"
+                    leg = {"workload": label, "value": round(nf3 * nsteps / w3 / 1e6, 2), "unit": "MLUPS",
+                           "ms_per_step": round(w3 * 1e3 / nsteps, 5), "steps": nsteps, "fluid_nodes": nf3, "kernel": dk3,
                            "state": C5_STATES[state], "cells_in_single_colour_rows": mv["cells_in_single_colour_rows"],
                            "roofline_frac": mv["counted_frac"] if mv["counted_frac"] is not None else mv["storage_frac"],
-                           "roofline_frac_by_survey_balg": round(B_ALG["c5"] * s3.num_fluid_nodes / (md3 / nsteps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "roofline_frac_by_survey_balg": round(B_ALG["c5"] * nf3 / (md3 / nsteps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "bytes_moved": mv}
-                    s3.close()
                     return leg
                 if not args.no_c5_legs:
                     for state in sorted(C5_STATES):
