@@ -57,7 +57,18 @@ def under_rocprof():
     return any(k.startswith("ROCPROF") or k == "ROCP_TOOL_LIBRARIES" for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
 
 
-def live_pmc_traffic(kernel, child_args, timeout=240):
+_LIVE = {"ok": True}        # one failed or overrunning counter pass and this run asks for no further one (the committed profile serves)
+
+
+def live_pmc_traffic(kernel, child_args, timeout=150):
+    if not _LIVE["ok"]:
+        return None
+    out = _live_pmc_traffic(kernel, child_args, timeout)
+    _LIVE["ok"] = out is not None
+    return out
+
+
+def _live_pmc_traffic(kernel, child_args, timeout):
     """HBM bytes per launch of `kernel` counted IN THIS RUN: two short rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`, then
     `--pmc WRITE_SIZE`: one counter group per pass and no other trace domain beside it, as the guide's HBM section prescribes) over a few
     steps of this same workload in a child process.  FETCH_SIZE is scaled by the factor the SAME pass measures on the calibration kernel
