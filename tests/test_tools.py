@@ -12,13 +12,37 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-@pytest.mark.parametrize("src", ["tile_pull_copy.hip", "march_pull_copy.hip", "march3d_pull_copy.hip"])
+@pytest.mark.parametrize("src", ["tile_pull_copy.hip", "march_pull_copy.hip", "march3d_pull_copy.hip", "tile_persist.hip"])
 def test_microbenchmarks_compile(src, tmp_path):
     out = tmp_path / "a.out"
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", os.path.join(ROOT, "tools", "microbench", src), "-o", str(out)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert out.exists()
+
+
+def test_live_traffic_passes_stand_down_without_side_effects(monkeypatch, tmp_path):
+    """bench.py counts its HBM bytes with rocprofv3 passes over a child process; it must start none when it is itself being profiled
+    (rocprofv3 exports ROCPROF_* to the profiled process), when rocprofv3 is missing, and after one pass of the run has failed"""
+    sys.path.insert(0, ROOT)
+    import bench
+    started = []
+    monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: started.append(a) or (_ for _ in ()).throw(AssertionError("a pass was started")))
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", str(tmp_path))
+    assert bench.under_rocprof()
+    bench._LIVE["ok"] = True
+    assert bench.live_pmc_traffic("rk3dq_fused<false", ["--steps", "1"]) is None and not started
+    # one failure ends the live passes of the run
+    assert bench._LIVE["ok"] is False
+    monkeypatch.delenv("ROCPROF_OUTPUT_PATH")
+    assert not bench.under_rocprof()
+    assert bench.live_pmc_traffic("rk3dq_fused<false", ["--steps", "1"]) is None and not started
+    # no rocprofv3 on the machine
+    bench._LIVE["ok"] = True
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    monkeypatch.setattr(os.path, "exists", lambda path: False)
+    assert bench.live_pmc_traffic("rk3dq_fused<false", ["--steps", "1"]) is None and not started
+    bench._LIVE["ok"] = True
 
 
 @pytest.mark.gpu
