@@ -12,7 +12,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-@pytest.mark.parametrize("src", ["tile_pull_copy.hip", "march_pull_copy.hip", "march3d_pull_copy.hip", "tile_persist.hip"])
+@pytest.mark.parametrize("src", ["tile_pull_copy.hip", "march_pull_copy.hip", "march3d_pull_copy.hip", "tile_persist.hip", "tile_compact.hip"])
 def test_microbenchmarks_compile(src, tmp_path):
     out = tmp_path / "a.out"
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", os.path.join(ROOT, "tools", "microbench", src), "-o", str(out)],
