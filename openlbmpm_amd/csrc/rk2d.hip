@@ -190,6 +190,18 @@ __device__ __forceinline__ double tau_of(const RKDev &p, double Phi, double rR, 
     return tau;
 }
 
+// e . v = (double)ex * vx + (double)ey * vy for a lattice direction (components 0, +-1) without the products by zero and the additions of
+// their results: x * 1 = x, x * -1 = -x and x + 0 * y = x hold exactly for finite operands, so the value is the reference's bit for bit (only
+// the sign of an exact zero can differ); hipcc may not drop 0 * y itself.  pm(e, t) = t * (double)e for e = +-1.
+__device__ __forceinline__ double pm(int e, double t) { return e > 0 ? t : -t; }
+__device__ __forceinline__ double edot(int ex, int ey, double vx, double vy)
+{
+    if (ex == 0 && ey == 0) return 0.;
+    if (ey == 0) return pm(ex, vx);
+    if (ex == 0) return pm(ey, vy);
+    return pm(ex, vx) + pm(ey, vy);
+}
+
 // A:170-176 calEquilibriumRK2D
 __device__ __forceinline__ double feq(double rho, double w, double ex, double ey, double vx, double vy)
 {
@@ -280,7 +292,7 @@ __device__ __forceinline__ void recolor(double beta, const double fT[9], double 
     const double A = (gn > 1.0e-8) ? beta * rhoR * rhoB * itot / gn : 0.;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const double a = A * W[i] * ((double)EXi[i] * gx + (double)EYi[i] * gy);
+        const double a = A * W[i] * edot(EXi[i], EYi[i], gx, gy);
         fR[i] = kR * fT[i] + a;
         fB[i] = kB * fT[i] - a;
     }
@@ -524,7 +536,7 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
                 // 0 * x to a finite sum changes nothing -- and 25 doubles leave the scalar registers)
                 constexpr double M5[25] = {1, 1, 1, 1, 1,   0, 1, -1, 0, 0,   0, 0, 0, 1, -1,   4, -1, -1, -1, -1,   0, 1, 1, -1, -1};
                 if (M5[5 * j + k] == 0.) continue;
-                const double eq = C * W5[k] * (1. + 3. * ((double)VX5[k] * vx + (double)VY5[k] * vy));
+                const double eq = C * W5[k] * (1. + 3. * edot(VX5[k], VY5[k], vx, vy));
                 ve += M5[5 * j + k] * eq;
                 vp += g[k] * M5[5 * j + k];
             }
@@ -795,8 +807,8 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
             const int rn = ri + EY[i] * RW + EX[i];
             const double v = s_phi[rn];
             solid_nb |= !s_fluid[rn];
-            ax += W[i] * v * (double)EX[i];
-            ay += W[i] * v * (double)EY[i];
+            if (EX[i] != 0) ax += pm(EX[i], W[i] * v);         // (no "+ W v * 0": see pm / edot)
+            if (EY[i] != 0) ay += pm(EY[i], W[i] * v);
         }
         gx = 3. * ax; gy = 3. * ay;
         if (solid_nb) {
@@ -865,10 +877,8 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
             if ((sn[m] >> (i - 1)) & 1u) continue;
             const int rn = ri + EY[i] * RW + EX[i];
             const double qx = s_ux[rn], qy = s_uy[rn];
-            pyx += 3. * W[i] * qy * (double)EX[i];
-            pxy += 3. * W[i] * qx * (double)EY[i];
-            px += 3. * W[i] * qx * (double)EX[i];
-            py += 3. * W[i] * qy * (double)EY[i];
+            if (EX[i] != 0) { pyx += pm(EX[i], 3. * W[i] * qy); px += pm(EX[i], 3. * W[i] * qx); }
+            if (EY[i] != 0) { pxy += pm(EY[i], 3. * W[i] * qx); py += pm(EY[i], 3. * W[i] * qy); }
         }
         const double K = ux * uy * (pyx + pxy) - uy * uy * px - ux * ux * py;
         const double sgn = (p.wetting == 2) ? -0.5 : 0.5;
