@@ -393,6 +393,28 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         rows_xcol.t.lrow = xrow + 2; rows_xcol.t.k = xc < 2 ? 0 : 2;
     };
     set_geometry(tid);
+    // ... re-derived from three packed words per thread in LDS since round 5: set_geometry costs ~ 80 vector instructions per march step, the
+    // unpacking ~ 30 (the words are read through an address the compiler cannot see through, so nothing is hoisted here either)
+    __shared__ unsigned sgeo[3][TX * TY];
+    sgeo[0][tid] = (unsigned)lx | ((unsigned)ly << 6) | ((unsigned)hlx << 9) | ((unsigned)hly << 16) | ((unsigned)(xrow + 2) << 20) | ((unsigned)xc << 24) |
+                   ((unsigned)own << 26) | ((unsigned)has_own << 27) | ((unsigned)has_rim << 28) | ((unsigned)has_x << 29);
+    sgeo[1][tid] = ((unsigned)hx & 0xffffu) | ((unsigned)hy << 16);
+    sgeo[2][tid] = ((unsigned)yo & 0xffffu) | ((unsigned)(xcol + 2) << 16);
+    auto load_geometry = [&](int t) {
+        const unsigned w0 = sgeo[0][t], w1 = sgeo[1][t], w2 = sgeo[2][t];
+        lx = (int)(w0 & 63u); ly = (int)((w0 >> 6) & 7u);
+        x = tx * TX + lx; y = ty * TY + ly;
+        hlx = (int)((w0 >> 9) & 127u); hly = (int)((w0 >> 16) & 15u);
+        xrow = (int)((w0 >> 20) & 15u) - 2; xc = (int)((w0 >> 24) & 3u);
+        own = (w0 >> 26) & 1u; has_own = (w0 >> 27) & 1u; has_rim = (w0 >> 28) & 1u; has_x = (w0 >> 29) & 1u;
+        hx = (int)(short)(w1 & 0xffffu); hy = (int)w1 >> 16;
+        yo = (int)(short)(w2 & 0xffffu); xcol = (int)(w2 >> 16) - 2;
+        rows_own.t.lrow = ly + 2;
+        rows_rimrow.t.lrow = hly + 1;
+        rows_rimcol.t.lrow = hly + 1; rows_rimcol.t.k = hlx == 0 ? 0 : 2;
+        rows_xrow.t.lrow = xrow + 2;
+        rows_xcol.t.lrow = xrow + 2; rows_xcol.t.k = xc < 2 ? 0 : 2;
+    };
     // chunks 0 .. nchunks1-1 march the planes z_first .. z_last, the chunks behind them z_first2 .. z_last2 (the two boundary ranges of a slab
     // in one launch)
     const int za = chunk < nchunks1 ? z_first + chunk * chunk_len : z_first2 + (chunk - nchunks1) * chunk_len;
@@ -556,7 +578,11 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         {
             int t = tid;
             asm volatile("" : "+v"(t));
+#ifdef LBMPM_RK3D_GEO_COMPUTE
             set_geometry(t);
+#else
+            load_geometry(t);
+#endif
         }
         // fetched here, in uniform control flow, as scalar loads: inside the collision's branch they become a vector load, and the
         // s_waitcnt vmcnt(0) in front of its use drains the pulls in flight (the collision then overlaps nothing)
