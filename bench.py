@@ -478,12 +478,9 @@ def main():
             win = sorted(nfluid_global * n / (ms * 1e-3) / 1e6 for n, ms in zip(win_steps, win_ms))
             ktag = dom_kernel + ("[SRT]" if args.relax == "SRT" else "") + ("" if args.c5_state == "initial" else "[%s]" % args.c5_state)
             committed = pmc_traffic(ktag, "c5 %dx%dx%d" % size) if world == 1 else None
-            live = None
-            if world == 1 and not args.no_live_traffic and dom_kernel == "rk3dq_fused":
-                # the instance that runs every step but the first (template argument FIRST = false)
-                live = live_pmc_traffic("rk3dq_fused<false", ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic",
-                                                               "--relax", args.relax, "--c5-state", args.c5_state, "--size"] + [str(v) for v in size])
-            traffic = live["traffic"] if live else committed
+            live = None          # counted in this run AFTER everything has been timed (deferred below): a profiler child process between two
+            deferred = []        # timed legs leaves the GPU idle for seconds, and the leg that follows pays for it
+            traffic = committed
             moved = c5_bytes_moved(storage, per_launch_ms, traffic)
             # roofline.achieved / frac: BYTES MOVED per launch / launch time (the counters' figure when a committed profile matches this
             # workload, else the storage's own count); SURVEY 8d's formula (608 B per update: both colour lattices read and written
@@ -534,7 +531,7 @@ def main():
                                                ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh over this "
                                                 "command on an MI355X box (committed; NOT measured in this run" + (
                                                     ": this process is itself under a profiler" if under_rocprof() else
-                                                    ": --no-live-traffic" if args.no_live_traffic else ": the live counter passes did not complete") + ")") if traffic else None,
+                                                    ": --no-live-traffic" if args.no_live_traffic else ": the live counter passes did not complete or do not apply") + ")") if traffic else None,
                              "traffic_live": live, "traffic_committed_profile": committed,
                              "bytes_moved": moved,
                              "kernel": dom_kernel,
@@ -544,6 +541,23 @@ def main():
                              "avg_launch_ms": round(per_launch_ms, 5),
                              "algorithmic_bytes_per_launch": B_ALG["c5"] * nfl_local},
             }
+            LIVE_TEXT = ("measured in THIS run, on this GPU: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE) over "
+                         "8 steps of this workload in a child process of bench.py, after everything has been timed; FETCH_SIZE x the factor the same pass "
+                         "measures on the calibration kernel of this kernel's access width")
+            if world == 1 and not args.no_live_traffic and dom_kernel == "rk3dq_fused":
+                def main_live(out=out, storage=storage, per_launch_ms=per_launch_ms, note=moved["note"]):
+                    # the instance that runs every step but the first (template argument FIRST = false)
+                    lv = live_pmc_traffic("rk3dq_fused<false", ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic",
+                                                                 "--relax", args.relax, "--c5-state", args.c5_state, "--size"] + [str(v) for v in size])
+                    if not lv:
+                        return
+                    mv = c5_bytes_moved(storage, per_launch_ms, lv["traffic"])
+                    mv["note"] = note
+                    r = out["roofline"]
+                    r.update({"achieved": round(mv["counted_GBs"], 1), "frac": round(mv["counted_GBs"] / HBM_PEAK_GBS, 4),
+                              "achieved_is": "bytes moved per launch / avg_launch_ms: hardware counters (traffic)", "traffic": lv["traffic"],
+                              "traffic_source": LIVE_TEXT, "traffic_live": lv, "bytes_moved": mv})
+                deferred.append(main_live)
             if world > 1:
                 # what the transport really was, and where a step's time went on every rank (HIP events inside
                 # lbmpm_rk3d_step_slab): exchange_exposed_ms = step - max(interior, boundary)
@@ -602,18 +616,25 @@ def main():
                     nf3, dk3 = s3.num_fluid_nodes, s3.dominant_kernel
                     ktag3 = dk3 + ("[SRT]" if relax == "SRT" else "") + ("" if state == "initial" else "[%s]" % state)
                     s3.close()
-                    live3 = None
-                    if not args.no_live_traffic and dk3 == "rk3dq_fused":
-                        live3 = live_pmc_traffic("rk3dq_fused<false", ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic",
-                                                                        "--relax", relax, "--c5-state", state, "--size"] + [str(v) for v in size])
-                    mv = c5_bytes_moved(st3, md3 / nsteps, live3["traffic"] if live3 else pmc_traffic(ktag3, "c5 %dx%dx%d" % size))
-                    mv["counted_in"] = "this run (rocprofv3 counter passes in a child process)" if live3 else "profiles/pmc_traffic.json (committed profile)"
+                    mv = c5_bytes_moved(st3, md3 / nsteps, pmc_traffic(ktag3, "c5 %dx%dx%d" % size))
+                    mv["counted_in"] = "profiles/pmc_traffic.json (committed profile)"
                     leg = {"workload": label, "value": round(nf3 * nsteps / w3 / 1e6, 2), "unit": "MLUPS",
                            "ms_per_step": round(w3 * 1e3 / nsteps, 5), "steps": nsteps, "fluid_nodes": nf3, "kernel": dk3,
                            "state": C5_STATES[state], "cells_in_single_colour_rows": mv["cells_in_single_colour_rows"],
                            "roofline_frac": mv["counted_frac"] if mv["counted_frac"] is not None else mv["storage_frac"],
                            "roofline_frac_by_survey_balg": round(B_ALG["c5"] * nf3 / (md3 / nsteps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "bytes_moved": mv}
+                    if not args.no_live_traffic and dk3 == "rk3dq_fused":
+                        def leg_live(leg=leg, st3=st3, ms=md3 / nsteps):
+                            lv = live_pmc_traffic("rk3dq_fused<false", ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic",
+                                                                         "--relax", relax, "--c5-state", state, "--size"] + [str(v) for v in size])
+                            if not lv:
+                                return
+                            m2 = c5_bytes_moved(st3, ms, lv["traffic"])
+                            m2["counted_in"] = "this run (rocprofv3 counter passes in a child process, after the timed legs)"
+                            leg["bytes_moved"] = m2
+                            leg["roofline_frac"] = m2["counted_frac"]
+                        deferred.append(leg_live)
                     return leg
                 if not args.no_c5_legs:
                     for state in sorted(C5_STATES):
@@ -626,6 +647,8 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_c5(args.relax)
                 out["cpu_baseline_reference_shape"] = cpu_baseline_simple_d2q9()
+            for fn in deferred:          # the counter passes: nothing is timed after this point
+                fn()
     else:
         size = tuple(args.size) if args.size else ((1024, 1024) if wl == "c2" else (2048, 2048))
         steps = args.steps if args.steps is not None else (2000 if wl == "c2" else 500)
