@@ -1334,6 +1334,8 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     TRY_RC(dev_alloc(c, &c->fB, fcount));
     if (c->q23) {
         if (!(getenv("LBMPM_RK3D_XCC") && atoi(getenv("LBMPM_RK3D_XCC")) == 0)) TRY_RC(dev_alloc(c, &c->slotq, 2 * 4096 * 8));     // zeroed
+        // (row segments of a slab are indexed with 32 bits in the kernels: rk3dq.h::row_index)
+        LBMPM_REQUIRE((size_t)(c->nzl + 2) * c->ny * c->nseg < ((size_t)1 << 31), "rk3d: more than 2^31 row segments in one slab");
         TRY_RC(dev_alloc(c, &c->purA, (size_t)(c->nzl + 2) * c->ny * c->nseg));
         TRY_RC(dev_alloc(c, &c->purB, (size_t)(c->nzl + 2) * c->ny * c->nseg));
     }

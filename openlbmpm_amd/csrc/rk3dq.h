@@ -109,7 +109,8 @@ __device__ __forceinline__ void pull_q(const RK3Dev &p, const Rows &rows, int zl
 // bit 0 / bit 1 = every fluid cell of the segment is pure red (k_R = 1, A = 0) / pure blue (k_R = 0, A = 0); 3 = no fluid cell.
 // A flagged segment's records are neither written nor read -- whoever needs them takes the constant; away from the
 // interface a step then moves 19 + 19 doubles per cell.
-__device__ __forceinline__ size_t row_index(const RK3Dev &p, int zl, int y, int sg) { return ((size_t)zl * p.ny + y) * p.nseg + sg; }
+// (32-bit: (nzl + 2) * ny * nseg row segments of a slab -- 2.1 M at 512^3, checked against 2^31 at set-up)
+__device__ __forceinline__ unsigned row_index(const RK3Dev &p, int zl, int y, int sg) { return ((unsigned)zl * (unsigned)p.ny + (unsigned)y) * (unsigned)p.nseg + (unsigned)sg; }
 
 // where the scalar records {k_R, A} of the cells around a node come from
 struct LdsScal {                  // the marching kernel's LDS tile (flagged rows are filled with the constant there)
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             if (yy < 0) yy += p.ny;
             int sg = tx - 1 + (k >> 1);
             sg = sg < 0 ? sg + p.nseg : (sg >= p.nseg ? sg - p.nseg : sg);
-            const size_t rr = ((size_t)zl * p.ny + yy) * p.nseg + sg;
+            const unsigned rr = ((unsigned)zl * (unsigned)p.ny + (unsigned)yy) * (unsigned)p.nseg + (unsigned)sg;
             q.v = (k & 1) ? p.seg2[rr] : p.seg[rr];
             if (k & 1) {
                 q.f0 = p.pur_in[rr];
