@@ -19,7 +19,7 @@ Infeasible paths are what a linear or a plain graph walk drowns in, so the walk 
   contradicts the flag's value on this path is not followed;
 * where the source guards a region by `if (__ballot(c) != 0) { if (c) {...} }` the compiler still emits an all-lanes-off branch around
   the inner region; the source marks such a region with `LBMPM_TAKEN` (`asm volatile("; lbmpm-taken")`) and the walk drops that edge.
-A kernel whose walk exceeds 150 000 distinct states is reported as GAVE_UP (rk3dq_fused<FIRST = false>: the 19 per-direction branches of
+A kernel whose walk exceeds STATE_BUDGET (600 000) distinct states is reported as GAVE_UP (rk3dq_fused<FIRST = false>: the 19 per-direction branches of
 its pull address arithmetic times the lanes-off variants).
 
 tests/test_codeobj.py compiles the sources with the product's flags and asserts an empty report for every instance;
@@ -33,6 +33,7 @@ _VREG_RANGE = re.compile(r'\bv\[(\d+):(\d+)\]')
 _VREG = re.compile(r'\bv(\d+)\b')
 _MAXPEND = 96
 MARK = 'lbmpm-taken'
+STATE_BUDGET = 600000
 GAVE_UP = 'the walk gave up (too many distinct states)'
 
 
@@ -183,7 +184,7 @@ def check_kernel(body, trace_line=None):
         key, parent = work.pop()
         if key in seen:
             continue
-        if len(seen) > 150000:
+        if len(seen) > STATE_BUDGET:
             problems[-1] = GAVE_UP
             break
         seen[key] = parent
