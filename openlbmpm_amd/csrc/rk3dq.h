@@ -515,13 +515,24 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         s.slot[0] = ((zp - 1) & 3) * SSLOT; s.slot[1] = (zp & 3) * SSLOT; s.slot[2] = ((zp + 1) & 3) * SSLOT;
         return s;
     };
-    for (int zl = za - 3; zl <= za + 2; ++zl) put_rows(zl, fetch_rows(zl));
+    // prologue: the six planes of row records, then the three planes of scalar records, each as ONE batch of loads (fetched and put plane
+    // by plane they were nine dependent memory round trips per workgroup -- a third of a slab's boundary launch, whose workgroups march
+    // two planes each)
+    {
+        RowRec rr[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rr[k] = fetch_rows(za - 3 + k);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) put_rows(za - 3 + k, rr[k]);
+    }
     RowRec staged = fetch_rows(za + 3);
     __syncthreads();
-    for (int zl = za - 2; zl <= za; ++zl) {
-        SRec e0, e1;
-        fetch_s(zl, e0, e1);
-        put_s(zl, e0, e1);
+    {
+        SRec e0[3], e1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fetch_s(za - 2 + k, e0[k], e1[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) put_s(za - 2 + k, e0[k], e1[k]);
     }
     bool fluid = false, fl_raw = false;         // node of the plane that waits / of the plane in flight is fluid
     bool padz = false, pad_raw = false;         // idle lane that writes line padding for that plane
