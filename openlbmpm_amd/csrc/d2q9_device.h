@@ -30,16 +30,16 @@ __device__ __forceinline__ void store_pair(double *f, size_t plane, int q, size_
 template <bool STREAM>
 __device__ __forceinline__ void store_pairs(double *f, size_t plane, size_t node, const double a[9], const double b[9])
 {
-    if (STREAM) {
+    // (plane base: uniform, 64 bits; the node inside a plane: one 32-bit byte offset for the nine stores)
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    char *base = reinterpret_cast<char *>(f);
+    const unsigned off = (unsigned)node * 16u;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            double *d = f + ((size_t)q * plane + node) * 2;
-            __builtin_nontemporal_store(a[q], d);
-            __builtin_nontemporal_store(b[q], d + 1);
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) store_pair(f, plane, q, node, a[q], b[q]);
+    for (int q = 0; q < 9; ++q) {
+        d2_t v = {a[q], b[q]};
+        d2_t *d = reinterpret_cast<d2_t *>(base + (size_t)q * plane * 16u + off);
+        if (STREAM) __builtin_nontemporal_store(v, d);
+        else *d = v;
     }
 }
 
@@ -51,19 +51,22 @@ template <typename P>
 __device__ __forceinline__ void pull_node(const P &p, int x, int y, double f0[9], double f1[9])
 {
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY, OPP[9] = LBMPM_D2Q9_OPP;
-    const size_t idx = (size_t)y * p.pitch + x;
-    const double2 *f2 = reinterpret_cast<const double2 *>(p.fin);
     // p.first: the state is already "post-streaming" (initial condition) -> read in place
     const bool first = p.first != 0;
-    const unsigned sn = first ? 0u : p.solidnbr[idx];
+    // addresses as in pull_issue_asm below: the plane's 64-bit base (uniform) + a 32-bit byte offset inside the plane
+    const unsigned pitch16 = (unsigned)p.pitch * 16u;
+    unsigned xo[3], yo[3];                    // [1 + e]: column x - e, row y - e
+    xo[1] = (unsigned)x * 16u; yo[1] = (unsigned)y * pitch16;
+    xo[0] = first ? xo[1] : (unsigned)wrapi(x + 1, p.nx) * 16u; xo[2] = first ? xo[1] : (unsigned)wrapi(x - 1, p.nx) * 16u;
+    yo[0] = first ? yo[1] : (unsigned)wrapi(y + 1, p.ny) * pitch16; yo[2] = first ? yo[1] : (unsigned)wrapi(y - 1, p.ny) * pitch16;
+    const char *base = reinterpret_cast<const char *>(p.fin);
+    const unsigned own = yo[1] + xo[1];
+    const unsigned sn = first ? 0u : p.solidnbr[own >> 4];
     // All 9 loads are issued without waiting for the solid-neighbour byte (solid nodes hold
     // finite junk that is never used); the rare bounce-back links are patched afterwards.
-    { const double2 v = f2[idx]; f0[0] = v.x; f1[0] = v.y; }
 #pragma unroll
-    for (int i = 1; i < 9; ++i) {
-        const int xs = wrapi(x - EX[i], p.nx), ys = wrapi(y - EY[i], p.ny);
-        const size_t s = first ? idx : (size_t)ys * p.pitch + xs;
-        const double2 v = f2[i * p.plane + s];
+    for (int i = 0; i < 9; ++i) {
+        const double2 v = *reinterpret_cast<const double2 *>(base + (size_t)i * p.plane * 16u + (yo[1 + EY[i]] + xo[1 + EX[i]]));
         f0[i] = v.x; f1[i] = v.y;
     }
     if (sn != 0) {
@@ -71,7 +74,7 @@ __device__ __forceinline__ void pull_node(const P &p, int x, int y, double f0[9]
         for (int i = 1; i < 9; ++i) {
             const int o = OPP[i];
             if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
-                const double2 v = f2[o * p.plane + idx];
+                const double2 v = *reinterpret_cast<const double2 *>(base + (size_t)o * p.plane * 16u + own);
                 f0[i] = v.x; f1[i] = v.y;
             }
         }

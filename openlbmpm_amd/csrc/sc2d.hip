@@ -1035,6 +1035,8 @@ extern "C" int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is
     LBMPM_REQUIRE(cfg && is_domain && out, "lbmpm_sc2d_create: null argument");
     LBMPM_REQUIRE(cfg->nx >= 4 && cfg->ny >= 8 && cfg->nx < (1 << 30) && cfg->ny < (1 << 30),
                   "lbmpm_sc2d_create: domain %lld x %lld out of range", (long long)cfg->nx, (long long)cfg->ny);
+    // (the kernels address a node inside a plane of 16-byte pairs with 32 bits: d2q9_device.h::pull_node)
+    LBMPM_REQUIRE((size_t)((cfg->nx + 31) / 32 * 32) * (size_t)cfg->ny < ((size_t)1 << 28), "lbmpm_sc2d_create: more than 2^28 nodes per lattice plane");
     LBMPM_REQUIRE(cfg->model == LBMPM_SC_MODEL_SHANCHEN || cfg->model == LBMPM_SC_MODEL_EFS, "bad model %d", cfg->model);
     LBMPM_REQUIRE(cfg->relaxation == LBMPM_RELAX_SRT || cfg->relaxation == LBMPM_RELAX_MRT, "bad relaxation %d", cfg->relaxation);
     if (cfg->model == LBMPM_SC_MODEL_SHANCHEN && cfg->relaxation == LBMPM_RELAX_MRT) {
