@@ -6,8 +6,12 @@ namespace lbmpm_dev {
 
 __device__ __forceinline__ int wrapi(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
 
+// v mod n for the coordinates a tile forms (tile origin < n, + at most a tile's region): on a lattice of at least 128 nodes they lie in
+// [-n, 2n) and one conditional add does it; the integer division by the runtime n (~ 20 vector instructions, ten times per lane in
+// rk2d_fused) is left to the lattices smaller than a tile's region.  A wave-uniform choice, the same value either way.
 __device__ __forceinline__ int wrapm(int v, int n)
 {
+    if (n >= 128) return wrapi(v, n);
     v %= n;
     return v < 0 ? v + n : v;
 }

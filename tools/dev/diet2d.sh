@@ -6,4 +6,4 @@ python tools/dev/eager_equal.py $out/b.npz > /dev/null
 python tools/dev/eager_equal.py $out/a.npz $out/b.npz
 LBMPM_LIBRARY=$PWD/$B/lib_prev.so python tools/dev/equal2d_sc.py $out/c.npz > /dev/null; python tools/dev/equal2d_sc.py $out/d.npz | tail -1; python tools/dev/equal2d_sc.py $out/c.npz $out/d.npz
 python tools/dev/ab2d.py ${ROUNDS:-3} $B/lib_prev.so openlbmpm_amd/liblbmpm_hip.so
-rm -f $out/a.npz $out/b.npz
+rm -f $out/*.npz
