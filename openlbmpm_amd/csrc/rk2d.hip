@@ -486,22 +486,25 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
     constexpr int SRCBIT[5] = {0, 2, 0, 3, 1};    // D2Q9 solid bit of the node a D2Q5 population comes from
     const bool first = p.first != 0;
     const int yo = (p.trFree && y == 0 && !first) ? 1 : y;          // own-node reads
-    const size_t own = (size_t)yo * p.pitch + x, idx = (size_t)y * p.pitch + x;
+    // (byte offsets inside a plane of doubles, 32 bits; the plane bases are uniform: as the populations' pulls in d2q9_device.h)
+    const unsigned own = ((unsigned)yo * (unsigned)p.pitch + (unsigned)x) * 8u, idx = ((unsigned)y * (unsigned)p.pitch + (unsigned)x) * 8u;
+    const size_t plane8 = p.plane * 8u;
     const double gn = sqrt(gx * gx + gy * gy);
     double ux = 0., uy = 0., un = 0.;
     if (gn > 1.0e-8) { ux = -gx / gn; uy = -gy / gn; un = sqrt(ux * ux + uy * uy); }
     const double ind = (rhoR > p.trCrit) ? -(1. - 1.) : -(1. - 0.);
     // streamed, inlet-corrected populations of tracer t at this node
     auto pull_g = [&](int t, double g[5]) {
-        const double *gi = p.gin + (size_t)t * 5 * p.plane;
-        g[0] = gi[own];
+        const char *gi = reinterpret_cast<const char *>(p.gin) + (size_t)t * 5 * plane8;
+        auto ld = [&](int j, unsigned off) { return *reinterpret_cast<const double *>(gi + (size_t)j * plane8 + off); };
+        g[0] = ld(0, own);
 #pragma unroll
         for (int j = 1; j < 5; ++j) {
-            if (first) { g[j] = gi[j * p.plane + idx]; continue; }
-            if ((sn >> SRCBIT[j]) & 1u) { g[j] = gi[OPP5[j] * p.plane + own]; continue; }     // bounce-back
+            if (first) { g[j] = ld(j, idx); continue; }
+            if ((sn >> SRCBIT[j]) & 1u) { g[j] = ld(OPP5[j], own); continue; }     // bounce-back
             int ys = lbmpm_dev::wrapi(y - VY5[j], p.ny);
             if (p.trFree && ys == 0) ys = 1;
-            g[j] = gi[j * p.plane + (size_t)ys * p.pitch + lbmpm_dev::wrapi(x - VX5[j], p.nx)];
+            g[j] = ld(j, ((unsigned)ys * (unsigned)p.pitch + (unsigned)lbmpm_dev::wrapi(x - VX5[j], p.nx)) * 8u);
         }
         if (!first && p.trDirichlet && y == p.ny - 1) {
             const double sm = g[0] + g[1] + g[2] + g[3];
@@ -549,11 +552,11 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
             for (int k = 0; k < 5; ++k) v += p.trA[t][5 * j + k] * diff[k];
             d[j] = v;
         }
-        double *go = p.gout + (size_t)t * 5 * p.plane;
+        char *go = reinterpret_cast<char *>(p.gout) + (size_t)t * 5 * plane8;
         const double S = (p.trRate != 0.) ? (t == 2 ? src : -src) : 0.;        // tracers 0, 1 consumed, 2 produced
         const double J0 = p.trJ[t], J1 = (1. - p.trJ[t]) / 4.;
         // (streaming stores like the populations': read again a whole lattice later)
-        __builtin_nontemporal_store(p.trRate != 0. ? (g[0] + d[0]) + J0 * S : g[0] + d[0], go + idx);
+        __builtin_nontemporal_store(p.trRate != 0. ? (g[0] + d[0]) + J0 * S : g[0] + d[0], reinterpret_cast<double *>(go + idx));
         // cos of the angle between direction j and the interface normal, (e_j . u) / |u| (T:995-1008): e_j is a unit axis vector, so the four
         // quotients are +-u_x / |u| and +-u_y / |u| -- two divisions instead of four, the same bits ((-a) / b == -(a / b); 1 * a + 0 * b == a)
         double cax = 0., cay = 0.;
@@ -562,7 +565,7 @@ __device__ __forceinline__ void tracer_substep(const RKDev &p, int x, int y, uns
         for (int j = 1; j < 5; ++j) {
             const double c = VX5[j] != 0 ? (VX5[j] > 0 ? cax : -cax) : (VY5[j] > 0 ? cay : -cay);
             const double v = (g[j] + d[j]) + p.trBeta[t] * ind * (W5[j] * C) * c;
-            __builtin_nontemporal_store((p.trRate != 0.) ? v + J1 * S : v, go + j * p.plane + idx);
+            __builtin_nontemporal_store((p.trRate != 0.) ? v + J1 * S : v, reinterpret_cast<double *>(go + (size_t)j * plane8 + idx));
         }
     }
 }
