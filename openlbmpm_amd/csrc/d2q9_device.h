@@ -91,6 +91,9 @@ typedef double lbmpm_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ lbmpm_d2 asm_ld16(const void *a) { lbmpm_d2 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(a)); return v; }
 __device__ __forceinline__ double asm_ld8_nt(const void *a) { double v; asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(a)); return v; }
 __device__ __forceinline__ unsigned asm_ldu8(const void *a) { unsigned v; asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(a)); return v; }
+// the same with a uniform 64-bit base (scalar registers) and a 32-bit byte offset per lane
+__device__ __forceinline__ unsigned asm_ldu8(const void *base, unsigned off) { unsigned v; asm volatile("global_load_ubyte %0, %1, %2" : "=v"(v) : "v"(off), "s"(base)); return v; }
+__device__ __forceinline__ double asm_ld8_nt(const void *base, unsigned off) { double v; asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(v) : "v"(off), "s"(base)); return v; }
 // s_waitcnt simm16 of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]; the other two counters left alone
 #define LBMPM_VMCNT(n) (((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
 // Head of a region guarded by `if (__ballot(c) != 0) { if (c) {` : states that some lane of the wave always enters.  hipcc still emits an
@@ -124,13 +127,13 @@ __device__ __forceinline__ void pull_patch(const P &p, int x, int y, unsigned sn
 {
     constexpr int OPP[9] = LBMPM_D2Q9_OPP;
     if (sn != 0) {
-        const size_t idx = (size_t)y * p.pitch + x;
-        const double2 *f2 = reinterpret_cast<const double2 *>(p.fin);
+        const unsigned own = ((unsigned)y * (unsigned)p.pitch + (unsigned)x) * 16u;       // (32-bit offset inside a plane, as in pull_issue_asm)
+        const char *base = reinterpret_cast<const char *>(p.fin);
 #pragma unroll
         for (int i = 1; i < 9; ++i) {
             const int o = OPP[i];
             if ((sn >> (o - 1)) & 1u) {        // x - e_i is solid: half-way bounce-back
-                const double2 v = f2[o * p.plane + idx];
+                const double2 v = *reinterpret_cast<const double2 *>(base + (size_t)o * p.plane * 16u + own);
                 f0[i] = v.x; f1[i] = v.y;
             }
         }

@@ -631,7 +631,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
             const int n = min(tid + k * THREADS, RH * RW - 1);
             const int rx = n % RW, ry = n / RW;
             const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
-            flr[k] = asm_ldu8(p.flags + (size_t)y * p.pitch + x);
+            flr[k] = asm_ldu8(p.flags, (unsigned)y * (unsigned)p.pitch + (unsigned)x);
         }
         lbmpm_d2 q[9], hq[9];
         unsigned hsn = 0;
@@ -642,9 +642,9 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         const int ys = node_source_row<true>(p, yw);
         {
             const size_t idx = (size_t)yw * p.pitch + xw;
-            sn[0] = asm_ldu8(p.solidnbr + idx);
-            Fpx[0] = asm_ld8_nt(p.F + idx);                  // read once, by its own node
-            Fpy[0] = asm_ld8_nt(p.F + p.plane + idx);
+            sn[0] = asm_ldu8(p.solidnbr, (unsigned)idx);
+            Fpx[0] = asm_ld8_nt(p.F, (unsigned)idx * 8u);                  // read once, by its own node
+            Fpy[0] = asm_ld8_nt(p.F + p.plane, (unsigned)idx * 8u);
             pull_issue_asm(p, xw, ys, q);
         }
         __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(12));          // the mask has landed; the own node's 12 loads may still be out
@@ -672,7 +672,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
                 LBMPM_TAKEN;                       // (a lane of this wave is here: openlbmpm_amd/inflight.py drops hipcc's all-lanes-off branch)
                 hx = wrapm(tx0 - H + hrx, p.nx); hy = wrapm(ty0 - H + hry, p.ny);
                 hys = node_source_row<true>(p, hy);
-                hsn = asm_ldu8(p.solidnbr + (size_t)hys * p.pitch + hx);
+                hsn = asm_ldu8(p.solidnbr, (unsigned)hys * (unsigned)p.pitch + (unsigned)hx);
                 pull_issue_asm(p, hx, hys, hq);
             }
             __builtin_amdgcn_s_waitcnt(LBMPM_VMCNT(10));      // the own node's loads have landed, the halo node's 10 are out
