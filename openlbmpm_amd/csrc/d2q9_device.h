@@ -6,14 +6,20 @@ namespace lbmpm_dev {
 
 __device__ __forceinline__ int wrapi(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
 
-// v mod n for the coordinates a tile forms (tile origin < n, + at most a tile's region): on a lattice of at least 128 nodes they lie in
-// [-n, 2n) and one conditional add does it; the integer division by the runtime n (~ 20 vector instructions, ten times per lane in
-// rk2d_fused) is left to the lattices smaller than a tile's region.  A wave-uniform choice, the same value either way.
 __device__ __forceinline__ int wrapm(int v, int n)
 {
-    if (n >= 128) return wrapi(v, n);
     v %= n;
     return v < 0 ? v + n : v;
+}
+// v mod n for the coordinates a tile forms (tile origin < n, + at most a tile's region): on a lattice of at least 128 nodes they lie in
+// [-n, 2n) and one conditional add does it; the integer division by the runtime n (~ 20 vector instructions) is left to the lattices
+// smaller than a tile's region.  A wave-uniform choice, the same value either way.  For the kernels WITHOUT asm loads (sc2d.hip): the
+// uniform branch it makes sits between the asm loads of rk2d_fused, where the static in-flight check (inflight.py) cannot follow it, and
+// bought nothing there (c2, c4 within the noise; c3 - 1.1 %).
+__device__ __forceinline__ int wrapm_fast(int v, int n)
+{
+    if (n >= 128) return wrapi(v, n);
+    return wrapm(v, n);
 }
 
 // The two D2Q9 lattices of a solver (red/blue, component 0/1) are stored side by side,
@@ -107,12 +113,15 @@ __device__ __forceinline__ void pull_issue_asm(const P &p, int x, int y, lbmpm_d
     // three rows' and the three columns' offsets once (periodic), one v_add per direction -- instead of a 64-bit index and pointer per
     // direction (~ 80 -> ~ 35 vector instructions per node; a plane is < 4 GiB, checked at set-up)
     constexpr int EX[9] = LBMPM_D2Q9_EX, EY[9] = LBMPM_D2Q9_EY;
-    const bool first = p.first != 0;          // the state is already "post-streaming" (initial condition): read in place
+    // p.first: the state is already "post-streaming" (initial condition): read in place.  As a mask, not as a condition: hipcc turns a
+    // uniform `first ? own : wrapped` into branches around the wrap arithmetic, and branches between asm loads are what the static
+    // in-flight check (openlbmpm_amd/inflight.py) cannot follow
+    const unsigned live = p.first != 0 ? 0u : ~0u;
     const unsigned pitch16 = (unsigned)p.pitch * 16u;
     unsigned xo[3], yo[3];                    // [1 + e]: column x - e, row y - e
     xo[1] = (unsigned)x * 16u; yo[1] = (unsigned)y * pitch16;
-    xo[0] = first ? xo[1] : (unsigned)wrapi(x + 1, p.nx) * 16u; xo[2] = first ? xo[1] : (unsigned)wrapi(x - 1, p.nx) * 16u;
-    yo[0] = first ? yo[1] : (unsigned)wrapi(y + 1, p.ny) * pitch16; yo[2] = first ? yo[1] : (unsigned)wrapi(y - 1, p.ny) * pitch16;
+    xo[0] = xo[1] + (((unsigned)wrapi(x + 1, p.nx) * 16u - xo[1]) & live); xo[2] = xo[1] + (((unsigned)wrapi(x - 1, p.nx) * 16u - xo[1]) & live);
+    yo[0] = yo[1] + (((unsigned)wrapi(y + 1, p.ny) * pitch16 - yo[1]) & live); yo[2] = yo[1] + (((unsigned)wrapi(y - 1, p.ny) * pitch16 - yo[1]) & live);
     const char *base = reinterpret_cast<const char *>(p.fin);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
     // round trip before the barrier
     const int x = tx0 + lx, y = ty0 + ly;
     const bool inside = (x < p.nx) && (y < p.ny);
-    const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);
+    const int xw = inside ? x : wrapm_fast(x, p.nx), yw = inside ? y : wrapm_fast(y, p.ny);
     const size_t idx = (size_t)yw * p.pitch + xw;
     const bool fluid = p.flags[idx] & 1;
     const bool act = inside && fluid;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(THREADS, 4) void sc2d_fused(SCDev p, int tiles_x)
         else if (tid < 2 * RW) { ry = RH - 1; rx = tid - RW; }
         else { const int m = tid - 2 * RW; ry = 1 + m / 2; rx = (m & 1) ? RW - 1 : 0; }
         hri = ry * RW + rx;
-        hx = wrapm(tx0 - HALO + rx, p.nx); hy = wrapm(ty0 - HALO + ry, p.ny);
+        hx = wrapm_fast(tx0 - HALO + rx, p.nx); hy = wrapm_fast(ty0 - HALO + ry, p.ny);
         hdo = p.flags[(size_t)hy * p.pitch + hx] & 1;
     }
     int ys = 0;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(512, 4) void sc2d_iso_fused(SCDev p, int tiles_x)
     const int tid = threadIdx.x, lx = tid % IW, ly = tid / IW;
     const int x = tx0 + lx, y = ty0 + ly;
     const bool inside = (x < p.nx) && (y < p.ny);
-    const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);
+    const int xw = inside ? x : wrapm_fast(x, p.nx), yw = inside ? y : wrapm_fast(y, p.ny);
     const size_t idx = (size_t)yw * p.pitch + xw;
     const bool fluid = p.flags[idx] & 1;
     const bool act = inside && fluid;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(512, 4) void sc2d_iso_fused(SCDev p, int tiles_x)
         else if ((m -= H * QW) < H * QW) { ry = QH - H + m / QW; rx = m % QW; }
         else { m -= H * QW; ry = H + m / (2 * H); const int c = m % (2 * H); rx = c < H ? c : IW + c; }
         hri = ry * QW + rx;
-        const int hx = wrapm(tx0 - H + rx, p.nx), hy = wrapm(ty0 - H + ry, p.ny);
+        const int hx = wrapm_fast(tx0 - H + rx, p.nx), hy = wrapm_fast(ty0 - H + ry, p.ny);
         hfl = p.flags[(size_t)hy * p.pitch + hx] & 1;
         if (hfl) {
             double g0[9], g1[9];
