@@ -130,7 +130,8 @@ typedef enum lbmpm_rk2d_field {
     LBMPM_RK_REC_RHO_B = 23, LBMPM_RK_REC_VX = 24, LBMPM_RK_REC_VY = 25
 } lbmpm_rk2d_field;
 
-/* is_domain: host [ny][nx] uint8, 1 = void/fluid, 0 = solid (isDomain, RKD2Q9.py:417-443). */
+/* is_domain: host [ny][nx] uint8, 1 = void/fluid, 0 = solid (isDomain, RKD2Q9.py:417-443).
+ * Size limit: roundup(nx, 32) * ny < 2^28 nodes (the kernels address a node inside a lattice plane with 32 bits); beyond it LBMPM_ERR_INVALID. */
 int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is_domain,
                       lbmpm_rk2d **out);
 void lbmpm_rk2d_destroy(lbmpm_rk2d *ctx);
@@ -271,6 +272,7 @@ typedef enum lbmpm_sc2d_field {
     LBMPM_SC_REC_PDF0 = 20, LBMPM_SC_REC_PDF1 = 21, LBMPM_SC_REC_RHO0 = 22, LBMPM_SC_REC_RHO1 = 23
 } lbmpm_sc2d_field;
 
+/* (size limit as lbmpm_rk2d_create: roundup(nx, 32) * ny < 2^28 nodes) */
 int lbmpm_sc2d_create(const lbmpm_sc2d_config *cfg, const uint8_t *is_domain, lbmpm_sc2d **out);
 void lbmpm_sc2d_destroy(lbmpm_sc2d *ctx);
 /* dense host arrays [ny][nx][9] per component (fluidPDF[k], ShanChenD2Q9.py:738) */
@@ -338,7 +340,8 @@ enum { LBMPM_RK3D_BUF_F_SEND_UP = 0, LBMPM_RK3D_BUF_F_SEND_DOWN = 1,
        LBMPM_RK3D_BUF_PHI_RECV_FROM_BELOW = 6, LBMPM_RK3D_BUF_PHI_RECV_FROM_ABOVE = 7 };
 
 /* is_domain_with_halo: host [nz_local + 2][ny][nx] uint8 (1 = fluid): the owned planes plus
- * the plane below and above them; planes outside the global lattice must be 0. */
+ * the plane below and above them; planes outside the global lattice must be 0.
+ * Compact storage: (nz_local + 2) * ny * (nx / 64) row segments per slab must stay below 2^31. */
 int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is_domain_with_halo, lbmpm_rk3d **out);
 void lbmpm_rk3d_destroy(lbmpm_rk3d *ctx);
 int lbmpm_rk3d_set_stream(lbmpm_rk3d *ctx, void *hip_stream);

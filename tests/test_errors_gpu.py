@@ -32,6 +32,21 @@ def test_rk2d_rejects_bad_configurations_and_shapes():
     s.close()
 
 
+def test_lattices_beyond_the_32_bit_plane_offsets_are_refused():
+    """the 2-D kernels address a node inside a lattice plane with 32 bits (d2q9_device.h::pull_issue_asm): roundup(nx, 32) * ny must stay
+    below 2^28 nodes, and create says so instead of wrapping an offset"""
+    from openlbmpm_amd._lib import LbmpmError
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.sc2d import SC2DSolver
+    dom = np.ones((16400, 16384), dtype=np.uint8)             # 2^28 + 2^18 nodes; nothing is allocated on the device
+    with pytest.raises(LbmpmError) as e:
+        RK2DSolver(dom, None)
+    assert "2^28" in str(e.value)
+    with pytest.raises(LbmpmError) as e:
+        SC2DSolver(dom, dict(inter="EFS"))
+    assert "2^28" in str(e.value)
+
+
 def test_sc2d_rejects_bad_configurations():
     from openlbmpm_amd._lib import LbmpmError
     from openlbmpm_amd.sc2d import SC2DSolver
