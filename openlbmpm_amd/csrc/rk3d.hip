@@ -67,8 +67,8 @@ struct RK3Dev {
     int first, fill;
     int mrt;                     // 0: BGK, 1: MRT (d'Humieres D3Q19 basis) on the colour-blind populations
     // compact storage (layout 1): only fluid cells are stored, see "compact storage" below
-    const u32x4 *seg;                 // [rows][nseg] {fluid mask lo, hi, j of the first fluid cell, fluid(x0-1) | fluid(x0+64) << 1 | pad << 2}, rows = (nzl+2)*ny
-    const u32x4 *seg2;                // [rows][nseg] {j of cell x0-1, j of cell x0+64 (periodic), -, -}
+    const u32x4 *seg;                 // [rows][nseg] {fluid mask lo, hi, j of the first fluid cell, fluid(x0-1) | fluid(x0+w) << 1 | pad << 2 | (64-w) << 8}, rows = (nzl+2)*ny
+    const u32x4 *seg2;                // [rows][nseg] {j of cell x0-1, j of cell x0+w (periodic), -, -}; w = cells of the segment (make_row)
     const unsigned long long *pstart; // [nzl+3] fluid cells before plane zl
     int nseg;
     const uint32_t *pur_in;           // [rows][nseg] row flags of the q23 storage (rk3dq.h), ping-pong with fin / fout
@@ -237,10 +237,25 @@ struct RowTab {
     unsigned first;                 // j of the segment's first fluid cell
     unsigned lbit, rbit, jl, jr;    // fluid bit and j of the cells x0-1 and x0+64 (periodic in x)
     unsigned pad;                   // cells of padding behind this segment's run (last row of a tile only)
+    unsigned last;                  // bit of the segment's last lattice cell: 63, or width - 1 where nx is not a multiple of 64 (seg_x0)
 };
 
-// segment records {mask lo, mask hi, first, lbit | rbit << 1 | pad << 2} and {jl, jr, -, -}
-template <bool UNI>
+// Row segments of a lattice whose nx is not a multiple of 64 ("ragged"): nseg = ceil(nx / 64) segments of nx / nseg cells, rounded
+// (segment s starts at x = s nx / nseg: widths differ by one cell at most, every one holds >= 32 cells, or all nx < 64 of them); the lanes
+// behind a segment's last cell are non-fluid bits of its mask.  With nx a multiple of 64 this is x0 = 64 s, width 64.
+__device__ __host__ __forceinline__ int seg_x0(int sg, int nx, int nseg) { return (int)(((long long)sg * nx) / nseg); }
+
+// lattice x of lane `lane` of row segment sg, or -1 for a lane behind the segment's last cell
+#define LBMPM_SEG_LANE_X(p, sg, lane) seg_lane_x((p).nx, (p).nseg, sg, lane)
+__device__ __forceinline__ int seg_lane_x(int nx, int nseg, int sg, int lane)
+{
+    const int x0 = seg_x0(sg, nx, nseg), w = seg_x0(sg + 1, nx, nseg) - x0;
+    return lane < w ? x0 + lane : -1;
+}
+
+// segment records {mask lo, mask hi, first, lbit | rbit << 1 | pad << 2 | (64 - width) << 8} and {jl, jr, -, -}
+// RAGGED = false: the caller knows every segment to be 64 cells wide (the words then hold no width field: compile-time 63)
+template <bool UNI, bool RAGGED = false>
 __device__ __forceinline__ RowTab make_row(u32x4 sg, u32x4 nb)
 {
     if (UNI) {
@@ -250,7 +265,9 @@ __device__ __forceinline__ RowTab make_row(u32x4 sg, u32x4 nb)
     }
     RowTab t;
     t.m = ((unsigned long long)sg.y << 32) | sg.x;
-    t.first = sg.z; t.lbit = sg.w & 1u; t.rbit = (sg.w >> 1) & 1u; t.pad = sg.w >> 2;
+    t.first = sg.z; t.lbit = sg.w & 1u; t.rbit = (sg.w >> 1) & 1u;
+    t.pad = RAGGED ? (sg.w >> 2) & 63u : sg.w >> 2;
+    t.last = RAGGED ? 63u - ((sg.w >> 8) & 63u) : 63u;
     t.jl = nb.x; t.jr = nb.y;
     return t;
 }
@@ -259,12 +276,12 @@ __device__ __forceinline__ RowTab make_row(u32x4 sg, u32x4 nb)
 struct GlobalRows {
     const u32x4 *seg, *seg2;     // (copies of the fields, not a reference to the kernel argument: a reference makes hipcc keep a private
     int ny, nseg;                //  copy of all of RK3Dev in scratch memory)
-    int x, y;
-    __device__ __forceinline__ GlobalRows(const RK3Dev &p, int x_, int y_) : seg(p.seg), seg2(p.seg2), ny(p.ny), nseg(p.nseg), x(x_), y(y_) {}
+    int sg, y;                   // the node's row segment and row
+    __device__ __forceinline__ GlobalRows(const RK3Dev &p, int sg_, int y_) : seg(p.seg), seg2(p.seg2), ny(p.ny), nseg(p.nseg), sg(sg_), y(y_) {}
     __device__ __forceinline__ RowTab operator()(int zl, int ry) const
     {
-        const size_t r = ((size_t)zl * ny + wrapi(y + ry, ny)) * nseg + (x >> 6);
-        return make_row<false>(seg[r], seg2[r]);
+        const size_t r = ((size_t)zl * ny + wrapi(y + ry, ny)) * nseg + sg;
+        return make_row<false, true>(seg[r], seg2[r]);
     }
 };
 
@@ -294,9 +311,9 @@ __device__ __forceinline__ void row_cell(const RowTab &t, int dx, unsigned b, un
         fl = bit_of<UNI>(M, b);
         j = b == 0u ? t.jl : t.first - t.lbit + bits_below<UNI>(M, b);
     } else {
-        const unsigned long long M = (t.m >> 1) | ((unsigned long long)t.rbit << 63);
+        const unsigned long long M = (t.m >> 1) | ((unsigned long long)t.rbit << t.last);
         fl = bit_of<UNI>(M, b);
-        j = b == 63u ? t.jr : t.first + bits_below<UNI>(t.m, b) + (bit_of<UNI>(t.m, b) ? 1u : 0u);
+        j = b == t.last ? t.jr : t.first + bits_below<UNI>(t.m, b) + (bit_of<UNI>(t.m, b) ? 1u : 0u);
     }
 }
 
@@ -784,7 +801,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dc_phase_field(RK3Dev p, int zl0)
     if (!(p.flags[idx] & 1)) return;
     double fR[Q], fB[Q], rR, rB;
     unsigned j;
-    const GlobalRows rows{p, x, y};
+    const GlobalRows rows{p, x >> 6, y};
     if (p.first) pull3c<true, false>(p, rows, x, source_plane(p, zl), (unsigned)(x & 63), fR, fB, j);
     else pull3c<false, false>(p, rows, x, source_plane(p, zl), (unsigned)(x & 63), fR, fB, j);
     finish_state3(p, zl, fR, fB, rR, rB);
@@ -809,17 +826,17 @@ struct TileRows {
     static constexpr int ROWS = TY + 4, SLOTS = 8;
     const u32x4 (*ring)[ROWS][6];
     int lrow, k;                 // this lane's row inside the staged rows, its segment slot
-    template <bool UNI>
+    template <bool UNI, bool RAGGED>
     __device__ __forceinline__ RowTab get(int zl, int ry) const
     {
         const u32x4 *r = ring[zl & (SLOTS - 1)][lrow + ry];
-        return make_row<UNI>(r[2 * k], r[2 * k + 1]);
+        return make_row<UNI, RAGGED>(r[2 * k], r[2 * k + 1]);
     }
 };
-template <int TY, bool UNI>
+template <int TY, bool UNI, bool RAGGED = false>
 struct TileRowsU {
     TileRows<TY> t;
-    __device__ __forceinline__ RowTab operator()(int zl, int ry) const { return t.template get<UNI>(zl, ry); }
+    __device__ __forceinline__ RowTab operator()(int zl, int ry) const { return t.template get<UNI, RAGGED>(zl, ry); }
 };
 
 // phase field of a cell of plane zl for the ring (compact storage); for a fluid node of an owned
@@ -1023,7 +1040,7 @@ __global__ void rk3dc_init_rest(RK3Dev p, const double *rho_r, const double *rho
     const int x = blockIdx.x * BX3 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;
     if (x >= p.nx || y >= p.ny) return;
     if (!(p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
-    const GlobalRows rows{p, x, y};
+    const GlobalRows rows{p, x >> 6, y};
     const RowTab t = rows(zl, 0);
     const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
     const size_t sd = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
@@ -1235,10 +1252,18 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny; c->nzl = (int)cfg->nz_local;
     c->variant = variant; c->tile = tile; c->chunk_len = chunk_len; c->fill = fill;
     if (const char *e = getenv("LBMPM_RK3D_BOUNDARY")) c->boundary = atoi(e) >= 2 ? atoi(e) : 2;
-    c->compact = variant == 0 && c->nx % 64 == 0;
+    // compact storage: the 23-value form for any nx (row segments of <= 64 cells, seg_x0); the 38-value cross-check keeps whole 64-cell segments
+    c->compact = variant == 0;
     if (const char *e = getenv("LBMPM_RK3D_LAYOUT")) if (!strcmp(e, "dense")) c->compact = false;
     c->q23 = c->compact && c->tile == 0;
     if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
+    if (!c->q23 && c->nx % 64 != 0) c->compact = false;
+    // (the marching kernel packs a thread's lattice coordinates into 16-bit fields: rk3dq.h::sgeo)
+    if (c->q23 && (c->nx > 32767 || c->ny > 32767)) {
+        set_error("lbmpm_rk3d_create: nx and ny must not exceed 32767 (%d x %d)", c->nx, c->ny);
+        delete c;
+        return LBMPM_ERR_INVALID;
+    }
 #ifdef LBMPM_DEV      // timing knock-outs of the slab step (results wrong): development builds only
     if (const char *e = getenv("LBMPM_RK3D_DBG")) c->dbg = atoi(e);
 #endif
@@ -1274,8 +1299,9 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     std::vector<uint32_t> hseg, hseg2;
     if (c->compact) {
         // segment records of the compact storage; numbering: plane, tile (64 x TILE_ROWS), row, x
-        c->nseg = c->nx / 64;
+        c->nseg = (c->nx + 63) / 64;
         const int ns = c->nseg;
+        auto sx0 = [&](int sg) { return seg_x0(sg, c->nx, ns); };
         const size_t rows = (size_t)(c->nzl + 2) * c->ny;
         hseg.assign(rows * ns * 4, 0u);
         hseg2.assign(rows * ns * 4, 0u);
@@ -1288,9 +1314,9 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
             c->h_pstart[z] = total;
             for (int y = 0; y < c->ny; ++y)
                 for (int sg = 0; sg < ns; ++sg) {
-                    const uint8_t *fl = hflags.data() + (size_t)z * c->plane2 + (size_t)y * c->pitch + sg * 64;
+                    const uint8_t *fl = hflags.data() + (size_t)z * c->plane2 + (size_t)y * c->pitch + sx0(sg);
                     unsigned long long w = 0;
-                    for (int b = 0; b < 64; ++b)
+                    for (int b = 0; b < sx0(sg + 1) - sx0(sg); ++b)
                         if (fl[b]) w |= 1ull << b;
                     m[(size_t)y * ns + sg] = w;
                 }
@@ -1317,7 +1343,8 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
                     hseg[r * 4 + 0] = (uint32_t)m[(size_t)y * ns + sg];
                     hseg[r * 4 + 1] = (uint32_t)(m[(size_t)y * ns + sg] >> 32);
                     hseg[r * 4 + 2] = first[(size_t)y * ns + sg];
-                    hseg[r * 4 + 3] |= (uint32_t)(ml >> 63) | ((uint32_t)(mr & 1ull) << 1);
+                    const int wl = sx0(sl + 1) - sx0(sl), wd = sx0(sg + 1) - sx0(sg);       // cells of the segment to the left, of this one
+                    hseg[r * 4 + 3] |= (uint32_t)((ml >> (wl - 1)) & 1ull) | ((uint32_t)(mr & 1ull) << 1) | ((uint32_t)(64 - wd) << 8);
                     hseg2[r * 4 + 0] = first[(size_t)y * ns + sl] + (unsigned)__builtin_popcountll(ml) - 1u;   // j of cell x0-1 (if fluid)
                     hseg2[r * 4 + 1] = first[(size_t)y * ns + sr];                                             // j of cell x0+64 (if fluid)
                 }
@@ -1573,8 +1600,12 @@ void launch_q23(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int
         q = c->slotq + ((size_t)ring * 4096u + i) * 8u;
     }
     auto go = [&](auto first, auto mrt) {
-        rk3dq_fused<decltype(first)::value, decltype(mrt)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, chunk_len, z_first, z_last,
-                                                                                            nchunks1, z_first2, z_last2, q);
+        if (c->nx % 64 == 0)
+            rk3dq_fused<decltype(first)::value, decltype(mrt)::value, false><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, chunk_len, z_first, z_last,
+                                                                                                   nchunks1, z_first2, z_last2, q);
+        else
+            rk3dq_fused<decltype(first)::value, decltype(mrt)::value, true><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, chunk_len, z_first, z_last,
+                                                                                                  nchunks1, z_first2, z_last2, q);
     };
     dispatch2(p.first != 0, p.mrt != 0, go);
 }
@@ -1678,7 +1709,7 @@ static int collide_boundary_ev(lbmpm_rk3d *c, hipEvent_t e0, hipEvent_t e1)
 // ---- transports of the slab exchange inside the library (include/lbmpm.h; rk3d_transport.h)
 static int tx_shape(lbmpm_rk3d *c)
 {
-    LBMPM_REQUIRE(c->q23, "the in-library transports move the one-exchange face message of the compact 23-value storage (nx a multiple of 64, LBMPM_RK3D_STORAGE unset)");
+    LBMPM_REQUIRE(c->q23, "the in-library transports move the one-exchange face message of the compact 23-value storage (LBMPM_RK3D_STORAGE, _LAYOUT, _TILE, _VARIANT unset)");
     const bool below = c->cfg.z_offset > 0, above = c->cfg.z_offset + c->cfg.nz_local < c->cfg.nz_global;
     return c->tx.set_shape(c->cfg.device, below, above, (size_t)face_bytes(c, c->nzl), (size_t)face_bytes(c, 1), (size_t)face_bytes(c, 0),
                            (size_t)face_bytes(c, c->nzl + 1));

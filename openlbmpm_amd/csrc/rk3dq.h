@@ -119,7 +119,7 @@ struct LdsScal {                  // the marching kernel's LDS tile (flagged row
     int slot[3];                  // index offset of the ring slots that hold the planes zp-1, zp, zp+1
     typedef int H;
     __device__ __forceinline__ H own_cell() const { return slot[1] + own; }
-    __device__ __forceinline__ H cell(int rz, int ry, int dx, bool fl, unsigned, unsigned) const { return fl ? slot[1 + rz] + own + ry * SC + dx : slot[1] + own; }
+    __device__ __forceinline__ H cell(int rz, int ry, int dx, bool fl, unsigned, unsigned, unsigned) const { return fl ? slot[1 + rz] + own + ry * SC + dx : slot[1] + own; }
     __device__ __forceinline__ double comp(H h, int k) const { return tile[h + k * SCOMP]; }
 };
 struct GlbScal {                  // straight from global memory (set-up, diagnostics and face kernels)
@@ -128,22 +128,22 @@ struct GlbScal {                  // straight from global memory (set-up, diagno
     const char *base;             // plane_addr_q(...).base
     unsigned soff[3];             // byte offsets of the s arrays of the planes zp-1, zp, zp+1
     unsigned own_j;
-    int zp, x, y;
+    int zp, sg, y;                // plane, row segment and row of the node
     struct H { unsigned off, cst; };      // cst: 0 read the record, else the row flag (bit 0 red)
     __device__ __forceinline__ H at(int rz, int ry, int sgs, unsigned j) const
     {
-        int sg = (x >> 6) + sgs;
-        sg = sg < 0 ? sg + nseg : (sg >= nseg ? sg - nseg : sg);
+        int s = sg + sgs;
+        s = s < 0 ? s + nseg : (s >= nseg ? s - nseg : s);
         H h;
-        h.cst = pur_in[((size_t)(zp + rz) * ny + wrapi(y + ry, ny)) * nseg + sg];
+        h.cst = pur_in[((size_t)(zp + rz) * ny + wrapi(y + ry, ny)) * nseg + s];
         h.off = soff[1 + rz] + j * 32u;
         return h;
     }
     __device__ __forceinline__ H own_cell() const { return at(0, 0, 0, own_j); }
-    __device__ __forceinline__ H cell(int rz, int ry, int dx, bool fl, unsigned j, unsigned b) const
+    __device__ __forceinline__ H cell(int rz, int ry, int dx, bool fl, unsigned j, unsigned b, unsigned last) const
     {
         if (!fl) return own_cell();
-        return at(rz, ry, (dx < 0 && b == 0u) ? -1 : ((dx > 0 && b == 63u) ? 1 : 0), j);
+        return at(rz, ry, (dx < 0 && b == 0u) ? -1 : ((dx > 0 && b == last) ? 1 : 0), j);
     }
     __device__ __forceinline__ double comp(H h, int k) const
     {
@@ -151,9 +151,9 @@ struct GlbScal {                  // straight from global memory (set-up, diagno
         return *reinterpret_cast<const double *>(base + h.off + 8u * (unsigned)k);
     }
 };
-__device__ __forceinline__ GlbScal glb_scal(const RK3Dev &p, const PlaneAddrQ &a, unsigned own_j, int zp, int x, int y)
+__device__ __forceinline__ GlbScal glb_scal(const RK3Dev &p, const PlaneAddrQ &a, unsigned own_j, int zp, int sg, int y)
 {
-    GlbScal s{p.pur_in, p.ny, p.nseg, a.base, {0u, 0u, 0u}, own_j, zp, x, y};
+    GlbScal s{p.pur_in, p.ny, p.nseg, a.base, {0u, 0u, 0u}, own_j, zp, sg, y};
 #pragma unroll
     for (int k = 0; k < 3; ++k) s.soff[k] = a.off[k] + (unsigned)Q * a.cnt[k] * 8u;
     return s;
@@ -189,7 +189,7 @@ __device__ __forceinline__ void class_sum_one(const RK3Dev &p, const Rows &rows,
             if (FIRST) h = sc.own_cell();
             else {
                 row_cell<UNI>(t, dx, b, j, fl);
-                h = sc.cell(rz, ry, dx, fl, j, b);
+                h = sc.cell(rz, ry, dx, fl, j, b, t.last);
             }
             const double k = sc.comp(h, 0);
             double ea = 0.;
@@ -315,7 +315,11 @@ __device__ __forceinline__ double phi_q(double rR, double rho) { return (rR - (r
 //     and of the rim's cells finds its upstream k_R and A there,
 //   * no LDS park: the 19 pulled values of the plane that waits for its neighbours' phase field stay in registers
 //     (38 VGPRs where the 38-value kernel carried 76 in flight).
-template <bool FIRST, bool MRT>
+// RAGGED: nx is not a multiple of 64 -- a tile's rows hold w = 32 .. 64 (or all nx < 64) lattice cells from x0 = tx nx / tilesX on
+// (seg_x0); the lanes behind them are idle (or write line padding), the tile's right rim column and record halo sit at tile columns
+// w and w + 1, and the segment to the left ends at its bit wl - 1.  All of that lives in the per-thread geometry words; the march
+// step differs by where it takes a rim column's bit from.  RAGGED = false is the kernel as it was (64-cell segments, constants).
+template <bool FIRST, bool MRT, bool RAGGED>
 __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last,
                                                        int nchunks1, int z_first2, int z_last2,      // a second range of planes in the same launch
                                                        unsigned *slotq)                              // eight zeroed counters of this launch
@@ -366,26 +370,32 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     // hoisted out of the loop these ~30 values stay in registers for good, the kernel spills, and every spill reload is followed by
     // s_waitcnt vmcnt(0).  ~60 integer instructions per step buy the registers back.
     int lx, ly, x, y, yo, hlx, hly, hx, hy, xrow, xc, xcol;
-    bool own, has_own, has_rim, has_x;
-    TileRowsU<TY, true> rows_own{{srow, 0, 1}}, rows_rimrow{{srow, 0, 1}}, rows_xrow{{srow, 0, 1}};
-    TileRowsU<TY, false> rows_rimcol{{srow, 0, 0}}, rows_xcol{{srow, 0, 0}};
+    bool own, has_own, has_rim, has_x, row_ok;
+    TileRowsU<TY, true, RAGGED> rows_own{{srow, 0, 1}}, rows_rimrow{{srow, 0, 1}}, rows_xrow{{srow, 0, 1}};
+    TileRowsU<TY, false, RAGGED> rows_rimcol{{srow, 0, 0}}, rows_xcol{{srow, 0, 0}};
+    // first lattice column of the tile, its width, the width of the tile to its left (periodic in x): wave-uniform, fixed for the kernel
+    const int x0 = RAGGED ? seg_x0(tx, p.nx, tilesX) : tx * TX;
+    const int tw = RAGGED ? seg_x0(tx + 1, p.nx, tilesX) - x0 : TX;
+    const int twl = RAGGED ? (tx > 0 ? x0 - seg_x0(tx - 1, p.nx, tilesX) : p.nx - seg_x0(tilesX - 1, p.nx, tilesX)) : TX;
     auto set_geometry = [&](int t) {
         lx = t % TX; ly = t / TX;
-        x = tx * TX + lx; y = ty * TY + ly;
-        own = y < p.ny;
+        x = x0 + lx; y = ty * TY + ly;
+        own = y < p.ny;                                  // (lanes behind a ragged row's last cell stay: they write line padding)
         yo = ring_coord(y, p.ny);
-        has_own = yo >= 0;
+        row_ok = yo >= 0;
+        has_own = row_ok && lx < tw;
         hlx = 0; hly = 0; hx = 0; hy = 0;
         has_rim = false;
         if (t < M::NH) {
-            if (t < 2 * TX) { hlx = 1 + t % TX; hly = t < TX ? 0 : M::FY - 1; }
-            else { const int k = t - 2 * TX; hlx = k < M::FY ? 0 : M::FX - 1; hly = k < M::FY ? k : k - M::FY; }
-            hx = ring_coord(tx * TX + hlx - 1, p.nx);
+            bool in_row = true;
+            if (t < 2 * TX) { hlx = 1 + t % TX; hly = t < TX ? 0 : M::FY - 1; in_row = t % TX < tw; }
+            else { const int k = t - 2 * TX; hlx = k < M::FY ? 0 : tw + 1; hly = k < M::FY ? k : k - M::FY; }
+            hx = ring_coord(x0 + hlx - 1, p.nx);
             hy = ring_coord(ty * TY + hly - 1, p.ny);
-            has_rim = hx >= 0 && hy >= 0;
+            has_rim = hx >= 0 && hy >= 0 && in_row;
         }
         xrow = ly >= 3 && ly <= 6 ? (ly < 5 ? ly - 5 : ly + 3) : (lx >> 2) - 2;            // tile row of the second entry
-        xc = lx & 3; xcol = ly == 7 ? (xc < 2 ? xc - 2 : TX + xc - 2) : lx;               // its tile column
+        xc = lx & 3; xcol = ly == 7 ? (xc < 2 ? xc - 2 : tw + xc - 2) : lx;               // its tile column
         has_x = (ly >= 3 && ly <= 6) || (ly == 7 && lx < 4 * SR);
         rows_own.t.lrow = ly + 2;
         rows_rimrow.t.lrow = hly + 1;
@@ -398,16 +408,17 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     // unpacking ~ 30 (the words are read through an address the compiler cannot see through, so nothing is hoisted here either)
     __shared__ unsigned sgeo[3][TX * TY];
     sgeo[0][tid] = (unsigned)lx | ((unsigned)ly << 6) | ((unsigned)hlx << 9) | ((unsigned)hly << 16) | ((unsigned)(xrow + 2) << 20) | ((unsigned)xc << 24) |
-                   ((unsigned)own << 26) | ((unsigned)has_own << 27) | ((unsigned)has_rim << 28) | ((unsigned)has_x << 29);
+                   ((unsigned)own << 26) | ((unsigned)has_own << 27) | ((unsigned)has_rim << 28) | ((unsigned)has_x << 29) | ((unsigned)row_ok << 30);
     sgeo[1][tid] = ((unsigned)hx & 0xffffu) | ((unsigned)hy << 16);
     sgeo[2][tid] = ((unsigned)yo & 0xffffu) | ((unsigned)(xcol + 2) << 16);
     auto load_geometry = [&](int t) {
         const unsigned w0 = sgeo[0][t], w1 = sgeo[1][t], w2 = sgeo[2][t];
         lx = (int)(w0 & 63u); ly = (int)((w0 >> 6) & 7u);
-        x = tx * TX + lx; y = ty * TY + ly;
+        x = x0 + lx; y = ty * TY + ly;
         hlx = (int)((w0 >> 9) & 127u); hly = (int)((w0 >> 16) & 15u);
         xrow = (int)((w0 >> 20) & 15u) - 2; xc = (int)((w0 >> 24) & 3u);
         own = (w0 >> 26) & 1u; has_own = (w0 >> 27) & 1u; has_rim = (w0 >> 28) & 1u; has_x = (w0 >> 29) & 1u;
+        row_ok = RAGGED ? (w0 >> 30) & 1u : has_own;
         hx = (int)(short)(w1 & 0xffffu); hy = (int)w1 >> 16;
         yo = (int)(short)(w2 & 0xffffu); xcol = (int)(w2 >> 16) - 2;
         rows_own.t.lrow = ly + 2;
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
             if (has_x) {
                 const RowTab t = rows_xcol(zl, 0);
                 const unsigned fg = row_flag(zl, xrow + 2, xc < 2 ? 0 : 2);
-                const unsigned bb = xc < 2 ? 62u + (unsigned)xc : (unsigned)xc - 2u;
+                const unsigned bb = xc < 2 ? (unsigned)(twl - 2) + (unsigned)xc : (unsigned)xc - 2u;      // the left segment's last two cells / the right one's first two
                 if (bit_of<false>(t.m, bb)) e1 = fg ? const_s(fg) : load_s(zl, t.first + bits_below<false>(t.m, bb));
             }
         }
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
     for (int i = 0; i < Q; ++i) { raw[i] = 0.; cur[i] = 0.; }
     auto issue = [&](int zl) {                  // pulls of the own cell of plane zl
         fl_raw = false; pad_raw = false;
-        if (!has_own || zl < 1 || zl > p.nzl || is_ghost(zl)) return;
+        if (!row_ok || zl < 1 || zl > p.nzl || is_ghost(zl)) return;
         const RowTab t = rows_own(zl, 0);
         fl_raw = bit_of<true>(t.m, (unsigned)lx);
         if (!fl_raw) {
@@ -615,7 +626,8 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
                     unsigned j;
                     Sums S;
                     const int pc = wave < 2 ? purity(zn, hly - 1, hly - 1) : purity(zn, -1, TY);
-                    const bool fl = wave < 2 ? bit_of<true>(rows_rimrow(zn, 0).m, (unsigned)lx) : bit_of<false>(rows_rimcol(zn, 0).m, (unsigned)(hx & 63));
+                    const unsigned hb = RAGGED ? (hlx == 0 ? (unsigned)(twl - 1) : 0u) : (unsigned)(hx & 63);      // a rim column's bit in its segment
+                    const bool fl = wave < 2 ? bit_of<true>(rows_rimrow(zn, 0).m, (unsigned)lx) : bit_of<false>(rows_rimcol(zn, 0).m, hb);
                     if (pc != 0) {          // single colour around: phi = +-1 (or the planes' boundary values) without a pull
                         if (fl) {
                             S.t0 = 1.; S.tp = S.tm = 0.; S.k0 = (pc & 1) ? 1. : 0.; S.kp = S.km = S.a0 = S.ap = S.am = 0.;
@@ -630,8 +642,8 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
                             ph = phi_q(a, c);
                         }
                     } else if (fl) {
-                        pull_q<FIRST, false>(p, rows_rimcol, zn, (unsigned)(hx & 63), g, j);
-                        class_sums<FIRST, false>(p, rows_rimcol, lds_scal(zn, hly - 1, hlx - 1), zn, (unsigned)(hx & 63), g, S);
+                        pull_q<FIRST, false>(p, rows_rimcol, zn, hb, g, j);
+                        class_sums<FIRST, false>(p, rows_rimcol, lds_scal(zn, hly - 1, hlx - 1), zn, hb, g, S);
                         bc_q<false>(p, zn, S, nullptr, a, c);
                         ph = phi_q(a, c);
                     }
@@ -745,14 +757,14 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
 // f = w rho at rest (3-D analogue of RKD2Q9.py:577-601): g_i = w_i (rho_R + rho_B), k_R = rho_R / rho, A = 0
 __global__ __launch_bounds__(BX3 *BY3) void rk3dq_init_rest(RK3Dev p, const double *rho_r, const double *rho_b, double *f, uint32_t *pur)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;    // a wave = a row segment
+    const int sg = blockIdx.x, x = LBMPM_SEG_LANE_X(p, sg, (int)threadIdx.x), y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + 1;    // a wave = a row segment
     if (y >= p.ny) return;
-    const bool fluid = p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1;
+    const bool fluid = x >= 0 && (p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1);
     double a = 0., b = 0.;
     if (fluid) {
-        const GlobalRows rows{p, x, y};
+        const GlobalRows rows{p, sg, y};
         const RowTab t = rows(zl, 0);
-        const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
+        const unsigned j = t.first + bits_below<false>(t.m, threadIdx.x);
         const size_t sd = ((size_t)(zl - 1) * p.ny + y) * p.nx + x;
         a = rho_r[sd]; b = rho_b[sd];
         const unsigned long long p0 = pstart_of(p, zl);
@@ -763,29 +775,29 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_init_rest(RK3Dev p, const doub
         s[0] = a / (a + b); s[1] = 0.; s[2] = 0.; s[3] = 0.;
     }
     const unsigned code = (__ballot(fluid && b != 0.) == 0ull ? 1u : 0u) | (__ballot(fluid && a != 0.) == 0ull ? 2u : 0u);
-    if ((x & 63) == 0) pur[row_index(p, zl, y, x >> 6)] = code;
+    if (threadIdx.x == 0) pur[row_index(p, zl, y, sg)] = code;
 }
 
 // phase field (and rho_R, rho_B, u with diag) of the streamed, boundary-corrected lattice on the planes zl0.. (diagnostics
 // and the planes a neighbour rank needs); ghost planes are pulled around their source plane like rk3dc_phase_field
 __global__ __launch_bounds__(BX3 *BY3) void rk3dq_phase_field(RK3Dev p, int zl0)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + zl0;
-    if (y >= p.ny || x >= p.nx) return;
+    const int sg = blockIdx.x, x = LBMPM_SEG_LANE_X(p, sg, (int)threadIdx.x), y = blockIdx.y * BY3 + threadIdx.y, zl = blockIdx.z + zl0;
+    if (y >= p.ny || x < 0) return;
     const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
     const int zs = source_plane(p, zl);
-    const unsigned b = (unsigned)(x & 63);
+    const unsigned b = threadIdx.x;
     double g[Q], rR, rho;
     unsigned j;
     Sums S;
-    const GlobalRows rows{p, x, y};
+    const GlobalRows rows{p, sg, y};
     if (p.first) {
         pull_q<true, false>(p, rows, zs, b, g, j);
-        class_sums<true, false>(p, rows, glb_scal(p, plane_addr_q(p, p.fin, zs), j, zs, x, y), zs, b, g, S);
+        class_sums<true, false>(p, rows, glb_scal(p, plane_addr_q(p, p.fin, zs), j, zs, sg, y), zs, b, g, S);
     } else {
         pull_q<false, false>(p, rows, zs, b, g, j);
-        class_sums<false, false>(p, rows, glb_scal(p, plane_addr_q(p, p.fin, zs), j, zs, x, y), zs, b, g, S);
+        class_sums<false, false>(p, rows, glb_scal(p, plane_addr_q(p, p.fin, zs), j, zs, sg, y), zs, b, g, S);
     }
     bc_q<true>(p, zl, S, g, rR, rho);
     p.phi[idx] = phi_q(rR, rho);
@@ -814,17 +826,17 @@ __device__ constexpr int FACE_UP[5] = {5, 11, 14, 15, 18}, FACE_DN[5] = {6, 12, 
 
 __global__ __launch_bounds__(BX3 *BY3) void rk3dq_face_pack(RK3Dev p, double *send_up, double *send_dn, int has_below, int has_above)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;    // face 0: top plane, upwards
+    const int sg = blockIdx.x, x = LBMPM_SEG_LANE_X(p, sg, (int)threadIdx.x), y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;    // face 0: top plane, upwards
     if ((face == 0 && !has_above) || (face == 1 && !has_below) || y >= p.ny) return;
     const int zf = face == 0 ? p.nzl : 1;
     double *msg = face == 0 ? send_up : send_dn;
     const unsigned long long p0 = pstart_of(p, zf);
     const size_t cnt = (size_t)(pstart_of(p, zf + 1) - p0);
-    const unsigned flag = p.pur_in[row_index(p, zf, y, x >> 6)];
-    if ((x & 63) == 0) reinterpret_cast<uint32_t *>(msg + FACE_DOUBLES * cnt)[y * p.nseg + (x >> 6)] = flag;
-    if (!(p.flags[(size_t)zf * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
-    const GlobalRows rows{p, x, y};
-    const unsigned b = (unsigned)(x & 63);
+    const unsigned flag = p.pur_in[row_index(p, zf, y, sg)];
+    if (threadIdx.x == 0) reinterpret_cast<uint32_t *>(msg + FACE_DOUBLES * cnt)[y * p.nseg + sg] = flag;
+    if (x < 0 || !(p.flags[(size_t)zf * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
+    const GlobalRows rows{p, sg, y};
+    const unsigned b = threadIdx.x;
     const RowTab t = rows(zf, 0);
     const unsigned j = t.first + bits_below<false>(t.m, b);
     const double *pl = p.fin + (size_t)p0 * QS;
@@ -834,7 +846,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_face_pack(RK3Dev p, double *se
     if (flag) { ms[0] = (flag & 1u) ? 1. : 0.; ms[1] = 0.; ms[2] = 0.; ms[3] = 0.; }
     else { ms[0] = s[0]; ms[1] = s[1]; ms[2] = s[2]; ms[3] = s[3]; }
     double g[Q], k0, a0, t0, kx, ax, tx;
-    const GlbScal sc = glb_scal(p, plane_addr_q(p, p.fin, zf), j, zf, x, y);
+    const GlbScal sc = glb_scal(p, plane_addr_q(p, p.fin, zf), j, zf, sg, y);
     double *mp = msg + 9 * cnt + (size_t)j * 4;
     if (p.first) {
         double km, am, tm;
@@ -856,17 +868,17 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_face_pack(RK3Dev p, double *se
 __global__ __launch_bounds__(BX3 *BY3) void rk3dq_face_unpack(RK3Dev p, double *f, uint32_t *pur, const double *recv_below, const double *recv_above,
                                                               int has_below, int has_above)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;    // face 0: halo plane 0
+    const int sg = blockIdx.x, x = LBMPM_SEG_LANE_X(p, sg, (int)threadIdx.x), y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;    // face 0: halo plane 0
     if ((face == 0 && !has_below) || (face == 1 && !has_above) || y >= p.ny) return;
     const int zh = face == 0 ? 0 : p.nzl + 1;
     const double *msg = face == 0 ? recv_below : recv_above;
     const unsigned long long p0 = pstart_of(p, zh);
     const size_t cnt = (size_t)(pstart_of(p, zh + 1) - p0);
-    if ((x & 63) == 0) pur[row_index(p, zh, y, x >> 6)] = reinterpret_cast<const uint32_t *>(msg + FACE_DOUBLES * cnt)[y * p.nseg + (x >> 6)];
-    if (!(p.flags[(size_t)zh * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
-    const GlobalRows rows{p, x, y};
+    if (threadIdx.x == 0) pur[row_index(p, zh, y, sg)] = reinterpret_cast<const uint32_t *>(msg + FACE_DOUBLES * cnt)[y * p.nseg + sg];
+    if (x < 0 || !(p.flags[(size_t)zh * p.plane2 + (size_t)y * p.pitch + x] & 1)) return;
+    const GlobalRows rows{p, sg, y};
     const RowTab t = rows(zh, 0);
-    const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
+    const unsigned j = t.first + bits_below<false>(t.m, threadIdx.x);
     double *pl = f + (size_t)p0 * QS;
     for (int k = 0; k < 5; ++k) pl[(size_t)(face == 0 ? FACE_UP[k] : FACE_DN[k]) * cnt + j] = msg[(size_t)k * cnt + j];
     double *s = pl + (size_t)Q * cnt + (size_t)j * 4;
@@ -878,15 +890,15 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_face_unpack(RK3Dev p, double *
 // whose halo planes rk3dq_face_unpack has just filled)
 __global__ __launch_bounds__(BX3 *BY3) void rk3dq_halo_phi(RK3Dev p, const double *recv_below, const double *recv_above, int has_below, int has_above)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;
-    if ((face == 0 && !has_below) || (face == 1 && !has_above) || y >= p.ny) return;
+    const int sg = blockIdx.x, x = LBMPM_SEG_LANE_X(p, sg, (int)threadIdx.x), y = blockIdx.y * BY3 + threadIdx.y, face = blockIdx.z;
+    if ((face == 0 && !has_below) || (face == 1 && !has_above) || y >= p.ny || x < 0) return;
     const int zh = face == 0 ? 0 : p.nzl + 1;
     const size_t idx = (size_t)zh * p.plane2 + (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
     const double *msg = face == 0 ? recv_below : recv_above;
     const size_t cnt = (size_t)(pstart_of(p, zh + 1) - pstart_of(p, zh));
-    const GlobalRows rows{p, x, y};
-    const unsigned b = (unsigned)(x & 63);
+    const GlobalRows rows{p, sg, y};
+    const unsigned b = threadIdx.x;
     const RowTab t = rows(zh, 0);
     const unsigned j = t.first + bits_below<false>(t.m, b);
     const double *mp = msg + 9 * cnt + (size_t)j * 4;
@@ -896,7 +908,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_halo_phi(RK3Dev p, const doubl
         S.k0 = mp[0]; S.kp = 0.; S.km = mp[1]; S.t0 = mp[2]; S.tp = 0.; S.tm = mp[3];
     } else {
         double g[Q];
-        const GlbScal sc = glb_scal(p, plane_addr_q(p, p.fin, zh), j, zh, x, y);
+        const GlbScal sc = glb_scal(p, plane_addr_q(p, p.fin, zh), j, zh, sg, y);
         S.k0 = mp[0]; S.t0 = mp[2];
         if (face == 0) {    // the neighbour below owns c_z = 0 and +1 of its top plane; c_z = -1 comes from this rank's plane 1
             S.kp = mp[1]; S.tp = mp[3];
@@ -917,13 +929,13 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_halo_phi(RK3Dev p, const doubl
 // nx x ny plane -- 0..18 the populations g_i, 19..22 the record as stored (not the constant of a flagged row); zeros off the fluid
 __global__ __launch_bounds__(BX3 *BY3) void rk3dq_debug_plane(RK3Dev p, const double *f, int zl, int comp, double *out)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BY3 + threadIdx.y;
-    if (y >= p.ny || x >= p.nx) return;
+    const int sg = blockIdx.x, x = LBMPM_SEG_LANE_X(p, sg, (int)threadIdx.x), y = blockIdx.y * BY3 + threadIdx.y;
+    if (y >= p.ny || x < 0) return;
     double v = 0.;
     if (p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1) {
-        const GlobalRows rows{p, x, y};
+        const GlobalRows rows{p, sg, y};
         const RowTab t = rows(zl, 0);
-        const unsigned j = t.first + bits_below<false>(t.m, (unsigned)(x & 63));
+        const unsigned j = t.first + bits_below<false>(t.m, threadIdx.x);
         const unsigned long long p0 = pstart_of(p, zl);
         const size_t cnt = (size_t)(pstart_of(p, zl + 1) - p0);
         const double *pl = f + (size_t)p0 * QS;

@@ -99,11 +99,14 @@ def test_sc2d_ragged(nx, ny):
 SIZES_3D = [(64, 5, 9), (128, 8, 10), (40, 5, 9), (192, 12, 8), (65, 9, 13), (64, 17, 40), (4, 4, 8)]
 
 
+@pytest.mark.parametrize("layout", ["q23", "dense"])
 @pytest.mark.parametrize("relax", ["SRT", "MRT"])
 @pytest.mark.parametrize("nx,ny,nz", SIZES_3D, ids=["%dx%dx%d" % s for s in SIZES_3D])
-def test_rk3d_ragged(nx, ny, nz, relax):
-    """nx % 64 == 0 runs the compact storage, anything else the dense layout; thin slabs end inside
-    the first march chunk; 4 x 4 x 8 is the smallest lattice lbmpm_rk3d_create accepts"""
+def test_rk3d_ragged(nx, ny, nz, relax, layout, monkeypatch):
+    """every nx runs the compact 23-value storage (row segments of nx / ceil(nx / 64) cells), LBMPM_RK3D_LAYOUT=dense the dense
+    layout; thin slabs end inside the first march chunk; 4 x 4 x 8 is the smallest lattice lbmpm_rk3d_create accepts"""
+    if layout == "dense":
+        monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")
     from openlbmpm_amd.rk3d import RK3DCluster
     from openlbmpm_amd.geometry import porous_spheres, initial_densities_rk3d
     from oracle.rk3d import RK3DOracle
@@ -118,7 +121,7 @@ def test_rk3d_ragged(nx, ny, nz, relax):
         if nz < 4 * k:
             continue
         c = RK3DCluster(dom, k, par)
-        assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if nx % 64 == 0 else "rk3d_fused")
+        assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if layout == "q23" else "rk3d_fused")
         c.set_density(rR, rB)
         o = RK3DOracle(dom, rR, rB, par)
         c.step(7); o.run(7)

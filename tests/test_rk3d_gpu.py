@@ -18,13 +18,18 @@ def _case(nx=40, ny=21, nz=38, seed=4):
     return dom, rR, rB
 
 
+@pytest.mark.parametrize("layout", ["q23", "dense"])
 @pytest.mark.parametrize("relax", ["SRT", "MRT"])
-def test_single_slab_vs_oracle(relax):
+def test_single_slab_vs_oracle(relax, layout, monkeypatch):
+    """nx = 40: the 23-value compact storage on row segments shorter than 64 cells (rk3dq_fused<.., RAGGED>), and the dense layout"""
     from openlbmpm_amd.rk3d import RK3DCluster
     from oracle.rk3d import RK3DOracle
     dom, rR, rB = _case()
     par = dict(tauR=1.0, tauB=0.8, relax=relax)
+    if layout == "dense":
+        monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")
     c = RK3DCluster(dom, 1, par)
+    assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if layout == "q23" else "rk3d_fused")
     c.set_density(rR, rB)
     o = RK3DOracle(dom, rR, rB, par)
     for n in (1, 19):
@@ -37,10 +42,13 @@ def test_single_slab_vs_oracle(relax):
     c.close()
 
 
+@pytest.mark.parametrize("layout", ["q23", "dense"])
 @pytest.mark.parametrize("k", [2, 3, 5])
-def test_slabs_equal_single_domain_bitwise(k):
+def test_slabs_equal_single_domain_bitwise(k, layout, monkeypatch):
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=33, ny=18, nz=41, seed=9)
+    if layout == "dense":
+        monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")
     out = []
     for kk in (1, k):
         c = RK3DCluster(dom, kk)
@@ -61,7 +69,9 @@ def test_kernel_schedules_agree_bitwise(env, monkeypatch):
     the halo exchange: all the same arithmetic, so the same bits as the default single-slab run"""
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=70, ny=19, nz=41, seed=11)
+    monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")          # (the default for any nx is the 23-value compact storage: other rounding)
     ref = RK3DCluster(dom, 1)
+    assert ref.slabs[0].dominant_kernel == "rk3d_fused"
     ref.set_density(rR, rB)
     ref.step(9); ref.observe()
     for k, v in env.items():
@@ -351,18 +361,24 @@ def _single_process_reference(nx=33):
     return ref
 
 
-@pytest.mark.parametrize("nx,transport,env", [(33, "callback", None), (64, "callback", None), (64, "ipc", None), (64, "ipc", {"LBMPM_IPC_FLAG_KERNELS": "1"})],
-                         ids=["dense-two-exchanges-callback", "q23-one-exchange-callback", "q23-ipc-stream-value-ops", "q23-ipc-flag-kernels"])
-def test_two_process_slab_run_equals_single_process(tmp_path, nx, transport, env):
+@pytest.mark.parametrize("nx,transport,env", [(33, "callback", {"LBMPM_RK3D_LAYOUT": "dense"}), (64, "callback", None), (64, "ipc", None),
+                                              (64, "ipc", {"LBMPM_IPC_FLAG_KERNELS": "1"}), (96, "ipc", None), (33, "callback", None)],
+                         ids=["dense-two-exchanges-callback", "q23-one-exchange-callback", "q23-ipc-stream-value-ops", "q23-ipc-flag-kernels",
+                              "q23-nx96-ipc", "q23-nx33-callback"])
+def test_two_process_slab_run_equals_single_process(tmp_path, nx, transport, env, monkeypatch):
     """The N>1 orchestration of bench.py / RK3DDistributed with two OS processes sharing this one GPU: the gathered result must
     equal the single-process run bit for bit; the per-phase timing is filled in.
     callback: the exchange as a Python callback per step over the gloo transport staged through the host (RCCL refuses duplicate
-    devices).  nx = 64: the bench's storage -- boundary planes first, ONE face exchange beside the interior planes.
+    devices).  nx = 64: the bench's storage -- boundary planes first, ONE face exchange beside the interior planes; nx = 96, 33: the
+    same on row segments of 48 and 33 cells (any nx runs the 23-value storage; LBMPM_RK3D_LAYOUT=dense keeps the two-exchange layout).
     ipc: the transport INSIDE the library (include/lbmpm.h LBMPM_TRANSPORT_IPC) -- each process maps the other's landing area with
     hipIpcOpenMemHandle, a message is one hipMemcpyAsync + hipStreamWriteValue64, the receiver's stream waits with
     hipStreamWaitValue64; no callback, torch.distributed only carries the handles at set-up.  flag-kernels: the same with the
     one-lane kernels that devices without stream value operations fall back on."""
     got, timing = _two_rank_run(tmp_path, "gloo", same_gpu=True, nx=nx, transport=transport, extra_env=env)
+    for k, v in (env or {}).items():
+        if k.startswith("LBMPM_RK3D"):
+            monkeypatch.setenv(k, v)
     ref = _single_process_reference(nx)
     for f in ref:
         assert np.array_equal(got[f], ref[f]), f
@@ -434,7 +450,7 @@ os._exit(0)                          # (no destroy_process_group: the peer is go
 
 
 def test_a_named_transport_on_the_two_exchange_storage_raises(tmp_path):
-    """advisor, round 4: transport='ipc' on a lattice that runs the 38-value storage (nx not a multiple of 64: two exchanges per step)
+    """advisor, round 4: transport='ipc' on a lattice that runs the 38-value storage (here: LBMPM_RK3D_LAYOUT=dense; two exchanges per step)
     was silently served by the callback; a named transport that cannot be had raises (on every rank alike: the decision depends on
     the lattice only), and 'auto' says in its log why it fell back"""
     import os
@@ -462,7 +478,7 @@ d.set_density(rR, rB); d.step(2); d.sync(); d.close()
 dist.destroy_process_group()
 ''' % (root, root))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                           "--master-port", str(_free_port()), str(script)], timeout=240)
+                           "--master-port", str(_free_port()), str(script)], env=dict(os.environ, LBMPM_RK3D_LAYOUT="dense"), timeout=240)
 
 
 @pytest.mark.parametrize("kind", ["ipc", "rccl"])
@@ -480,7 +496,7 @@ def test_transport_selftest_on_one_gpu(kind):
                                           path.encode() if path else None), "lbmpm_transport_selftest(%s)" % kind)
 
 
-def test_a_transport_needs_the_compact_storage_and_matching_neighbours():
+def test_a_transport_needs_the_compact_storage_and_matching_neighbours(monkeypatch):
     """error paths of the connect calls: the dense storage has no in-library transport; a blob for a neighbour the slab lacks, a
     blob that is none and a neighbour that expects another message size are refused with a status, nothing hangs"""
     from openlbmpm_amd import _lib
@@ -504,6 +520,7 @@ def test_a_transport_needs_the_compact_storage_and_matching_neighbours():
     lo.transport_disconnect()
     assert lo.transport == "callback"
     dense_dom, _, _ = _case(nx=33, ny=18, nz=41, seed=9)
+    monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")
     d = RK3DSlab(dense_dom, 0, 20)
     with pytest.raises(LbmpmError) as e:
         d.ipc_init()

@@ -126,8 +126,10 @@ def test_oracle3d_default_weights_equal_the_pinned_2d_oracle(name):
 # ------------------------------------------------------------------------------------------- the HIP kernels
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,ny,env", [
-    ("srt_capillary", 4, {}),                                  # dense storage, fused z-marching kernel (rk3d_fused)
+    ("srt_capillary", 4, {}),                                  # nx = 16, 28: compact storage of 23 values on short row segments (rk3dq_fused<.., RAGGED>)
     ("srt_porous", 5, {}),
+    ("srt_capillary", 4, {"LBMPM_RK3D_LAYOUT": "dense"}),      # dense storage, fused z-marching kernel (rk3d_fused)
+    ("srt_porous", 5, {"LBMPM_RK3D_LAYOUT": "dense"}),
     ("srt_porous", 8, {"LBMPM_RK3D_VARIANT": "1"}),            # split schedule (rk3d_phase_field + rk3d_collide)
     ("srt_porous64", 8, {}),                                   # nx = 64: compact storage of 23 values, rk3dq_fused (the bench kernel)
     ("srt_porous64", 11, {"LBMPM_RK3D_CHUNK": "7"}),           # ... cut tiles, several chunks per column
@@ -143,6 +145,8 @@ def test_hip_reproduces_the_reference_2d_driver(name, ny, env, monkeypatch):
     c = RK3DCluster(dom3, 1, dict(par3, **RC_EXACT))
     if name == "srt_porous64":
         assert c.slabs[0].dominant_kernel == ("rk3dc_fused" if env.get("LBMPM_RK3D_STORAGE") == "38" else "rk3dq_fused")
+    else:
+        assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if not env else ("rk3d_collide" if "LBMPM_RK3D_VARIANT" in env else "rk3d_fused"))
     c.set_density(extrude(dense2(d, d["init_rhoR"]), ny), extrude(dense2(d, d["init_rhoB"]), ny))
     done, worst = 0, 0.0
     for k in d["snaps"]:
