@@ -341,12 +341,37 @@ enum { LBMPM_RK3D_BUF_F_SEND_UP = 0, LBMPM_RK3D_BUF_F_SEND_DOWN = 1,
 
 /* is_domain_with_halo: host [nz_local + 2][ny][nx] uint8 (1 = fluid): the owned planes plus
  * the plane below and above them; planes outside the global lattice must be 0.
- * Compact storage: (nz_local + 2) * ny * (nx / 64) row segments per slab must stay below 2^31. */
+ * Compact storage (the default for every nx: 23 doubles per fluid cell, rows cut into ceil(nx / 64) segments of <= 64 cells):
+ * (nz_local + 2) * ny * ceil(nx / 64) row segments per slab must stay below 2^31; nx, ny <= 32767. */
 int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is_domain_with_halo, lbmpm_rk3d **out);
 void lbmpm_rk3d_destroy(lbmpm_rk3d *ctx);
 int lbmpm_rk3d_set_stream(lbmpm_rk3d *ctx, void *hip_stream);
 /* owned planes [nz_local][ny][nx]; f = w rho at rest */
 int lbmpm_rk3d_set_density(lbmpm_rk3d *ctx, const double *rho_r, const double *rho_b);
+/* ---- State in and out (the reference's 2-D drivers: initial f from densities + velocity RKD2Q9.py:577-601; restart from recorded
+ * populations, [CyclesSetup] IsCycle = 'yes', RKD2Q9.py:491-559; populations recorded RKD2Q9.py:938-957).  Host arrays cover the owned
+ * planes, dense, zeros / ignored off the fluid.  Every set_* resets the step counter (set_state: to the value given).
+ *
+ * "post_collision": what the populations are.  0 = the lattice as a time step finds it after streaming (what set_density / set_macro
+ * give: the first step streams nothing); 1 = the lattice as a time step leaves it -- collided and recoloured, to be streamed by the
+ * next step: what the reference's arrays hold when it records them, and what get_pdf / get_state return after at least one step.
+ *
+ * set_macro: f_c,i = rho_c w_i (1 + 3 e_i.u + 4.5 (e_i.u)^2 - 1.5 u^2); vx, vy, vz [nz_local][ny][nx] or NULL (= 0; all NULL is
+ *   set_density bit for bit).
+ * get_pdf / set_pdf: f_R, f_B as [nz_local][ny][nx][19] each -- the 3-D analogue of fluidPDFR / fluidPDFB [ny][nx][9]; direction order
+ *   rest, +x -x +y -y +z -z, (x,y) ++ -- +- -+, (x,z) ++ -- +- -+, (y,z) ++ -- +- -+.  The 23-value storage converts inside
+ *   (f_R,i = k_R g_i + c_i e_i.A; back: g = f_R + f_B, k_R = rho_R / rho, A from the first moment of f_R): the round trip is good to
+ *   rounding (1e-15), not to the bit, and populations that are not a state of the model are projected onto one.
+ * get_state / set_state: the doubles a cell stores, as stored, [nz_local][ny][nx][S] with S = state_info out[0] (23: g_0..18, k_R,
+ *   A_x, A_y, A_z; 38: f_R,0..18, f_B,0..18): a run continued from (get_state, steps, post_collision) in a NEW context -- same lattice,
+ *   same parameters, same storage, any slab decomposition -- equals the uninterrupted run bit for bit.
+ * state_info: out[0] doubles per cell of get_state, out[1] steps done, out[2] post_collision of the current state. */
+int lbmpm_rk3d_set_macro(lbmpm_rk3d *ctx, const double *rho_r, const double *rho_b, const double *vx, const double *vy, const double *vz);
+int lbmpm_rk3d_set_pdf(lbmpm_rk3d *ctx, const double *pdf_r, const double *pdf_b, int post_collision);
+int lbmpm_rk3d_get_pdf(lbmpm_rk3d *ctx, double *pdf_r, double *pdf_b);
+int lbmpm_rk3d_state_info(const lbmpm_rk3d *ctx, int64_t *out);
+int lbmpm_rk3d_get_state(lbmpm_rk3d *ctx, double *state);
+int lbmpm_rk3d_set_state(lbmpm_rk3d *ctx, const double *state, int64_t doubles_per_cell, int64_t steps_done, int post_collision);
 int lbmpm_rk3d_pack_halo(lbmpm_rk3d *ctx);
 int lbmpm_rk3d_unpack_halo(lbmpm_rk3d *ctx, int have_below, int have_above);
 /* with_diagnostics: also keep rhoR, rhoB, u of the streamed, boundary-corrected lattice */

@@ -80,6 +80,7 @@ def _declare(L):
         "H5Aclose": (C.c_int, [hid]),
         "H5Lget_name_by_idx": (C.c_ssize_t, [hid, C.c_char_p, C.c_int, C.c_int, hsz, C.c_char_p, C.c_size_t, hid]),
         "H5Eset_auto2": (C.c_int, [hid, C.c_void_p, C.c_void_p]),
+        "H5Sselect_hyperslab": (C.c_int, [hid, C.c_int, C.POINTER(hsz), C.POINTER(hsz), C.POINTER(hsz), C.POINTER(hsz)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -168,12 +169,23 @@ def _members(L, f, group):
     return out
 
 
-def _read_dataset(L, d):
+def _read_dataset(L, d, z0=None, n=None):
+    """the whole dataset, or its planes [z0, z0 + n) along the first axis (a hyperslab: the rest of the file is not read)"""
     s, t = L.H5Dget_space(d), L.H5Dget_type(d)
     nd = L.H5Sget_simple_extent_ndims(s)
     dims = (C.c_uint64 * max(nd, 1))()
     if nd > 0:
         L.H5Sget_simple_extent_dims(s, dims, None)
+    mem_space = H5S_ALL
+    if z0 is not None:
+        if nd < 1 or z0 < 0 or n < 0 or z0 + n > dims[0]:
+            L.H5Tclose(t); L.H5Sclose(s)
+            raise Hdf5Error("planes [%d, %d) outside a dataset of shape %s" % (z0, z0 + n, tuple(dims[:nd])))
+        start = (C.c_uint64 * nd)(*([z0] + [0] * (nd - 1)))
+        count = (C.c_uint64 * nd)(*([n] + list(dims[1:nd])))
+        _ok(L.H5Sselect_hyperslab(s, 0, start, None, count, None), "H5Sselect_hyperslab")
+        mem_space = _ok(L.H5Screate_simple(nd, count, None), "H5Screate_simple")
+        dims[0] = n
     cls, size = L.H5Tget_class(t), L.H5Tget_size(t)
     if cls == H5T_FLOAT:
         dt = np.dtype("f%d" % size)
@@ -183,7 +195,9 @@ def _read_dataset(L, d):
         L.H5Tclose(t); L.H5Sclose(s)
         return None                               # strings, compounds: not part of the drivers' output
     out = np.empty(tuple(dims[:nd]), dtype=dt)
-    rc = L.H5Dread(d, _native(L, dt), H5S_ALL, H5S_ALL, H5P_DEFAULT, out.ctypes.data_as(C.c_void_p))
+    rc = L.H5Dread(d, _native(L, dt), mem_space, s if z0 is not None else H5S_ALL, H5P_DEFAULT, out.ctypes.data_as(C.c_void_p))
+    if mem_space != H5S_ALL:
+        L.H5Sclose(mem_space)
     L.H5Tclose(t); L.H5Sclose(s)
     _ok(rc, "H5Dread")
     return out
@@ -211,3 +225,19 @@ def read_all(path):
     finally:
         L.H5Fclose(f)
     return out
+
+
+def read_planes(path, name, z0=None, n=None):
+    """dataset `name` (absolute HDF5 path), or only its planes [z0, z0 + n) along the first axis"""
+    L = _need()
+    f = _ok(L.H5Fopen(path.encode(), H5F_ACC_RDONLY, H5P_DEFAULT), "H5Fopen(%s)" % path)
+    try:
+        d = L.H5Dopen2(f, name.encode(), H5P_DEFAULT)
+        if d < 0:
+            raise KeyError(name)
+        try:
+            return _read_dataset(L, d, z0, n)
+        finally:
+            L.H5Dclose(d)
+    finally:
+        L.H5Fclose(f)

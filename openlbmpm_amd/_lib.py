@@ -120,6 +120,12 @@ _SIGNATURES = {
     "lbmpm_rk3d_destroy": (None, [C.c_void_p]),
     "lbmpm_rk3d_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lbmpm_rk3d_set_density": (C.c_int, [C.c_void_p, F64P, F64P]),
+    "lbmpm_rk3d_set_macro": (C.c_int, [C.c_void_p, F64P, F64P, F64P, F64P, F64P]),
+    "lbmpm_rk3d_set_pdf": (C.c_int, [C.c_void_p, F64P, F64P, C.c_int]),
+    "lbmpm_rk3d_get_pdf": (C.c_int, [C.c_void_p, F64P, F64P]),
+    "lbmpm_rk3d_state_info": (C.c_int, [C.c_void_p, I64P]),
+    "lbmpm_rk3d_get_state": (C.c_int, [C.c_void_p, F64P]),
+    "lbmpm_rk3d_set_state": (C.c_int, [C.c_void_p, F64P, C.c_int64, C.c_int64, C.c_int]),
     "lbmpm_rk3d_pack_halo": (C.c_int, [C.c_void_p]),
     "lbmpm_rk3d_unpack_halo": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lbmpm_rk3d_phase_field": (C.c_int, [C.c_void_p, C.c_int]),

@@ -158,8 +158,9 @@ def read_rk3d(ini_dir):
     p["relax"] = c.str("RelaxationType", "Type", default="'SRT'")
     if p["relax"] not in ("SRT", "MRT"):
         raise ConfigError("[RelaxationType] Type must be 'SRT' or 'MRT'")
-    if c.str("CyclesSetup", "IsCycle", default="'no'") == "yes":
-        raise ConfigError("[CyclesSetup] IsCycle = 'yes' is not supported in 3-D")
+    # [CyclesSetup] (RKtwophasesetup3D.ini:57-59): the 2-D rules of RKD2Q9.py:491-559 carried to z (RKColorGradientD3Q19.py)
+    p["cycle"] = c.str("CyclesSetup", "IsCycle", default="'no'") == "yes"
+    p["last_step"] = c.int("CyclesSetup", "LastStep", default=0)
     return p
 
 

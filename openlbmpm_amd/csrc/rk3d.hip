@@ -1125,6 +1125,7 @@ __global__ void rk3d_setup_solidnbr(RK3Dev p, uint32_t *solidnbr)
 }
 
 #include "rk3dq.h"
+#include "rk3d_state.h"
 
 }  // namespace
 
@@ -1458,6 +1459,138 @@ extern "C" int lbmpm_rk3d_set_density(lbmpm_rk3d *c, const double *rho_r, const 
     c->steps = 0;
     c->observed_at = -1;
     return LBMPM_OK;
+}
+
+// ---- state in and out (rk3d_state.h): macroscopic start, populations per colour, the stored values themselves
+namespace {
+template <int MODE>
+void launch_state_io(lbmpm_rk3d *c, const RK3Dev &p, double *f, int zl0, int planes, double *a, double *b)
+{
+    const dim3 block(BX3, BY3);
+    const unsigned gy = (unsigned)((c->ny + BY3 - 1) / BY3);
+    if (c->q23) rk3d_state_io<ST_Q23, MODE><<<dim3(c->nseg, gy, planes), block, 0, c->stream>>>(p, f, zl0, a, b);
+    else if (c->compact) rk3d_state_io<ST_C38, MODE><<<dim3(c->nseg, gy, planes), block, 0, c->stream>>>(p, f, zl0, a, b);
+    else rk3d_state_io<ST_DENSE, MODE><<<dim3((c->nx + 63) / 64, gy, planes), block, 0, c->stream>>>(p, f, zl0, a, b);
+}
+
+int state_width(const lbmpm_rk3d *c) { return c->q23 ? QS : 2 * Q; }
+size_t state_fbytes(const lbmpm_rk3d *c) { return (c->q23 ? (size_t)QS * (c->ncells + 2) : (c->compact ? 2 * Q * (c->ncells + 1) : 2 * Q * c->vol)) * sizeof(double); }
+
+// The owned planes in batches through a staging buffer on the device.  wa / wb: doubles per cell of the host arrays ha / hb (MACRO: the
+// five host arrays m[0..4], one double per cell each; a NULL velocity component is zero).
+template <int MODE>
+int state_transfer(lbmpm_rk3d *c, double *ha, int wa, double *hb, int wb, const double *const *m)
+{
+    constexpr bool GET = MODE == IO_GET_STATE || MODE == IO_GET_PDF;
+    LBMPM_REQUIRE(!c->interior_pending, "state transfer inside a step: finish it with lbmpm_rk3d_collide_boundary first");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->aux) LBMPM_HIP_TRY(hipStreamSynchronize(c->aux));
+    const size_t pcells = (size_t)c->nx * c->ny;
+    const int per = MODE == IO_SET_MACRO ? 5 : wa + wb;
+    int batch = (int)(((size_t)256 << 20) / (pcells * (size_t)per * sizeof(double)));
+    batch = batch < 1 ? 1 : (batch > c->nzl ? c->nzl : batch);
+    double *stage = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&stage), (size_t)batch * pcells * per * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("state transfer: hipMalloc of the %d-plane staging buffer failed", batch);
+        return LBMPM_ERR_NOMEM;
+    }
+    hipError_t e = hipSuccess;
+    if (!GET) e = hipMemsetAsync(c->fA, 0, state_fbytes(c), c->stream);
+    const RK3Dev p = make_dev(c);
+    for (int z0 = 0; z0 < c->nzl && e == hipSuccess; z0 += batch) {
+        const int n = c->nzl - z0 < batch ? c->nzl - z0 : batch;
+        const size_t cells = (size_t)n * pcells;
+        double *a = stage, *b = stage + cells * (size_t)wa;
+        if (MODE == IO_SET_MACRO) {
+            for (int k = 0; k < 5 && e == hipSuccess; ++k)
+                e = m[k] ? hipMemcpyAsync(stage + (size_t)k * cells, m[k] + (size_t)z0 * pcells, cells * sizeof(double), hipMemcpyHostToDevice, c->stream)
+                         : hipMemsetAsync(stage + (size_t)k * cells, 0, cells * sizeof(double), c->stream);
+        } else if (!GET) {
+            e = hipMemcpyAsync(a, ha + (size_t)z0 * pcells * wa, cells * wa * sizeof(double), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess && wb) e = hipMemcpyAsync(b, hb + (size_t)z0 * pcells * wb, cells * wb * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        }
+        if (e != hipSuccess) break;
+        launch_state_io<MODE>(c, p, c->fA, z0 + 1, n, a, b);
+        e = hipGetLastError();
+        if (e == hipSuccess && GET) {
+            e = hipMemcpyAsync(ha + (size_t)z0 * pcells * wa, a, cells * wa * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && wb) e = hipMemcpyAsync(hb + (size_t)z0 * pcells * wb, b, cells * wb * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // the staging buffer is reused by the next batch
+    }
+    if (e == hipSuccess && !GET) {
+        if (c->q23) {
+            // row flags from the records; the ghost planes' rows and segments without a fluid cell keep "any colour" for good (as set_density)
+            const size_t pbytes = (size_t)(c->nzl + 2) * c->ny * c->nseg * sizeof(uint32_t);
+            e = hipMemsetAsync(c->purA, 0xff, pbytes, c->stream);
+            rk3dq_flags_from_records<<<dim3(c->nseg, (c->ny + BY3 - 1) / BY3, c->nzl), dim3(BX3, BY3), 0, c->stream>>>(p, c->fA, c->purA, 1);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(c->purB, c->purA, pbytes, hipMemcpyDeviceToDevice, c->stream);
+        }
+        // both buffers start from the same image (the ghost planes of the q23 storage are never written again)
+        if (e == hipSuccess) e = hipMemcpyAsync(c->fB, c->fA, state_fbytes(c), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(stage);
+    if (e != hipSuccess) { set_error("state transfer: %s", hipGetErrorString(e)); return LBMPM_ERR_HIP; }
+    return LBMPM_OK;
+}
+
+void state_was_set(lbmpm_rk3d *c, int64_t steps, bool streamed)
+{
+    c->streamed = streamed;
+    c->halo_valid = false;
+    c->steps = steps;
+    c->observed_at = -1;
+}
+}  // namespace
+
+extern "C" int lbmpm_rk3d_set_macro(lbmpm_rk3d *c, const double *rho_r, const double *rho_b, const double *vx, const double *vy, const double *vz)
+{
+    LBMPM_REQUIRE(c && rho_r && rho_b, "lbmpm_rk3d_set_macro: null argument");
+    const double *m[5] = {rho_r, rho_b, vx, vy, vz};
+    const int rc = state_transfer<IO_SET_MACRO>(c, nullptr, 0, nullptr, 0, m);
+    if (rc == LBMPM_OK) state_was_set(c, 0, false);
+    return rc;
+}
+
+extern "C" int lbmpm_rk3d_set_pdf(lbmpm_rk3d *c, const double *pdf_r, const double *pdf_b, int post_collision)
+{
+    LBMPM_REQUIRE(c && pdf_r && pdf_b, "lbmpm_rk3d_set_pdf: null argument");
+    const int rc = state_transfer<IO_SET_PDF>(c, const_cast<double *>(pdf_r), Q, const_cast<double *>(pdf_b), Q, nullptr);
+    if (rc == LBMPM_OK) state_was_set(c, 0, post_collision != 0);
+    return rc;
+}
+
+extern "C" int lbmpm_rk3d_get_pdf(lbmpm_rk3d *c, double *pdf_r, double *pdf_b)
+{
+    LBMPM_REQUIRE(c && pdf_r && pdf_b, "lbmpm_rk3d_get_pdf: null argument");
+    return state_transfer<IO_GET_PDF>(c, pdf_r, Q, pdf_b, Q, nullptr);
+}
+
+extern "C" int lbmpm_rk3d_state_info(const lbmpm_rk3d *c, int64_t *out)
+{
+    LBMPM_REQUIRE(c && out, "lbmpm_rk3d_state_info: null argument");
+    out[0] = state_width(c); out[1] = c->steps; out[2] = c->streamed ? 1 : 0;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3d_get_state(lbmpm_rk3d *c, double *state)
+{
+    LBMPM_REQUIRE(c && state, "lbmpm_rk3d_get_state: null argument");
+    return state_transfer<IO_GET_STATE>(c, state, state_width(c), nullptr, 0, nullptr);
+}
+
+extern "C" int lbmpm_rk3d_set_state(lbmpm_rk3d *c, const double *state, int64_t doubles_per_cell, int64_t steps_done, int post_collision)
+{
+    LBMPM_REQUIRE(c && state && steps_done >= 0, "lbmpm_rk3d_set_state: bad argument");
+    LBMPM_REQUIRE(doubles_per_cell == state_width(c), "lbmpm_rk3d_set_state: the state holds %lld doubles per cell, this context stores %d (lbmpm_rk3d_state_info; "
+                  "a state of the other storage goes through lbmpm_rk3d_get_pdf / set_pdf)", (long long)doubles_per_cell, state_width(c));
+    const int rc = state_transfer<IO_SET_STATE>(c, const_cast<double *>(state), state_width(c), nullptr, 0, nullptr);
+    if (rc == LBMPM_OK) state_was_set(c, steps_done, post_collision != 0);
+    return rc;
 }
 
 // bytes of the face message that describes plane zl (compact storages move the fluid cells of the plane only)
@@ -2129,7 +2262,7 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             if (c->interior_pending) { (void)hipStreamSynchronize(c->aux); c->interior_pending = false; }
             return code;        // fA / fB are half-updated: the caller has to set_density (or restart) before stepping again
         };
-        if (nb && c->steps > 0) {
+        if (nb && c->streamed) {
             rc = lbmpm_rk3d_pack_halo(c);
             if (rc == LBMPM_OK && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed (populations)"); rc = LBMPM_ERR_STATE; }
             if (rc == LBMPM_OK) rc = lbmpm_rk3d_unpack_halo(c, has_below, has_above);

@@ -115,6 +115,46 @@ def load_results(path):
         return out
 
 
+def read_planes(path, key, z0=None, n=None):
+    """dataset `key` ("/group/name") of a result file, or its planes [z0, z0 + n) along the first axis -- read as a slab where the
+    backend can (a rank of a distributed run takes its own planes of a 512^3 record, not the record); KeyError when absent"""
+    sl = slice(None) if z0 is None else slice(int(z0), int(z0) + int(n))
+    if path.endswith(".npz"):
+        d = np.load(path)
+        if key not in d.files:
+            raise KeyError(key)
+        return d[key][sl]
+    try:
+        import h5py
+        with h5py.File(path, "r") as f:
+            return np.asarray(f[key][sl])
+    except ImportError:
+        pass
+    try:
+        import tables as tb
+    except ImportError:
+        from . import _hdf5
+        return _hdf5.read_planes(path, key, None if z0 is None else int(z0), None if z0 is None else int(n))
+    f = tb.open_file(path, "r")
+    try:
+        try:
+            node = f.get_node(key)
+        except tb.NoSuchNodeError:
+            raise KeyError(key)
+        return np.asarray(node[sl])
+    finally:
+        f.close()
+
+
+def find_result_file(directory, stem):
+    """<directory>/<stem>.h5 or .npz, else None"""
+    for ext in (".h5", ".npz"):
+        p = os.path.join(directory, stem + ext)
+        if os.path.isfile(p):
+            return p
+    return None
+
+
 class SimulationDiverged(FloatingPointError):
     """a recorded field holds NaN or Inf (the reference lets them propagate silently into its result files)"""
 

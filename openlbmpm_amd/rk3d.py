@@ -70,6 +70,53 @@ class RK3DSlab:
             raise TypeError("density arrays must have shape %s" % ((self.nzl, self.ny, self.nx),))
         check(self._L.lbmpm_rk3d_set_density(self._h, a.ctypes.data_as(F64P), b.ctypes.data_as(F64P)), "set_density")
 
+    # ---- state in and out (include/lbmpm.h: "State in and out"); arrays cover the slab's own planes
+    def _plane_array(self, a, name, last=()):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != (self.nzl, self.ny, self.nx) + tuple(last):
+            raise TypeError("%s must have shape %s" % (name, (self.nzl, self.ny, self.nx) + tuple(last)))
+        return a, a.ctypes.data_as(F64P)
+
+    def set_macro(self, rhoR, rhoB, vx=None, vy=None, vz=None):
+        """f = rho w (1 + 3 e.u + 4.5 (e.u)^2 - 1.5 u^2) per colour (RKD2Q9.py:577-601 in 3-D); the state is the streamed lattice"""
+        keep = [self._plane_array(a, n) for a, n in ((rhoR, "rhoR"), (rhoB, "rhoB"), (vx, "vx"), (vy, "vy"), (vz, "vz"))]
+        check(self._L.lbmpm_rk3d_set_macro(self._h, *[k[1] for k in keep]), "lbmpm_rk3d_set_macro")
+
+    def set_pdf(self, fR, fB, post_collision=True):
+        """populations per colour, [nzl][ny][nx][19] (the 3-D fluidPDFR / fluidPDFB); post_collision: as a time step leaves them"""
+        a, pa = self._plane_array(fR, "fR", (19,)); b, pb = self._plane_array(fB, "fB", (19,))
+        check(self._L.lbmpm_rk3d_set_pdf(self._h, pa, pb, int(bool(post_collision))), "lbmpm_rk3d_set_pdf")
+
+    def get_pdf(self):
+        fR = np.empty((self.nzl, self.ny, self.nx, 19)); fB = np.empty_like(fR)
+        check(self._L.lbmpm_rk3d_get_pdf(self._h, fR.ctypes.data_as(F64P), fB.ctypes.data_as(F64P)), "lbmpm_rk3d_get_pdf")
+        return fR, fB
+
+    def state_info(self):
+        out = (C.c_int64 * 3)()
+        check(self._L.lbmpm_rk3d_state_info(self._h, out), "lbmpm_rk3d_state_info")
+        return dict(doubles_per_cell=int(out[0]), steps=int(out[1]), post_collision=bool(out[2]))
+
+    def get_state(self):
+        """(state [nzl][ny][nx][S], info): what a cell stores, as stored -- the argument of set_state for a bit-exact continuation"""
+        info = self.state_info()
+        st = np.empty((self.nzl, self.ny, self.nx, info["doubles_per_cell"]))
+        check(self._L.lbmpm_rk3d_get_state(self._h, st.ctypes.data_as(F64P)), "lbmpm_rk3d_get_state")
+        return st, info
+
+    def set_state(self, state, steps=0, post_collision=True):
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        if st.ndim != 4 or st.shape[:3] != (self.nzl, self.ny, self.nx):
+            raise TypeError("state must have shape %s + (S,)" % ((self.nzl, self.ny, self.nx),))
+        check(self._L.lbmpm_rk3d_set_state(self._h, st.ctypes.data_as(F64P), st.shape[3], int(steps), int(bool(post_collision))), "lbmpm_rk3d_set_state")
+
+    @property
+    def post_collision(self):
+        """the stored populations are those a time step left (the next step streams them); False right after set_density / set_macro"""
+        return self.state_info()["post_collision"]
+
     def use_torch_stream(self, stream):
         """Run this slab's kernels on a torch.cuda.Stream so that they are ordered with torch's
         copies / RCCL operations issued under `with torch.cuda.stream(stream)`.  (Handle 0, the
@@ -269,6 +316,27 @@ class RK3DCluster:
         for s, (z0, n) in zip(self.slabs, self.parts):
             s.set_density(rhoR[z0:z0 + n], rhoB[z0:z0 + n])
 
+    def set_macro(self, rhoR, rhoB, vx=None, vy=None, vz=None):
+        cut = lambda a, z0, n: None if a is None else a[z0:z0 + n]
+        for s, (z0, n) in zip(self.slabs, self.parts):
+            s.set_macro(*[cut(a, z0, n) for a in (rhoR, rhoB, vx, vy, vz)])
+
+    def set_pdf(self, fR, fB, post_collision=True):
+        for s, (z0, n) in zip(self.slabs, self.parts):
+            s.set_pdf(fR[z0:z0 + n], fB[z0:z0 + n], post_collision)
+
+    def get_pdf(self):
+        got = [s.get_pdf() for s in self.slabs]
+        return np.concatenate([g[0] for g in got], axis=0), np.concatenate([g[1] for g in got], axis=0)
+
+    def get_state(self):
+        got = [s.get_state() for s in self.slabs]
+        return np.concatenate([g[0] for g in got], axis=0), got[0][1]
+
+    def set_state(self, state, steps=0, post_collision=True):
+        for s, (z0, n) in zip(self.slabs, self.parts):
+            s.set_state(state[z0:z0 + n], steps, post_collision)
+
     def _exchange(self, kind):
         S = self.slabs
         if S[0].buffer(kind + "_send_up") is None:
@@ -288,7 +356,7 @@ class RK3DCluster:
             for _ in range(int(n)):
                 for s in self.slabs:
                     s.collide_interior()
-                if self.slabs[0].steps_done > 0 or self.slabs[0].one_exchange:
+                if self.slabs[0].post_collision or self.slabs[0].one_exchange:
                     self._halo_f()
                 for s in self.slabs:
                     s.phase_field()
@@ -299,7 +367,7 @@ class RK3DCluster:
     def observe(self):
         """rho, u, phi of the streamed + boundary-corrected lattice (what the next step starts from)"""
         with self._torch.cuda.stream(self.stream):
-            if self.slabs[0].steps_done > 0 or self.slabs[0].one_exchange:
+            if self.slabs[0].post_collision or self.slabs[0].one_exchange:
                 self._halo_f()
             for s in self.slabs:
                 s.phase_field(diagnostics=True)
@@ -325,7 +393,8 @@ class RK3DDistributed:
         rank's set-up self-test passes within its deadline, else the callback; a named transport that fails raises on every rank."""
         import torch.distributed as dist
         self.rank, self.world, self.group = dist.get_rank(group), dist.get_world_size(group), group
-        z0, n = self.partition(is_domain_global, self.world, balance, plane_cost)[self.rank]
+        self.parts = self.partition(is_domain_global, self.world, balance, plane_cost)      # every rank's (z0, planes)
+        z0, n = self.parts[self.rank]
         self.z0, self.nzl = z0, n
         import os
         import torch
@@ -503,6 +572,24 @@ class RK3DDistributed:
     def set_density(self, rhoR_global, rhoB_global):
         self.slab.set_density(rhoR_global[self.z0:self.z0 + self.nzl], rhoB_global[self.z0:self.z0 + self.nzl])
 
+    def _mine(self, a):
+        return None if a is None else a[self.z0:self.z0 + self.nzl]
+
+    def set_macro(self, rhoR, rhoB, vx=None, vy=None, vz=None):
+        """global arrays (every rank takes its planes); see RK3DSlab.set_macro"""
+        self.slab.set_macro(*[self._mine(a) for a in (rhoR, rhoB, vx, vy, vz)])
+
+    def set_pdf(self, fR, fB, post_collision=True):
+        self.slab.set_pdf(self._mine(fR), self._mine(fB), post_collision)
+
+    def set_state(self, state, steps=0, post_collision=True):
+        self.slab.set_state(self._mine(state), steps, post_collision)
+
+    def gather(self, local):
+        """this rank's planes of a field / state -> the whole lattice's array on rank 0 (None elsewhere); collective"""
+        from .slab import gather_planes
+        return gather_planes(local, self.parts, self.rank, self.world, self.group, self.device)
+
     def _exchange(self, kind):
         s = self.slab
         if s.buffer(kind + "_send_up") is None:
@@ -513,7 +600,7 @@ class RK3DDistributed:
 
     def _halo_f(self):
         s = self.slab
-        if (s.steps_done > 0 or s.one_exchange) and self.world > 1:
+        if (s.post_collision or s.one_exchange) and self.world > 1:
             if s.transport != "callback":
                 s.halo_exchange()
                 return

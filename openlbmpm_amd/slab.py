@@ -92,6 +92,33 @@ def local_exchange(slabs_send_up, slabs_send_down, slabs_recv_below, slabs_recv_
             slabs_recv_above[r].copy_(slabs_send_down[r + 1])
 
 
+def gather_planes(local, parts, rank, world, group=None, device=None):
+    """Stack the ranks' planes on rank 0 (the reference's record is ONE dense array per field, RKD2Q9.py:938-957): `local` is this
+    rank's numpy array [n_r, ...], parts = [(z0, n)] of all ranks.  Returns the [nz, ...] array on rank 0, None elsewhere.
+    Point-to-point (send / recv to rank 0), through device memory under NCCL, host memory under gloo."""
+    import numpy as np
+    if world == 1:
+        return np.asarray(local)
+    import torch
+    import torch.distributed as dist
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", device if device is not None else torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    local = np.ascontiguousarray(local)
+    if rank != 0:
+        dist.send(torch.from_numpy(local).to(dev), dst=peer(0), group=group)
+        return None
+    tail = local.shape[1:]
+    out = np.empty((sum(n for _, n in parts),) + tail, dtype=local.dtype)
+    out[parts[0][0]:parts[0][0] + parts[0][1]] = local
+    for r in range(1, world):
+        z0, n = parts[r]
+        buf = torch.empty((n,) + tail, dtype=torch.from_numpy(local[:0]).dtype, device=dev)
+        dist.recv(buf, src=peer(r), group=group)
+        out[z0:z0 + n] = buf.cpu().numpy()
+    return out
+
+
 class DeviceBuffer:
     """Zero-copy torch view of a raw device allocation owned by liblbmpm_hip.so."""
 

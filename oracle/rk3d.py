@@ -50,6 +50,16 @@ class RK3DOracle:
         a = np.ascontiguousarray(rhoR0, dtype=np.float64); b = np.ascontiguousarray(rhoB0, dtype=np.float64)
         L.rk3d_init(C.byref(s), a.ctypes.data_as(F64P), b.ctypes.data_as(F64P))
 
+    def set_populations(self, fR, fB):
+        """start from given populations of the streamed lattice, [nz][ny][nx][19] per colour (zeros off the fluid), instead of
+        w rho at rest: the counterpart of lbmpm_rk3d_set_pdf(..., post_collision = 0) / set_macro for the tests"""
+        n = int(np.prod(self.shape)) * 19
+        fluid = (self.dom.reshape(-1) == 1)[:, None]
+        for name, a in (("fR", fR), ("fB", fB)):
+            dst = np.ctypeslib.as_array(getattr(self._s, name), shape=(n,)).reshape(-1, 19)
+            dst[:] = np.where(fluid, np.asarray(a, dtype=np.float64).reshape(-1, 19), 0.0)
+        return self
+
     def run(self, n):
         self._L.rk3d_run(C.byref(self._s), C.c_int64(int(n)))
         return self

@@ -96,6 +96,7 @@ def test_rk3d_ini(tmp_path):
     assert (p["nx"], p["ny"], p["nz"], p["steps"]) == (32, 32, 96, 1000)
     assert p["relax"] == "MRT" and p["AkR"] == 7.0e-3 and p["tauB"] == 0.9 and p["velocityZB"] == -1.0e-4
     assert p["SolidRhoR"] == 0.7 and p["densityRL"] == 1.0e-8 and not p["image"]
+    assert p["cycle"] is False and p["last_step"] == 350          # [CyclesSetup] as shipped (RKtwophasesetup3D.ini:57-59)
     write_rk3d(str(tmp_path), alpha="0.2")          # read, warned about, without effect (AcceleratedRKGPU2D.py:1140: loaded, never used)
     with pytest.warns(UserWarning, match="no effect"):
         assert config.read_rk3d(str(tmp_path))["AlphaR"] == 0.2

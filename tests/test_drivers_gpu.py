@@ -1,5 +1,7 @@
 """GPU tests of the driver counterparts (ini in -> result file out with the reference's dataset
 names) against what the real reference drivers recorded (golden 'h5|' captures)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -268,11 +270,12 @@ def test_cli_runs(tmp_path):
     assert main(["rk3d", str(tmp_path), "--out", str(tmp_path / "o3")]) == 0
 
 
-@pytest.mark.parametrize("calibrate", [False, True], ids=["equal-fluid-cuts", "measured-re-cut"])
-def test_rk3d_driver_under_two_processes_writes_the_same_records(tmp_path, calibrate):
-    """RKColorGradient3D under torchrun (two ranks sharing this GPU, gloo transport): every rank writes the
-    planes it owns; stacked, the records equal those of the single-process driver bit for bit -- also after the one measured re-cut of
-    the slabs a long run makes at its start (calibrate_partition; wherever the cuts land, the slab step equals the single domain)."""
+@pytest.mark.parametrize("calibrate,gather", [(False, True), (True, True), (False, False)], ids=["equal-fluid-cuts", "measured-re-cut", "a-file-per-rank"])
+def test_rk3d_driver_under_two_processes_writes_the_same_records(tmp_path, calibrate, gather):
+    """RKColorGradient3D under torchrun (two ranks sharing this GPU, gloo transport): rank 0 writes ONE file with the whole lattice's
+    arrays (the reference's record is one dense array per field, RKD2Q9.py:938-957), equal to the single-process driver's bit for bit --
+    also after the one measured re-cut of the slabs a long run makes at its start (calibrate_partition; wherever the cuts land, the slab
+    step equals the single domain); gather_records = False: every rank writes the planes it owns, stacked they are the same arrays."""
     import os
     import subprocess
     import sys
@@ -291,21 +294,151 @@ dist.init_process_group("gloo")
 torch.cuda.set_device(0)
 sim = RKColorGradient3D(%r, output_dir=%r, record_every=8, device=0)
 sim.calibrate_partition = %r
+sim.gather_records = %r
 sim.runRKColorGradient3D()
 dist.destroy_process_group()
-''' % (root, str(tmp_path), str(tmp_path / "out2"), calibrate))
+''' % (root, str(tmp_path), str(tmp_path / "out2"), calibrate, gather))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], env=dict(os.environ), timeout=300)
     single = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out1"), record_every=8)
     ref = load_results(single.runRKColorGradient3D())
+    assert len(ref) == 5 * single.records
+    if gather:
+        files = os.listdir(tmp_path / "out2")
+        assert len(files) == 1 and files[0].startswith("SimulationResultsRK3D."), files
+        got = load_results(str(tmp_path / "out2" / files[0]))
+        assert set(got) == set(ref)
+        for key in ref:
+            assert np.array_equal(got[key], ref[key]), key
+        return
     parts = []
     for r in range(2):
         files = [f for f in os.listdir(tmp_path / "out2") if f.startswith("SimulationResultsRK3D_rank%d." % r)]
         assert len(files) == 1
         parts.append(load_results(str(tmp_path / "out2" / files[0])))
-    assert set(parts[0]) == set(ref) and len(ref) == 5 * single.records
+    assert set(parts[0]) == set(ref)
     for key in ref:
         assert np.array_equal(np.concatenate([parts[0][key], parts[1][key]], axis=0), ref[key]), key
+
+
+def test_rk3d_shipped_ini_sizes_run_the_fast_kernel_through_the_cli(tmp_path):
+    """the reference's own 3-D input is 32 x 32 x 96 (IniFiles/RKtwophasesetup3D.ini:5-7): `python -m openlbmpm_amd rk3d` runs it on
+    rk3dq_fused (the compact 23-value storage serves every nx), records equal the oracle's"""
+    from ini_fixtures import write_rk3d
+    from openlbmpm_amd.__main__ import main
+    from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D, duct
+    from openlbmpm_amd.geometry import initial_densities_rk3d
+    from openlbmpm_amd.results import load_results
+    from oracle.rk3d import RK3DOracle
+    write_rk3d(str(tmp_path), steps=40)                        # the ini's sizes and parameters, fewer steps
+    assert main(["rk3d", str(tmp_path), "--out", str(tmp_path / "cli")]) == 0
+    sim = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out"), record_every=40)
+    res = load_results(sim.runRKColorGradient3D())
+    assert sim.solver.dominant_kernel == "rk3dq_fused" and sim.isDomain.shape == (96, 32, 32)
+    dom = duct(32, 32, 96)
+    rR, rB = initial_densities_rk3d(dom, 10)
+    o = RK3DOracle(dom, rR, rB, dict(tauB=0.9)).run(40).macro()
+    for name, f in (("FluidMacro/FluidDensityRin1", "rhoR"), ("FluidMacro/FluidDensityBin1", "rhoB"), ("FluidVelocity/FluidVelocityZAt1", "vz")):
+        assert rel_err(res["/" + name], o.field(f)) < 1e-10, name
+
+
+def _set_cycle(ini_dir, last_step):
+    import re
+    f = os.path.join(ini_dir, "RKtwophasesetup3D.ini")
+    text = open(f).read()
+    text = re.sub(r"(?m)^(\s*IsCycle\s*=).*$", r"\1 'yes'", text)
+    text = re.sub(r"(?m)^(\s*LastStep\s*=).*$", r"\1 %d" % last_step, text)
+    open(f, "w").write(text)
+
+
+def test_rk3d_cycle_restart_from_the_last_record(tmp_path):
+    """[CyclesSetup] IsCycle = 'yes' without an image (RKD2Q9.py:492-508 in 3-D): densities and velocity of record LastStep of
+    ~/LBMInitial/SimulationResultsRK3D, the top 20 planes refilled with blue, populations = their equilibria -- checked against
+    the oracle started from exactly those equilibria"""
+    import shutil
+    from ini_fixtures import write_rk3d
+    from test_rk3d_state_gpu import equilibrium
+    from openlbmpm_amd import config
+    from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D, duct
+    from openlbmpm_amd.results import load_results
+    from oracle.rk3d import RK3DOracle
+    write_rk3d(str(tmp_path), nx=20, ny=14, nz=60, steps=24)
+    first = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out"), record_every=12)
+    prev = load_results(first.runRKColorGradient3D())
+    init = tmp_path / "LBMInitial"; init.mkdir()
+    _set_cycle(str(tmp_path), 2)
+    with pytest.raises(config.ConfigError, match="SimulationResultsRK3D"):
+        RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "o2"), initial_dir=str(init)).runRKColorGradient3D()
+    shutil.copy(first.result_path, str(init))
+    sim = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "o2"), initial_dir=str(init), record_every=10)
+    sim.timeSteps = 10
+    res = load_results(sim.runRKColorGradient3D())
+    dom = duct(20, 14, 60)
+    rR, rB = prev["/FluidMacro/FluidDensityRin2"].copy(), prev["/FluidMacro/FluidDensityBin2"].copy()
+    rR[-20:] = 0.0; rB[-20:] = np.where(dom[-20:] == 1, 1.0, 0.0)
+    v = [prev["/FluidVelocity/FluidVelocity%sAt2" % ax] for ax in "XYZ"]
+    # record 0 = the fields the run starts from (away from the Zou-He planes, which impose their own densities)
+    assert rel_err(res["/FluidMacro/FluidDensityRin0"][2:-2], rR[2:-2]) < 1e-14 and rel_err(res["/FluidMacro/FluidDensityBin0"][2:-2], rB[2:-2]) < 1e-14
+    o = RK3DOracle(dom, rR, rB, dict(tauB=0.9)).set_populations(equilibrium(rR, *v), equilibrium(rB, *v)).run(10).macro()
+    for name, f in (("FluidMacro/FluidDensityRin1", "rhoR"), ("FluidMacro/FluidDensityBin1", "rhoB"), ("FluidVelocity/FluidVelocityZAt1", "vz")):
+        assert rel_err(res["/" + name], o.field(f)) < 1e-10, name
+
+
+def test_rk3d_image_cycle_takes_the_populations_over_with_the_colours_swapped(tmp_path):
+    """the image branch (RKD2Q9.py:532-556 in 3-D): cycleInitialRK3D's populations, colours swapped in the top buffer planes; below
+    them the run continues the previous one (to rounding: the populations pass through the 38-value form)"""
+    from ini_fixtures import write_rk3d
+    from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D
+    from openlbmpm_amd.geometry import porous_spheres
+    from openlbmpm_amd.results import load_results
+    write_rk3d(str(tmp_path), steps=30)
+    vox = porous_spheres(40, 18, 30, porosity=0.7, rmin=2.0, rmax=5.0, seed=8, nbuf=0, walls=False)
+    init = tmp_path / "LBMInitial"
+    a = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "a"), domain=None, record_every=30, num_buffering_layers=6)
+    from openlbmpm_amd.geometry import voxel_domain
+    a._domain = voxel_domain(vox, 6)
+    a.runRKColorGradient3D()
+    path = a.write_cycle_initial(str(init))
+    stored = load_results(path)
+    fR, fB = a.solver.get_pdf()
+    assert np.array_equal(stored["/FluidPDF/FluidPDFR"], fR) and stored["/FluidPDF/FluidPDFR"].shape == a._domain.shape + (19,)
+    a.solver.step_single(6)
+    a.solver.phase_field(diagnostics=True)
+    want = {f: a.solver.get(f) for f in ("rhoR", "rhoB", "vz")}
+    _set_cycle(str(tmp_path), 0)
+    b = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "b"), domain=a._domain, record_every=6, num_buffering_layers=6, initial_dir=str(init))
+    b.timeSteps = 6
+    b.initializeDomainBorder(); b.initializeDomainCondition()
+    # the swap, plane by plane (RKD2Q9.py:540-556)
+    assert np.array_equal(b.fluidPDFR[:-6], fR[:-6]) and np.array_equal(b.fluidPDFB[:-6], fB[:-6])
+    assert np.array_equal(b.fluidPDFR[-6:], fB[-6:]) and np.array_equal(b.fluidPDFB[-6:], fR[-6:])
+    assert np.array_equal(b.fluidsRhoR[-6:], stored["/FluidMacro/FluidDensityB"][-6:])
+    res = load_results(b.runRKColorGradient3D())
+    # below the buffer (and the planes the swapped colours reach in 6 steps: two per step) the run continues the previous one
+    z = slice(0, a._domain.shape[0] - 6 - 14)
+    for name, f in (("FluidMacro/FluidDensityRin1", "rhoR"), ("FluidMacro/FluidDensityBin1", "rhoB"), ("FluidVelocity/FluidVelocityZAt1", "vz")):
+        assert rel_err(res["/" + name][z], want[f][z], scale=float(np.max(np.abs(want[f])))) < 1e-11, name
+    # ... and in the buffer the colours have changed places
+    assert res["/FluidMacro/FluidDensityBin0"][-4:-2].sum() < 1e-2 * res["/FluidMacro/FluidDensityRin0"][-4:-2].sum()
+
+
+def test_rk3d_checkpoint_restart_is_bit_exact(tmp_path):
+    """checkpoint() / restart_from=: records of the continued run == records of the uninterrupted run, bit for bit"""
+    from ini_fixtures import write_rk3d
+    from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D
+    from openlbmpm_amd.results import load_results
+    write_rk3d(str(tmp_path), nx=36, ny=14, nz=40, steps=40, relax="MRT")
+    whole = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "whole"), record_every=10)
+    ref = load_results(whole.runRKColorGradient3D())
+    a = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "a"), record_every=10, checkpoint_every=20)
+    a.runRKColorGradient3D()
+    assert os.path.isfile(a.checkpoint_path)
+    b = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "b"), record_every=10, restart_from=a.checkpoint_path)
+    got = load_results(b.runRKColorGradient3D())
+    assert b.records == whole.records == 5
+    for k in (2, 3, 4):
+        for name in ("FluidMacro/FluidDensityRin%d", "FluidMacro/FluidDensityBin%d", "FluidVelocity/FluidVelocityXAt%d", "FluidVelocity/FluidVelocityZAt%d"):
+            assert np.array_equal(got["/" + name % k], ref["/" + name % k]), (name, k)
 
 
 def test_records_are_checked_for_nan_and_logged(tmp_path, caplog):

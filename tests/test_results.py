@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from openlbmpm_amd import _hdf5
-from openlbmpm_amd.results import ResultFile, load_results
+from openlbmpm_amd.results import ResultFile, load_results, read_planes, find_result_file
 
 needs_hdf5 = pytest.mark.skipif(not _hdf5.available(), reason="no HDF5 C library on this machine")
 GROUPS = (("FluidMacro", "MacroData"), ("FluidVelocity", "MacroVelocity"))
@@ -57,3 +57,27 @@ def test_npz_fallback_and_backend_switch(tmp_path, monkeypatch):
     monkeypatch.setenv("LBMPM_RESULT_BACKEND", "sqlite")
     with pytest.raises(ValueError):
         ResultFile(str(tmp_path), "r2", GROUPS)
+
+
+@pytest.mark.parametrize("backend", ["libhdf5", "npz"])
+def test_read_planes_takes_a_slab_of_a_record(tmp_path, monkeypatch, backend):
+    """a rank of a distributed run reads its own planes of a record ([CyclesSetup] IsCycle = 'yes', checkpoints): a hyperslab read"""
+    if backend == "libhdf5" and not _hdf5.available():
+        pytest.skip("no HDF5 C library on this machine")
+    monkeypatch.setenv("LBMPM_RESULT_BACKEND", backend)
+    out = ResultFile(str(tmp_path), "SimulationResultsRK3D", GROUPS)
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((11, 4, 6)); b = rng.standard_normal((11, 4, 6, 19)); c = np.arange(7, dtype=np.int64)
+    out.write("FluidMacro", "FluidDensityRin3", a); out.write("FluidMacro", "PDF", b); out.write("FluidVelocity", "Info", c)
+    assert find_result_file(str(tmp_path), "SimulationResultsRK3D") == out.path and find_result_file(str(tmp_path), "other") is None
+    assert np.array_equal(read_planes(out.path, "/FluidMacro/FluidDensityRin3"), a)
+    assert np.array_equal(read_planes(out.path, "/FluidMacro/FluidDensityRin3", 3, 5), a[3:8])
+    assert np.array_equal(read_planes(out.path, "/FluidMacro/PDF", 9, 2), b[9:])
+    assert np.array_equal(read_planes(out.path, "/FluidMacro/PDF", 0, 1), b[:1])
+    got = read_planes(out.path, "/FluidVelocity/Info")
+    assert got.dtype == np.int64 and np.array_equal(got, c)
+    with pytest.raises(KeyError):
+        read_planes(out.path, "/FluidMacro/missing")
+    if backend == "libhdf5":
+        with pytest.raises(_hdf5.Hdf5Error):
+            read_planes(out.path, "/FluidMacro/PDF", 10, 2)

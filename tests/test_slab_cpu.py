@@ -83,6 +83,41 @@ def test_neighbour_exchange_gloo(world):
     assert sorted(results) == [(r, True) for r in range(world)]
 
 
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openlbmpm_amd.slab import gather_planes, partition_z_balanced
+        rng = np.random.default_rng(7)
+        full = rng.standard_normal((23, 5, 4, 3))
+        parts = partition_z_balanced(rng.integers(1, 9, 23), world)        # uneven cuts
+        z0, n = parts[rank]
+        ok = True
+        for a in (full, full[..., 0], (full[..., 0, 0] > 0).astype(np.uint8)):   # [nz][ny][nx][S], [nz][ny][nx], another dtype
+            got = gather_planes(a[z0:z0 + n], parts, rank, world)
+            ok = ok and ((got is None) if rank else (got.dtype == a.dtype and np.array_equal(got, a)))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gather_planes_stacks_the_ranks_records_on_rank_0(world):
+    """the one result file of a distributed run (RKColorGradientD3Q19._record): every rank's planes, point to point to rank 0"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]
+
+
 def test_balanced_partition_equalises_fluid_cells():
     rng = np.random.default_rng(3)
     w = np.full(512, 170000); w[:10] = 262144; w[-10:] = 262144
