@@ -451,7 +451,10 @@ int lbmpm_rk3d_step(lbmpm_rk3d *ctx, int64_t nsteps);
 int lbmpm_rk3d_step_timed(lbmpm_rk3d *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
 int lbmpm_rk3d_sync(lbmpm_rk3d *ctx);
 /* The steady-state watchdog of a slab run.  Like lbmpm_rk3d_sync, but the host polls the context's streams and gives up after
- * `seconds`: the stream then sits in a wait for a neighbour's face message that will not come (the neighbour died, or hangs itself).
+ * `seconds` WITHOUT PROGRESS -- the exchange chain of every slab step ends by writing its step number into a pinned host word, and the
+ * deadline counts from the last time that word moved (from the call, if it never does): however many steps are queued and however
+ * slow a healthy neighbour is, only a stream that sits in a wait for a face message that will not come (the neighbour died, or hangs
+ * itself) runs into it.
  * IPC transport: the host releases the waits (lbmpm_rk3d_ipc_release_waits), drains the streams and returns LBMPM_ERR_TIMEOUT;
  * RCCL transport: the communicator is aborted (ncclCommAbort) first.  The context's lattice state is garbage afterwards and the
  * transport is marked dead (every later exchange returns LBMPM_ERR_TIMEOUT): the caller reports and ends the run, or sets it up

@@ -1177,6 +1177,10 @@ struct lbmpm_rk3d {
     int64_t steps = 0, bytes = 0;
     lbmpm::EventPool slab_pool;      // lbmpm_rk3d_step_slab(timed): 4 event pairs per step {step, interior, exchange chain, boundary}
     int64_t slab_timed_steps = 0;
+    // steady-state watchdog (lbmpm_rk3d_sync_deadline): a word in pinned host memory that the exchange chain of every slab step writes
+    // its step number into -- the host's evidence of progress -- and a private stream for the watchdog's own copies
+    unsigned long long *beat_host = nullptr, *beat_dev = nullptr;
+    hipStream_t wd_stream = nullptr;
     int64_t observed_at = -1;        // value of `steps` when lbmpm_rk3d_phase_field(ctx, 1) last filled phi / diag for all owned planes
     lbmpm::EventPool pool;
 };
@@ -1399,6 +1403,8 @@ extern "C" void lbmpm_rk3d_destroy(lbmpm_rk3d *c)
     if (c->aux) (void)hipStreamSynchronize(c->aux);
     c->tx.disconnect();
     if (c->probe_bad) (void)hipFree(c->probe_bad);
+    if (c->beat_host) (void)hipHostFree(c->beat_host);
+    if (c->wd_stream) (void)hipStreamDestroy(c->wd_stream);
     for (void *ptr : {(void *)c->seg, (void *)c->seg2, (void *)c->pstart, (void *)c->flags, (void *)c->solidnbr, (void *)c->fA, (void *)c->fB, (void *)c->purA, (void *)c->purB, (void *)c->trace, (void *)c->slotq, (void *)c->phi, (void *)c->diag,
                       (void *)c->send_up, (void *)c->send_dn, (void *)c->recv_below, (void *)c->recv_above})
         if (ptr) (void)hipFree(ptr);
@@ -1931,13 +1937,12 @@ extern "C" int lbmpm_rk3d_transport_kind(lbmpm_rk3d *c, int *value_ops)
     return c->tx.connected ? c->tx.kind : LBMPM_TRANSPORT_NONE;
 }
 
+static int release_ipc_waits(lbmpm_rk3d *c);
 extern "C" int lbmpm_rk3d_ipc_release_waits(lbmpm_rk3d *c)
 {
     LBMPM_REQUIRE(c && c->tx.kind == LBMPM_TRANSPORT_IPC && c->tx.flags, "lbmpm_rk3d_ipc_release_waits: no IPC transport");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
-    const unsigned long long big[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-    LBMPM_HIP_TRY(hipMemcpy(c->tx.flags, big, sizeof big, hipMemcpyHostToDevice));
-    return LBMPM_OK;
+    return release_ipc_waits(c);
 }
 
 namespace { __global__ void tx_fill(double *p, size_t n, double v) { const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) p[i] = v + (double)i; } }
@@ -2098,6 +2103,13 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             c->halo_valid = false;
             return code;
         };
+        // every error exit of this block goes through fail(): the lattice launches live on the second stream (advisor, round 5)
+#define SLAB_HIP_TRY(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return fail(LBMPM_ERR_HIP); } } while (0)
+        if (!c->beat_host) {
+            SLAB_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->beat_host), 64, hipHostMallocMapped));
+            *c->beat_host = 0ull;
+            SLAB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->beat_dev), c->beat_host, 0));
+        }
         if (!c->halo_valid) {
             int rc;
             if (own_tx) rc = lbmpm_rk3d_halo_exchange(c);
@@ -2127,9 +2139,9 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
                 if (hipExtStreamCreateWithCUMask(&c->aux, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); c->aux = nullptr; }
             }
 #endif
-            if (!c->aux) LBMPM_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-            LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
-            LBMPM_HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+            if (!c->aux) SLAB_HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+            SLAB_HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
+            SLAB_HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
         }
         const int cb = c->boundary;
         const bool has_interior = c->nzl >= 2 * cb + 1;
@@ -2144,57 +2156,58 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
         const char *sched = getenv("LBMPM_RK3D_SLAB_SCHEDULE");
         const bool one_stream = has_interior && !(sched && !strcmp(sched, "split")) && ((sched && !strcmp(sched, "one")) || !own_tx || c->tx.kind != LBMPM_TRANSPORT_RCCL);
         if (one_stream) {
-            LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // everything enqueued so far (the primed halo planes included)
+            SLAB_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // everything enqueued so far (the primed halo planes included)
             for (int64_t k = 0; k < nsteps; ++k) {
                 hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
                 if (k < tsteps) for (int i = 0; i < 4; ++i) c->slab_pool.take(&ev[2 * i], &ev[2 * i + 1]);
                 const RK3Dev p = make_dev(c);
-                if (ev[0]) LBMPM_HIP_TRY(hipEventRecord(ev[0], c->aux));     // (before the wait: a chain that ended late counts into this step)
-                LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));     // the previous step's chain: its halo planes
-                if (ev[6]) LBMPM_HIP_TRY(hipEventRecord(ev[6], c->aux));
+                if (ev[0]) SLAB_HIP_TRY(hipEventRecord(ev[0], c->aux));     // (before the wait: a chain that ended late counts into this step)
+                SLAB_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));     // the previous step's chain: its halo planes
+                if (ev[6]) SLAB_HIP_TRY(hipEventRecord(ev[6], c->aux));
                 const int zi0 = has_below ? cb + 1 : 1, zi1 = has_above ? c->nzl - cb : c->nzl;
                 if (has_below && has_above) launch_q23(c, p, c->aux, 1, cb, c->nzl - cb + 1, c->nzl);
                 else if (has_below) launch_q23(c, p, c->aux, 1, cb, 1, 0);
                 else launch_q23(c, p, c->aux, c->nzl - cb + 1, c->nzl, 1, 0);
-                if (ev[7]) LBMPM_HIP_TRY(hipEventRecord(ev[7], c->aux));
+                if (ev[7]) SLAB_HIP_TRY(hipEventRecord(ev[7], c->aux));
                 RK3Dev q = p;                                                 // the state this step writes
                 q.fin = c->fB; q.pur_in = c->purB; q.first = 0;
                 rk3dq_face_pack<<<fgrid, fblock, 0, c->aux>>>(q, c->send_up, c->send_dn, has_below, has_above);
-                LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));           // (here: "the face message is packed")
+                SLAB_HIP_TRY(hipEventRecord(c->ev_done, c->aux));           // (here: "the face message is packed")
                 if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
                 // the interior planes, straight behind the pack in the lattice stream
-                if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], c->aux));
+                if (ev[2]) SLAB_HIP_TRY(hipEventRecord(ev[2], c->aux));
                 launch_step_range(c, p, c->aux, zi0, zi1);
-                if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], c->aux));
+                if (ev[3]) SLAB_HIP_TRY(hipEventRecord(ev[3], c->aux));
                 // the chain.  (Enqueued BEHIND the interior launch: its dispatch is then in the lattice stream's queue when the pack retires, and the
                 // interior's workgroups take the CUs first -- with the chain first, a rank's copy / unpack kernels sometimes won that race and the
                 // interior started 0.05 ms late (one rank in eight on one GPU).  A copy engine needs no CU; RCCL keeps the split schedule.)
-                LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
-                if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
+                SLAB_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+                if (ev[4]) SLAB_HIP_TRY(hipEventRecord(ev[4], c->stream));
                 const double *from_below = c->recv_below, *from_above = c->recv_above;
                 if (own_tx) { const int rc = c->tx.exchange(c->stream, c->send_up, c->send_dn, &from_below, &from_above); if (rc != LBMPM_OK) return fail(rc); }
                 else if (exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
                 rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, from_below, from_above, has_below, has_above);
                 rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, from_below, from_above, has_below, has_above);
-                if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
-                LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
+                slabtx::flag_store<<<1, 1, 0, c->stream>>>(c->beat_dev, (unsigned long long)(c->steps + 1));      // "the exchange of this step is through"
+                if (ev[5]) SLAB_HIP_TRY(hipEventRecord(ev[5], c->stream));
+                SLAB_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
                 if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
                 finish_step(c);
                 c->halo_valid = true;
-                if (ev[1]) LBMPM_HIP_TRY(hipEventRecord(ev[1], c->aux));
+                if (ev[1]) SLAB_HIP_TRY(hipEventRecord(ev[1], c->aux));
             }
             // join: whoever uses the context's stream next finds the lattice launches done
-            LBMPM_HIP_TRY(hipEventRecord(c->ev_done, c->aux));
-            LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+            SLAB_HIP_TRY(hipEventRecord(c->ev_done, c->aux));
+            SLAB_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
             return LBMPM_OK;
         }
         for (int64_t k = 0; k < nsteps; ++k) {
             hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (k < tsteps) for (int i = 0; i < 4; ++i) c->slab_pool.take(&ev[2 * i], &ev[2 * i + 1]);
-            if (ev[0]) LBMPM_HIP_TRY(hipEventRecord(ev[0], c->stream));
+            if (ev[0]) SLAB_HIP_TRY(hipEventRecord(ev[0], c->stream));
             const RK3Dev p = make_dev(c);
-            LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // the previous step, its unpack included
-            if (ev[6]) LBMPM_HIP_TRY(hipEventRecord(ev[6], c->stream));
+            SLAB_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // the previous step, its unpack included
+            if (ev[6]) SLAB_HIP_TRY(hipEventRecord(ev[6], c->stream));
             // the boundary ranges that feed a face message, in one launch; a face without a neighbour (the lattice's inlet / outlet end)
             // has no message to hurry for: its planes march with the interior (one range, one prologue and two fill steps less on the end ranks)
             const int zi0 = has_below ? cb + 1 : 1, zi1 = has_above ? c->nzl - cb : c->nzl;
@@ -2204,9 +2217,9 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
                 else launch_q23(c, p, c->stream, c->nzl - cb + 1, c->nzl, 1, 0);
             }
             else launch_step_range(c, p, c->stream, 1, c->nzl);
-            if (ev[7]) LBMPM_HIP_TRY(hipEventRecord(ev[7], c->stream));
+            if (ev[7]) SLAB_HIP_TRY(hipEventRecord(ev[7], c->stream));
             if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: kernel launch failed"); return fail(LBMPM_ERR_HIP); }
-            if (ev[4]) LBMPM_HIP_TRY(hipEventRecord(ev[4], c->stream));
+            if (ev[4]) SLAB_HIP_TRY(hipEventRecord(ev[4], c->stream));
             RK3Dev q = p;                                                     // the state this step writes
             q.fin = c->fB; q.pur_in = c->purB; q.first = 0;
 #ifdef LBMPM_DEV
@@ -2221,8 +2234,8 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
                 // of 6.3 us per march step, second-round workgroups start late).  Hence: boundary launch -> pack -> THEN the interior
                 // launch, enqueued at the same moment as the exchange: the transport's few workgroups (RCCL send / recv, or copies) are
                 // placed first on an empty GPU, the interior's workgroups take the rest, the transfer runs beside them.
-                LBMPM_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
-                LBMPM_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));
+                SLAB_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
+                SLAB_HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_dep, 0));
             }
             const double *from_below = c->recv_below, *from_above = c->recv_above;
             if (own_tx) {          // copies / ncclSend + ncclRecv and the waits for the neighbours' messages, enqueued here
@@ -2231,24 +2244,26 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
             else if (!(skip & 2) && exchange(user, 0) != 0) { set_error("lbmpm_rk3d_step_slab: the exchange callback failed"); return fail(LBMPM_ERR_STATE); }
             if (has_interior) {
                 hipStream_t ist = (skip & 8) ? c->stream : c->aux;       // (knock-out 8: the interior on the context's own stream)
-                if (ev[2]) LBMPM_HIP_TRY(hipEventRecord(ev[2], ist));
+                if (ev[2]) SLAB_HIP_TRY(hipEventRecord(ev[2], ist));
                 launch_step_range(c, p, ist, zi0, zi1);
-                if (ev[3]) LBMPM_HIP_TRY(hipEventRecord(ev[3], ist));
-                LBMPM_HIP_TRY(hipEventRecord(c->ev_done, ist));
+                if (ev[3]) SLAB_HIP_TRY(hipEventRecord(ev[3], ist));
+                SLAB_HIP_TRY(hipEventRecord(c->ev_done, ist));
             }
             if (!(skip & 4)) {
                 rk3dq_face_unpack<<<fgrid, fblock, 0, c->stream>>>(q, c->fB, c->purB, from_below, from_above, has_below, has_above);
                 rk3dq_halo_phi<<<fgrid, fblock, 0, c->stream>>>(q, from_below, from_above, has_below, has_above);
+                slabtx::flag_store<<<1, 1, 0, c->stream>>>(c->beat_dev, (unsigned long long)(c->steps + 1));
             }
             if (hipGetLastError() != hipSuccess) { set_error("lbmpm_rk3d_step_slab: face kernel launch failed"); return fail(LBMPM_ERR_HIP); }
-            if (ev[5]) LBMPM_HIP_TRY(hipEventRecord(ev[5], c->stream));
-            if (has_interior) LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+            if (ev[5]) SLAB_HIP_TRY(hipEventRecord(ev[5], c->stream));
+            if (has_interior) SLAB_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
             finish_step(c);
             c->halo_valid = !(skip & 6);       // the face message of the state just written has been exchanged and unpacked above
-            if (ev[1]) LBMPM_HIP_TRY(hipEventRecord(ev[1], c->stream));
+            if (ev[1]) SLAB_HIP_TRY(hipEventRecord(ev[1], c->stream));
         }
         return LBMPM_OK;
     }
+#undef SLAB_HIP_TRY
     for (int64_t k = 0; k < nsteps; ++k) {
         hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (k < tsteps) for (int i = 0; i < 4; ++i) c->slab_pool.take(&ev[2 * i], &ev[2 * i + 1]);
@@ -2366,6 +2381,17 @@ extern "C" int lbmpm_rk3d_sync(lbmpm_rk3d *c)
 
 // The steady-state watchdog (include/lbmpm.h): host-side polling, so that a stream stuck in hipStreamWaitValue64 / flag_wait / an
 // ncclRecv on a neighbour that died does not hang this process for good.
+static int release_ipc_waits(lbmpm_rk3d *c)
+{
+    // from a private non-blocking stream: a copy on the legacy null stream would queue behind the very wait it is to release when the
+    // context runs on a blocking stream (advisor, round 5)
+    static const unsigned long long big[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    if (!c->wd_stream) LBMPM_HIP_TRY(hipStreamCreateWithFlags(&c->wd_stream, hipStreamNonBlocking));
+    LBMPM_HIP_TRY(hipMemcpyAsync(c->tx.flags, big, sizeof big, hipMemcpyHostToDevice, c->wd_stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->wd_stream));
+    return LBMPM_OK;
+}
+
 extern "C" int lbmpm_rk3d_sync_deadline(lbmpm_rk3d *c, double seconds)
 {
     LBMPM_REQUIRE(c && seconds > 0., "lbmpm_rk3d_sync_deadline: bad argument");
@@ -2380,19 +2406,25 @@ extern "C" int lbmpm_rk3d_sync_deadline(lbmpm_rk3d *c, double seconds)
         set_error("lbmpm_rk3d_sync_deadline: %s", hipGetErrorString(e));
         return -1;
     };
+    // The deadline counts from the last PROGRESS, not from the call: every slab step's exchange chain ends by writing its step number
+    // into a pinned host word (lbmpm_rk3d_step_slab); while that word moves, the neighbours answer and the queued steps drain, however
+    // many there are and however slow a neighbour is (advisor, round 5: an absolute deadline voided healthy long queues).
+    volatile unsigned long long *beat = c->beat_host;
+    unsigned long long last = beat ? *beat : 0ull;
     unsigned spins = 0;
     for (;;) {
         const int s = idle();
         if (s == 1) return LBMPM_OK;
         if (s < 0) return LBMPM_ERR_HIP;
         clock_gettime(CLOCK_MONOTONIC, &t);
+        if (beat && *beat != last) { last = *beat; t0 = t; }
         if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > seconds) break;
         if (++spins > 2000) { struct timespec nap = {0, 200000}; nanosleep(&nap, nullptr); }       // busy for the first moments, then 0.2 ms naps
     }
     const int kind = c->tx.connected ? c->tx.kind : LBMPM_TRANSPORT_NONE;
     if (kind == LBMPM_TRANSPORT_IPC) {
-        const unsigned long long big[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-        (void)hipMemcpy(c->tx.flags, big, sizeof big, hipMemcpyHostToDevice);       // every wait of this context returns
+        const int rc = release_ipc_waits(c);       // every wait of this context returns
+        if (rc != LBMPM_OK) return rc;
         c->tx.dead = true;
         (void)hipStreamSynchronize(c->stream);
         if (c->aux) (void)hipStreamSynchronize(c->aux);
@@ -2402,9 +2434,11 @@ extern "C" int lbmpm_rk3d_sync_deadline(lbmpm_rk3d *c, double seconds)
         (void)hipStreamSynchronize(c->stream);
         if (c->aux) (void)hipStreamSynchronize(c->aux);
     }
-    c->halo_valid = false;
-    c->interior_pending = false;
-    set_error("lbmpm_rk3d_sync_deadline: the slab's streams were still busy after %.1f s -- %s (rank with planes %d..%d of %d)", seconds,
+    if (kind != LBMPM_TRANSPORT_NONE) {      // (nothing released: the work is still running, the step protocol's flags stay what they are)
+        c->halo_valid = false;
+        c->interior_pending = false;
+    }
+    set_error("lbmpm_rk3d_sync_deadline: the slab's streams were busy and no face exchange completed for %.1f s -- %s (rank with planes %d..%d of %d)", seconds,
               kind == LBMPM_TRANSPORT_IPC ? "a neighbour's face message did not arrive; the waits were released, the lattice state is void" :
               kind == LBMPM_TRANSPORT_RCCL ? "a neighbour did not answer; the communicator was aborted, the lattice state is void" :
                                              "no in-library transport is connected: nothing was released",

@@ -650,7 +650,8 @@ class RK3DDistributed:
 
     def sync(self, deadline_s=None):
         """Wait for this rank's work.  With an in-library transport the wait is the library's watchdog (lbmpm_rk3d_sync_deadline,
-        `deadline_s` or self.deadline_s = LBMPM_SLAB_DEADLINE_S, default 120 s): a rank whose neighbour died mid-run raises
+        `deadline_s` or self.deadline_s = LBMPM_SLAB_DEADLINE_S, default 120 s WITHOUT a completed face exchange -- queued steps that
+        drain, slowly or not, keep resetting it): a rank whose neighbour died mid-run raises
         LbmpmError (status -6) after the deadline instead of hanging in hipStreamWaitValue64 for good -- and so does every other
         rank of the broken chain, each at its own deadline."""
         if self.world > 1 and self.slab.transport != "callback":
