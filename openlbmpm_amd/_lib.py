@@ -186,25 +186,42 @@ def _share_hip_runtime_with_torch():
             pass
 
 
-def lib():
-    """Load (once) and return the shared library; raise LbmpmError if unavailable."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+_loaded = {}
+
+
+def _load(path):
+    if path in _loaded:
+        return _loaded[path]
+    if not os.path.exists(path):
         raise LbmpmError("%s is missing: the HIP library is the only compute path "
-                         "(no CPU fallback). Build it: python -m openlbmpm_amd.build" % LIB_PATH)
+                         "(no CPU fallback). Build it: python -m openlbmpm_amd.build" % path)
     _share_hip_runtime_with_torch()
     try:
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
     except OSError as e:
-        raise LbmpmError("cannot load %s: %s" % (LIB_PATH, e))
+        raise LbmpmError("cannot load %s: %s" % (path, e))
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = L
+    _loaded[path] = L
     return L
+
+
+def lib():
+    """Load (once) and return the shared library; raise LbmpmError if unavailable."""
+    global _lib
+    if _lib is None:
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def use_library(path=None):
+    """Tests and dev tools: contexts created from now on come from the library at `path` (None: the product library again).  Objects
+    keep the library they were created with; two builds of the sources can serve one process side by side."""
+    global _lib
+    _lib = _load(path or LIB_PATH)
+    return _lib
 
 
 def check(rc, what=""):

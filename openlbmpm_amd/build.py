@@ -70,6 +70,19 @@ def build_dev(out, verbose=True, extra=()):
     return _compile_and_link(out, ["-DLBMPM_DEV"] + list(extra), os.path.join(os.path.dirname(out), "obj" + "".join(e.replace("-D", "_") for e in extra)), verbose)
 
 
+DEV_LIB = os.path.join(os.path.dirname(PKG), "tools", "dev", "_build", "liblbmpm_hip_dev.so")
+
+
+def build_dev_if_stale(verbose=True):
+    """tools/dev/_build/liblbmpm_hip_dev.so: the product's sources with the tuning knobs (LBMPM_RK3D_TILE | CHUNK | FILL | BOUNDARY | XCC |
+    SLAB_SCHEDULE, LBMPM_RK2D_SHAPE, LBMPM_IPC_LAND) and the instrumentation compiled in.  Tests that vary a knob load it (tests/conftest.py
+    `knobs`); nothing of the package does."""
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(PKG), "include", "*.h")) + [os.path.abspath(__file__)]
+    if not os.path.exists(DEV_LIB) or any(os.path.getmtime(d) > os.path.getmtime(DEV_LIB) for d in deps):
+        build_dev(DEV_LIB, verbose)
+    return DEV_LIB
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB

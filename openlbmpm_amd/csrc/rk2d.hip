@@ -1523,7 +1523,9 @@ extern "C" int lbmpm_rk2d_create(const lbmpm_rk2d_config *cfg, const uint8_t *is
     lbmpm_rk2d *c = new (std::nothrow) lbmpm_rk2d();
     if (!c) { set_error("out of host memory"); return LBMPM_ERR_NOMEM; }
     c->cfg = *cfg;
+#ifdef LBMPM_DEV      // tile shapes other than the default 64 x 8: development builds only (openlbmpm_amd/build.py::build_dev)
     if (const char *e = getenv("LBMPM_RK2D_SHAPE")) c->shape = atoi(e);
+#endif
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny;
     c->pitch = (c->nx + 31) / 32 * 32;           // rows start on 256-byte boundaries
     c->plane = (size_t)c->pitch * c->ny;

@@ -1240,10 +1240,16 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     LBMPM_REQUIRE((double)cfg->nx * cfg->ny * (cfg->nz_local + 2) < 2.0e9, "slab too large for 32-bit plane indices");
     LBMPM_REQUIRE((double)(cfg->nx + 31) * cfg->ny * 8.0 * 6 * Q < 4.0e9, "xy plane too large: 114 planes must fit 32-bit byte offsets (about 4.3M cells per plane)");
     int variant = cfg->variant, tile = 0, chunk_len = 32, fill = 16;
+    // Environment switches of the PRODUCT library: the cross-checks LBMPM_RK3D_VARIANT (split sweeps), _LAYOUT (dense), _STORAGE (38 values
+    // per cell) -- other statements of the same step, which the tests hold against each other.  The tuning knobs (_TILE, _CHUNK, _FILL,
+    // _BOUNDARY, _XCC, _SLAB_SCHEDULE) exist in development builds only (-DLBMPM_DEV, openlbmpm_amd/build.py::build_dev).
+    bool chunk_fixed = false;
     if (const char *e = getenv("LBMPM_RK3D_VARIANT")) variant = atoi(e);
+#ifdef LBMPM_DEV
     if (const char *e = getenv("LBMPM_RK3D_TILE")) tile = atoi(e);
-    if (const char *e = getenv("LBMPM_RK3D_CHUNK")) chunk_len = atoi(e) > 0 ? atoi(e) : 32;
+    if (const char *e = getenv("LBMPM_RK3D_CHUNK")) { chunk_len = atoi(e) > 0 ? atoi(e) : 32; chunk_fixed = true; }
     if (const char *e = getenv("LBMPM_RK3D_FILL")) fill = atoi(e);
+#endif
     LBMPM_REQUIRE(variant == 0 || variant == 1, "lbmpm_rk3d_create: variant must be 0 (fused) or 1 (split)");
     LBMPM_REQUIRE(cfg->relaxation == 0 || cfg->relaxation == 1, "lbmpm_rk3d_create: relaxation must be 0 (SRT) or 1 (MRT)");
     LBMPM_REQUIRE(cfg->recolor_axis >= 0. && cfg->recolor_diag >= 0. && cfg->recolor_axis < 1. && cfg->recolor_diag < 1.,
@@ -1256,7 +1262,9 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     c->cfg = *cfg;
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny; c->nzl = (int)cfg->nz_local;
     c->variant = variant; c->tile = tile; c->chunk_len = chunk_len; c->fill = fill;
+#ifdef LBMPM_DEV
     if (const char *e = getenv("LBMPM_RK3D_BOUNDARY")) c->boundary = atoi(e) >= 2 ? atoi(e) : 2;
+#endif
     // compact storage: the 23-value form for any nx (row segments of <= 64 cells, seg_x0); the 38-value cross-check keeps whole 64-cell segments
     c->compact = variant == 0;
     if (const char *e = getenv("LBMPM_RK3D_LAYOUT")) if (!strcmp(e, "dense")) c->compact = false;
@@ -1273,7 +1281,7 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     if (const char *e = getenv("LBMPM_RK3D_DBG")) c->dbg = atoi(e);
 #endif
     // q23 storage: the chunk length is chosen per launch (chunk_planes below) unless LBMPM_RK3D_CHUNK fixes it
-    c->chunk_auto = c->q23 && !getenv("LBMPM_RK3D_CHUNK");
+    c->chunk_auto = c->q23 && !chunk_fixed;
     if (c->chunk_auto) { c->chunk_len = 64; (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, cfg->device); if (c->ncu <= 0) c->ncu = 256; }
 #ifdef LBMPM_DEV
     if (c->q23 && getenv("LBMPM_RK3D_TRACE")) { (void)hipMalloc(reinterpret_cast<void **>(&c->trace), (size_t)1 << 22); (void)hipMemset(c->trace, 0, (size_t)1 << 22); }
@@ -1365,7 +1373,11 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
     TRY_RC(dev_alloc(c, &c->fA, fcount));
     TRY_RC(dev_alloc(c, &c->fB, fcount));
     if (c->q23) {
-        if (!(getenv("LBMPM_RK3D_XCC") && atoi(getenv("LBMPM_RK3D_XCC")) == 0)) TRY_RC(dev_alloc(c, &c->slotq, 2 * 4096 * 8));     // zeroed
+        bool by_xcc = true;       // tiles handed out by the XCD a workgroup runs on (rk3dq_fused); LBMPM_RK3D_XCC=0 (development builds): by block index
+#ifdef LBMPM_DEV
+        if (getenv("LBMPM_RK3D_XCC") && atoi(getenv("LBMPM_RK3D_XCC")) == 0) by_xcc = false;
+#endif
+        if (by_xcc) TRY_RC(dev_alloc(c, &c->slotq, 2 * 4096 * 8));     // zeroed
         // (row segments of a slab are indexed with 32 bits in the kernels: rk3dq.h::row_index)
         LBMPM_REQUIRE((size_t)(c->nzl + 2) * c->ny * c->nseg < ((size_t)1 << 31), "rk3d: more than 2^31 row segments in one slab");
         TRY_RC(dev_alloc(c, &c->purA, (size_t)(c->nzl + 2) * c->ny * c->nseg));
@@ -2153,7 +2165,11 @@ extern "C" int lbmpm_rk3d_step_slab(lbmpm_rk3d *c, int64_t nsteps, int has_below
         // stream, the interior behind an event on the second, the step ends with the context's stream waiting for it) pays two such
         // waits per step on the critical path (~ 10 - 15 us each) but enqueues the exchange ahead of the interior launch: it stays the
         // choice for the RCCL transport, whose send / recv kernels need CUs that the interior launch would otherwise take first.
+#ifdef LBMPM_DEV
         const char *sched = getenv("LBMPM_RK3D_SLAB_SCHEDULE");
+#else
+        const char *sched = nullptr;
+#endif
         const bool one_stream = has_interior && !(sched && !strcmp(sched, "split")) && ((sched && !strcmp(sched, "one")) || !own_tx || c->tx.kind != LBMPM_TRANSPORT_RCCL);
         if (one_stream) {
             SLAB_HIP_TRY(hipEventRecord(c->ev_dep, c->stream));            // everything enqueued so far (the primed halo planes included)

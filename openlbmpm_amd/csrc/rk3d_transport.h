@@ -127,7 +127,11 @@ struct Transport {
         // over xGMI, past this GPU's L2, and ordinary (coarse-grained) memory is coherent at kernel boundaries only -- a slot is reused
         // every second step, and a line of it left in L2 by the previous unpack would be served stale.  (The probe at set-up would catch
         // that and the selection would fall back to RCCL; this keeps the copy-engine path.  LBMPM_IPC_LAND=coarse: ordinary memory.)
+#ifdef LBMPM_DEV
         const char *lk = getenv("LBMPM_IPC_LAND");
+#else
+        const char *lk = nullptr;
+#endif
         land_fine = !(lk && !strcmp(lk, "coarse")) &&
                     hipExtMallocWithFlags(reinterpret_cast<void **>(&land), 4 * slot, hipDeviceMallocFinegrained) == hipSuccess;
         if (!land_fine) {

@@ -67,6 +67,13 @@ def test_the_product_library_holds_no_knock_out_switches():
     blob = open(LIB, "rb").read()
     for name in (b"LBMPM_RK3D_DBG", b"LBMPM_RK3D_COMM_CUS", b"LBMPM_RK3D_TRACE"):
         assert name not in blob, name.decode()
+    # ... nor the tuning knobs (round 6): tile shapes, chunk lengths, fill widths, boundary depth, tile hand-out, slab schedule, landing memory
+    for name in (b"LBMPM_RK3D_TILE", b"LBMPM_RK3D_CHUNK", b"LBMPM_RK3D_FILL", b"LBMPM_RK3D_BOUNDARY", b"LBMPM_RK3D_XCC", b"LBMPM_RK3D_SLAB_SCHEDULE",
+                 b"LBMPM_RK2D_SHAPE", b"LBMPM_IPC_LAND"):
+        assert name not in blob, name.decode()
+    # the cross-checks the tests hold against each other stay: other statements of the same step, not tuning
+    for name in (b"LBMPM_RK3D_VARIANT", b"LBMPM_RK3D_LAYOUT", b"LBMPM_RK3D_STORAGE", b"LBMPM_SC2D_ISO_SWEEPS"):
+        assert name in blob, name.decode()
     src = open(os.path.join(ROOT, "openlbmpm_amd", "build.py")).read()
     assert src.count("LBMPM_DEV") >= 1 and '"-DLBMPM_DEV"' in src.split("def build(")[0] and "LBMPM_DEV" not in src.split("def build(")[1]
 

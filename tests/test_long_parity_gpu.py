@@ -27,7 +27,7 @@ def _front_case(nx, ny, nz, z_front, seed=11):
     return dom, rR, rB
 
 
-def test_c5_model_200_steps_against_the_oracle_with_the_front_crossing_a_chunk_border_and_a_slab_cut(monkeypatch):
+def test_c5_model_200_steps_against_the_oracle_with_the_front_crossing_a_chunk_border_and_a_slab_cut(knobs):
     """rk3dq_fused (23 stored values per cell, row flags, chunked marching) and the three-slab run of the same lattice against the
     oracle after 100 and 200 steps.  Inlet 2e-2 (200 x the ini's): the front, started between the planes 171 and 172, moves ~4 planes
     down -- across the border 170 | 171, which is a chunk border of the single-domain run (chunks of 57 planes) and the upper cut of
@@ -39,10 +39,9 @@ def test_c5_model_200_steps_against_the_oracle_with_the_front_crossing_a_chunk_b
     dom, rR, rB = _front_case(nx, ny, nz, 172)
     par = dict(relax="MRT", velocityZB=-2.0e-2, tauR=1.0, tauB=0.8)
     o = RK3DOracle(dom, rR, rB, par)
-    monkeypatch.setenv("LBMPM_RK3D_CHUNK", "57")
-    single = RK3DCluster(dom, 1, par)
-    monkeypatch.delenv("LBMPM_RK3D_CHUNK")
     slabs = RK3DCluster(dom, 3, par)
+    knobs({"LBMPM_RK3D_CHUNK": "57"})              # (a development-build knob: this context comes from that library)
+    single = RK3DCluster(dom, 1, par)
     assert single.slabs[0].dominant_kernel == "rk3dq_fused" and [n for _, n in slabs.parts] == [86, 85, 85]
     for c in (single, slabs):
         c.set_density(rR, rB)

@@ -82,7 +82,7 @@ def test_porous_vs_oracle(shape, variant):
 
 
 @pytest.mark.parametrize("tracer", [False, True], ids=["flow", "flow+tracer"])
-def test_tile_shapes_and_schedules_agree_bit_for_bit(tracer, monkeypatch):
+def test_tile_shapes_and_schedules_agree_bit_for_bit(tracer, knobs):
     """rk2d_fused issues the own node's pulls as asm loads ahead of the fluid mask and waits with hand-counted s_waitcnt; the count of
     mask loads, halo nodes per lane and boundary-row variants differs between the tile shapes (LBMPM_RK2D_SHAPE = 0: 64 x 8, 2: 64 x 16
     with 1 024 threads, 3: 64 x 4 whose halo outnumbers its threads, 1: two nodes per lane -- the plain C++ pull phase).  On a porous
@@ -93,7 +93,7 @@ def test_tile_shapes_and_schedules_agree_bit_for_bit(tracer, monkeypatch):
     par = dict(theta=65.0, tauR=1.0, tauB=0.9)
 
     def run(shape, variant=0):
-        monkeypatch.setenv("LBMPM_RK2D_SHAPE", str(shape))
+        knobs({"LBMPM_RK2D_SHAPE": str(shape)})       # (tile shapes other than the default: the development build)
         s = RK2DSolver(dom, par, variant=variant)
         s.set_macro(rR, rB)
         if tracer:

@@ -76,7 +76,7 @@ def test_any_nx_equals_the_dense_38_value_layout_to_roundoff(nx, relax, monkeypa
 @pytest.mark.parametrize("env,k", [({}, 2), ({}, 3), ({"LBMPM_RK3D_CHUNK": "7"}, 2)],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
 @pytest.mark.parametrize("nx,walls", [(96, False), (100, True), (33, False), (200, False)])
-def test_any_nx_slabs_equal_the_single_domain_bitwise(nx, walls, env, k, monkeypatch):
+def test_any_nx_slabs_equal_the_single_domain_bitwise(nx, walls, env, k, monkeypatch, knobs):
     from openlbmpm_amd.rk3d import RK3DCluster
     from openlbmpm_amd.geometry import initial_densities_rk3d
     dom = _dom(nx, 19, 38, walls)
@@ -84,8 +84,7 @@ def test_any_nx_slabs_equal_the_single_domain_bitwise(nx, walls, env, k, monkeyp
     par = dict(relax="MRT", tauR=0.9, tauB=0.7)
     ref = RK3DCluster(dom, 1, par)
     ref.set_density(rR, rB)
-    for kk, v in env.items():
-        monkeypatch.setenv(kk, v)
+    knobs(env)
     c = RK3DCluster(dom, k, par)
     assert c.slabs[0].dominant_kernel == "rk3dq_fused" and c.slabs[0].one_exchange
     c.set_density(rR, rB)

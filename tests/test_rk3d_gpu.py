@@ -64,7 +64,7 @@ def test_slabs_equal_single_domain_bitwise(k, layout, monkeypatch):
 @pytest.mark.parametrize("env", [{"LBMPM_RK3D_BOUNDARY": "4"}, {"LBMPM_RK3D_VARIANT": "1"}, {"LBMPM_RK3D_TILE": "1"},
                                  {"LBMPM_RK3D_TILE": "2", "LBMPM_RK3D_CHUNK": "5"}, {"LBMPM_RK3D_FILL": "0"}],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()))
-def test_kernel_schedules_agree_bitwise(env, monkeypatch):
+def test_kernel_schedules_agree_bitwise(env, monkeypatch, knobs):
     """split sweeps, other tile shapes / chunk lengths, the interior|boundary split used to overlap
     the halo exchange: all the same arithmetic, so the same bits as the default single-slab run"""
     from openlbmpm_amd.rk3d import RK3DCluster
@@ -74,8 +74,7 @@ def test_kernel_schedules_agree_bitwise(env, monkeypatch):
     assert ref.slabs[0].dominant_kernel == "rk3d_fused"
     ref.set_density(rR, rB)
     ref.step(9); ref.observe()
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    knobs(env)
     c = RK3DCluster(dom, 3)
     c.set_density(rR, rB)
     c.step(9); c.observe()
@@ -111,7 +110,7 @@ def test_compact_storage_vs_oracle(relax, storage, monkeypatch):
 @pytest.mark.parametrize("env,k", [({}, 2), ({}, 3), ({"LBMPM_RK3D_BOUNDARY": "4"}, 3), ({"LBMPM_RK3D_TILE": "1"}, 1),
                                    ({"LBMPM_RK3D_CHUNK": "7"}, 2)],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
-def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch):
+def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch, knobs):
     """the 38-value compact storage is the dense layout with the solid cells left out: the same bits"""
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=64, ny=19, nz=41, seed=12)
@@ -122,8 +121,7 @@ def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch):
     ref.set_density(rR, rB)
     ref.step(11); ref.observe()
     monkeypatch.delenv("LBMPM_RK3D_LAYOUT")
-    for kk, v in env.items():
-        monkeypatch.setenv(kk, v)
+    knobs(env)
     c = RK3DCluster(dom, k)
     assert c.slabs[0].dominant_kernel == "rk3dc_fused"
     c.set_density(rR, rB)
@@ -136,7 +134,7 @@ def test_compact_storage_equals_dense_bitwise(env, k, monkeypatch):
 @pytest.mark.parametrize("env,k", [({"LBMPM_RK3D_LAYOUT": "dense"}, 1), ({"LBMPM_RK3D_LAYOUT": "dense", "LBMPM_RK3D_VARIANT": "1"}, 2),
                                    ({}, 3), ({"LBMPM_RK3D_TILE": "1", "LBMPM_RK3D_CHUNK": "6"}, 2)],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
-def test_mrt_schedules_agree_bitwise(env, k, monkeypatch):
+def test_mrt_schedules_agree_bitwise(env, k, monkeypatch, knobs):
     """MRT relaxation: dense / compact (38-value) storage, split sweeps, slab decomposition -- one arithmetic"""
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=64, ny=19, nz=41, seed=12)
@@ -145,8 +143,7 @@ def test_mrt_schedules_agree_bitwise(env, k, monkeypatch):
     ref = RK3DCluster(dom, 1, par)
     ref.set_density(rR, rB)
     ref.step(11); ref.observe()
-    for kk, v in env.items():
-        monkeypatch.setenv(kk, v)
+    knobs(env)
     c = RK3DCluster(dom, k, par)
     c.set_density(rR, rB)
     c.step(11); c.observe()
@@ -182,7 +179,7 @@ def test_q23_storage_equals_the_38_value_kernels_to_roundoff(relax, monkeypatch)
 @pytest.mark.parametrize("env,k", [({}, 2), ({}, 3), ({}, 5), ({"LBMPM_RK3D_BOUNDARY": "4"}, 3), ({"LBMPM_RK3D_CHUNK": "7"}, 2)],
                          ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) if isinstance(e, dict) else "k%d" % e)
 @pytest.mark.parametrize("relax", ["SRT", "MRT"])
-def test_q23_slabs_equal_single_domain_bitwise(relax, env, k, monkeypatch):
+def test_q23_slabs_equal_single_domain_bitwise(relax, env, k, monkeypatch, knobs):
     """q23 storage, k virtual ranks: ONE face message per cut and step (populations, records, row flags and the class sums from which
     the neighbour completes the phase field of its halo plane) -- the same bits as the single domain, mixed and single-colour
     regions alike (the initial state is red below a blue buffer: most row segments carry a flag instead of records)"""
@@ -192,8 +189,7 @@ def test_q23_slabs_equal_single_domain_bitwise(relax, env, k, monkeypatch):
     ref = RK3DCluster(dom, 1, par)
     assert ref.slabs[0].dominant_kernel == "rk3dq_fused"
     ref.set_density(rR, rB)
-    for kk, v in env.items():
-        monkeypatch.setenv(kk, v)
+    knobs(env)
     c = RK3DCluster(dom, k, par)
     assert c.slabs[0].dominant_kernel == "rk3dq_fused" and c.slabs[0].one_exchange
     c.set_density(rR, rB)
@@ -626,7 +622,7 @@ def test_bench_with_eight_ranks_on_a_wide_lattice():
 
 
 @pytest.mark.parametrize("medium", ["porous, red-wetting grains", "open duct, neutral walls"])
-def test_row_flags_while_a_front_sweeps_the_lattice(monkeypatch, medium):
+def test_row_flags_while_a_front_sweeps_the_lattice(monkeypatch, medium, knobs):
     """The row flags of the 23-value storage under a moving interface.  Blue is driven in at 2e-2 lattice units through a porous
     lattice of two row segments per row; over 1600 steps the front crosses more than 40 planes, i.e. row segments go single-colour ->
     mixed -> single-colour of the other colour (the minority colour's tail is exactly zero some 30 planes away from the interface:
@@ -645,7 +641,7 @@ def test_row_flags_while_a_front_sweeps_the_lattice(monkeypatch, medium):
         dom[:, :, 0] = 0; dom[:, :, -1] = 0
         par.update(SolidRhoR=0.5, SolidRhoB=0.5)
     rR, rB = initial_densities_rk3d(dom, 5)
-    monkeypatch.setenv("LBMPM_RK3D_CHUNK", "8")
+    knobs({"LBMPM_RK3D_CHUNK": "8"})
     runs = {}
     for name, storage, k in (("q23", "23", 1), ("q23 x3", "23", 3), ("both lattices", "38", 1)):
         monkeypatch.setenv("LBMPM_RK3D_STORAGE", storage)

@@ -135,11 +135,10 @@ def test_oracle3d_default_weights_equal_the_pinned_2d_oracle(name):
     ("srt_porous64", 11, {"LBMPM_RK3D_CHUNK": "7"}),           # ... cut tiles, several chunks per column
     ("srt_porous64", 8, {"LBMPM_RK3D_STORAGE": "38"}),         # compact storage of both colour lattices, rk3dc_fused
 ], ids=lambda v: v if isinstance(v, str) else (str(v) if isinstance(v, int) else ",".join("%s=%s" % (k[11:], x) for k, x in v.items()) or "default"))
-def test_hip_reproduces_the_reference_2d_driver(name, ny, env, monkeypatch):
+def test_hip_reproduces_the_reference_2d_driver(name, ny, env, monkeypatch, knobs):
     """y-uniform D3Q19 lattice through the C ABI == captures of the real D2Q9 perturbation driver, every snapshot"""
     from openlbmpm_amd.rk3d import RK3DCluster
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    knobs(env)
     d, dom2, par2, par3 = scenario(name)
     dom3 = extrude(dom2, ny)
     c = RK3DCluster(dom3, 1, dict(par3, **RC_EXACT))

@@ -33,5 +33,9 @@ for e in envs:
     for kv in filter(None, e.split(",")):
         k, v = kv.split("=")
         os.environ[k] = v
+        if k in ("LBMPM_RK3D_TILE", "LBMPM_RK3D_CHUNK", "LBMPM_RK3D_FILL", "LBMPM_RK3D_BOUNDARY", "LBMPM_RK3D_XCC"):
+            # knobs of the development build: contexts from here on come from that library
+            from openlbmpm_amd import _lib, build
+            _lib.use_library(build.build_dev_if_stale(verbose=False))
     for dom, label in doms:
         run(dom, (label + " " + e).strip())

@@ -9,7 +9,10 @@ for c in cases:
     if c.startswith("v"):
         args = ["--variant", c[1:]]
     else:
-        env["LBMPM_RK2D_SHAPE"] = c[1:]
+        env["LBMPM_RK2D_SHAPE"] = c[1:]      # a knob of the development build (openlbmpm_amd/build.py::build_dev_if_stale)
+        sys.path.insert(0, ROOT)
+        from openlbmpm_amd import build
+        env["LBMPM_LIBRARY"] = build.build_dev_if_stale(verbose=False)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "1000",
                           "--warmup", "100"] + args, env=env, capture_output=True, text=True)
     try:
