@@ -1347,6 +1347,11 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
                     hseg[(((size_t)z * c->ny + last) * ns + sg) * 4 + 3] = pad << 2;
                     j += pad;
                 }
+            // "odd stride": the 19 direction regions of a plane lie j stored cells apart.  Where that is a multiple of 16 KiB (regular lattices:
+            // an all-fluid 512^2 plane puts them exactly 2 MiB apart) a wave's 19 pulls fall on the same channels and banks -- measured on the
+            // kernel's access shape: 15.5 -> 16.3 G cells/s with 9 KB of padding per region (profiles/r06_march3d_layouts.txt).  Porous planes
+            // never meet it; regular ones get 73 x 16 unused cells behind their last tile.
+            if (j > 0 && ((size_t)j * (c->q23 ? 8u : 16u)) % 16384u == 0) j += 73u * 16u;
             for (int y = 0; y < c->ny; ++y)
                 for (int sg = 0; sg < ns; ++sg) {
                     const size_t r = ((size_t)z * c->ny + y) * ns + sg;

@@ -4,6 +4,9 @@
 //   LAYOUT 0: plane-major  f[z][q][y][x]            (today: a wave's 19 pulls go to 19 regions 2 MB apart)
 //   LAYOUT 1: blocked      f[z][y][x / 16][q][16]   (the 19 directions of 16 consecutive cells = one 2 432-byte run)
 //   LAYOUT 2: blocked      f[z][y][x / 64][q][64]   (a wave's row segment = one 9 728-byte run)
+//   LAYOUT 3: plane-major with an ODD direction stride: f[z][q][ny * nx + 1168]  (round 6: at 512^2 all-fluid the 19 regions of LAYOUT 0 lie exactly 2 MiB
+//             apart -- a power of two; the porous bench lattice's planes hold ~ 172 k cells, its regions are 1.38 MB apart.  Is the blocked layouts' gain
+//             the blocking, or the end of that stride?)
 //   BAR: with / without the barrier and the LDS phase-field ring;  NT: non-temporal stores
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench/march3d_layouts.hip -o /tmp/m3l && /tmp/m3l
 #include <hip/hip_runtime.h>
@@ -19,6 +22,7 @@ template <int LAYOUT>
 __device__ __forceinline__ size_t at(int z, int q, int y, int x, int nx, int ny)
 {
     if (LAYOUT == 0) return (((size_t)z * Q + q) * ny + y) * nx + x;
+    if (LAYOUT == 3) return ((size_t)z * Q + q) * ((size_t)ny * nx + 1168) + (size_t)y * nx + x;
     constexpr int B = LAYOUT == 1 ? 16 : 64;
     return ((((size_t)z * ny + y) * (nx / B) + x / B) * Q + q) * B + (x % B);
 }
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(64 * TY) void march(const double *__restrict__ in, 
 template <int LAYOUT, int WORK, bool BAR, bool NT, int TY>
 int run(const char *name, int n, int nz, int chunk_len)
 {
-    const size_t plane = (size_t)n * n, cells = plane * nz;
+    const size_t plane = (size_t)n * n, cells = (plane + (LAYOUT == 3 ? 1168 : 0)) * nz;
     double *a, *b;
     CK(hipMalloc(&a, Q * cells * sizeof(double))); CK(hipMalloc(&b, Q * cells * sizeof(double)));
     CK(hipMemset(a, 0, Q * cells * sizeof(double))); CK(hipMemset(b, 0, Q * cells * sizeof(double)));
@@ -110,6 +114,8 @@ int main()
     run<0, 52, false, false, 8>("plane-major, NO barrier / ring, 988 fma", n, nz, 256);
     run<0, 0, false, false, 8>("plane-major, NO barrier / ring, no fma", n, nz, 256);
     run<0, 52, true, true, 8>("plane-major, barrier, 988 fma, non-temporal stores", n, nz, 256);
+    run<3, 0, true, false, 8>("plane-major, direction stride 2 MiB + 9 344 B, barrier, no fma", n, nz, 256);
+    run<3, 52, true, false, 8>("plane-major, direction stride 2 MiB + 9 344 B, barrier, 988 fma", n, nz, 256);
     run<1, 0, true, false, 8>("blocked x16, barrier, no fma", n, nz, 256);
     run<1, 52, true, false, 8>("blocked x16, barrier, 988 fma", n, nz, 256);
     run<2, 0, true, false, 8>("blocked x64, barrier, no fma", n, nz, 256);
