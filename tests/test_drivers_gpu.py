@@ -176,6 +176,63 @@ def test_restart_from_previous_results(tmp_path):
         RKColorGradientLBM(str(second), output_dir=str(tmp_path / "o3"), initial_dir=str(tmp_path / "nowhere")).runRKColorGradient2D()
 
 
+def test_rk_image_cycle_takes_cycleInitialRK_over_with_the_colours_swapped_in_the_buffer_rows(tmp_path):
+    """[CyclesSetup] IsCycle = 'yes' WITH a pore image (RKD2Q9.py:532-556): densities and populations of ~/LBMInitial/cycleInitialRK
+    taken over, red and blue changing places in the top numBufferingLayers rows (:540-556), the velocity whole -- asserted row by row
+    against a hand-built file; then a real previous state run on from there."""
+    import re
+    from openlbmpm_amd import config
+    from openlbmpm_amd.RKD2Q9 import RKColorGradientLBM
+    from openlbmpm_amd.geometry import porous_disks
+    from openlbmpm_amd.results import ResultFile
+    img = porous_disks(44, 60, porosity=0.7, rmin=2.5, rmax=5.0, seed=3)
+    write_rk(str(tmp_path), steps=30, interval=30)
+    ini = tmp_path / "RKtwophasesetup2D.ini"
+    ini.write_text(re.sub(r"(?m)^(\s*Existance\s*=).*$", r"\1 'yes'", ini.read_text()))
+    a = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "a"), image=img)
+    a.runRKColorGradient2D()
+    dom, nb = a.isDomain, a.par["nbuf"]
+    fluid = dom == 1
+    init = tmp_path / "LBMInitial"
+
+    def write(rR, rB, fR, fB, vx, vy):
+        out = ResultFile(str(init), "cycleInitialRK", (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity")))
+        out.write("FluidMacro", "FluidDensityR", rR); out.write("FluidMacro", "FluidDensityB", rB)
+        out.write("FluidPDF", "FluidPDFR", fR); out.write("FluidPDF", "FluidPDFB", fB)
+        out.write("FluidVelocity", "FluidVelocityX", vx); out.write("FluidVelocity", "FluidVelocityY", vy)
+
+    rng = np.random.default_rng(11)
+    hand = [np.where(fluid, rng.random(dom.shape), 0.0) for _ in range(2)] + [np.where(fluid[..., None], rng.random(dom.shape + (9,)), 0.0) for _ in range(2)] + \
+           [np.where(fluid, rng.standard_normal(dom.shape), 0.0) for _ in range(2)]
+    write(*hand)
+    ini.write_text(re.sub(r"(?m)^(\s*IsCycle\s*=).*$", r"\1 'yes'", ini.read_text()))
+    b = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "b"), image=img, initial_dir=str(init))
+    b.initializeDomainBorder(); b.initializeDomainCondition()
+    rR, rB, fR, fB, vx, vy = hand
+    ny = dom.shape[0]
+    for i in range(ny):
+        top = i >= ny - nb
+        assert np.array_equal(b.fluidsRhoR[i], rB[i] if top else rR[i]) and np.array_equal(b.fluidsRhoB[i], rR[i] if top else rB[i]), i
+        assert np.array_equal(b.fluidPDFR[i], fB[i] if top else fR[i]) and np.array_equal(b.fluidPDFB[i], fR[i] if top else fB[i]), i
+        assert np.array_equal(b.physicalVX[i], vx[i]) and np.array_equal(b.physicalVY[i], vy[i]), i
+    # a dataset of another shape, or none, is refused with the dataset's name
+    write(hand[0], hand[1], hand[2][:, :-1], hand[3], hand[4], hand[5])
+    with pytest.raises(config.ConfigError, match="FluidPDFR"):
+        RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "c"), image=img, initial_dir=str(init)).runRKColorGradient2D()
+    # the state run a left behind, run on with the colours swapped in the buffer rows
+    s = a.solver
+    write(s.get("rec_rhoR"), s.get("rec_rhoB"), s.get("fR"), s.get("fB"), s.get("rec_vx"), s.get("rec_vy"))
+    c = RKColorGradientLBM(str(tmp_path), output_dir=str(tmp_path / "c"), image=img, initial_dir=str(init))
+    c.timeSteps = 20
+    from openlbmpm_amd.results import load_results
+    res = load_results(c.runRKColorGradient2D())
+    r0, b0 = res["/FluidMacro/FluidDensityRin0"], res["/FluidMacro/FluidDensityBin0"]
+    assert np.isfinite(r0).all() and np.isfinite(b0).all()
+    # blue filled the top buffer rows of run a; after the swap they are red
+    assert float(b0[-nb + 2:-2].sum()) < 0.05 * float(r0[-nb + 2:-2].sum())
+    assert abs(float(r0[:-nb].sum()) - float(s.get("rec_rhoR")[:-nb].sum())) < 1e-2 * float(r0.sum())
+
+
 def test_sc_driver_with_iso8_scheme_matches_reference(tmp_path):
     """[ForceScheme] ExplicitScheme = 8 through the driver: the run ends where the reference's ends"""
     from openlbmpm_amd.ShanChenD2Q9 import ShanChenD2Q9
@@ -270,12 +327,14 @@ def test_cli_runs(tmp_path):
     assert main(["rk3d", str(tmp_path), "--out", str(tmp_path / "o3")]) == 0
 
 
-@pytest.mark.parametrize("calibrate,gather", [(False, True), (True, True), (False, False)], ids=["equal-fluid-cuts", "measured-re-cut", "a-file-per-rank"])
-def test_rk3d_driver_under_two_processes_writes_the_same_records(tmp_path, calibrate, gather):
+@pytest.mark.parametrize("calibrate,gather,ranks", [(False, True, 2), (True, True, 2), (False, False, 2), (False, True, 8)],
+                         ids=["equal-fluid-cuts", "measured-re-cut", "a-file-per-rank", "eight-ranks"])
+def test_rk3d_driver_under_two_processes_writes_the_same_records(tmp_path, calibrate, gather, ranks):
     """RKColorGradient3D under torchrun (two ranks sharing this GPU, gloo transport): rank 0 writes ONE file with the whole lattice's
     arrays (the reference's record is one dense array per field, RKD2Q9.py:938-957), equal to the single-process driver's bit for bit --
     also after the one measured re-cut of the slabs a long run makes at its start (calibrate_partition; wherever the cuts land, the slab
-    step equals the single domain); gather_records = False: every rank writes the planes it owns, stacked they are the same arrays."""
+    step equals the single domain); gather_records = False: every rank writes the planes it owns, stacked they are the same arrays.
+    eight-ranks: the node's rank count rehearsed on this one GPU (slabs of five planes), the stitched record read back."""
     import os
     import subprocess
     import sys
@@ -298,8 +357,8 @@ sim.gather_records = %r
 sim.runRKColorGradient3D()
 dist.destroy_process_group()
 ''' % (root, str(tmp_path), str(tmp_path / "out2"), calibrate, gather))
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], env=dict(os.environ), timeout=300)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], env=dict(os.environ), timeout=600)
     single = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out1"), record_every=8)
     ref = load_results(single.runRKColorGradient3D())
     assert len(ref) == 5 * single.records
