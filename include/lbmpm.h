@@ -308,6 +308,18 @@ int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
  * lbmpm_rk3d_step does all of it.  variant 0 (default): collide is one fused z-marching kernel
  * that computes the phase field itself, phase_field(ctx, 0) then only produces the planes the
  * neighbours need; variant 1: phase_field and collide are two full sweeps.
+ *
+ * Scope of the 3-D model against SURVEY.md 8 a17 ("extend a3-a11 to D3Q19").  Built: streaming + half-way bounce-back, densities /
+ * phase field / velocity, solid phase field (SolidRhoR, SolidRhoB), isotropic gradient, BGK and MRT, perturbation operator,
+ * recolouring, velocity inlet and pressure outlet as z planes with their ghost planes -- everything IniFiles/RKtwophasesetup3D.ini
+ * parametrises -- plus state in / out and restart (below).  NOT built, and refused where a caller could ask for them
+ * (openlbmpm_amd/config.py::read_rk3d raises ConfigError naming the key; there is no field for them in this struct):
+ *   - [BoundaryCondition] BoundaryTypeInlet = 'Dirichlet' (pressure inlet per colour, 2-D: AcceleratedRKGPU2D.py:925-962) and
+ *     BoundaryTypeOutlet = 'Convective' (2-D: :700-784) as z-plane rules: no 3-D ini selects them, and their 2-D perturbation-loop
+ *     twins are pinned at kernel level only (no capture of the real driver to reduce a 3-D statement to);
+ *   - [SurfaceTension] SurfaceTensionType = 'CSF' in 3-D (curvature force, 2-D: :2499-2551) with its wetting rules (:2430): the 3-D ini
+ *     carries the perturbation parameters AkR / AkB and no surface-tension section at all;
+ *   - body force: read and never used by the reference's colour-gradient loops.
  * ---------------------------------------------------------------------------------- */
 typedef struct lbmpm_rk3d_config {
     int64_t nx, ny, nz_local, nz_global, z_offset;

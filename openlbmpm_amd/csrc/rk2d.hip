@@ -319,8 +319,12 @@ __device__ __forceinline__ void wetting_fix(const RKDev &p, double nsx, double n
         double ux = 0., uy = 0.;
         if (nrm > 1.0e-8) { ux = -gx / nrm; uy = -gy / nrm; }
         const double ang = ux * nsx + uy * nsy;
+#ifdef LBMPM_RELAXED   // measurement build only (tools/relaxed_parity.py): cos(acos a) = a, sin(acos a) = sqrt(1 - a^2), no libm calls
+        const double cth = ang, sth = sqrt(1. - ang * ang);
+#else
         const double th = acos(ang);
         const double sth = sin(th), cth = cos(th);
+#endif
         double c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
         if (fabs(sth) > 1.0e-9) {
             c1 = p.sinT * cth / sth;
