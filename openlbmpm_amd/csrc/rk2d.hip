@@ -585,6 +585,11 @@ __device__ unsigned long long rk2d_ph[256 * 16];
 #define PH2(k)
 #endif
 // the step of tile t; s_*: the workgroup's LDS arrays of RH x RW entries each
+#if defined(LBMPM_DEV) && defined(RK2D_KO_BC)      // timing knock-out (tools/dev/ab2d.py): no boundary rows at all -- what an interior-tile instance could save
+#define RK2D_BC false
+#else
+#define RK2D_BC true
+#endif
 template <bool MRT, bool TRACER, typename SH, int TR>
 __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int t, double *s_phi, double *s_ux, double *s_uy, double *s_gx, double *s_gy,
                                                 uint16_t *s_list, int *s_cnt, uint8_t *s_fluid)
@@ -643,7 +648,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         const bool inside = (x < p.nx) && (y < p.ny);
         // nodes beyond the lattice edge of a partial tile are periodic images of real nodes and serve as halo for the valid part of the tile
         const int xw = inside ? x : wrapm(x, p.nx), yw = inside ? y : wrapm(y, p.ny);
-        const int ys = node_source_row<true>(p, yw);
+        const int ys = node_source_row<RK2D_BC>(p, yw);
         {
             const size_t idx = (size_t)yw * p.pitch + xw;
             sn[0] = asm_ldu8(p.solidnbr, (unsigned)idx);
@@ -675,7 +680,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
             if (hdo) {
                 LBMPM_TAKEN;                       // (a lane of this wave is here: openlbmpm_amd/inflight.py drops hipcc's all-lanes-off branch)
                 hx = wrapm(tx0 - H + hrx, p.nx); hy = wrapm(ty0 - H + hry, p.ny);
-                hys = node_source_row<true>(p, hy);
+                hys = node_source_row<RK2D_BC>(p, hy);
                 hsn = asm_ldu8(p.solidnbr, (unsigned)hys * (unsigned)p.pitch + (unsigned)hx);
                 pull_issue_asm(p, hx, hys, hq);
             }
@@ -695,7 +700,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
                 for (int i = 0; i < 9; ++i) { fR[i] = q[i].x; fB[i] = q[i].y; }
                 const unsigned psn = first ? 0u : (ys == yw ? sn[0] : (unsigned)p.solidnbr[(size_t)ys * p.pitch + xw]);
                 pull_patch(p, xw, ys, psn, fR, fB);
-                node_finish<true, TR>(p, yw, ys, fR, fB, rR[0], rB[0]);
+                node_finish<RK2D_BC, TR>(p, yw, ys, fR, fB, rR[0], rB[0]);
 #pragma unroll
                 for (int i = 0; i < 9; ++i) fT[0][i] = fR[i] + fB[i];
                 s_phi[ri] = (rR[0] - rB[0]) / (rR[0] + rB[0]);
@@ -710,7 +715,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
             for (int i = 0; i < 9; ++i) { hR[i] = hq[i].x; hB[i] = hq[i].y; }
             pull_patch(p, hx, hys, first ? 0u : hsn, hR, hB);
             double a, c;
-            node_finish<true, TR>(p, hy, hys, hR, hB, a, c);
+            node_finish<RK2D_BC, TR>(p, hy, hys, hR, hB, a, c);
             s_phi[hry * RW + hrx] = (a - c) / (a + c);
         }
     } else {
@@ -734,7 +739,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         hdo = s_fluid[hry * RW + hrx] && (need3 || !(hrx == 0 || hrx == RW - 1 || hry == 0 || hry == RH - 1));
         if (hdo) {
             hx = wrapm(tx0 - H + hrx, p.nx); hy = wrapm(ty0 - H + hry, p.ny);
-            hys = node_source_row<true>(p, hy);
+            hys = node_source_row<RK2D_BC>(p, hy);
             pull_node(p, hx, hys, hR, hB);
         }
     }
@@ -755,7 +760,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
             sn[m] = p.solidnbr[idx];
             Fpx[m] = __builtin_nontemporal_load(p.F + idx);          // read once, by its own node
             Fpy[m] = __builtin_nontemporal_load(p.F + p.plane + idx);
-            node_state<true, TR>(p, xw, yw, fR, fB, rR[m], rB[m]);
+            node_state<RK2D_BC, TR>(p, xw, yw, fR, fB, rR[m], rB[m]);
 #pragma unroll
             for (int i = 0; i < 9; ++i) fT[m][i] = fR[i] + fB[i];
             s_phi[ri] = (rR[m] - rB[m]) / (rR[m] + rB[m]);
@@ -763,7 +768,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
     }
     if (hdo) {
         double a, c;
-        node_finish<true, TR>(p, hy, hys, hR, hB, a, c);
+        node_finish<RK2D_BC, TR>(p, hy, hys, hR, hB, a, c);
         s_phi[hry * RW + hrx] = (a - c) / (a + c);
     }
     }
@@ -775,7 +780,7 @@ __device__ __forceinline__ void rk2d_fused_tile(const RKDev &p, int tiles_x, int
         if (!need3 && (rx == 0 || rx == RW - 1 || ry == 0 || ry == RH - 1)) continue;
         const int x = wrapm(tx0 - H + rx, p.nx), y = wrapm(ty0 - H + ry, p.ny);
         double fR[9], fB[9], a, c;
-        node_state<true, TR>(p, x, y, fR, fB, a, c);
+        node_state<RK2D_BC, TR>(p, x, y, fR, fB, a, c);
         s_phi[ri] = (a - c) / (a + c);
     }
     PH2(1)
