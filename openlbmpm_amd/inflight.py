@@ -19,8 +19,10 @@ Infeasible paths are what a linear or a plain graph walk drowns in, so the walk 
   contradicts the flag's value on this path is not followed;
 * where the source guards a region by `if (__ballot(c) != 0) { if (c) {...} }` the compiler still emits an all-lanes-off branch around
   the inner region; the source marks such a region with `LBMPM_TAKEN` (`asm volatile("; lbmpm-taken")`) and the walk drops that edge.
-A kernel whose walk exceeds STATE_BUDGET (600 000) distinct states is reported as GAVE_UP (rk3dq_fused<FIRST = false>: the 19 per-direction branches of
-its pull address arithmetic times the lanes-off variants).
+A kernel whose path-by-path walk exceeds STATE_BUDGET (600 000) distinct states (rk3dq_fused<FIRST = false>: the 19 per-direction branches
+of its pull address arithmetic times the lanes-off variants) is walked again by `check_kernel_merged`: one in-flight list per control state, lists
+united age by age where paths meet -- an over-approximation of the first walk that finishes in blocks x flag variants; GAVE_UP is reported only
+if that gives up too.
 
 tests/test_codeobj.py compiles the sources with the product's flags and asserts an empty report for every instance;
 `python -m openlbmpm_amd.inflight file.s [filter]` prints it.
@@ -277,6 +279,139 @@ def check_kernel(body, trace_line=None):
     return nloads, sorted(problems.items()), sorted(harmless.items())
 
 
+def _join(a, b):
+    """two lists of in-flight register sets (youngest last) -> their union age by age: what may be in flight at each age on either path"""
+    if len(a) < len(b):
+        a, b = b, a
+    out = list(a)
+    for i in range(1, len(b) + 1):
+        out[-i] = out[-i] | b[-i]
+    return tuple(out)
+
+
+def _covers(a, b):
+    """every register b may have in flight at an age, a has too"""
+    return len(a) >= len(b) and all(b[-i] <= a[-i] for i in range(1, len(b) + 1))
+
+
+def check_kernel_merged(body):
+    """The same walk as check_kernel with ONE in-flight list per control state (block, lanes off or on, structurizer flags, vcc
+    knowledge): lists that meet in a state are united age by age (vmcnt retires in order: `vmcnt(n)` leaves the youngest n ages), the
+    scalar masks known to be zero on a lanes-off path are intersected, and a state is walked again only when either changed.  Over-approximates check_kernel (a register in flight on ANY path into a state
+    counts on all of them), never under: what it passes, the path-by-path walk passes.  Its state count is blocks x flag variants, not
+    paths: it finishes where the 19 per-direction branches of rk3dq_fused<FIRST = false> multiply the path-by-path walk beyond its
+    budget."""
+    blocks = _blocks(body)
+    index = {b[0]: i for i, b in enumerate(blocks) if b[0]}
+    nloads = sum(1 for b in blocks for ins in b[1] if ins[2])
+    if not nloads:
+        return 0, [], []
+    problems, harmless, visited = {}, {}, set()
+    relevant = _mask_registers(blocks)
+    flagregs = set(m.group(1) for b in blocks for _k, t, _l in b[1] for m in [re.match(r's_andn?2?_b64\s+vcc,\s*exec,\s*(s\[\d+:\d+\])$', t)] if m)
+    # control state: (block, lanes off?, structurizer flags, vcc knowledge); value: (in-flight list, scalar masks known to be zero on a
+    # lanes-off path -- the INTERSECTION over the paths that meet: knowing less only switches lanes back on earlier)
+    state = {(0, False, frozenset(), False): ((), None)}
+    work = [(0, False, frozenset(), False)]
+    steps = 0
+    while work:
+        ctrl = work.pop()
+        steps += 1
+        if steps > 40 * STATE_BUDGET or len(state) > STATE_BUDGET:
+            problems[-1] = GAVE_UP
+            break
+        bi, off, ones, vnz = ctrl
+        pend = list(state[ctrl][0])
+        visited.add(bi)
+        ones = set(ones)
+        zero = set(state[ctrl][1]) if off else None
+        ins_list = blocks[bi][1]
+        for n, (k, t, isload) in enumerate(ins_list):
+            if isload:
+                if not off:
+                    pend.append(frozenset(_regs(t.split()[1].rstrip(','))))
+                if len(pend) > _MAXPEND:
+                    problems[k] = "asm loads pile up without a wait: " + t
+                    pend = pend[-_MAXPEND:]
+                continue
+            if t.startswith('s_waitcnt'):
+                m = re.search(r'vmcnt\((\d+)\)', t)
+                if m:
+                    c = int(m.group(1))
+                    pend = pend[len(pend) - c:] if 0 < c < len(pend) else ([] if c == 0 else pend)
+                continue
+            if off and t.startswith('s_'):
+                off = _scalar_while_off(t, zero)
+                continue
+            if not off and t.startswith('s_'):
+                m = re.match(r's_mov_b64\s+(s\[\d+:\d+\]),\s*(-1|0)$', t)
+                if m:
+                    ones.discard((m.group(1), '0')); ones.discard((m.group(1), '-1'))
+                    if m.group(1) in flagregs:
+                        ones.add((m.group(1), m.group(2)))
+                    continue
+                m = re.match(r's_(and|andn2)_b64\s+vcc,\s*exec,\s*(s\[\d+:\d+\])$', t)
+                if m and ((m.group(2), '-1') in ones or (m.group(2), '0') in ones):
+                    full = (m.group(2), '-1') in ones
+                    vnz = 'nz' if full == (m.group(1) == 'and') else 'z'
+                    continue
+                d = re.match(r's_\w+\s+(s\[\d+:\d+\]|vcc)', t)
+                if d and not t.startswith('s_cbranch'):
+                    ones.discard((d.group(1), '0')); ones.discard((d.group(1), '-1'))
+                    if d.group(1) == 'vcc':
+                        vnz = False
+            elif 'vcc' in t or (t.startswith('v_cmp') and '_e32' in t):
+                vnz = False
+            if not pend or off:
+                continue
+            flight = set().union(*pend)
+            op, _, ops = t.partition(' ')
+            hit = _regs(ops) & flight
+            if not hit:
+                continue
+            if op == 'v_mad_u64_u32':
+                parts = [p.strip() for p in ops.split(',')]
+                d, a = _VREG_RANGE.match(parts[0]), _VREG_RANGE.match(parts[-1])
+                if d and a and hit == {int(a.group(2))} and int(a.group(2)) not in _regs(','.join(parts[:-1])):
+                    dhi, dead = int(d.group(2)), False
+                    for _k2, t2, _l2 in ins_list[n + 1:]:
+                        w, r = _dst_src(t2)
+                        if dhi in r:
+                            break
+                        if dhi in w:
+                            dead = True
+                            break
+                    if dead:
+                        harmless[k] = t
+                        continue
+            problems[k] = t
+        last = ins_list[-1][1] if ins_list else ''
+        st = frozenset(zero & relevant) if off else None
+        fo = frozenset(ones)
+        succ = []
+        for s_ in blocks[bi][2]:
+            if s_ in index and not (vnz == 'nz' and last.startswith('s_cbranch_vccz')) and not (vnz == 'z' and last.startswith('s_cbranch_vccnz')):
+                succ.append((index[s_], (st or frozenset()) if last.startswith('s_cbranch_execz') else st, fo, vnz))
+        if blocks[bi][3] and bi + 1 < len(blocks) and not (vnz == 'nz' and last.startswith('s_cbranch_vccnz')) and not (vnz == 'z' and last.startswith('s_cbranch_vccz')):
+            succ.append((bi + 1, (st or frozenset()) if last.startswith('s_cbranch_execnz') else st, fo, vnz))
+        out = tuple(pend)
+        for b2, z2, fo2, v2 in succ:
+            c2 = (b2, z2 is not None, fo2, v2)
+            old = state.get(c2)
+            if old is None:
+                state[c2] = (out, z2)
+                work.append(c2)
+            else:
+                zj = (old[1] & z2) if z2 is not None else None
+                if not _covers(old[0], out) or zj != old[1]:
+                    state[c2] = (_join(old[0], out), zj)
+                    work.append(c2)
+    missed = [ins[0] for i, b in enumerate(blocks) if i not in visited for ins in b[1] if ins[2]]
+    if missed and -1 not in problems:
+        problems[-2] = "asm loads the walk never reached (lines %s ...)" % missed[:4]
+    return nloads, sorted(problems.items()), sorted(harmless.items())
+
+
 def check(asm, name_filter=""):
     """{kernel: (asm loads, problems, harmless)} for every kernel of the assembly text that holds asm loads"""
     out = {}
@@ -284,6 +419,8 @@ def check(asm, name_filter=""):
         if name_filter and name_filter not in name:
             continue
         n, bad, ok = check_kernel(body)
+        if n and any(k == -1 for k, _t in bad):        # the path-by-path walk ran out of budget: one in-flight list per control state
+            n, bad, ok = check_kernel_merged(body)
         if n:
             out[name] = (n, bad, ok)
     return out

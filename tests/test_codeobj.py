@@ -119,8 +119,12 @@ def test_nothing_touches_a_register_an_asm_load_has_in_flight(device_asm, kernel
     rep3 = inflight.check(device_asm["rk3d"], "rk3dq_fused")
     assert len(rep3) == 8                           # <FIRST, MRT, RAGGED>
     for n, (nloads, bad, _h) in rep3.items():
-        assert nloads == 38
-        if "rk3dq_fusedILb1E" in n:                 # the first step's instances: walked to the end
-            assert not bad, (n, bad[:4])
-        else:                                       # the walk of the steady-state instances exceeds its state budget (19 per-direction
-            assert all(k < 0 and t == inflight.GAVE_UP for k, t in bad), (n, bad[:4])      # branches x lanes-off variants): no finding either
+        # every instance walked to the end, the steady-state ones (the kernel that runs every step but the first) included: where the
+        # path-by-path walk exceeds its budget -- their 19 per-direction branches -- check() repeats it with one in-flight list per
+        # control state (check_kernel_merged: an over-approximation; advisor, round 5)
+        assert nloads == 38 and not bad, (n, bad[:4])
+    # ... and the merged walk does see what it is there to see: the same kernel without its hand-written waits
+    name, body = next((n, b) for n, b in inflight._kernels(device_asm["rk3d"]) if "rk3dq_fusedILb0ELb1ELb0" in n)
+    nowait = [l for l in body if not l.strip().startswith("s_waitcnt vmcnt(0)")]
+    _n, bad, _h = inflight.check_kernel_merged(nowait)
+    assert len(bad) > 100 and all(k >= 0 for k, _t in bad), bad[:3]

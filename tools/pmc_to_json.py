@@ -107,9 +107,11 @@ def collect(fetch, write, kernels, suffix, only=None):
         m3 = re.search(r"rk3d[cq]?_fused<([^>]*)>", name)
         if m3:                            # <.., FIRST, MRT>: first-step instances carry one launch; SRT is the secondary entry
             targs = [t.strip() for t in m3.group(1).split(",")]
-            if targs[-2] == "true":
+            # rk3dq_fused<FIRST, MRT, RAGGED> (round 6; <FIRST, MRT> before), rk3dc_fused<TY, FIRST, MRT>, rk3d_fused<TX, TY, FIRST, MRT>
+            first, mrt = (targs[0], targs[1]) if "rk3dq_fused" in name else (targs[-2], targs[-1])
+            if first == "true":
                 continue
-            if targs[-1] == "false":
+            if mrt == "false":
                 k += "[SRT]"
         k += suffix
         if k in kernels and kernels[k]["launches_profiled"] >= n:
