@@ -1389,7 +1389,11 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
         TRY_RC(dev_alloc(c, &c->purB, (size_t)(c->nzl + 2) * c->ny * c->nseg));
     }
     TRY_RC(dev_alloc(c, &c->phi, c->vol));
-    const size_t face_doubles = (c->q23 ? FACE_DOUBLES + 1 : 10) * c->plane2;     // q23: 13 per cell + the row flags (rk3dq.h)
+    // q23: 13 per cell + the row flags (rk3dq.h).  Per STORED cell of a plane: the tile padding and the odd-stride padding count (a regular
+    // plane's cnt exceeds its nx * ny cells), so the buffers follow the largest plane
+    size_t max_cnt = c->plane2;
+    if (c->compact) for (int z = 0; z < c->nzl + 2; ++z) max_cnt = std::max(max_cnt, (size_t)(c->h_pstart[z + 1] - c->h_pstart[z]));
+    const size_t face_doubles = (c->q23 ? FACE_DOUBLES + 1 : 10) * max_cnt;
     TRY_RC(dev_alloc(c, &c->send_up, face_doubles));
     TRY_RC(dev_alloc(c, &c->send_dn, face_doubles));
     TRY_RC(dev_alloc(c, &c->recv_below, face_doubles));
@@ -1727,14 +1731,18 @@ void launch_fused_c(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first,
 // Planes per workgroup of a launch over n planes.  A march costs two fill steps per chunk, so chunks should be long; but the launch
 // should still hand every CU several workgroups.  Measured at 512^3 (512 tiles, MRT): chunks of 16 / 32 / 64 / 128 / 256 / 512 planes
 // 7.87 / 7.32 / 7.08 / 6.91 / 6.72 / 6.81 ms per step -> as few chunks as keep ~4 workgroups per CU in the launch, none shorter than
-// 64 planes unless the range is, all of equal length.
+// 64 planes unless the range is (or the lattice is small, below), all of equal length.
 int chunk_planes(const lbmpm_rk3d *c, int n)
 {
     if (!c->chunk_auto) return c->chunk_len;
     const int tiles = c->nseg * ((c->ny + 7) / 8);
     const int want = (4 * c->ncu + tiles - 1) / tiles;              // chunks for ~4 workgroups per CU
     int len = (n + want - 1) / want;
-    if (len < 64) len = 64;
+    // none shorter than 64 planes -- unless the lattice is so small that chunks of 64 leave CUs without a workgroup (the reference's own
+    // 32 x 32 x 96 ini: four tiles): then rather shorter chunks, down to 8 planes, than idle CUs (100^3 porous: 0.32 -> 0.16 ms per step)
+    int minlen = 64;
+    while (minlen > 8 && tiles * ((n + minlen - 1) / minlen) < c->ncu) minlen /= 2;
+    if (len < minlen) len = minlen;
     const int nch = (n + len - 1) / len;
     return nch > 0 ? (n + nch - 1) / nch : 64;
 }
