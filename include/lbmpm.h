@@ -314,9 +314,10 @@ int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
  * recolouring, velocity inlet and pressure outlet as z planes with their ghost planes -- everything IniFiles/RKtwophasesetup3D.ini
  * parametrises -- plus state in / out and restart (below).  NOT built, and refused where a caller could ask for them
  * (openlbmpm_amd/config.py::read_rk3d raises ConfigError naming the key; there is no field for them in this struct):
- *   - [BoundaryCondition] BoundaryTypeInlet = 'Dirichlet' (pressure inlet per colour, 2-D: AcceleratedRKGPU2D.py:925-962) and
- *     BoundaryTypeOutlet = 'Convective' (2-D: :700-784) as z-plane rules: no 3-D ini selects them, and their 2-D perturbation-loop
- *     twins are pinned at kernel level only (no capture of the real driver to reduce a 3-D statement to);
+ *   - [BoundaryCondition] BoundaryTypeOutlet = 'Convective' (2-D: AcceleratedRKGPU2D.py:700-784: the three lowest rows take the
+ *     streamed populations of the fourth) as a z-plane rule: no 3-D ini selects it, and in the marching kernel it is not a boundary
+ *     closure but three planes collided on another plane's pulls.  (The pressure INLET, :925-962, is built since round 6:
+ *     inlet_type, pinned by reduction to the 2-D fused loop, whose kernels are pinned to the reference's one by one.)
  *   - [SurfaceTension] SurfaceTensionType = 'CSF' in 3-D (curvature force, 2-D: :2499-2551) with its wetting rules (:2430): the 3-D ini
  *     carries the perturbation parameters AkR / AkB and no surface-tension section at all;
  *   - body force: read and never used by the reference's colour-gradient loops.
@@ -334,12 +335,15 @@ typedef struct lbmpm_rk3d_config {
     int32_t relaxation;         /* [RelaxationType] Type: 0 'SRT', 1 'MRT' (RKtwophasesetup3D.ini:53-55;
                                  * D3Q19 moment basis of d'Humieres et al. 2002: s_e 1.19, s_eps = s_pi 1.4,
                                  * s_q = s_m 1.2, stress moments at 1/tau) */
-    int32_t reserved;
+    int32_t inlet_type;         /* [BoundaryCondition] BoundaryTypeInlet: LBMPM_INLET_VELOCITY 'Neumann' (the shipped ini; inlet_vz_*) |
+                                 * LBMPM_INLET_PRESSURE 'Dirichlet' (inlet_rho_*: Zou-He pressure per colour on the plane nz-2, the z-plane
+                                 * form of AcceleratedRKGPU2D.py:925-962; ghost plane as :968-1002) */
     double recolor_axis, recolor_diag;  /* weights w_i / |e_i| of the recolouring term beta rhoR rhoB / rho^2 w_i cos(theta_i)
                                  * (AcceleratedRKGPU2D.py:1241-1267) for the directions with |e_i| = 1 and sqrt 2.
                                  * 0 = the model's own, 1/18 and 1/(36 sqrt 2).  Other values exist for the parity pin:
                                  * recolor_axis = 1/9 - 2/(36 sqrt 2) makes a y-uniform lattice project exactly onto the
                                  * reference's D2Q9 perturbation loop (tests/test_rk3d_reduction.py) */
+    double inlet_rho_r, inlet_rho_b;    /* densityRH, densityBH (pressure inlet only) */
 } lbmpm_rk3d_config;
 
 typedef struct lbmpm_rk3d lbmpm_rk3d;

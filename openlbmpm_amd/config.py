@@ -143,10 +143,16 @@ def read_rk3d(ini_dir):
     p["SolidRhoR"] = c.float("BoundariesSetup", "SolidRhoR"); p["SolidRhoB"] = c.float("BoundariesSetup", "SolidRhoB")
     if p["SolidRhoR"] + p["SolidRhoB"] == 0.0:
         raise ConfigError("[BoundariesSetup] SolidRhoR + SolidRhoB must not be zero")
-    if c.str("BoundaryCondition", "BoundaryTypeInlet") != "Neumann" or c.str("BoundaryCondition", "NeumannType", default="'ZouHe'") != "ZouHe":
-        raise ConfigError("3-D inlet: only BoundaryTypeInlet = 'Neumann' with NeumannType = 'ZouHe'")
+    p["inlet"] = c.str("BoundaryCondition", "BoundaryTypeInlet")
+    if p["inlet"] not in ("Neumann", "Dirichlet") or (p["inlet"] == "Neumann" and c.str("BoundaryCondition", "NeumannType", default="'ZouHe'") != "ZouHe"):
+        raise ConfigError("3-D inlet: BoundaryTypeInlet = 'Neumann' with NeumannType = 'ZouHe' (velocityZR / velocityZB) or 'Dirichlet' "
+                          "(densityRH / densityBH: Zou-He pressure per colour, the keys of RKtwophasesetup2D.ini)")
+    p["densityRH"] = c.float("BoundaryCondition", "densityRH", default=1.0)
+    p["densityBH"] = c.float("BoundaryCondition", "densityBH", default=1.0)
+    if p["inlet"] == "Dirichlet" and not (p["densityRH"] > 0.0 and p["densityBH"] > 0.0):
+        raise ConfigError("3-D pressure inlet: densityRH and densityBH must be positive (the closure divides by them; the absent colour gets e.g. 1e-8)")
     if c.str("BoundaryCondition", "BoundaryTypeOutlet") != "Dirichlet":
-        raise ConfigError("3-D outlet: only BoundaryTypeOutlet = 'Dirichlet'")
+        raise ConfigError("3-D outlet: only BoundaryTypeOutlet = 'Dirichlet' ('Convective', AcceleratedRKGPU2D.py:700-784, is not built as a z-plane rule: include/lbmpm.h)")
     p["velocityZR"] = c.float("BoundaryCondition", "velocityZR", default=0.0)
     p["velocityZB"] = c.float("BoundaryCondition", "velocityZB", default=0.0)
     p["densityBL"] = c.float("BoundaryCondition", "densityBL", default=1.0)

@@ -76,6 +76,9 @@ struct RK3Dev {
 #ifdef LBMPM_DEV                       // development builds only (tools/dev/devlib.py); the product library has neither
     unsigned long long *trace;        // LBMPM_RK3D_TRACE: four words per workgroup of rk3dq_fused (start, prologue done, end, planes)
 #endif
+    int inletP;                       // 0 velocity inlet: vzR, vzB are velocities; 1 pressure inlet per colour: vzR, vzB hold densityRH, densityBH
+                                      // (one pair of kernel arguments for both, and this word behind everything else: the marching kernel's
+                                      // argument loads and registers stay what they were -- it has no scalar register to spare)
 };
 
 // ---- addressing.  Populations are stored plane-major, f[zl][colour][q][y][x]: everything a node
@@ -173,6 +176,21 @@ __device__ __forceinline__ double zouhe_inlet(double uz, double f[Q])
     return rho;
 }
 
+// Zou-He pressure inlet, top plane, unknown e_z = -1 (2-D analogue A:925-962): u_z = -1 + (S0 + 2 S+) / rho, then the closure above
+__device__ __forceinline__ void zouhe_inlet_pressure(double rho, double f[Q])
+{
+    const double s0 = f[0] + f[1] + f[2] + f[3] + f[4] + f[7] + f[8] + f[9] + f[10];
+    const double sp = f[5] + f[11] + f[14] + f[15] + f[18];
+    const double uz = -1. + (s0 + 2. * sp) / rho;
+    const double Nx = 0.5 * ((f[1] + f[7] + f[9]) - (f[2] + f[8] + f[10]));
+    const double Ny = 0.5 * ((f[3] + f[7] + f[10]) - (f[4] + f[8] + f[9]));
+    f[6] = f[5] - 1. / 3. * rho * uz;
+    f[12] = f[11] - 1. / 6. * rho * uz + Nx;
+    f[13] = f[14] - 1. / 6. * rho * uz - Nx;
+    f[16] = f[15] - 1. / 6. * rho * uz + Ny;
+    f[17] = f[18] - 1. / 6. * rho * uz - Ny;
+}
+
 // Zou-He pressure outlet, bottom plane, unknown e_z = +1 (2-D analogue A:1008-1039)
 __device__ __forceinline__ void zouhe_outlet(double rho, double f[Q])
 {
@@ -195,9 +213,14 @@ __device__ __forceinline__ void finish_state3(const RK3Dev &p, int zl, double fR
     rR = sum19(fR);
     rB = sum19(fB);
     if (zsg == p.nzg - 2) {
-        rR = zouhe_inlet(p.vzR, fR);
-        rB = zouhe_inlet(p.vzB, fB);
-        if (zg == p.nzg - 1) { rR = sum19(fR); rB = sum19(fB); }
+        if (p.inletP) {                // the ghost plane copies populations and densities (A:968-1002)
+            zouhe_inlet_pressure(p.vzR, fR); rR = p.vzR;
+            zouhe_inlet_pressure(p.vzB, fB); rB = p.vzB;
+        } else {
+            rR = zouhe_inlet(p.vzR, fR);
+            rB = zouhe_inlet(p.vzB, fB);
+            if (zg == p.nzg - 1) { rR = sum19(fR); rB = sum19(fB); }
+        }
     }
     if (zsg == 1) {
         zouhe_outlet(p.rhoOutR, fR); rR = p.rhoOutR;
@@ -1198,6 +1221,8 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     p.ak = (c->cfg.ak_r + c->cfg.ak_b) * 0.5; p.beta = c->cfg.beta; p.cR = 1. / (2. * (c->cfg.tau_r - 0.5)); p.cB = 1. / (2. * (c->cfg.tau_b - 0.5));
     p.solidPhi = c->cfg.solid_phi; p.vzR = c->cfg.inlet_vz_r; p.vzB = c->cfg.inlet_vz_b;
     p.rhoOutR = c->cfg.outlet_rho_r; p.rhoOutB = c->cfg.outlet_rho_b;
+    p.inletP = c->cfg.inlet_type == LBMPM_INLET_PRESSURE ? 1 : 0;
+    if (p.inletP) { p.vzR = c->cfg.inlet_rho_r; p.vzB = c->cfg.inlet_rho_b; }
     p.rcA = c->cfg.beta * (c->cfg.recolor_axis > 0. ? c->cfg.recolor_axis : 1. / 18.);
     p.rcD = c->cfg.beta * (c->cfg.recolor_diag > 0. ? c->cfg.recolor_diag : (1. / 36.) * 0.70710678118654752440);
     p.first = c->streamed ? 0 : 1;
@@ -1252,6 +1277,8 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
 #endif
     LBMPM_REQUIRE(variant == 0 || variant == 1, "lbmpm_rk3d_create: variant must be 0 (fused) or 1 (split)");
     LBMPM_REQUIRE(cfg->relaxation == 0 || cfg->relaxation == 1, "lbmpm_rk3d_create: relaxation must be 0 (SRT) or 1 (MRT)");
+    LBMPM_REQUIRE(cfg->inlet_type == LBMPM_INLET_VELOCITY || (cfg->inlet_type == LBMPM_INLET_PRESSURE && cfg->inlet_rho_r > 0. && cfg->inlet_rho_b > 0.),
+                  "lbmpm_rk3d_create: inlet_type must be LBMPM_INLET_VELOCITY or LBMPM_INLET_PRESSURE with positive densityRH / densityBH (the Zou-He pressure plane divides by them)");
     LBMPM_REQUIRE(cfg->recolor_axis >= 0. && cfg->recolor_diag >= 0. && cfg->recolor_axis < 1. && cfg->recolor_diag < 1.,
                   "lbmpm_rk3d_create: recolor_axis / recolor_diag must be 0 (the model's weights) or a weight in (0, 1)");
     LBMPM_REQUIRE(fill == 0 || fill == 4 || fill == 8 || fill == 16 || fill == 32 || fill == 64,
@@ -1764,12 +1791,12 @@ void launch_q23(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int
         q = c->slotq + ((size_t)ring * 4096u + i) * 8u;
     }
     auto go = [&](auto first, auto mrt) {
-        if (c->nx % 64 == 0)
-            rk3dq_fused<decltype(first)::value, decltype(mrt)::value, false><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, chunk_len, z_first, z_last,
-                                                                                                   nchunks1, z_first2, z_last2, q);
-        else
-            rk3dq_fused<decltype(first)::value, decltype(mrt)::value, true><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, chunk_len, z_first, z_last,
-                                                                                                  nchunks1, z_first2, z_last2, q);
+        constexpr bool F = decltype(first)::value, M = decltype(mrt)::value;
+        auto launch = [&](auto ragged, auto pin) {
+            rk3dq_fused<F, M, decltype(ragged)::value, decltype(pin)::value><<<grid, block, 0, st>>>(p, tilesX, tilesY, rpx, chunk_len, z_first, z_last,
+                                                                                                     nchunks1, z_first2, z_last2, q);
+        };
+        dispatch2(c->nx % 64 != 0, p.inletP != 0, launch);
     };
     dispatch2(p.first != 0, p.mrt != 0, go);
 }

@@ -267,21 +267,31 @@ __device__ __forceinline__ void class_sums_pure(const double g[Q], bool red, Sum
 // densities of the streamed, boundary-corrected node on plane zl from its class sums; on the inlet / outlet plane pairs
 // the per-colour Zou-He closures (zouhe_inlet / zouhe_outlet above, summed over the colours: they are linear in the
 // populations once rho_c is known) rewrite the unknown colour-blind populations in g
-template <bool WITH_G>
+// PIN: 0 velocity inlet, 1 pressure inlet, -1 decided at run time (p.inletP).  The marching kernel knows it at compile time: the
+// run-time test cost rk3dq_fused two registers and 1.2 % (A/B, round 6)
+template <bool WITH_G, int PIN = -1>
 __device__ __forceinline__ void bc_q(const RK3Dev &p, int zl, const Sums &S, double *g, double &rR, double &rho)
 {
 #pragma clang fp contract(off)
+    const bool pin = PIN < 0 ? p.inletP != 0 : PIN == 1;
     const int zsg = p.z0 + source_plane(p, zl) - 1;
     const double r0 = S.k0 + S.a0, rp = S.kp + S.ap, rm = S.km + S.am;
     rR = (r0 + rp) + rm;
     rho = (S.t0 + S.tp) + S.tm;
     if (zsg == p.nzg - 2) {                    // velocity inlet: unknown e_z = -1
         const double wR = r0 + 2. * rp, wT = S.t0 + 2. * S.tp;
-        const double dR = wR / (1. + p.vzR), dB = (wT - wR) / (1. + p.vzB);
-        rR = dR;
-        rho = dR + dB;
+        double J;
+        if (pin) {                             // pressure inlet per colour: rho_c u_c = (S0 + 2 S+)_c - rho_c, summed over the colours
+            rR = p.vzR;                        // (densityRH, densityBH: RK3Dev::inletP)
+            rho = p.vzR + p.vzB;
+            J = wT - rho;
+        } else {
+            const double dR = wR / (1. + p.vzR), dB = (wT - wR) / (1. + p.vzB);
+            rR = dR;
+            rho = dR + dB;
+            J = dR * p.vzR + dB * p.vzB;
+        }
         if (WITH_G) {
-            const double J = dR * p.vzR + dB * p.vzB;
             const double Nx = 0.5 * ((g[1] + g[7] + g[9]) - (g[2] + g[8] + g[10]));
             const double Ny = 0.5 * ((g[3] + g[7] + g[10]) - (g[4] + g[8] + g[9]));
             g[6] = g[5] - 1. / 3. * J;
@@ -319,7 +329,7 @@ __device__ __forceinline__ double phi_q(double rR, double rho) { return (rR - (r
 // (seg_x0); the lanes behind them are idle (or write line padding), the tile's right rim column and record halo sit at tile columns
 // w and w + 1, and the segment to the left ends at its bit wl - 1.  All of that lives in the per-thread geometry words; the march
 // step differs by where it takes a rim column's bit from.  RAGGED = false is the kernel as it was (64-cell segments, constants).
-template <bool FIRST, bool MRT, bool RAGGED>
+template <bool FIRST, bool MRT, bool RAGGED, bool PIN = false>       // PIN: [BoundaryCondition] BoundaryTypeInlet = 'Dirichlet' (bc_q)
 __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int tilesY, int rows_per_xcd, int chunk_len, int z_first, int z_last,
                                                        int nchunks1, int z_first2, int z_last2,      // a second range of planes in the same launch
                                                        unsigned *slotq)                              // eight zeroed counters of this launch
@@ -631,20 +641,20 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
                     if (pc != 0) {          // single colour around: phi = +-1 (or the planes' boundary values) without a pull
                         if (fl) {
                             S.t0 = 1.; S.tp = S.tm = 0.; S.k0 = (pc & 1) ? 1. : 0.; S.kp = S.km = S.a0 = S.ap = S.am = 0.;
-                            bc_q<false>(p, zn, S, nullptr, a, c);
+                            bc_q<false, PIN ? 1 : 0>(p, zn, S, nullptr, a, c);
                             ph = phi_q(a, c);
                         }
                     } else if (wave < 2) {
                         if (fl) {
                             pull_q<FIRST, true>(p, rows_rimrow, zn, (unsigned)lx, g, j);
                             class_sums<FIRST, true>(p, rows_rimrow, lds_scal(zn, hly - 1, hlx - 1), zn, (unsigned)lx, g, S);
-                            bc_q<false>(p, zn, S, nullptr, a, c);
+                            bc_q<false, PIN ? 1 : 0>(p, zn, S, nullptr, a, c);
                             ph = phi_q(a, c);
                         }
                     } else if (fl) {
                         pull_q<FIRST, false>(p, rows_rimcol, zn, hb, g, j);
                         class_sums<FIRST, false>(p, rows_rimcol, lds_scal(zn, hly - 1, hlx - 1), zn, hb, g, S);
-                        bc_q<false>(p, zn, S, nullptr, a, c);
+                        bc_q<false, PIN ? 1 : 0>(p, zn, S, nullptr, a, c);
                         ph = phi_q(a, c);
                     }
                 }
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
                 mixed_n = pc == 0;
                 if (pc != 0) class_sums_pure(raw, (pc & 1) != 0, S);
                 else class_sums<FIRST, true>(p, rows_own, lds_scal(zn, ly, lx), zn, (unsigned)lx, raw, S);
-                bc_q<true>(p, zn, S, raw, rRn, rhon);
+                bc_q<true, PIN ? 1 : 0>(p, zn, S, raw, rRn, rhon);
                 ph = phi_q(rRn, rhon);
             }
             if (has_own) {

@@ -412,18 +412,25 @@ def check_kernel_merged(body):
     return nloads, sorted(problems.items()), sorted(harmless.items())
 
 
-def check(asm, name_filter=""):
-    """{kernel: (asm loads, problems, harmless)} for every kernel of the assembly text that holds asm loads"""
-    out = {}
-    for name, body in _kernels(asm):
-        if name_filter and name_filter not in name:
-            continue
-        n, bad, ok = check_kernel(body)
-        if n and any(k == -1 for k, _t in bad):        # the path-by-path walk ran out of budget: one in-flight list per control state
-            n, bad, ok = check_kernel_merged(body)
-        if n:
-            out[name] = (n, bad, ok)
-    return out
+def _check_one(item):
+    name, body = item
+    n, bad, ok = check_kernel(body)
+    if n and any(k == -1 for k, _t in bad):        # the path-by-path walk ran out of budget: one in-flight list per control state
+        n, bad, ok = check_kernel_merged(body)
+    return name, n, bad, ok
+
+
+def check(asm, name_filter="", workers=1):
+    """{kernel: (asm loads, problems, harmless)} for every kernel of the assembly text that holds asm loads; workers > 1: kernels
+    side by side in that many processes (a walk of rk3dq_fused<FIRST = false> takes half a minute)"""
+    items = [(name, body) for name, body in _kernels(asm) if not name_filter or name_filter in name]
+    if workers > 1 and len(items) > 1:
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=min(workers, len(items))) as ex:
+            res = list(ex.map(_check_one, items))
+    else:
+        res = [_check_one(it) for it in items]
+    return {name: (n, bad, ok) for name, n, bad, ok in res if n}
 
 
 if __name__ == "__main__":

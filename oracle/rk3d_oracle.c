@@ -69,6 +69,9 @@ typedef struct {
                                     makes a y-uniform lattice project exactly onto the reference's D2Q9 loop
                                     (tests/test_rk3d_reduction.py; the D3Q19 w_i, B_i, gradient and Zou-He closures project
                                     onto their D2Q9 counterparts by themselves, the |e_i| of cos(theta_i) does not) */
+    int inletP;                  /* 0: Zou-He velocity inlet (vzR, vzB); 1: Zou-He PRESSURE inlet per colour (rhoInR, rhoInB), the z-plane
+                                    form of calConstPressureInletGPU, AcceleratedRKGPU2D.py:925-962, ghost plane as :968-1002 */
+    double rhoInR, rhoInB;
 } rk3d_sim;
 
 static i64 wrap(i64 v, i64 n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
@@ -86,6 +89,21 @@ static void zouhe_inlet(double uz, double *f, double *rho_out)
     f[16] = f[15] - 1. / 6. * rho * uz + Ny;
     f[17] = f[18] - 1. / 6. * rho * uz - Ny;
     *rho_out = rho;
+}
+
+/* AcceleratedRKGPU2D.py:925-962 in 3-D: u_z = -1 + (S0 + 2 S+) / rho, unknown e_z = -1 as in zouhe_inlet */
+static void zouhe_inlet_pressure(double rho, double *f)
+{
+    double s0 = f[0] + f[1] + f[2] + f[3] + f[4] + f[7] + f[8] + f[9] + f[10];
+    double sp = f[5] + f[11] + f[14] + f[15] + f[18];
+    double uz = -1. + (s0 + 2. * sp) / rho;
+    double Nx = 0.5 * ((f[1] + f[7] + f[9]) - (f[2] + f[8] + f[10]));
+    double Ny = 0.5 * ((f[3] + f[7] + f[10]) - (f[4] + f[8] + f[9]));
+    f[6] = f[5] - 1. / 3. * rho * uz;
+    f[12] = f[11] - 1. / 6. * rho * uz + Nx;
+    f[13] = f[14] - 1. / 6. * rho * uz - Nx;
+    f[16] = f[15] - 1. / 6. * rho * uz + Ny;
+    f[17] = f[18] - 1. / 6. * rho * uz - Ny;
 }
 
 static void zouhe_outlet(double rho, double *f)
@@ -119,14 +137,19 @@ static void rk3d_bc_and_macro(rk3d_sim *s)
     for (i64 k = 0; k < pl; ++k) {          /* inlet plane nz-2, ghost nz-1 */
         i64 n = (nz - 2) * pl + k, g = (nz - 1) * pl + k;
         if (s->dom[n]) {
-            zouhe_inlet(s->vzR, s->fR + Q * n, &s->rhoR[n]);
-            zouhe_inlet(s->vzB, s->fB + Q * n, &s->rhoB[n]);
+            if (s->inletP) {
+                zouhe_inlet_pressure(s->rhoInR, s->fR + Q * n); s->rhoR[n] = s->rhoInR;
+                zouhe_inlet_pressure(s->rhoInB, s->fB + Q * n); s->rhoB[n] = s->rhoInB;
+            } else {
+                zouhe_inlet(s->vzR, s->fR + Q * n, &s->rhoR[n]);
+                zouhe_inlet(s->vzB, s->fB + Q * n, &s->rhoB[n]);
+            }
         }
         if (s->dom[g]) {
             memcpy(s->fR + Q * g, s->fR + Q * n, sizeof(double) * Q);
             memcpy(s->fB + Q * g, s->fB + Q * n, sizeof(double) * Q);
-            s->rhoR[g] = sum19(s->fR + Q * g);
-            s->rhoB[g] = sum19(s->fB + Q * g);
+            if (s->inletP) { s->rhoR[g] = s->rhoR[n]; s->rhoB[g] = s->rhoB[n]; }      /* the ghost copies the densities too (A:968-1002) */
+            else { s->rhoR[g] = sum19(s->fR + Q * g); s->rhoB[g] = sum19(s->fB + Q * g); }
         }
     }
     for (i64 k = 0; k < pl; ++k) {          /* outlet plane 1, ghost 0 */

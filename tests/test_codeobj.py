@@ -28,8 +28,8 @@ def test_q23_kernels_use_no_scratch_memory(kernels):
     ~600 such waves lost the stores of whole waves at random (a slab run went NaN at 192^2 planes and up; 128^2 passed).
     For rk3dq_fused scratch would also mean spill reloads, each followed by s_waitcnt vmcnt(0)."""
     q = {n: m for n, m in kernels.items() if "rk3dq_" in n or "rk3d_state_io" in n}
-    # rk3dq_fused<FIRST, MRT, RAGGED>: eight instances; rk3d_state_io<storage, mode>: fifteen
-    assert len(q) >= 9 + 15 and sum("rk3dq_fused" in n for n in q) == 8 and sum("rk3d_state_io" in n for n in q) == 15
+    # rk3dq_fused<FIRST, MRT, RAGGED, PIN>: sixteen instances; rk3d_state_io<storage, mode>: fifteen
+    assert len(q) >= 9 + 15 and sum("rk3dq_fused" in n for n in q) == 16 and sum("rk3d_state_io" in n for n in q) == 15
     for n, m in q.items():
         assert m[".private_segment_fixed_size"] == 0, n
         assert m[".vgpr_spill_count"] == 0, n          # (scalar registers may spill into vector-register lanes: no memory involved)
@@ -116,8 +116,8 @@ def test_nothing_touches_a_register_an_asm_load_has_in_flight(device_asm, kernel
     # kernels of the 2-D file that use scratch at all (the two-nodes-per-lane tuning shape): none of them is an instance with asm loads
     scratch = [n for n, m in kernels.items() if ("rk2d_fused" in n or "rk2dp_fused" in n) and m[".private_segment_fixed_size"]]
     assert all(n not in rep for n in scratch), scratch
-    rep3 = inflight.check(device_asm["rk3d"], "rk3dq_fused")
-    assert len(rep3) == 8                           # <FIRST, MRT, RAGGED>
+    rep3 = inflight.check(device_asm["rk3d"], "rk3dq_fused", workers=os.cpu_count() or 1)
+    assert len(rep3) == 16                          # <FIRST, MRT, RAGGED, PIN>
     for n, (nloads, bad, _h) in rep3.items():
         # every instance walked to the end, the steady-state ones (the kernel that runs every step but the first) included: where the
         # path-by-path walk exceeds its budget -- their 19 per-direction branches -- check() repeats it with one in-flight list per

@@ -97,6 +97,16 @@ def test_rk3d_ini(tmp_path):
     assert p["relax"] == "MRT" and p["AkR"] == 7.0e-3 and p["tauB"] == 0.9 and p["velocityZB"] == -1.0e-4
     assert p["SolidRhoR"] == 0.7 and p["densityRL"] == 1.0e-8 and not p["image"]
     assert p["cycle"] is False and p["last_step"] == 350          # [CyclesSetup] as shipped (RKtwophasesetup3D.ini:57-59)
+    assert p["inlet"] == "Neumann"
+    import re
+    ini = tmp_path / "RKtwophasesetup3D.ini"
+    text = ini.read_text()
+    ini.write_text(re.sub(r"(?m)^(\s*BoundaryTypeInlet\s*=).*$", r"\1 'Dirichlet'\ndensityRH = 1e-8\ndensityBH = 1.003", text))
+    q = config.read_rk3d(str(tmp_path))
+    assert q["inlet"] == "Dirichlet" and q["densityBH"] == 1.003 and q["densityRH"] == 1e-8
+    ini.write_text(re.sub(r"(?m)^(\s*BoundaryTypeOutlet\s*=).*$", r"\1 'Convective'", text))
+    with pytest.raises(config.ConfigError, match="Convective"):
+        config.read_rk3d(str(tmp_path))
     write_rk3d(str(tmp_path), alpha="0.2")          # read, warned about, without effect (AcceleratedRKGPU2D.py:1140: loaded, never used)
     with pytest.warns(UserWarning, match="no effect"):
         assert config.read_rk3d(str(tmp_path))["AlphaR"] == 0.2

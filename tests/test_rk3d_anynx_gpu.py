@@ -95,6 +95,32 @@ def test_any_nx_slabs_equal_the_single_domain_bitwise(nx, walls, env, k, monkeyp
     ref.close(); c.close()
 
 
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+@pytest.mark.parametrize("nx,layout", [(64, "q23"), (100, "q23"), (40, "dense"), (64, "compact38")])
+def test_pressure_inlet_against_the_oracle(nx, layout, relax, monkeypatch):
+    """BoundaryTypeInlet = 'Dirichlet' (Zou-He pressure per colour on the plane nz-2; rk3dq_fused<.., PIN>): every storage vs the oracle,
+    two slabs; the prescribed densities stand on the inlet plane"""
+    from openlbmpm_amd.rk3d import RK3DCluster
+    from oracle.rk3d import RK3DOracle
+    for k, v in {"dense": {"LBMPM_RK3D_LAYOUT": "dense"}, "compact38": {"LBMPM_RK3D_STORAGE": "38"}}.get(layout, {}).items():
+        monkeypatch.setenv(k, v)
+    dom = _dom(nx, 14, 30, walls=True)
+    rR, rB = _two_colours(dom)
+    par = dict(tauR=0.9, tauB=1.1, relax=relax, inlet="Dirichlet", densityRH=0.3, densityBH=0.75)
+    c = RK3DCluster(dom, 2, par)
+    c.set_density(rR, rB)
+    o = RK3DOracle(dom, rR, rB, par)
+    for n in (1, 14):
+        c.step(n); o.run(n)
+        c.observe(); o.macro()
+        umax = max(float(np.max(np.abs(o.field(f)))) for f in ("vx", "vy", "vz"))
+        for f in FIELDS:
+            assert rel_err(c.get(f), o.field(f), scale=umax if f[0] == "v" else None) < 1e-10, (f, n)
+    top = dom[-2] == 1
+    assert np.all(c.get("rhoR")[-2][top] == 0.3) and np.allclose(c.get("rhoB")[-2][top], 0.75, rtol=0, atol=1e-15)
+    c.close()
+
+
 def test_a_lattice_wider_than_the_packed_coordinates_is_refused():
     """advisor, round 5: rk3dq_fused packs a thread's lattice coordinates into signed 16-bit fields"""
     from openlbmpm_amd._lib import LbmpmError, ERR_INVALID

@@ -176,3 +176,44 @@ def test_hip_default_weights_equal_the_pinned_2d_oracle(relax_slabs):
     ref = {f: o2.dense(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy")}
     check_against(got, ref, dom2, ny, "default weights")
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["q23", "dense"])
+def test_pressure_inlet_reduces_to_the_2d_loops_pressure_inlet(layout, monkeypatch):
+    """[BoundaryCondition] BoundaryTypeInlet = 'Dirichlet' in 3-D (round 6: lbmpm_rk3d_config.inlet_type; the z-plane form of
+    calConstPressureInletGPU, AcceleratedRKGPU2D.py:925-962, ghost plane :968-1002).  No capture of the real 2-D driver runs that inlet
+    in the perturbation loop; the chain of pins is: the reference's kernel -> its same-named entry point (rkpert / kats fixtures, 1e-13)
+    -> rk2dp_fused with the pressure inlet (tests/test_rk2d_pert_gpu.py, 1e-9) -> this test: a y-uniform D3Q19 lattice through
+    rk3dq_fused / rk3d_fused AND through oracle/rk3d_oracle.c, with the projection-exact recolouring weights, against rk2dp_fused."""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.rk3d import RK3DCluster
+    d, dom2, par2, par3 = scenario("srt_capillary")
+    ny, steps = 4, 60
+    pin = dict(inlet="Dirichlet", densityRH=1.0e-8, densityBH=1.004)
+    rR2 = dense2(d, d["init_rhoR"]); rB2 = dense2(d, d["init_rhoB"])
+    o2 = RKPertOracle(dom2, par2, rhoR0=rR2, rhoB0=rB2)                      # (only for its node tables: unstream)
+    nxy = dom2.shape
+    def dense_pdf(compact):
+        out = np.zeros(nxy[0] * nxy[1] * 9).reshape(-1, 9)
+        out[d["fluidNodes"]] = compact
+        return out.reshape(nxy + (9,))
+    s2 = RK2DSolver(dom2, dict(beta=par2["beta"], tauR=par2["tauR"], tauB=par2["tauB"], relax="SRT", inlet="Dirichlet", outlet="Dirichlet",
+                               rhoRH=pin["densityRH"], rhoBH=pin["densityBH"], rhoRL=par2["rhoRL"], rhoBL=par2["rhoBL"]),
+                    diagnostics=True, perturbation=dict(AkR=par2["AkR"], AkB=par2["AkB"], solidPhi=par2["solidPhi"]))
+    s2.set_pdf(dense_pdf(unstream(rR2, o2)), dense_pdf(unstream(rB2, o2)))
+    s2.step(steps + 1)
+    ref = {f: s2.get(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy")}
+    s2.close()
+    assert np.isfinite(ref["phi"]).all() and float(np.max(np.abs(ref["vy"]))) > 1e-5       # the pressure difference drives a flow
+    if layout == "dense":
+        monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")
+    par = dict(par3, **RC_EXACT, **pin)
+    c = RK3DCluster(extrude(dom2, ny), 2, par)
+    assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if layout == "q23" else "rk3d_fused")
+    c.set_density(extrude(rR2, ny), extrude(rB2, ny))
+    c.step(steps); c.observe()
+    check_against({f: c.get(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz")}, ref, dom2, ny, ("pressure inlet", layout))
+    c.close()
+    o3 = RK3DOracle(extrude(dom2, ny), extrude(rR2, ny), extrude(rB2, ny), par).run(steps).macro()
+    check_against({f: o3.field(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz")}, ref, dom2, ny, "pressure inlet, oracle")
