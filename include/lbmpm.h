@@ -312,12 +312,10 @@ int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
  * Scope of the 3-D model against SURVEY.md 8 a17 ("extend a3-a11 to D3Q19").  Built: streaming + half-way bounce-back, densities /
  * phase field / velocity, solid phase field (SolidRhoR, SolidRhoB), isotropic gradient, BGK and MRT, perturbation operator,
  * recolouring, velocity inlet and pressure outlet as z planes with their ghost planes -- everything IniFiles/RKtwophasesetup3D.ini
- * parametrises -- plus state in / out and restart (below).  NOT built, and refused where a caller could ask for them
- * (openlbmpm_amd/config.py::read_rk3d raises ConfigError naming the key; there is no field for them in this struct):
- *   - [BoundaryCondition] BoundaryTypeOutlet = 'Convective' (2-D: AcceleratedRKGPU2D.py:700-784: the three lowest rows take the
- *     streamed populations of the fourth) as a z-plane rule: no 3-D ini selects it, and in the marching kernel it is not a boundary
- *     closure but three planes collided on another plane's pulls.  (The pressure INLET, :925-962, is built since round 6:
- *     inlet_type, pinned by reduction to the 2-D fused loop, whose kernels are pinned to the reference's one by one.)
+ * parametrises -- plus, since round 6, the loop's other two boundary kernels as z-plane rules: the pressure INLET per colour
+ * (AcceleratedRKGPU2D.py:925-962, inlet_type) and the convective OUTLET (:700-784, outlet_type), each pinned by reduction to the 2-D fused
+ * loop, whose kernels are pinned to the reference's one by one; and state in / out and restart (below).  NOT built (there is no field
+ * for them in this struct, and the 3-D ini has no key that would ask for them):
  *   - [SurfaceTension] SurfaceTensionType = 'CSF' in 3-D (curvature force, 2-D: :2499-2551) with its wetting rules (:2430): the 3-D ini
  *     carries the perturbation parameters AkR / AkB and no surface-tension section at all;
  *   - body force: read and never used by the reference's colour-gradient loops.
@@ -344,6 +342,11 @@ typedef struct lbmpm_rk3d_config {
                                  * recolor_axis = 1/9 - 2/(36 sqrt 2) makes a y-uniform lattice project exactly onto the
                                  * reference's D2Q9 perturbation loop (tests/test_rk3d_reduction.py) */
     double inlet_rho_r, inlet_rho_b;    /* densityRH, densityBH (pressure inlet only) */
+    int32_t outlet_type;        /* [BoundaryCondition] BoundaryTypeOutlet: LBMPM_OUTLET_PRESSURE 'Dirichlet' (the shipped ini; outlet_rho_*) |
+                                 * LBMPM_OUTLET_CONVECTIVE 'Convective': the planes z = 2, 1, 0 take the streamed populations of plane 3 and
+                                 * re-sum their densities (AcceleratedRKGPU2D.py:700-784 as z planes).  Needs the masks of the planes
+                                 * z = 0 .. 3 to coincide, nz_global >= 8, and the lattice's bottom slab to own >= 6 planes */
+    int32_t reserved;
 } lbmpm_rk3d_config;
 
 typedef struct lbmpm_rk3d lbmpm_rk3d;

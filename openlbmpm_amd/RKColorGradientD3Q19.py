@@ -29,7 +29,7 @@ from .results import RecordGuard, ResultFile, find_result_file, read_planes
 from .rk3d import RK3DSlab, RK3DDistributed
 
 PARAM_KEYS = ("AkR", "AkB", "beta", "tauR", "tauB", "SolidRhoR", "SolidRhoB", "velocityZR", "velocityZB",
-              "densityRL", "densityBL", "relax", "inlet", "densityRH", "densityBH")
+              "densityRL", "densityBL", "relax", "inlet", "densityRH", "densityBH", "outlet")
 GROUPS = (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity"))
 
 

@@ -71,7 +71,8 @@ class RK3DConfig(C.Structure):
                [(n, C.c_double) for n in ("ak_r", "ak_b", "beta", "tau_r", "tau_b", "solid_phi", "inlet_vz_r",
                                           "inlet_vz_b", "outlet_rho_r", "outlet_rho_b")] + \
                [("device", C.c_int32), ("variant", C.c_int32), ("relaxation", C.c_int32), ("inlet_type", C.c_int32),
-                ("recolor_axis", C.c_double), ("recolor_diag", C.c_double), ("inlet_rho_r", C.c_double), ("inlet_rho_b", C.c_double)]
+                ("recolor_axis", C.c_double), ("recolor_diag", C.c_double), ("inlet_rho_r", C.c_double), ("inlet_rho_b", C.c_double),
+                ("outlet_type", C.c_int32), ("reserved", C.c_int32)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # lbmpm_rk3d_exchange_fn

@@ -151,8 +151,9 @@ def read_rk3d(ini_dir):
     p["densityBH"] = c.float("BoundaryCondition", "densityBH", default=1.0)
     if p["inlet"] == "Dirichlet" and not (p["densityRH"] > 0.0 and p["densityBH"] > 0.0):
         raise ConfigError("3-D pressure inlet: densityRH and densityBH must be positive (the closure divides by them; the absent colour gets e.g. 1e-8)")
-    if c.str("BoundaryCondition", "BoundaryTypeOutlet") != "Dirichlet":
-        raise ConfigError("3-D outlet: only BoundaryTypeOutlet = 'Dirichlet' ('Convective', AcceleratedRKGPU2D.py:700-784, is not built as a z-plane rule: include/lbmpm.h)")
+    p["outlet"] = c.str("BoundaryCondition", "BoundaryTypeOutlet")
+    if p["outlet"] not in ("Dirichlet", "Convective"):
+        raise ConfigError("3-D outlet: BoundaryTypeOutlet = 'Dirichlet' (densityRL / densityBL) or 'Convective' (the planes 0 .. 2 copy plane 3)")
     p["velocityZR"] = c.float("BoundaryCondition", "velocityZR", default=0.0)
     p["velocityZB"] = c.float("BoundaryCondition", "velocityZB", default=0.0)
     p["densityBL"] = c.float("BoundaryCondition", "densityBL", default=1.0)

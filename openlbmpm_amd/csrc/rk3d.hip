@@ -76,6 +76,11 @@ struct RK3Dev {
 #ifdef LBMPM_DEV                       // development builds only (tools/dev/devlib.py); the product library has neither
     unsigned long long *trace;        // LBMPM_RK3D_TRACE: four words per workgroup of rk3dq_fused (start, prologue done, end, planes)
 #endif
+    int halo_lo;                      // planes zl <= halo_lo are not this launch's to compute: their phase field is read from `phi`, their stored state
+                                      // pulled from as it stands -- 0: the halo plane below the slab; 3 on the lattice's bottom rank with the
+                                      // convective outlet (the planes z = 0, 1, 2 take the streamed populations of plane 3: rk3d_state.h / conv kernels)
+    int conv;                         // [BoundaryCondition] BoundaryTypeOutlet = 'Convective' (A:700-784 as z planes): the planes z = 2, 1, 0 take the
+                                      // streamed populations of plane 3 and re-sum their densities, no pressure rule on plane 1 (source_plane_x)
     int inletP;                       // 0 velocity inlet: vzR, vzB are velocities; 1 pressure inlet per colour: vzR, vzB hold densityRH, densityBH
                                       // (one pair of kernel arguments for both, and this word behind everything else: the marching kernel's
                                       // argument loads and registers stay what they were -- it has no scalar register to spare)
@@ -151,6 +156,15 @@ __device__ __forceinline__ int source_plane(const RK3Dev &p, int zl)
     return zg == p.nzg - 1 ? zl - 1 : (zg == 0 ? zl + 1 : zl);
 }
 
+// ... with the convective outlet (the 38-value dense kernels, the diagnostics and set-up kernels; NOT the marching kernel of the
+// 23-value storage, which never computes those planes: rk3dq_conv_*)
+__device__ __forceinline__ int source_plane_x(const RK3Dev &p, int zl)
+{
+    const int zg = p.z0 + zl - 1;
+    if (p.conv && zg <= 2) return zl + (3 - zg);
+    return source_plane(p, zl);
+}
+
 __device__ __forceinline__ double sum19(const double f[Q])
 {
     double r = 0.;
@@ -209,7 +223,7 @@ __device__ __forceinline__ void zouhe_outlet(double rho, double f[Q])
 // boundary planes: Zou-He per colour on the pulled populations of plane zl (pulled around source_plane(zl))
 __device__ __forceinline__ void finish_state3(const RK3Dev &p, int zl, double fR[Q], double fB[Q], double &rR, double &rB)
 {
-    const int zg = p.z0 + zl - 1, zsg = p.z0 + source_plane(p, zl) - 1;
+    const int zg = p.z0 + zl - 1, zsg = p.z0 + source_plane_x(p, zl) - 1;
     rR = sum19(fR);
     rB = sum19(fB);
     if (zsg == p.nzg - 2) {
@@ -232,7 +246,7 @@ __device__ __forceinline__ void finish_state3(const RK3Dev &p, int zl, double fR
 __device__ __forceinline__ void node_state3(const RK3Dev &p, const Cell &c, int zl, double fR[Q], double fB[Q], double &rR,
                                             double &rB)
 {
-    const int zs = source_plane(p, zl);
+    const int zs = source_plane_x(p, zl);
     if (p.first) pull3<true>(p, c, zs, 0u, fR, fB);
     else pull3<false>(p, c, zs, load_meta(p, zs, c.o[1][1]), fR, fB);
     finish_state3(p, zl, fR, fB, rR, rB);
@@ -711,7 +725,7 @@ __device__ __forceinline__ int ring_coord(int g, int n) { return g < -1 || g > n
 __device__ __forceinline__ unsigned plane_meta(const RK3Dev &p, int zl, unsigned own)
 {
     if (zl < 1 || zl > p.nzl) return 0u;
-    return load_meta(p, source_plane(p, zl), own);
+    return load_meta(p, source_plane_x(p, zl), own);
 }
 
 // phase field of a cell of plane zl for the ring; leaves the pulled, boundary-corrected populations
@@ -722,7 +736,7 @@ __device__ __forceinline__ double ring_phi(const RK3Dev &p, const Cell &c, int z
 {
     if (zl == 0 || zl == p.nzl + 1) return (p.phi + (size_t)zl * p.plane2)[c.o[1][1] >> 3];   // neighbour rank's plane (or outside: solidPhi)
     if (!(meta >> 31)) return p.solidPhi;
-    pull3<FIRST>(p, c, source_plane(p, zl), meta, fR, fB);
+    pull3<FIRST>(p, c, source_plane_x(p, zl), meta, fR, fB);
     finish_state3(p, zl, fR, fB, rR, rB);
     return (rR - rB) / (rR + rB);
 }
@@ -1169,6 +1183,10 @@ struct lbmpm_rk3d {
     double *send_up = nullptr, *send_dn = nullptr, *recv_below = nullptr, *recv_above = nullptr;
     std::vector<uint8_t> h_domain;   // owned planes only, [nzl][ny][nx]
     // compact storage (fluid cells only): default whenever nx is a multiple of 64; LBMPM_RK3D_LAYOUT=dense overrides
+    // [BoundaryCondition] BoundaryTypeOutlet = 'Convective'; conv_lo: on the slab that holds the lattice's bottom, the local index of the last
+    // of the three planes that copy plane 3 (3), else 0
+    bool conv = false;
+    int conv_lo = 0;
     bool compact = false;
     // q23: compact storage of 19 colour-blind populations + {k_R, A} per cell instead of 2 x 19 (rk3dq.h); default on compact
     // storage, LBMPM_RK3D_STORAGE=38 keeps the 38-value kernels (the cross-check)
@@ -1221,6 +1239,8 @@ RK3Dev make_dev(const lbmpm_rk3d *c)
     p.ak = (c->cfg.ak_r + c->cfg.ak_b) * 0.5; p.beta = c->cfg.beta; p.cR = 1. / (2. * (c->cfg.tau_r - 0.5)); p.cB = 1. / (2. * (c->cfg.tau_b - 0.5));
     p.solidPhi = c->cfg.solid_phi; p.vzR = c->cfg.inlet_vz_r; p.vzB = c->cfg.inlet_vz_b;
     p.rhoOutR = c->cfg.outlet_rho_r; p.rhoOutB = c->cfg.outlet_rho_b;
+    p.conv = c->conv ? 1 : 0;
+    p.halo_lo = 0;
     p.inletP = c->cfg.inlet_type == LBMPM_INLET_PRESSURE ? 1 : 0;
     if (p.inletP) { p.vzR = c->cfg.inlet_rho_r; p.vzB = c->cfg.inlet_rho_b; }
     p.rcA = c->cfg.beta * (c->cfg.recolor_axis > 0. ? c->cfg.recolor_axis : 1. / 18.);
@@ -1277,6 +1297,19 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
 #endif
     LBMPM_REQUIRE(variant == 0 || variant == 1, "lbmpm_rk3d_create: variant must be 0 (fused) or 1 (split)");
     LBMPM_REQUIRE(cfg->relaxation == 0 || cfg->relaxation == 1, "lbmpm_rk3d_create: relaxation must be 0 (SRT) or 1 (MRT)");
+    LBMPM_REQUIRE(cfg->outlet_type == LBMPM_OUTLET_PRESSURE || cfg->outlet_type == LBMPM_OUTLET_CONVECTIVE, "lbmpm_rk3d_create: outlet_type must be LBMPM_OUTLET_PRESSURE or LBMPM_OUTLET_CONVECTIVE");
+    if (cfg->outlet_type == LBMPM_OUTLET_CONVECTIVE) {
+        LBMPM_REQUIRE(cfg->nz_global >= 8 && (cfg->z_offset == 0 ? cfg->nz_local >= 6 : cfg->z_offset >= 6),
+                      "lbmpm_rk3d_create: the convective outlet needs nz >= 8 and the lattice's bottom slab to own the planes 0 .. 5 at least (slab [%lld, %lld))",
+                      (long long)cfg->z_offset, (long long)(cfg->z_offset + cfg->nz_local));
+        LBMPM_REQUIRE(cfg->variant == 0 && !getenv("LBMPM_RK3D_VARIANT"), "lbmpm_rk3d_create: the convective outlet runs the fused schedule only");
+        if (cfg->z_offset == 0) {
+            const size_t hp = (size_t)cfg->nx * cfg->ny;
+            for (int z = 2; z <= 4; ++z)        // (with-halo array: global plane g is plane g + 1)
+                LBMPM_REQUIRE(memcmp(is_domain_with_halo + hp, is_domain_with_halo + (size_t)z * hp, hp) == 0,
+                              "lbmpm_rk3d_create: the convective outlet copies plane 3 onto the planes 2, 1, 0: their masks must coincide (plane %d differs from plane 0)", z - 1);
+        }
+    }
     LBMPM_REQUIRE(cfg->inlet_type == LBMPM_INLET_VELOCITY || (cfg->inlet_type == LBMPM_INLET_PRESSURE && cfg->inlet_rho_r > 0. && cfg->inlet_rho_b > 0.),
                   "lbmpm_rk3d_create: inlet_type must be LBMPM_INLET_VELOCITY or LBMPM_INLET_PRESSURE with positive densityRH / densityBH (the Zou-He pressure plane divides by them)");
     LBMPM_REQUIRE(cfg->recolor_axis >= 0. && cfg->recolor_diag >= 0. && cfg->recolor_axis < 1. && cfg->recolor_diag < 1.,
@@ -1292,12 +1325,15 @@ extern "C" int lbmpm_rk3d_create(const lbmpm_rk3d_config *cfg, const uint8_t *is
 #ifdef LBMPM_DEV
     if (const char *e = getenv("LBMPM_RK3D_BOUNDARY")) c->boundary = atoi(e) >= 2 ? atoi(e) : 2;
 #endif
+    c->conv = cfg->outlet_type == LBMPM_OUTLET_CONVECTIVE;
+    c->conv_lo = c->conv && cfg->z_offset == 0 ? 3 : 0;
     // compact storage: the 23-value form for any nx (row segments of <= 64 cells, seg_x0); the 38-value cross-check keeps whole 64-cell segments
     c->compact = variant == 0;
     if (const char *e = getenv("LBMPM_RK3D_LAYOUT")) if (!strcmp(e, "dense")) c->compact = false;
     c->q23 = c->compact && c->tile == 0;
     if (const char *e = getenv("LBMPM_RK3D_STORAGE")) if (atoi(e) == 38) c->q23 = false;
     if (!c->q23 && c->nx % 64 != 0) c->compact = false;
+    if (c->conv && !c->q23) c->compact = false;      // (the 38-value compact kernels stage their row records too few planes ahead for the copied planes)
     // (the marching kernel packs a thread's lattice coordinates into 16-bit fields: rk3dq.h::sgeo)
     if (c->q23 && (c->nx > 32767 || c->ny > 32767)) {
         set_error("lbmpm_rk3d_create: nx and ny must not exceed 32767 (%d x %d)", c->nx, c->ny);
@@ -1805,6 +1841,26 @@ void launch_q23(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int
 void launch_step_range(lbmpm_rk3d *c, const RK3Dev &p, hipStream_t st, int z_first, int z_last)
 {
     if (z_last < z_first) return;
+    if (c->q23 && c->conv_lo > 0) {
+        // convective outlet (rk3dq.h, "convective outlet"): the launch that owns plane zs = conv_lo + 1 also does the planes below it
+        const int zs = c->conv_lo + 1;
+        if (z_last < zs) return;                           // (a range of copied planes only: done with plane zs)
+        if (z_first <= zs) {
+            const dim3 block(BX3, BY3);
+            const unsigned gy = (unsigned)((c->ny + BY3 - 1) / BY3);
+            RK3Dev q = p;
+            q.diag = nullptr;
+            rk3dq_phase_field<<<dim3(c->nseg, gy, 1), block, 0, st>>>(q, zs);
+            rk3dq_conv_phi<<<dim3((unsigned)((c->plane2 + 255) / 256)), dim3(256), 0, st>>>(q, zs);
+            RK3Dev m = p;
+            m.halo_lo = c->conv_lo;
+            launch_q23(c, m, st, zs, z_last, 1, 0);
+            dispatch2(p.first != 0, p.mrt != 0, [&](auto first, auto mrt) {
+                rk3dq_conv_collide<decltype(first)::value, decltype(mrt)::value><<<dim3(c->nseg, gy, 2), block, 0, st>>>(p, zs);
+            });
+            return;
+        }
+    }
     if (c->q23) { launch_q23(c, p, st, z_first, z_last, 1, 0); return; }
     if (c->compact) {
         if (c->tile == 1) launch_fused_c<4>(c, p, st, z_first, z_last);

@@ -623,7 +623,7 @@ __global__ __launch_bounds__(512, 1) void rk3dq_fused(RK3Dev p, int tilesX, int 
         put_rows(z + 5, staged);
         SRec e0, e1;
         fetch_s(z + 3, e0, e1);                 // in LDS before this step's barrier, read from the next step on
-        const bool halo_n = zn <= 0 || zn >= p.nzl + 1, ghost_n = !halo_n && is_ghost(zn);
+        const bool halo_n = zn <= p.halo_lo || zn >= p.nzl + 1, ghost_n = !halo_n && is_ghost(zn);
         const bool fill_gb = !halo_n && !ghost_n && zn - 1 == zl_gb && zn - 1 >= 1;     // the bottom ghost's phase field = this plane's
         // ---- plane z + 1, rim cells: phase field only
         if (wave < 3) {
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_phase_field(RK3Dev p, int zl0)
     if (y >= p.ny || x < 0) return;
     const size_t idx = (size_t)zl * p.plane2 + (size_t)y * p.pitch + x;
     if (!(p.flags[idx] & 1)) return;
-    const int zs = source_plane(p, zl);
+    const int zs = source_plane_x(p, zl);          // (convective outlet: the planes z <= 2 are plane 3's streamed populations)
     const unsigned b = threadIdx.x;
     double g[Q], rR, rho;
     unsigned j;
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_phase_field(RK3Dev p, int zl0)
         pull_q<false, false>(p, rows, zs, b, g, j);
         class_sums<false, false>(p, rows, glb_scal(p, plane_addr_q(p, p.fin, zs), j, zs, sg, y), zs, b, g, S);
     }
-    bc_q<true>(p, zl, S, g, rR, rho);
+    bc_q<true>(p, p.conv && p.z0 + zl - 1 <= 2 ? zs : zl, S, g, rR, rho);
     p.phi[idx] = phi_q(rR, rho);
     if (p.diag) {
         constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
@@ -819,6 +819,61 @@ __global__ __launch_bounds__(BX3 *BY3) void rk3dq_phase_field(RK3Dev p, int zl0)
         p.diag[idx] = rR; p.diag[p.vol + idx] = rho - rR;
         p.diag[2 * p.vol + idx] = mx / rho; p.diag[3 * p.vol + idx] = my / rho; p.diag[4 * p.vol + idx] = mz / rho;
     }
+}
+
+// ---------------------------------------------------------------------------------------------- convective outlet
+// [BoundaryCondition] BoundaryTypeOutlet = 'Convective' (AcceleratedRKGPU2D.py:700-784: convectiveOutletGPU, ...Ghost2GPU, ...Ghost3GPU copy
+// the streamed populations of row 3 onto the rows 2, 1, 0 and re-sum the densities) as z planes.  The marching kernel does not compute
+// those planes at all: on the slab that holds the lattice's bottom it starts at plane 3 (local zs) and takes the planes below as it takes a
+// neighbour rank's halo plane (RK3Dev::halo_lo) -- phase field from `phi`, stored state as it stands.  Around it, per step:
+//   before:  rk3dq_phase_field on plane zs (the streamed lattice's phase field there), rk3dq_conv_phi copies it onto the planes below;
+//   after:   rk3dq_conv_collide collides the planes zs-1, zs-2 (z = 2, 1; the ghost plane z = 0 is neither collided nor stored, as ever)
+//            from the populations pulled around plane zs, with the colour gradient of the copied phase field.
+// The masks of the planes z = 0 .. 3 must coincide (lbmpm_rk3d_create checks): cell numbers and row records are then the same.
+__global__ __launch_bounds__(256) void rk3dq_conv_phi(RK3Dev p, int zs)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.plane2 || !(p.flags[(size_t)zs * p.plane2 + k] & 1)) return;
+    const double v = p.phi[(size_t)zs * p.plane2 + k];
+    for (int zl = zs - 3; zl < zs; ++zl) p.phi[(size_t)zl * p.plane2 + k] = v;
+}
+
+template <bool FIRST, bool MRT>
+__global__ __launch_bounds__(BX3 *BY3) void rk3dq_conv_collide(RK3Dev p, int zs)
+{
+    constexpr int CX[Q] = LBMPM_D3Q19_CX, CY[Q] = LBMPM_D3Q19_CY, CZ[Q] = LBMPM_D3Q19_CZ;
+    const int sg = blockIdx.x, x = LBMPM_SEG_LANE_X(p, sg, (int)threadIdx.x), y = blockIdx.y * BY3 + threadIdx.y, zl = zs - 1 - (int)blockIdx.z;
+    if (y >= p.ny) return;
+    const bool fluid = x >= 0 && (p.flags[(size_t)zl * p.plane2 + (size_t)y * p.pitch + x] & 1);
+    if (__ballot(fluid) == 0ull) {        // (a wave = a row segment) nothing here: flag 3, as the marching kernel writes it
+        if (threadIdx.x == 0) p.pur_out[row_index(p, zl, y, sg)] = 3u;
+        return;
+    }
+    if (!fluid) return;
+    const GlobalRows rows{p, sg, y};
+    const unsigned b = threadIdx.x;
+    double g[Q], rR, rho;
+    unsigned js;
+    Sums S;
+    pull_q<FIRST, false>(p, rows, zs, b, g, js);
+    class_sums<FIRST, false>(p, rows, glb_scal(p, plane_addr_q(p, p.fin, zs), js, zs, sg, y), zs, b, g, S);
+    bc_q<true>(p, zs, S, g, rR, rho);             // (plane 3 carries no boundary rule: densities re-summed, A:718-719)
+    // colour gradient of the copied phase field (the planes zl-1, zl, zl+1 all hold plane zs's; non-fluid cells solidPhi)
+    double gx = 0., gy = 0., gz = 0.;
+    const int xs[3] = {wrapi(x - 1, p.nx), x, wrapi(x + 1, p.nx)}, ys[3] = {wrapi(y - 1, p.ny), y, wrapi(y + 1, p.ny)};
+#pragma unroll
+    for (int i = 1; i < Q; ++i) {
+        const double ph = p.phi[(size_t)(zl + CZ[i]) * p.plane2 + (size_t)ys[1 + CY[i]] * p.pitch + xs[1 + CX[i]]];
+        gx += 3. * wq(i) * (double)CX[i] * ph;
+        gy += 3. * wq(i) * (double)CY[i] * ph;
+        gz += 3. * wq(i) * (double)CZ[i] * ph;
+    }
+    const RowTab t = rows(zl, 0);
+    const unsigned j = t.first + bits_below<false>(t.m, b);
+    const unsigned long long p0 = pstart_of(p, zl);
+    const unsigned cnt = (unsigned)(pstart_of(p, zl + 1) - p0);
+    collide_store<2, MRT>(p, reinterpret_cast<char *>(p.fout) + (size_t)p0 * CELLB, cnt * 8u, j * 8u, true, g, rR, rho - rR, gx, gy, gz,
+                          p.pur_out + row_index(p, zl, y, sg));
 }
 
 // ---------------------------------------------------------------------------------------------- slab exchange (one per step)

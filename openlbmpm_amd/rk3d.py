@@ -17,7 +17,8 @@ BUF = dict(f_send_up=0, f_send_down=1, f_recv_below=2, f_recv_above=3,
 DEFAULT_PARAMS = dict(AkR=7.0e-3, AkB=7.0e-3, beta=1.0, tauR=1.0, tauB=1.0, SolidRhoR=0.7, SolidRhoB=0.0,
                       velocityZR=0.0, velocityZB=-1.0e-4, densityRL=1.0e-8, densityBL=1.0, relax="SRT",
                       recolor_axis=0.0, recolor_diag=0.0,      # recolor_*: lbmpm_rk3d_config (0 = the model's own weights)
-                      inlet="Neumann", densityRH=1.0e-8, densityBH=1.0)      # BoundaryTypeInlet 'Dirichlet': pressure inlet per colour
+                      inlet="Neumann", densityRH=1.0e-8, densityBH=1.0,      # BoundaryTypeInlet 'Dirichlet': pressure inlet per colour
+                      outlet="Dirichlet")                                    # BoundaryTypeOutlet 'Convective': planes 0 .. 2 copy plane 3
 
 
 class RK3DSlab:
@@ -52,6 +53,9 @@ class RK3DSlab:
         if p["inlet"] not in ("Neumann", "Dirichlet"):
             raise ValueError("BoundaryTypeInlet must be 'Neumann' or 'Dirichlet'")
         cfg.inlet_type, cfg.inlet_rho_r, cfg.inlet_rho_b = int(p["inlet"] == "Dirichlet"), float(p["densityRH"]), float(p["densityBH"])
+        if p["outlet"] not in ("Dirichlet", "Convective"):
+            raise ValueError("BoundaryTypeOutlet must be 'Dirichlet' or 'Convective'")
+        cfg.outlet_type = int(p["outlet"] == "Convective")
         self._h = C.c_void_p()
         check(L.lbmpm_rk3d_create(C.byref(cfg), halo.ctypes.data_as(U8P), C.byref(self._h)), "lbmpm_rk3d_create")
         self._L = L

@@ -16,12 +16,12 @@ class _Sim(C.Structure):
                                           "rhoOutR", "rhoOutB")] + \
                [("mrt", C.c_int)] + \
                [(n, F64P) for n in ("fR", "fB", "gR", "gB", "rhoR", "rhoB", "phi", "vx", "vy", "vz", "Gx", "Gy", "Gz")] + \
-               [("rcA", C.c_double), ("rcD", C.c_double), ("inletP", C.c_int), ("rhoInR", C.c_double), ("rhoInB", C.c_double)]
+               [("rcA", C.c_double), ("rcD", C.c_double), ("inletP", C.c_int), ("rhoInR", C.c_double), ("rhoInB", C.c_double), ("conv", C.c_int)]
 
 
 DEFAULT_PARAMS = dict(AkR=7.0e-3, AkB=7.0e-3, beta=1.0, tauR=1.0, tauB=1.0, SolidRhoR=0.7, SolidRhoB=0.0,
                       velocityZR=0.0, velocityZB=-1.0e-4, densityRL=1.0e-8, densityBL=1.0, relax="SRT",
-                      inlet="Neumann", densityRH=1.0e-8, densityBH=1.0)
+                      inlet="Neumann", densityRH=1.0e-8, densityBH=1.0, outlet="Dirichlet")
 
 
 class RK3DOracle:
@@ -45,6 +45,7 @@ class RK3DOracle:
         s.mrt = 1 if p["relax"] == "MRT" else 0
         s.rcA, s.rcD = float(p.get("recolor_axis", 0.0)), float(p.get("recolor_diag", 0.0))
         s.inletP, s.rhoInR, s.rhoInB = int(p["inlet"] == "Dirichlet"), float(p["densityRH"]), float(p["densityBH"])
+        s.conv = int(p["outlet"] == "Convective")
         self._names = ("fR", "fB", "gR", "gB", "rhoR", "rhoB", "phi", "vx", "vy", "vz", "Gx", "Gy", "Gz")
         for name in self._names:
             setattr(s, name, getattr(self, "_" + name).ctypes.data_as(F64P))

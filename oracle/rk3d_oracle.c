@@ -72,6 +72,8 @@ typedef struct {
     int inletP;                  /* 0: Zou-He velocity inlet (vzR, vzB); 1: Zou-He PRESSURE inlet per colour (rhoInR, rhoInB), the z-plane
                                     form of calConstPressureInletGPU, AcceleratedRKGPU2D.py:925-962, ghost plane as :968-1002 */
     double rhoInR, rhoInB;
+    int conv;                    /* 1: convective outlet, AcceleratedRKGPU2D.py:700-784 as z planes: the planes 2, 1, 0 take the streamed
+                                    populations of plane 3 (cell by cell; same masks) and re-sum their densities; no pressure rule on plane 1 */
 } rk3d_sim;
 
 static i64 wrap(i64 v, i64 n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
@@ -152,7 +154,18 @@ static void rk3d_bc_and_macro(rk3d_sim *s)
             else { s->rhoR[g] = sum19(s->fR + Q * g); s->rhoB[g] = sum19(s->fB + Q * g); }
         }
     }
-    for (i64 k = 0; k < pl; ++k) {          /* outlet plane 1, ghost 0 */
+    if (s->conv) {
+        for (i64 z = 2; z >= 0; --z)
+            for (i64 k = 0; k < pl; ++k) {
+                i64 n = z * pl + k, up = (z + 1) * pl + k;
+                if (!s->dom[n]) continue;
+                memcpy(s->fR + Q * n, s->fR + Q * up, sizeof(double) * Q);
+                memcpy(s->fB + Q * n, s->fB + Q * up, sizeof(double) * Q);
+                s->rhoR[n] = sum19(s->fR + Q * n);
+                s->rhoB[n] = sum19(s->fB + Q * n);
+            }
+    }
+    for (i64 k = 0; k < pl && !s->conv; ++k) {          /* outlet plane 1, ghost 0 */
         i64 n = pl + k, g = k;
         if (s->dom[n]) {
             zouhe_outlet(s->rhoOutR, s->fR + Q * n); s->rhoR[n] = s->rhoOutR;

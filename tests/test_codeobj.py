@@ -29,7 +29,7 @@ def test_q23_kernels_use_no_scratch_memory(kernels):
     For rk3dq_fused scratch would also mean spill reloads, each followed by s_waitcnt vmcnt(0)."""
     q = {n: m for n, m in kernels.items() if "rk3dq_" in n or "rk3d_state_io" in n}
     # rk3dq_fused<FIRST, MRT, RAGGED, PIN>: sixteen instances; rk3d_state_io<storage, mode>: fifteen
-    assert len(q) >= 9 + 15 and sum("rk3dq_fused" in n for n in q) == 16 and sum("rk3d_state_io" in n for n in q) == 15
+    assert len(q) >= 9 + 15 + 5 and sum("rk3dq_fused" in n for n in q) == 16 and sum("rk3d_state_io" in n for n in q) == 15 and sum("rk3dq_conv" in n for n in q) == 5
     for n, m in q.items():
         assert m[".private_segment_fixed_size"] == 0, n
         assert m[".vgpr_spill_count"] == 0, n          # (scalar registers may spill into vector-register lanes: no memory involved)

@@ -105,6 +105,8 @@ def test_rk3d_ini(tmp_path):
     q = config.read_rk3d(str(tmp_path))
     assert q["inlet"] == "Dirichlet" and q["densityBH"] == 1.003 and q["densityRH"] == 1e-8
     ini.write_text(re.sub(r"(?m)^(\s*BoundaryTypeOutlet\s*=).*$", r"\1 'Convective'", text))
+    assert config.read_rk3d(str(tmp_path))["outlet"] == "Convective"
+    ini.write_text(re.sub(r"(?m)^(\s*BoundaryTypeOutlet\s*=).*$", r"\1 'Freeflow'", text))
     with pytest.raises(config.ConfigError, match="Convective"):
         config.read_rk3d(str(tmp_path))
     write_rk3d(str(tmp_path), alpha="0.2")          # read, warned about, without effect (AcceleratedRKGPU2D.py:1140: loaded, never used)

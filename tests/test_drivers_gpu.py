@@ -401,9 +401,9 @@ def test_rk3d_shipped_ini_sizes_run_the_fast_kernel_through_the_cli(tmp_path):
         assert rel_err(res["/" + name], o.field(f)) < 1e-10, name
 
 
-def test_rk3d_driver_with_a_pressure_inlet(tmp_path):
-    """[BoundaryCondition] BoundaryTypeInlet = 'Dirichlet' + densityRH / densityBH (the keys of RKtwophasesetup2D.ini) through the 3-D
-    driver: records equal the oracle's"""
+def test_rk3d_driver_with_a_pressure_inlet_and_a_convective_outlet(tmp_path):
+    """[BoundaryCondition] BoundaryTypeInlet = 'Dirichlet' + densityRH / densityBH (the keys of RKtwophasesetup2D.ini) and
+    BoundaryTypeOutlet = 'Convective' through the 3-D driver: records equal the oracle's"""
     import re
     from ini_fixtures import write_rk3d
     from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D, duct
@@ -412,12 +412,13 @@ def test_rk3d_driver_with_a_pressure_inlet(tmp_path):
     from oracle.rk3d import RK3DOracle
     write_rk3d(str(tmp_path), nx=24, ny=14, nz=40, steps=30, relax="MRT")
     ini = tmp_path / "RKtwophasesetup3D.ini"
-    ini.write_text(re.sub(r"(?m)^(\s*BoundaryTypeInlet\s*=).*$", r"\1 'Dirichlet'\ndensityRH = 1e-8\ndensityBH = 1.004", ini.read_text()))
+    text = re.sub(r"(?m)^(\s*BoundaryTypeInlet\s*=).*$", r"\1 'Dirichlet'\ndensityRH = 1e-8\ndensityBH = 1.004", ini.read_text())
+    ini.write_text(re.sub(r"(?m)^(\s*BoundaryTypeOutlet\s*=).*$", r"\1 'Convective'", text))         # ... and the convective outlet
     sim = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out"), record_every=30)
     res = load_results(sim.runRKColorGradient3D())
     dom = duct(24, 14, 40)
     rR, rB = initial_densities_rk3d(dom, 10)
-    o = RK3DOracle(dom, rR, rB, dict(tauB=0.9, relax="MRT", inlet="Dirichlet", densityRH=1e-8, densityBH=1.004)).run(30).macro()
+    o = RK3DOracle(dom, rR, rB, dict(tauB=0.9, relax="MRT", inlet="Dirichlet", densityRH=1e-8, densityBH=1.004, outlet="Convective")).run(30).macro()
     for name, f in (("FluidMacro/FluidDensityRin1", "rhoR"), ("FluidMacro/FluidDensityBin1", "rhoB"), ("FluidVelocity/FluidVelocityZAt1", "vz")):
         assert rel_err(res["/" + name], o.field(f)) < 1e-10, name
     assert float(np.abs(res["/FluidVelocity/FluidVelocityZAt1"]).max()) > 1e-5

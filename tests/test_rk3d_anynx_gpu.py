@@ -121,6 +121,60 @@ def test_pressure_inlet_against_the_oracle(nx, layout, relax, monkeypatch):
     c.close()
 
 
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+@pytest.mark.parametrize("nx,layout,k", [(64, "q23", 1), (100, "q23", 3), (37, "q23", 2), (40, "dense", 2), (64, "compact38", 1)])
+def test_convective_outlet_against_the_oracle(nx, layout, k, relax, monkeypatch):
+    """BoundaryTypeOutlet = 'Convective' (AcceleratedRKGPU2D.py:700-784 as z planes: the planes 2, 1, 0 take plane 3's streamed
+    populations).  The 23-value storage computes those planes outside its marching kernel (rk3dq_conv_*), the dense layout through the
+    source plane of its pulls; LBMPM_RK3D_STORAGE=38 runs the dense layout here.  Against the oracle from the first step on, k slabs;
+    then a restart from the stored state continues bit for bit."""
+    from openlbmpm_amd.rk3d import RK3DCluster
+    from oracle.rk3d import RK3DOracle
+    for kk, v in {"dense": {"LBMPM_RK3D_LAYOUT": "dense"}, "compact38": {"LBMPM_RK3D_STORAGE": "38"}}.get(layout, {}).items():
+        monkeypatch.setenv(kk, v)
+    from openlbmpm_amd.geometry import porous_spheres
+    dom = porous_spheres(nx, 14, 34, porosity=0.72, rmin=2.0, rmax=5.0, seed=nx, nbuf=4, walls=True)
+    assert all(np.array_equal(dom[0], dom[z]) for z in (1, 2, 3))
+    rR, rB = _two_colours(dom)
+    par = dict(tauR=0.9, tauB=1.1, relax=relax, outlet="Convective", velocityZB=-2.0e-3)
+    c = RK3DCluster(dom, k, par)
+    assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if layout == "q23" else "rk3d_fused")
+    c.set_density(rR, rB)
+    o = RK3DOracle(dom, rR, rB, par)
+    for n in (0, 1, 1, 14):
+        c.step(n); o.run(n)
+        c.observe(); o.macro()
+        umax = max(float(np.max(np.abs(o.field(f)))) for f in ("vx", "vy", "vz"))
+        for f in FIELDS:
+            assert rel_err(c.get(f), o.field(f), scale=umax if f[0] == "v" else None) < 1e-10, (f, c.slabs[0].steps_done)
+    got = {f: c.get(f) for f in FIELDS}
+    for f in ("rhoR", "rhoB", "phi"):          # the copied planes
+        assert np.array_equal(got[f][0], got[f][3]) and np.array_equal(got[f][1], got[f][3]) and np.array_equal(got[f][2], got[f][3]), f
+    st, info = c.get_state()
+    c.step(9); want = {f: v for f, v in ((f, None) for f in FIELDS)}
+    c.observe(); want = {f: c.get(f) for f in FIELDS}
+    c.close()
+    b = RK3DCluster(dom, 1, par)
+    b.set_state(st, info["steps"], info["post_collision"])
+    b.step(9); b.observe()
+    for f in FIELDS:
+        assert np.array_equal(b.get(f), want[f]), ("restart", f)
+    b.close()
+
+
+def test_convective_outlet_needs_equal_masks_on_the_copied_planes():
+    from openlbmpm_amd._lib import LbmpmError, ERR_INVALID
+    from openlbmpm_amd.rk3d import RK3DSlab
+    dom = np.ones((20, 8, 64), dtype=np.uint8)
+    dom[2, 3, 10] = 0
+    with pytest.raises(LbmpmError) as e:
+        RK3DSlab(dom, 0, 20, dict(outlet="Convective"))
+    assert e.value.status == ERR_INVALID and "masks must coincide" in str(e.value)
+    with pytest.raises(LbmpmError) as e:          # a cut through the copied planes
+        RK3DSlab(np.ones((20, 8, 64), dtype=np.uint8), 0, 4, dict(outlet="Convective"))
+    assert e.value.status == ERR_INVALID
+
+
 def test_a_lattice_wider_than_the_packed_coordinates_is_refused():
     """advisor, round 5: rk3dq_fused packs a thread's lattice coordinates into signed 16-bit fields"""
     from openlbmpm_amd._lib import LbmpmError, ERR_INVALID

@@ -217,3 +217,42 @@ def test_pressure_inlet_reduces_to_the_2d_loops_pressure_inlet(layout, monkeypat
     c.close()
     o3 = RK3DOracle(extrude(dom2, ny), extrude(rR2, ny), extrude(rB2, ny), par).run(steps).macro()
     check_against({f: o3.field(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz")}, ref, dom2, ny, "pressure inlet, oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["q23", "dense"])
+def test_convective_outlet_reduces_to_the_2d_loops_convective_outlet(layout, monkeypatch):
+    """[BoundaryCondition] BoundaryTypeOutlet = 'Convective' in 3-D (round 6: lbmpm_rk3d_config.outlet_type): the z-plane form of
+    convectiveOutletGPU / ...Ghost2GPU / ...Ghost3GPU (AcceleratedRKGPU2D.py:700-784).  Chain of pins as for the pressure inlet: the
+    reference's kernels -> their same-named entry points -> rk2dp_fused with the convective outlet (tests/test_rk2d_pert_gpu.py) ->
+    this test, for rk3dq_fused + rk3dq_conv_*, rk3d_fused and oracle/rk3d_oracle.c, with the projection-exact recolouring weights."""
+    from openlbmpm_amd.rk2d import RK2DSolver
+    from openlbmpm_amd.rk3d import RK3DCluster
+    d, dom2, par2, par3 = scenario("srt_capillary")
+    ny, steps = 4, 60
+    rR2 = dense2(d, d["init_rhoR"]); rB2 = dense2(d, d["init_rhoB"])
+    o2 = RKPertOracle(dom2, par2, rhoR0=rR2, rhoB0=rB2)                      # (only for its node tables: unstream)
+    nxy = dom2.shape
+    def dense_pdf(compact):
+        out = np.zeros(nxy[0] * nxy[1] * 9).reshape(-1, 9)
+        out[d["fluidNodes"]] = compact
+        return out.reshape(nxy + (9,))
+    s2 = RK2DSolver(dom2, dict(beta=par2["beta"], tauR=par2["tauR"], tauB=par2["tauB"], relax="SRT", inlet="Neumann", outlet="Convective",
+                               vyR=par2["vyR"], vyB=par2["vyB"]),
+                    diagnostics=True, perturbation=dict(AkR=par2["AkR"], AkB=par2["AkB"], solidPhi=par2["solidPhi"]))
+    s2.set_pdf(dense_pdf(unstream(rR2, o2)), dense_pdf(unstream(rB2, o2)))
+    s2.step(steps + 1)
+    ref = {f: s2.get(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy")}
+    s2.close()
+    assert np.isfinite(ref["phi"]).all()
+    if layout == "dense":
+        monkeypatch.setenv("LBMPM_RK3D_LAYOUT", "dense")
+    par = dict(par3, **RC_EXACT, outlet="Convective")
+    c = RK3DCluster(extrude(dom2, ny), 2, par)
+    assert c.slabs[0].dominant_kernel == ("rk3dq_fused" if layout == "q23" else "rk3d_fused")
+    c.set_density(extrude(rR2, ny), extrude(rB2, ny))
+    c.step(steps); c.observe()
+    check_against({f: c.get(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz")}, ref, dom2, ny, ("convective outlet", layout))
+    c.close()
+    o3 = RK3DOracle(extrude(dom2, ny), extrude(rR2, ny), extrude(rB2, ny), par).run(steps).macro()
+    check_against({f: o3.field(f) for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz")}, ref, dom2, ny, "convective outlet, oracle")
