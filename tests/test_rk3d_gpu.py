@@ -329,7 +329,7 @@ if %r == "nccl":
 else:
     dist.init_process_group("gloo")
 dom, rR, rB = _case(nx=int(os.environ["LBMPM_TEST_NX"]), ny=18, nz=41, seed=9)
-d = RK3DDistributed(dom, device=dev, transport=os.environ["LBMPM_TEST_TRANSPORT"])
+d = RK3DDistributed(dom, json.loads(os.environ.get("LBMPM_TEST_PAR", "{}")) or None, device=dev, transport=os.environ["LBMPM_TEST_TRANSPORT"])
 d.set_density(rR, rB)
 d.step(9); d.step(6, timed=True)
 t = d.timing()
@@ -346,10 +346,10 @@ d.close(); dist.destroy_process_group()
     return fields, [json.load(open(tmp_path / ("t_%d.json" % r))) for r in range(2)]
 
 
-def _single_process_reference(nx=33):
+def _single_process_reference(nx=33, par=None):
     from openlbmpm_amd.rk3d import RK3DCluster
     dom, rR, rB = _case(nx=nx, ny=18, nz=41, seed=9)
-    c = RK3DCluster(dom, 1)
+    c = RK3DCluster(dom, 1, par)
     c.set_density(rR, rB)
     c.step(15); c.observe()
     ref = {f: c.get(f) for f in ("phi", "vz")}
@@ -358,9 +358,10 @@ def _single_process_reference(nx=33):
 
 
 @pytest.mark.parametrize("nx,transport,env", [(33, "callback", {"LBMPM_RK3D_LAYOUT": "dense"}), (64, "callback", None), (64, "ipc", None),
-                                              (64, "ipc", {"LBMPM_IPC_FLAG_KERNELS": "1"}), (96, "ipc", None), (33, "callback", None)],
+                                              (64, "ipc", {"LBMPM_IPC_FLAG_KERNELS": "1"}), (96, "ipc", None), (33, "callback", None),
+                                              (64, "ipc", {"LBMPM_TEST_PAR": '{"outlet": "Convective", "inlet": "Dirichlet", "densityRH": 1e-8, "densityBH": 1.003, "relax": "MRT"}'})],
                          ids=["dense-two-exchanges-callback", "q23-one-exchange-callback", "q23-ipc-stream-value-ops", "q23-ipc-flag-kernels",
-                              "q23-nx96-ipc", "q23-nx33-callback"])
+                              "q23-nx96-ipc", "q23-nx33-callback", "q23-ipc-convective-outlet-pressure-inlet"])
 def test_two_process_slab_run_equals_single_process(tmp_path, nx, transport, env, monkeypatch):
     """The N>1 orchestration of bench.py / RK3DDistributed with two OS processes sharing this one GPU: the gathered result must
     equal the single-process run bit for bit; the per-phase timing is filled in.
@@ -375,14 +376,15 @@ def test_two_process_slab_run_equals_single_process(tmp_path, nx, transport, env
     for k, v in (env or {}).items():
         if k.startswith("LBMPM_RK3D"):
             monkeypatch.setenv(k, v)
-    ref = _single_process_reference(nx)
+    import json
+    ref = _single_process_reference(nx, json.loads((env or {}).get("LBMPM_TEST_PAR", "null")))
     for f in ref:
         assert np.array_equal(got[f], ref[f]), f
     for t in timing:
         assert t["world"] == 2 and t["steps"] == 6 and t["step_ms"] > 0 and t["interior_ms"] > 0 and t["boundary_ms"] > 0
         assert t["bytes_per_face"] > 0 and t["step_ms"] >= t["boundary_ms"]
         if transport == "ipc":
-            assert "in-library ipc" in t["transport"] and ("one-lane flag kernels" if env else "stream value operations") in t["transport"]
+            assert "in-library ipc" in t["transport"] and ("one-lane flag kernels" if env and "LBMPM_IPC_FLAG_KERNELS" in env else "stream value operations") in t["transport"]
         else:
             assert t["transport"] == "callback"
 
