@@ -15,7 +15,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liblbmpm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rk_oracle.c", "rk_pert_oracle.c", "sc_oracle.c", "rk3d_oracle.c", "tr_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rk_oracle.c", "rk_pert_oracle.c", "sc_oracle.c", "rk3d_oracle.c", "rk3d_csf_oracle.c", "tr_oracle.c", "Makefile")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))

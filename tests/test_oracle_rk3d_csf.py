@@ -1,0 +1,212 @@
+"""The pin of the 3-D CSF colour-gradient model (oracle/rk3d_csf_oracle.c): reduction to the reference's D2Q9 CSF loop.
+
+The reference has no 3-D code, but SURVEY.md 8 a17 asks for its 2-D CSF loop (runRKColorGradient2DCSF, RKD2Q9.py:1295-1490) carried to
+D3Q19.  A lattice that is uniform along y (periodic, any ny) projects onto D2Q9 in (x, z) term by term -- the list is in the oracle's
+header -- so with SRT the 3-D code must reproduce
+
+* the capture of the REAL 2-D driver (tests/golden/rk_csf_srt_capillary.npz: wetting rule 2, tau type 2, velocity inlet, pressure outlet)
+  on every recorded field at every snapshot, and
+* the pinned 2-D oracle (oracle/rk_oracle.c, tests/test_oracle_rk.py) on the set-ups the captures hold only with MRT: pressure inlet,
+  convective outlet, tau type 1, a porous image.
+
+Tolerance 1e-9 field-relative (the suite's 2-D bar): the projection holds in exact arithmetic, sums over c_y round differently.
+What the reduction cannot see -- y components, MRT -- is held by the symmetry and BGK-limit tests below.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_params, rel_err
+from oracle.rk import RKOracle, simple_geometry, initial_densities
+from oracle.rk3dcsf import RK3DCSFOracle
+
+CX = np.array([0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 1, -1, 1, -1, 0, 0, 0, 0])
+CY = np.array([0, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 0, 0, 1, -1, 1, -1])
+CZ = np.array([0, 0, 0, 0, 0, 1, -1, 0, 0, 0, 0, 1, -1, -1, 1, 1, -1, -1, 1])
+EX2 = np.array([0, 1, 0, -1, 0, 1, -1, -1, 1])
+EY2 = np.array([0, 0, 1, 0, -1, 1, 1, -1, -1])
+TOL = 1e-9
+# 3-D field -> 2-D field of the (x, z) plane
+PAIRS = (("rhoR", "rhoR"), ("rhoB", "rhoB"), ("phi", "phi"), ("vx", "vx"), ("vz", "vy"), ("Gx", "Gx"), ("Gz", "Gy"),
+         ("Fx", "Fx"), ("Fz", "Fy"), ("K", "K"))
+
+
+def extrude(a2, ny):
+    return np.ascontiguousarray(np.repeat(np.asarray(a2)[:, None, :], ny, axis=1))
+
+
+def project_pdf(f3):
+    """[z][y][x][19] -> [z][x][9] of the plane y = 0: sum over c_y"""
+    out = np.zeros(f3.shape[:1] + f3.shape[2:3] + (9,))
+    for i in range(19):
+        j = int(np.flatnonzero((EX2 == CX[i]) & (EY2 == CZ[i]))[0])
+        out[..., j] += f3[:, 0, :, i]
+    return out
+
+
+def params3(p):
+    return dict(sigma=p["sigma"], theta=p["theta"], wetting=p["wetting"], beta=p["beta"], delta=p["delta"], tauR=p["tauR"], tauB=p["tauB"],
+                tautype=p["tautype"], relax=p["relax"], inlet=p["inlet"], outlet=p["outlet"], velocityZR=p["vyR"], velocityZB=p["vyB"],
+                densityBH=p["rhoBH"], densityRH=p["rhoRH"], densityBL=p["rhoBL"], densityRL=p["rhoRL"])
+
+
+def dense2(o2, a):
+    out = np.zeros((o2.ny * o2.nx,) + a.shape[1:])
+    out[o2.fluidNodes] = a
+    return out.reshape((o2.ny, o2.nx) + a.shape[1:])
+
+
+def compare(o3, ref2, dom2, what):
+    """ref2: name -> dense [z][x] (or [z][x][9] for fR, fB)"""
+    fl = dom2 == 1
+    worst = 0.0
+    umax = max(float(np.max(np.abs(ref2[n][fl]))) for n in ("vx", "vy"))
+    gmax = max(float(np.max(np.abs(ref2[n][fl]))) for n in ("Gx", "Gy"))
+    fmax = max(float(np.max(np.abs(ref2[n][fl]))) for n in ("Fx", "Fy"))
+    for f3, f2 in PAIRS:
+        a = o3.field(f3)
+        assert np.max(np.abs(a - a[:, :1, :])) <= 1e-13 * max(np.max(np.abs(a)), 1e-300), "%s: %s not uniform along y" % (what, f3)
+        scale = {"v": umax, "G": gmax, "F": fmax}.get(f3[0])
+        e = rel_err(a[:, 0, :][fl], ref2[f2][fl], scale=scale)
+        assert e < TOL, "%s: %s vs the 2-D %s: %.3e" % (what, f3, f2, e)
+        worst = max(worst, e)
+    for f in ("fR", "fB"):
+        e = rel_err(project_pdf(o3.field(f))[fl], ref2[f][fl])
+        assert e < TOL, "%s: %s projected: %.3e" % (what, f, e)
+        worst = max(worst, e)
+    for f3, s in (("vy", umax), ("Gy", gmax), ("Fy", fmax)):
+        assert float(np.max(np.abs(o3.field(f3)))) <= 1e-12 * max(s, 1e-300), "%s: %s must vanish on a y-uniform lattice" % (what, f3)
+    return worst
+
+
+@pytest.mark.parametrize("ny", [1, 3])
+def test_reduces_to_the_capture_of_the_real_2d_driver(ny):
+    d = np.load(os.path.join(GOLDEN, "rk_csf_srt_capillary.npz"))
+    p = load_params(d)
+    assert p["relax"] == "SRT" and p["wetting"] == 2
+    dom2 = d["isDomain"]
+    rR2, rB2 = initial_densities(dom2, False, p["nbuf"])
+    o3 = RK3DCSFOracle(extrude(dom2, ny), extrude(rR2, ny), extrude(rB2, ny), params3(p))
+    assert o3.W == ny * d["wettingSolidNodes"].size
+    # set-up tables: the cells next to solid and their normals
+    kind = o3.field("kind")[:, 0, :].reshape(-1)
+    assert np.array_equal(np.flatnonzero(kind == 3), np.sort(d["fluidNodesWithSolidOriginal"]))
+    assert np.array_equal(np.flatnonzero(kind == 2), np.sort(d["wettingSolidNodes"]))
+    order = np.argsort(d["fluidNodesWithSolidOriginal"])
+    cells = d["fluidNodesWithSolidOriginal"][order]
+    assert rel_err(o3.field("nsx")[:, 0, :].reshape(-1)[cells], d["nsX"][order]) < 1e-14
+    assert rel_err(o3.field("nsz")[:, 0, :].reshape(-1)[cells], d["nsY"][order]) < 1e-14
+    assert np.max(np.abs(o3.field("nsy"))) < 1e-15
+    done = 0
+    for k in d["snaps"]:
+        o3.run(int(k) - done)
+        done = int(k)
+        ref = {}
+        for f in ("rhoR", "rhoB", "phi", "vx", "vy", "Gx", "Gy", "Fx", "Fy", "K", "fR", "fB"):
+            a = d["s%d_%s" % (k, f)]
+            out = np.zeros((dom2.size,) + a.shape[1:]); out[d["fluidNodes"]] = a
+            ref[f] = out.reshape(dom2.shape + a.shape[1:])
+        compare(o3, ref, dom2, "capture, step %d" % k)
+
+
+def porous2(nx=28, nz=48, nbuf=6, seed=5):
+    """a small pore image: side walls along the medium, nbuf all-fluid buffer rows at both ends"""
+    rng = np.random.default_rng(seed)
+    dom = np.ones((nz, nx), dtype=np.uint8)
+    zz, xx = np.mgrid[0:nz, 0:nx]
+    for _ in range(7):
+        cz, cx, r = rng.uniform(nbuf + 3, nz - nbuf - 3), rng.uniform(2, nx - 2), rng.uniform(2.0, 4.0)
+        dom[(zz - cz) ** 2 + (xx - cx) ** 2 <= r * r] = 0
+    dom[:, 0] = 0; dom[:, -1] = 0
+    dom[:nbuf] = 1; dom[-nbuf:] = 1        # all-fluid buffer rows: the ghost-row kernel A:1045-1081 takes compact indices < nx for row 0
+    return dom
+
+
+SCENARIOS = {
+    "capillary pressure inlet": (lambda: simple_geometry(16, 44), dict(inlet="Dirichlet"), False),
+    "capillary convective outlet": (lambda: simple_geometry(16, 44), dict(outlet="Convective"), False),
+    "capillary tau type 1": (lambda: simple_geometry(16, 44), dict(tautype=1, tauB=0.7), False),
+    "porous image": (lambda: porous2(), dict(theta=45.0), True),
+    "porous image, no wetting solids seen (theta 90)": (lambda: porous2(seed=11), dict(theta=90.0, tauB=0.8), True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_reduces_to_the_pinned_2d_oracle(name):
+    make, over, image = SCENARIOS[name]
+    dom2 = make()
+    p = dict(sigma=0.1, theta=60.0, wetting=2, beta=0.7, delta=0.98, tauR=1.0, tauB=0.8, tautype=2, relax="SRT", inlet="Neumann",
+             outlet="Dirichlet", vyR=-1.0e-4, vyB=0.0, rhoBH=5e-8, rhoRH=1.00536, rhoBL=1.0, rhoRL=5e-8)
+    p.update(over)
+    rR2, rB2 = initial_densities(dom2, image, 6)
+    o2 = RKOracle(dom2, p, rR2, rB2)
+    ny = 2
+    o3 = RK3DCSFOracle(extrude(dom2, ny), extrude(rR2, ny), extrude(rB2, ny), params3(p))
+    done = 0
+    for k in (1, 40, 100):
+        o2.run(k - done); o3.run(k - done)
+        done = k
+        ref = {f: dense2(o2, getattr(o2, f)) for f in ("rhoR", "rhoB", "phi", "vx", "vy", "Gx", "Gy", "Fx", "Fy", "K", "fR", "fB")}
+        compare(o3, ref, dom2, "%s, step %d" % (name, k))
+
+
+def blob3(nx=14, ny=12, nz=22, seed=2):
+    """a 3-D sample without any symmetry: two spheres and a slanted wall piece between all-fluid buffer planes"""
+    dom = np.ones((nz, ny, nx), dtype=np.uint8)
+    zz, yy, xx = np.mgrid[0:nz, 0:ny, 0:nx]
+    dom[(zz - 9.3) ** 2 + (yy - 4.1) ** 2 + (xx - 5.2) ** 2 <= 9.0] = 0
+    dom[(zz - 14.2) ** 2 + (yy - 8.7) ** 2 + (xx - 9.9) ** 2 <= 6.0] = 0
+    dom[5:17, :, 0] = 0
+    dom[5:17, 0, :] = 0
+    dom[:4] = 1; dom[-4:] = 1
+    rR = np.where((zz < nz - 7) & (dom == 1), 1.0, 0.0)
+    rB = np.where((zz >= nz - 7) & (dom == 1), 1.0, 0.0)
+    return dom, rR, rB
+
+
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+def test_exchanging_x_and_y_exchanges_the_fields(relax):
+    """what the reduction cannot see: the y components.  The model has no preferred direction in the (x, y) plane."""
+    dom, rR, rB = blob3()
+    par = dict(relax=relax, theta=50.0, tauB=0.8)
+    a = RK3DCSFOracle(dom, rR, rB, par).run(25)
+    t = lambda f: np.ascontiguousarray(np.swapaxes(f, 1, 2))
+    b = RK3DCSFOracle(t(dom), t(rR), t(rB), par).run(25)
+    for fa, fb in (("rhoR", "rhoR"), ("rhoB", "rhoB"), ("phi", "phi"), ("vx", "vy"), ("vy", "vx"), ("vz", "vz"), ("Gx", "Gy"), ("Gy", "Gx"),
+                   ("Gz", "Gz"), ("Fx", "Fy"), ("Fy", "Fx"), ("Fz", "Fz"), ("K", "K"), ("nsx", "nsy"), ("nsy", "nsx"), ("nsz", "nsz")):
+        x, y = a.field(fa), t(b.field(fb))
+        scale = max(np.max(np.abs(a.field(fa[0] + c))) for c in "xyz") if fa[0] in "vGF" and len(fa) == 2 else None
+        assert rel_err(y, x, scale=scale) < 1e-8, (fa, fb)        # the sums over the 19 directions run in another order: rounding only
+    assert np.max(np.abs(a.field("K"))) > 1e-3 and np.max(np.abs(a.field("Fy"))) > 1e-7      # the test sees an interface
+
+
+def test_mrt_with_every_rate_at_one_over_tau_is_bgk():
+    dom, rR, rB = blob3()
+    tau = 0.9
+    par = dict(theta=70.0, tauR=tau, tauB=tau)
+    a = RK3DCSFOracle(dom, rR, rB, dict(par, relax="SRT")).run(30)
+    b = RK3DCSFOracle(dom, rR, rB, dict(par, relax="MRT", rates=(1. / tau,) * 6)).run(30)
+    for f in ("rhoR", "rhoB", "phi", "vx", "vy", "vz", "K"):
+        scale = max(np.max(np.abs(a.field("v" + c))) for c in "xyz") if f[0] == "v" else None
+        assert rel_err(b.field(f), a.field(f), scale=scale) < 1e-11, f
+    c = RK3DCSFOracle(dom, rR, rB, dict(par, relax="MRT")).run(30)
+    assert rel_err(c.field("vz"), a.field("vz")) > 1e-6          # and the model's own rates are not BGK
+
+
+def test_mass_is_conserved_away_from_the_open_planes_and_the_force_sums_to_little():
+    """closed box (walls on the planes next to the open ones removed from the flow: zero inlet velocity, both colours kept inside by a solid shell)"""
+    nx, ny, nz = 12, 12, 20
+    dom = np.ones((nz, ny, nx), dtype=np.uint8)
+    dom[4, :, :] = 0; dom[15, :, :] = 0
+    dom[4:16, 0, :] = 0; dom[4:16, :, 0] = 0
+    zz, yy, xx = np.mgrid[0:nz, 0:ny, 0:nx]
+    inside = (zz > 4) & (zz < 15) & (dom == 1)
+    red = ((zz - 9.5) ** 2 + (yy - 6.0) ** 2 + (xx - 6.0) ** 2 <= 9.0)
+    rR = np.where(dom == 1, np.where(red & inside, 1.0, 0.0), 0.0)
+    rB = np.where(dom == 1, np.where(red & inside, 0.0, 1.0), 0.0)
+    o = RK3DCSFOracle(dom, rR, rB, dict(relax="MRT", velocityZR=0.0, velocityZB=0.0, densityBL=1.0, densityRL=0.0, theta=90.0))
+    m0 = (o.field("rhoR")[inside].sum(), o.field("rhoB")[inside].sum())
+    o.run(60)
+    m1 = (o.field("rhoR")[inside].sum(), o.field("rhoB")[inside].sum())
+    assert abs(m1[0] - m0[0]) < 1e-10 * m0[0] and abs(m1[1] - m0[1]) < 1e-10 * m0[1]
+    assert np.all(np.isfinite(o.field("vz")))
