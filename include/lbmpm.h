@@ -316,8 +316,7 @@ int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
  * (AcceleratedRKGPU2D.py:925-962, inlet_type) and the convective OUTLET (:700-784, outlet_type), each pinned by reduction to the 2-D fused
  * loop, whose kernels are pinned to the reference's one by one; and state in / out and restart (below).  NOT built (there is no field
  * for them in this struct, and the 3-D ini has no key that would ask for them):
- *   - [SurfaceTension] SurfaceTensionType = 'CSF' in 3-D (curvature force, 2-D: :2499-2551) with its wetting rules (:2430): the 3-D ini
- *     carries the perturbation parameters AkR / AkB and no surface-tension section at all;
+ *   - [SurfaceTension] SurfaceTensionType = 'CSF' in 3-D is a model of its own: lbmpm_rk3dcsf_* at the end of this header;
  *   - body force: read and never used by the reference's colour-gradient loops.
  * ---------------------------------------------------------------------------------- */
 typedef struct lbmpm_rk3d_config {
@@ -499,6 +498,84 @@ int64_t lbmpm_rk3d_num_fluid_nodes(const lbmpm_rk3d *ctx);
 int64_t lbmpm_rk3d_steps_done(const lbmpm_rk3d *ctx);
 const char *lbmpm_rk3d_dominant_kernel(const lbmpm_rk3d *ctx);
 int64_t lbmpm_rk3d_device_bytes(const lbmpm_rk3d *ctx);
+
+/* ------------------------------------------------------------------------------------
+ * Colour-gradient D3Q19 two-phase solver with continuum-surface-force (CSF) tension: [SurfaceTension] SurfaceTensionType = 'CSF' in
+ * three dimensions ("extend a3-a11 to D3Q19 ... CSF kappa = -div n in 3-D").  The reference has no 3-D source; this
+ * is its 2-D CSF loop RKColorGradientLBM.runRKColorGradient2DCSF (RKCG2D/RKD2Q9.py:1295-1490 -- the kernel list is the one above
+ * lbmpm_rk2d_config) carried to D3Q19 kernel by kernel with z as the flow axis: the inlet acts on the plane nz-2 (ghost plane nz-1),
+ * the outlet on the plane 1 (ghost plane 0), every edge wraps periodically like fillNeighboringNodes (walls are what the mask says).
+ * Pinned by reduction: a lattice uniform along y reproduces the capture of the real 2-D driver (SRT) and the pinned 2-D oracle
+ * (tests/test_oracle_rk3d_csf.py, tests/test_rk3d_csf_gpu.py).  What differs from the 2-D loop:
+ *   - wetting rule: WettingType 2 (Akai et al. 2018, AcceleratedRKGPU2D.py:2430-2492; a vector rule, valid as it stands in 3-D) with the
+ *     solid normals from the 3-D E8 stencil of Sbragaglia et al. 2007 (92 points), whose sums along one axis are the reference's
+ *     24-point weights (RKD2Q9.py:811-885).  WettingType 1 (Xu 2017, :1639-1679) is a rotation in the plane: LBMPM_ERR_UNSUPPORTED.
+ *     "Wetting solids" / "fluid next to solid" are taken over the 18 lattice neighbours (2-D: the 8 of the 3 x 3 block).
+ *   - curvature K = -(I - n n) : grad n (the 2-D formula :2512-2551 is its restriction), Zou-He closures with the transverse terms of
+ *     Hecht & Harting 2010 (their 2-D image is the 1/2 (f_1 - f_3) of :943-944),
+ *   - MRT: moment basis of d'Humieres et al. 2002, rates s_e 1.19, s_eps = s_pi 1.4, s_q = s_m 1.2 (as lbmpm_rk3d_config), stress
+ *     moments at 1/tau, conserved moments 0; Guo source in moment space M^-1 (I - S/2) M (:2027-2113).  mrt_rates overrides (tests).
+ * One context = one GPU (the curvature reaches two cells: no slab decomposition of this model yet).
+ * ---------------------------------------------------------------------------------- */
+typedef struct lbmpm_rk3dcsf_config {
+    int64_t nx, ny, nz;        /* xDomain, yDomain, zDomain (incl. the ghost planes 0 and nz-1); nz >= 8 */
+    double surface_tension;    /* [SurfaceTension] SurfaceTensionValue                      */
+    double contact_angle_deg;  /* [SurfaceTension] ContactAngle                             */
+    double beta, delta;        /* [RKParameters] BetaThickness, DeltaValue                  */
+    double tau_r, tau_b;       /* [FluidParameters] TauR, TauB                              */
+    double inlet_velocity_z;   /* velocityZR + velocityZB (2-D: RKD2Q9.py:1300)             */
+    double inlet_rho_r, inlet_rho_b;   /* densityRH, densityBH (pressure inlet)             */
+    double outlet_rho_total;   /* densityBL + densityRL (RKD2Q9.py:1344)                    */
+    int32_t wetting_type;      /* 2 (Akai 2018) | 0: no correction of the gradient at walls */
+    int32_t tau_type;          /* [FluidParameters] TauType 1 | 2                           */
+    int32_t relaxation;        /* LBMPM_RELAX_*                                             */
+    int32_t inlet_type;        /* LBMPM_INLET_VELOCITY | LBMPM_INLET_PRESSURE               */
+    int32_t outlet_type;       /* LBMPM_OUTLET_PRESSURE | LBMPM_OUTLET_CONVECTIVE           */
+    int32_t device;
+    double mrt_rates[6];       /* all 0: the model's own; else s_e, s_eps, s_q, s_pi, s_m, rate of the conserved moments */
+} lbmpm_rk3dcsf_config;
+
+typedef struct lbmpm_rk3dcsf lbmpm_rk3dcsf;
+
+/* "current" fields: the lattice as the reference's device arrays would hold it after the last completed step (populations streamed,
+ * densities re-summed; phi, G, F, K, u of that step).  REC_*: what the next step's first half makes of it -- boundary planes,
+ * velocity with half the force, phase field -- i.e. what the reference records (RKD2Q9.py:1382-1393).  All [nz][ny][nx]
+ * (populations [nz][ny][nx][19], direction order as lbmpm_rk3d_get_pdf), zeros off the fluid. */
+typedef enum lbmpm_rk3dcsf_field {
+    LBMPM_RK3DCSF_PDF_R = 0, LBMPM_RK3DCSF_PDF_B = 1, LBMPM_RK3DCSF_RHO_R = 2, LBMPM_RK3DCSF_RHO_B = 3,
+    LBMPM_RK3DCSF_VX = 4, LBMPM_RK3DCSF_VY = 5, LBMPM_RK3DCSF_VZ = 6,        /* need enable_diagnostics */
+    LBMPM_RK3DCSF_PHI = 7,                                                    /* carries phi_s on the wetting solids */
+    LBMPM_RK3DCSF_GX = 8, LBMPM_RK3DCSF_GY = 9, LBMPM_RK3DCSF_GZ = 10,
+    LBMPM_RK3DCSF_FX = 11, LBMPM_RK3DCSF_FY = 12, LBMPM_RK3DCSF_FZ = 13,
+    LBMPM_RK3DCSF_K = 14,                                                     /* needs enable_diagnostics */
+    LBMPM_RK3DCSF_NSX = 15, LBMPM_RK3DCSF_NSY = 16, LBMPM_RK3DCSF_NSZ = 17,   /* solid normal at the fluid cells next to solid */
+    LBMPM_RK3DCSF_KIND = 18,   /* 0 solid, 1 fluid, 2 wetting solid, 3 fluid next to solid */
+    LBMPM_RK3DCSF_REC_PDF_R = 30, LBMPM_RK3DCSF_REC_PDF_B = 31, LBMPM_RK3DCSF_REC_RHO_R = 32, LBMPM_RK3DCSF_REC_RHO_B = 33,
+    LBMPM_RK3DCSF_REC_VX = 34, LBMPM_RK3DCSF_REC_VY = 35, LBMPM_RK3DCSF_REC_VZ = 36, LBMPM_RK3DCSF_REC_PHI = 37
+} lbmpm_rk3dcsf_field;
+
+/* is_domain: host [nz][ny][nx] uint8, 1 = fluid.  The ghost planes must carry the mask of the plane they copy (nz-1 <- nz-2; 0 <- 1,
+ * or 0, 1, 2 <- 3 with the convective outlet). */
+int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8_t *is_domain, lbmpm_rk3dcsf **out);
+void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *ctx);
+/* f_c,i = rho_c w_i (1 + 3 e_i.u + 4.5 (e_i.u)^2 - 1.5 u^2) (RKD2Q9.py:577-601); vx, vy, vz may be NULL (= 0); the force of "the step
+ * before" starts at zero.  Resets the step counter. */
+int lbmpm_rk3dcsf_set_macro(lbmpm_rk3dcsf *ctx, const double *rho_r, const double *rho_b, const double *vx, const double *vy, const double *vz);
+/* restart ([CyclesSetup] IsCycle, RKD2Q9.py:491-559): streamed populations [nz][ny][nx][19] per colour as LBMPM_RK3DCSF_PDF_* returns
+ * them, and the force of the last step (LBMPM_RK3DCSF_F*; NULL = 0): a run continued from them equals the uninterrupted run bit for bit */
+int lbmpm_rk3dcsf_set_pdf(lbmpm_rk3dcsf *ctx, const double *pdf_r, const double *pdf_b, const double *fx, const double *fy, const double *fz);
+int lbmpm_rk3dcsf_step(lbmpm_rk3dcsf *ctx, int64_t nsteps);
+/* ms_total: HIP events around the steps; ms_dominant: sum over the launches of csf3d_collide */
+int lbmpm_rk3dcsf_step_timed(lbmpm_rk3dcsf *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
+int lbmpm_rk3dcsf_sync(lbmpm_rk3dcsf *ctx);
+/* keep u and K of every step (four more stores per cell) */
+int lbmpm_rk3dcsf_enable_diagnostics(lbmpm_rk3dcsf *ctx, int on);
+int lbmpm_rk3dcsf_get_field(lbmpm_rk3dcsf *ctx, int field, double *out);
+int64_t lbmpm_rk3dcsf_num_fluid_nodes(const lbmpm_rk3dcsf *ctx);
+int64_t lbmpm_rk3dcsf_num_wetting_solids(const lbmpm_rk3dcsf *ctx);
+int64_t lbmpm_rk3dcsf_steps_done(const lbmpm_rk3dcsf *ctx);
+int64_t lbmpm_rk3dcsf_device_bytes(const lbmpm_rk3dcsf *ctx);
+const char *lbmpm_rk3dcsf_dominant_kernel(const lbmpm_rk3dcsf *ctx);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,15 @@ class RK3DConfig(C.Structure):
                 ("outlet_type", C.c_int32), ("reserved", C.c_int32)]
 
 
+class RK3DCSFConfig(C.Structure):
+    # mirrors struct lbmpm_rk3dcsf_config (include/lbmpm.h)
+    _fields_ = [(n, C.c_int64) for n in ("nx", "ny", "nz")] + \
+               [(n, C.c_double) for n in ("surface_tension", "contact_angle_deg", "beta", "delta", "tau_r", "tau_b", "inlet_velocity_z",
+                                          "inlet_rho_r", "inlet_rho_b", "outlet_rho_total")] + \
+               [(n, C.c_int32) for n in ("wetting_type", "tau_type", "relaxation", "inlet_type", "outlet_type", "device")] + \
+               [("mrt_rates", C.c_double * 6)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # lbmpm_rk3d_exchange_fn
 IPC_BLOB_BYTES, RCCL_ID_BYTES = 256, 128                     # LBMPM_IPC_BLOB_BYTES, LBMPM_RCCL_ID_BYTES
 TRANSPORT_NONE, TRANSPORT_IPC, TRANSPORT_RCCL = 0, 1, 2
@@ -160,6 +169,20 @@ _SIGNATURES = {
     "lbmpm_rk3d_storage_info": (C.c_int, [C.c_void_p, I64P]),
     "lbmpm_rk3d_debug_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "lbmpm_rk3d_debug_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, F64P]),
+    "lbmpm_rk3dcsf_create": (C.c_int, [C.POINTER(RK3DCSFConfig), U8P, C.POINTER(C.c_void_p)]),
+    "lbmpm_rk3dcsf_destroy": (None, [C.c_void_p]),
+    "lbmpm_rk3dcsf_set_macro": (C.c_int, [C.c_void_p, F64P, F64P, F64P, F64P, F64P]),
+    "lbmpm_rk3dcsf_set_pdf": (C.c_int, [C.c_void_p, F64P, F64P, F64P, F64P, F64P]),
+    "lbmpm_rk3dcsf_step": (C.c_int, [C.c_void_p, C.c_int64]),
+    "lbmpm_rk3dcsf_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),
+    "lbmpm_rk3dcsf_sync": (C.c_int, [C.c_void_p]),
+    "lbmpm_rk3dcsf_enable_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
+    "lbmpm_rk3dcsf_get_field": (C.c_int, [C.c_void_p, C.c_int, F64P]),
+    "lbmpm_rk3dcsf_num_fluid_nodes": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk3dcsf_num_wetting_solids": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk3dcsf_steps_done": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk3dcsf_device_bytes": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk3dcsf_dominant_kernel": (C.c_char_p, [C.c_void_p]),
 }
 
 

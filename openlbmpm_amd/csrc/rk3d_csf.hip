@@ -1,0 +1,930 @@
+// rk3d_csf.hip -- D3Q19 colour gradient with continuum-surface-force tension ([SurfaceTension] SurfaceTensionType = 'CSF' in 3-D).
+//
+// "extend a3-a11 to D3Q19 (... 3-D isotropic gradient 3 sum w e phi; CSF kappa = -div n in 3-D)".  The
+// reference ships no 3-D source; this is its 2-D CSF loop, RKColorGradientLBM.runRKColorGradient2DCSF (RKCG2D/RKD2Q9.py:1295-1490, kernels
+// of RKCG2D/AcceleratedRKGPU2D.py = "A:"), carried to three dimensions operator by operator with z as the flow axis:
+//   inlet plane nz-2 / ghost nz-1   A:2348-2412 + A:607-650 (velocity on f_tot, ratioB quirk kept) | A:925-962 + A:968-1002 (pressure per colour)
+//   outlet plane 1 / ghost 0        A:2560-2590 + A:1045-1081 (pressure on f_tot) | A:700-784 (convective copies of plane 3 onto 2, 1, 0)
+//   f_tot, u with the lagged force, phi   A:1414-1424, A:2634-2654, A:1348-1357
+//   phi on the wetting solids       A:1560-1581            gradient   A:1584-1634
+//   wetting rule 2 (Akai 2018)      A:2430-2492, solid normals from the 3-D E8 stencil (Sbragaglia et al. 2007) whose sums along one axis
+//                                   are the reference's 24-point weights (RKD2Q9.py:811-885)
+//   curvature, force                A:2499-2551: K = -(I - n n) : grad n, F = -1/2 sigma K G
+//   BGK / MRT + Guo source          A:1804-1848 + A:1743-1798 | A:1938-2017 + A:2027-2113 (D3Q19 basis of d'Humieres et al. 2002)
+//   recolouring, streaming          A:1857-1899, A:340-417 (as a pull)
+// The parity oracle is oracle/rk3d_csf_oracle.c (pinned by reduction to the capture of the real 2-D driver, tests/test_oracle_rk3d_csf.py);
+// the arithmetic below keeps that file's evaluation order (no FMA contraction in this file), so the two agree to rounding.
+//
+// Schedule of one time step (four launches; populations q-major SoA, two buffers, pull):
+//   csf3d_phase     pull + boundary planes -> rho_R, rho_B -> phi                                 38 reads, 1 write per fluid cell
+//   csf3d_solid_phi phi of the wetting solids (compact list)
+//   csf3d_gradient  G (18 cached phi reads), wetting rule on the cells next to solid, n = -G / |G|   6 writes
+//   csf3d_collide   pull + boundary planes again (bit-identical to the first pass), curvature from the neighbours' n, force, collision,
+//                   recolouring -> the other buffer                                                38 reads, 41 writes
+// The curvature needs n one cell around and n needs phi one cell around that: two global dependencies per step, hence the two
+// passes over the populations (~1.06 kB per cell and step against the perturbation model's 0.30 - 0.37 kB in rk3dq_fused).
+#include "lbmpm_common.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+using lbmpm::set_error;
+
+constexpr int Q = 19;
+#define CSF_CX {0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 1, -1, 1, -1, 0, 0, 0, 0}
+#define CSF_CY {0, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 0, 0, 1, -1, 1, -1}
+#define CSF_CZ {0, 0, 0, 0, 0, 1, -1, 0, 0, 0, 0, 1, -1, -1, 1, 1, -1, -1, 1}
+#define CSF_OPP {0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15, 18, 17}
+__device__ __host__ __forceinline__ constexpr double wq(int i) { return i == 0 ? 1. / 3. : (i < 7 ? 1. / 18. : 1. / 36.); }
+
+// meta word of a cell: bit 0 fluid, bits 1 .. 18 "the neighbour in direction i is fluid", bits 20 - 21 kind
+// (0 solid, 1 fluid, 2 wetting solid: >= 1 fluid among its 18 neighbours, 3 fluid with >= 1 solid among them)
+constexpr unsigned KIND_SHIFT = 20;
+
+struct CsfDev {
+    int nx, ny, nz;
+    unsigned N;                  // cells
+    size_t NS;                   // stride between the planes of a SoA array (N rounded up to 16: 128-byte lines start on plane boundaries)
+    const uint32_t *meta;
+    const double *fin;
+    double *fout;
+    double *phi, *G, *nh, *F, *K, *U;
+    const double *ns;
+    double sigma, cosT, sinT, beta, delta, tauR, tauB, vzIn, pInB, pInR, pOut;
+    int tauType, inletP, conv, wetting, nwet;
+    double rate[6];
+};
+
+struct Nb { unsigned xo[3], yo[3], zo[3]; };
+__device__ __forceinline__ Nb make_nb(const CsfDev &p, int x, int y, int z)
+{
+    Nb n;
+    n.xo[0] = (unsigned)(x == 0 ? p.nx - 1 : x - 1); n.xo[1] = (unsigned)x; n.xo[2] = (unsigned)(x == p.nx - 1 ? 0 : x + 1);
+    const unsigned nx = (unsigned)p.nx, pl = (unsigned)p.nx * (unsigned)p.ny;
+    n.yo[0] = (unsigned)(y == 0 ? p.ny - 1 : y - 1) * nx; n.yo[1] = (unsigned)y * nx; n.yo[2] = (unsigned)(y == p.ny - 1 ? 0 : y + 1) * nx;
+    n.zo[0] = (unsigned)(z == 0 ? p.nz - 1 : z - 1) * pl; n.zo[1] = (unsigned)z * pl; n.zo[2] = (unsigned)(z == p.nz - 1 ? 0 : z + 1) * pl;
+    return n;
+}
+__device__ __forceinline__ unsigned at(const Nb &n, int dx, int dy, int dz) { return n.zo[dz + 1] + n.yo[dy + 1] + n.xo[dx + 1]; }
+
+__device__ __forceinline__ double sum19(const double f[Q])
+{
+    double r = 0.;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) r += f[i];
+    return r;
+}
+// +-v or nothing for a lattice component (the oracle's `c * v` with c in {-1, 0, 1})
+__device__ __forceinline__ void addc(double &acc, int c, double v) { if (c > 0) acc += v; else if (c < 0) acc -= v; }
+__device__ __forceinline__ double edotv(int cx, int cy, int cz, double x, double y, double z)
+{   // CX * x + CY * y + CZ * z as the oracle's left-to-right sum (products by 0 and 1 are exact)
+    double r = cx > 0 ? x : (cx < 0 ? -x : 0.);
+    r = cy > 0 ? r + y : (cy < 0 ? r - y : r + 0.);
+    r = cz > 0 ? r + z : (cz < 0 ? r - z : r + 0.);
+    return r;
+}
+// A:170-176
+__device__ __forceinline__ double feq(double rho, int i, int cx, int cy, int cz, double vx, double vy, double vz)
+{
+    const double eu = edotv(cx, cy, cz, vx, vy, vz);
+    return rho * wq(i) * (1 + (3. * eu + 4.5 * eu * eu - 1.5 * (vx * vx + vy * vy + vz * vz)));
+}
+__device__ __forceinline__ double sum_inplane(const double f[Q]) { return f[0] + f[1] + f[2] + f[3] + f[4] + f[7] + f[8] + f[9] + f[10]; }
+
+// The populations, densities of one fluid cell as the loop's first half leaves them: pulled (FIRST: taken where they stand -- the state
+// given by set_macro / set_pdf has been streamed already), then the boundary-plane rule of the cell's plane.  BC = false: the pull alone
+// (what the reference's arrays hold after a step).
+template <bool FIRST, bool BC>
+__device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z, double fR[Q], double fB[Q], double &rR, double &rB)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ, OPP[Q] = CSF_OPP;
+    constexpr int UP[5] = {5, 11, 14, 15, 18}, DN[5] = {6, 12, 13, 16, 17};
+    int zs = z;                                   // the plane whose streamed populations this cell takes
+    if (BC) {
+        if (z == p.nz - 1) zs = p.nz - 2;
+        else if (p.conv) { if (z <= 2) zs = 3; }
+        else if (z == 0) zs = 1;
+    }
+    const Nb nb = make_nb(p, x, y, zs);
+    const unsigned own = at(nb, 0, 0, 0);
+    const uint32_t m = p.meta[own];
+    const double *fr = p.fin, *fb = p.fin + (size_t)Q * p.NS;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        if (FIRST || i == 0) {
+            fR[i] = fr[(size_t)i * p.NS + own]; fB[i] = fb[(size_t)i * p.NS + own];
+        } else {
+            const bool from_fluid = (m >> OPP[i]) & 1u;                 // the cell the population comes from, x - e_i
+            const unsigned src = from_fluid ? at(nb, -CX[i], -CY[i], -CZ[i]) : own;
+            const size_t off = (size_t)(from_fluid ? i : OPP[i]) * p.NS + src;      // half-way bounce-back: the cell's own opposite population
+            fR[i] = fr[off]; fB[i] = fb[off];
+        }
+    }
+    rR = sum19(fR); rB = sum19(fB);
+    if (!BC) return;
+    if (zs == p.nz - 2) {
+        if (!p.inletP) {                         // A:2348-2412 constantTotalVelocityInlet
+            double t[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) t[i] = fR[i] + fB[i];
+            const double v = p.vzIn;
+            const double rho = (sum_inplane(t) + 2. * (t[5] + t[11] + t[14] + t[15] + t[18])) / (1. + v);
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+                t[DN[a]] = feq(rho, DN[a], CX[DN[a]], CY[DN[a]], CZ[DN[a]], 0., 0., v) + (t[UP[a]] - feq(rho, UP[a], CX[UP[a]], CY[UP[a]], CZ[UP[a]], 0., 0., v));
+            const double ratioR = rR / (rR + rB);
+            rR = ratioR * rho;
+#pragma unroll
+            for (int a = 0; a < 5; ++a) fR[DN[a]] = ratioR * t[DN[a]];
+            const double ratioB = rB / (rR + rB);             // with the new rho_R: the reference's quirk
+            rB = ratioB * rho;
+#pragma unroll
+            for (int a = 0; a < 5; ++a) fB[DN[a]] = ratioB * t[DN[a]];
+            if (z == p.nz - 1) { rR = sum19(fR); rB = sum19(fB); }          // A:607-650: the ghost plane re-sums
+        } else {                                 // A:925-962 calConstPressureInletGPU; the ghost plane copies the densities too (A:968-1002)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double *f = c == 0 ? fB : fR;
+                const double pr = c == 0 ? p.pInB : p.pInR;
+                const double v = -1. + (sum_inplane(f) + 2. * (f[5] + f[11] + f[14] + f[15] + f[18])) / pr;
+                const double Nx = 0.5 * ((f[1] + f[7] + f[9]) - (f[2] + f[8] + f[10]));
+                const double Ny = 0.5 * ((f[3] + f[7] + f[10]) - (f[4] + f[8] + f[9]));
+                f[6] = f[5] - 1. / 3. * pr * v;
+                f[12] = f[11] + Nx - 1. / 6. * pr * v;
+                f[13] = f[14] - Nx - 1. / 6. * pr * v;
+                f[16] = f[15] + Ny - 1. / 6. * pr * v;
+                f[17] = f[18] - Ny - 1. / 6. * pr * v;
+            }
+            rB = p.pInB; rR = p.pInR;
+        }
+    } else if (!p.conv && zs == 1) {             // A:2560-2590 calConstPressureLowerGPUTotal; ghost plane 0: A:1045-1081
+        double t[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) t[i] = fR[i] + fB[i];
+        const double pL = p.pOut;
+        const double v = 1. - 1. / pL * (sum_inplane(t) + 2. * (t[6] + t[12] + t[13] + t[16] + t[17]));
+        const double Nx = 0.5 * ((t[1] + t[7] + t[9]) - (t[2] + t[8] + t[10]));
+        const double Ny = 0.5 * ((t[3] + t[7] + t[10]) - (t[4] + t[8] + t[9]));
+        t[5] = t[6] + 1. / 3. * (pL * v);
+        t[11] = t[12] - Nx + 1. / 6. * pL * v;
+        t[14] = t[13] + Nx + 1. / 6. * pL * v;
+        t[15] = t[16] - Ny + 1. / 6. * pL * v;
+        t[18] = t[17] + Ny + 1. / 6. * pL * v;
+        const double ratioR = rR / (rR + rB), ratioB = rB / (rR + rB);
+#pragma unroll
+        for (int a = 0; a < 5; ++a) { fR[UP[a]] = ratioR * t[UP[a]]; fB[UP[a]] = ratioB * t[UP[a]]; }
+    }
+}
+
+__device__ __forceinline__ bool cell_of(const CsfDev &p, unsigned n, int &x, int &y, int &z)
+{
+    if (n >= p.N) return false;
+    const unsigned pl = (unsigned)p.nx * (unsigned)p.ny;
+    z = (int)(n / pl);
+    const unsigned r = n - (unsigned)z * pl;
+    y = (int)(r / (unsigned)p.nx);
+    x = (int)(r - (unsigned)y * (unsigned)p.nx);
+    return true;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void csf3d_phase(CsfDev p)
+{
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    int x, y, z;
+    if (!cell_of(p, n, x, y, z)) return;
+    if (!(p.meta[n] & 1u)) return;
+    double fR[Q], fB[Q], rR, rB;
+    cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
+    p.phi[n] = (rR - rB) / (rR + rB);
+}
+
+// A:1560-1581 calColorValueOnSolid over the list of wetting solids
+__global__ __launch_bounds__(256) void csf3d_solid_phi(CsfDev p, const uint32_t *wetlist)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= (unsigned)p.nwet) return;
+    const unsigned n = wetlist[k];
+    int x, y, z;
+    cell_of(p, n, x, y, z);
+    const Nb nb = make_nb(p, x, y, z);
+    const uint32_t m = p.meta[n];
+    double sum = 0., sw = 0.;
+#pragma unroll
+    for (int i = 1; i < Q; ++i)
+        if ((m >> i) & 1u) { sum += wq(i) * p.phi[at(nb, CX[i], CY[i], CZ[i])]; sw += wq(i); }
+    p.phi[n] = sum / sw;
+}
+
+// A:1584-1634 gradient, A:2430-2492 wetting rule, and the unit normal n = -G / |G| (threshold 1e-8, A:2512-2520) the curvature reads
+__global__ __launch_bounds__(256) void csf3d_gradient(CsfDev p)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    int x, y, z;
+    if (!cell_of(p, n, x, y, z)) return;
+    const uint32_t m = p.meta[n];
+    if (!(m & 1u)) return;
+    const Nb nb = make_nb(p, x, y, z);
+    double gx = 0., gy = 0., gz = 0.;
+#pragma unroll
+    for (int i = 1; i < Q; ++i) {
+        const double t = wq(i) * p.phi[at(nb, CX[i], CY[i], CZ[i])];
+        addc(gx, CX[i], t); addc(gy, CY[i], t); addc(gz, CZ[i], t);
+    }
+    gx = 3. * gx; gy = 3. * gy; gz = 3. * gz;
+    if (p.nwet > 0 && p.wetting == 2 && ((m >> KIND_SHIFT) & 3u) == 3u) {
+        const double nrm = sqrt(gx * gx + gy * gy + gz * gz);
+        double ux = 0., uy = 0., uz = 0.;
+        if (nrm > 1.0e-8) { ux = -gx / nrm; uy = -gy / nrm; uz = -gz / nrm; }
+        const double sx = p.ns[n], sy = p.ns[p.NS + n], sz = p.ns[2 * p.NS + n];
+        const double ang = ux * sx + uy * sy + uz * sz;
+        const double th = acos(ang);
+        double c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
+        if (fabs(sin(th)) > 1.0e-9) {
+            c1 = p.sinT * cos(th) / sin(th);
+            c2 = p.sinT / sin(th);
+            c3 = -p.sinT * cos(th) / sin(th);
+            c4 = -p.sinT / sin(th);
+        }
+        const double ax = (p.cosT - c1) * sx + c2 * ux, ay = (p.cosT - c1) * sy + c2 * uy, az = (p.cosT - c1) * sz + c2 * uz;
+        const double bx = (p.cosT - c3) * sx + c4 * ux, by = (p.cosT - c3) * sy + c4 * uy, bz = (p.cosT - c3) * sz + c4 * uz;
+        const double d1 = sqrt((ax - ux) * (ax - ux) + (ay - uy) * (ay - uy) + (az - uz) * (az - uz));
+        const double d2 = sqrt((bx - ux) * (bx - ux) + (by - uy) * (by - uy) + (bz - uz) * (bz - uz));
+        if (d1 < d2) { gx = -nrm * ax; gy = -nrm * ay; gz = -nrm * az; }
+        else if (d1 > d2) { gx = -nrm * bx; gy = -nrm * by; gz = -nrm * bz; }
+    }
+    p.G[n] = gx; p.G[p.NS + n] = gy; p.G[2 * p.NS + n] = gz;
+    const double gn = sqrt(gx * gx + gy * gy + gz * gz);
+    double hx = 0., hy = 0., hz = 0.;
+    if (gn > 1.0e-8) { hx = -gx / gn; hy = -gy / gn; hz = -gz / gn; }
+    p.nh[n] = hx; p.nh[p.NS + n] = hy; p.nh[2 * p.NS + n] = hz;
+}
+
+// rows of the D3Q19 moment basis of d'Humieres et al. 2002:
+// rho, e, eps, jx, qx, jy, qy, jz, qz, 3pxx, 3pixx, pww, piww, pxy, pyz, pxz, mx, my, mz  (fold to constants in the unrolled loops)
+__device__ __host__ constexpr double mrow(int k, int i)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const double x = CX[i], y = CY[i], z = CZ[i], c2 = x * x + y * y + z * z;
+    switch (k) {
+    case 0: return 1.;
+    case 1: return 19. * c2 - 30.;
+    case 2: return (21. * c2 * c2 - 53. * c2 + 24.) / 2.;
+    case 3: return x;
+    case 4: return (5. * c2 - 9.) * x;
+    case 5: return y;
+    case 6: return (5. * c2 - 9.) * y;
+    case 7: return z;
+    case 8: return (5. * c2 - 9.) * z;
+    case 9: return 3. * x * x - c2;
+    case 10: return (3. * c2 - 5.) * (3. * x * x - c2);
+    case 11: return y * y - z * z;
+    case 12: return (3. * c2 - 5.) * (y * y - z * z);
+    case 13: return x * y;
+    case 14: return y * z;
+    case 15: return x * z;
+    case 16: return (y * y - z * z) * x;
+    case 17: return (z * z - x * x) * y;
+    default: return (x * x - y * y) * z;
+    }
+}
+__device__ __host__ constexpr double mnorm(int k)
+{
+    double a = 0.;
+    for (int i = 0; i < Q; ++i) a += mrow(k, i) * mrow(k, i);
+    return a;
+}
+template <int K>
+__device__ __forceinline__ double moment(const double d[Q])
+{
+    double acc = 0.;
+#pragma unroll
+    for (int i = 0; i < Q; ++i)
+        if (mrow(K, i) != 0.) acc += mrow(K, i) * d[i];
+    return acc;
+}
+template <int K>
+__device__ __forceinline__ void moments_from(const double S[Q], const double d[Q], double m[Q])
+{
+    constexpr double inv = 1. / mnorm(K);        // (the oracle divides; one rounding apart)
+    m[K] = S[K] * moment<K>(d) * inv;
+    if constexpr (K + 1 < Q) moments_from<K + 1>(S, d, m);
+}
+// d <- M^-1 diag(S) M d
+__device__ __forceinline__ void mrt_apply(const double S[Q], double d[Q])
+{
+    double m[Q];
+    moments_from<0>(S, d, m);
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        double acc = 0.;
+#pragma unroll
+        for (int k = 0; k < Q; ++k)
+            if (mrow(k, i) != 0.) acc += mrow(k, i) * m[k];
+        d[i] = acc;
+    }
+}
+
+// tau(phi), A:1815-1827
+__device__ __forceinline__ double tau_of(const CsfDev &p, double Phi, double rR, double rB)
+{
+    double tau = 1.;
+    if (Phi > p.delta) tau = p.tauR;
+    else if (Phi < -p.delta) tau = p.tauB;
+    else if (fabs(Phi) <= p.delta) {
+        if (p.tauType == 1) {
+            tau = 0.5 + 1. / ((1. + Phi) / (2. * (p.tauR - 0.5)) + (1. - Phi) / (2. * (p.tauB - 0.5)));
+        } else if (p.tauType == 2) {
+            const double ratioR = rR / (rR + rB), ratioB = rB / (rR + rB);
+            const double miuR = 3. / (p.tauR - 0.5), miuB = 3. / (p.tauB - 0.5);
+            const double miu = 1. / (ratioR * miuR + ratioB * miuB);
+            tau = 3. * miu + 0.5;
+        }
+    }
+    return tau;
+}
+
+// second half of the loop for one cell: curvature and force, collision with the Guo source, recolouring; stores the post-collision
+// populations (the next step pulls them).  DIAG: also keep u and K of the step.
+template <bool FIRST, bool MRT, bool DIAG>
+__global__ __launch_bounds__(256) void csf3d_collide(CsfDev p)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    int x = 0, y = 0, z = 0;
+    const bool inside = cell_of(p, n, x, y, z);
+    const uint32_t m = inside ? p.meta[n] : 0u;
+    const bool fluid = m & 1u;
+    double *fr = p.fout, *fb = p.fout + (size_t)Q * p.NS;
+    // a solid cell whose 128-byte line (16 cells) holds fluid writes zeros: partially written lines cost a read-modify-write
+    {
+        const unsigned long long fl = __ballot(fluid);
+        const unsigned lane = threadIdx.x & 63u;
+        const bool line = ((fl >> (lane & ~15u)) & 0xFFFFull) != 0ull;
+        if (!fluid) {
+            if (inside && line) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) { fr[(size_t)i * p.NS + n] = 0.; fb[(size_t)i * p.NS + n] = 0.; }
+            }
+            return;
+        }
+    }
+    double fR[Q], fB[Q], rR, rB;
+    cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
+    double t[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) t[i] = fR[i] + fB[i];
+    // A:2634-2654: u = (sum e f_tot + F / 2) / rho with the force of the step before
+    double mx = 0., my = 0., mz = 0.;
+#pragma unroll
+    for (int i = 1; i < Q; ++i) { addc(mx, CX[i], t[i]); addc(my, CY[i], t[i]); addc(mz, CZ[i], t[i]); }
+    const double rs = rB + rR;
+    const double vx = (mx + 0.5 * p.F[n]) / rs, vy = (my + 0.5 * p.F[p.NS + n]) / rs, vz = (mz + 0.5 * p.F[2 * p.NS + n]) / rs;
+    const double phi = (rR - rB) / (rR + rB);
+    // A:2499-2551: derivatives of n over the fluid neighbours, K = -(I - n n) : grad n
+    const Nb nb = make_nb(p, x, y, z);
+    const double gx = p.G[n], gy = p.G[p.NS + n], gz = p.G[2 * p.NS + n];
+    const double ux = p.nh[n], uy = p.nh[p.NS + n], uz = p.nh[2 * p.NS + n];
+    double dxx = 0., dxy = 0., dxz = 0., dyx = 0., dyy = 0., dyz = 0., dzx = 0., dzy = 0., dzz = 0.;     // d<a><b> = d_a n_b
+#pragma unroll
+    for (int i = 1; i < Q; ++i) {
+        if (!((m >> i) & 1u)) continue;
+        const unsigned q = at(nb, CX[i], CY[i], CZ[i]);
+        const double qx = 3. * wq(i) * p.nh[q], qy = 3. * wq(i) * p.nh[p.NS + q], qz = 3. * wq(i) * p.nh[2 * p.NS + q];
+        addc(dxx, CX[i], qx); addc(dxy, CX[i], qy); addc(dxz, CX[i], qz);
+        addc(dyx, CY[i], qx); addc(dyy, CY[i], qy); addc(dyz, CY[i], qz);
+        addc(dzx, CZ[i], qx); addc(dzy, CZ[i], qy); addc(dzz, CZ[i], qz);
+    }
+    const double k = ux * uy * (dyx + dxy) + ux * uz * (dzx + dxz) + uy * uz * (dzy + dyz)
+                     - (uy * uy + uz * uz) * dxx - (ux * ux + uz * uz) * dyy - (ux * ux + uy * uy) * dzz;
+    const double fx = -0.5 * p.sigma * k * gx, fy = -0.5 * p.sigma * k * gy, fz = -0.5 * p.sigma * k * gz;
+    p.F[n] = fx; p.F[p.NS + n] = fy; p.F[2 * p.NS + n] = fz;
+    if (DIAG) { p.K[n] = k; p.U[n] = vx; p.U[p.NS + n] = vy; p.U[2 * p.NS + n] = vz; }
+    const double tau = tau_of(p, phi, rR, rB);
+    if (!MRT) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {                    // A:1804-1848
+            const double eT = feq(rR, i, CX[i], CY[i], CZ[i], vx, vy, vz) + feq(rB, i, CX[i], CY[i], CZ[i], vx, vy, vz);
+            t[i] = -1. / tau * (t[i] - eT) + t[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {                    // A:1743-1798
+            const double eu = edotv(CX[i], CY[i], CZ[i], vx, vy, vz);
+            const double src = wq(i) * ((3. * ((double)CX[i] - vx) + 9. * (double)CX[i] * eu) * fx + (3. * ((double)CY[i] - vy) + 9. * (double)CY[i] * eu) * fy +
+                                        (3. * ((double)CZ[i] - vz) + 9. * (double)CZ[i] * eu) * fz) * (1. - 1. / (2. * tau));
+            t[i] = t[i] + src;
+        }
+    } else {
+        const double it = 1. / tau;
+        double S[Q] = {p.rate[5], p.rate[0], p.rate[1], p.rate[5], p.rate[2], p.rate[5], p.rate[2], p.rate[5], p.rate[2], it, p.rate[3], it, p.rate[3],
+                       it, it, it, p.rate[4], p.rate[4], p.rate[4]};
+        double d[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) d[i] = t[i] - (feq(rR, i, CX[i], CY[i], CZ[i], vx, vy, vz) + feq(rB, i, CX[i], CY[i], CZ[i], vx, vy, vz));
+        mrt_apply(S, d);                                 // A:1938-2017
+#pragma unroll
+        for (int i = 0; i < Q; ++i) t[i] = -d[i] + t[i];
+        const double uf = vx * fx + vy * fy + vz * fz;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {                    // A:2027-2113
+            const double ef = edotv(CX[i], CY[i], CZ[i], fx, fy, fz), eu = edotv(CX[i], CY[i], CZ[i], vx, vy, vz);
+            d[i] = wq(i) * (3. * ef + 9. * eu * ef - 3. * uf);
+            S[i] = 1. - 0.5 * S[i];
+        }
+        mrt_apply(S, d);
+#pragma unroll
+        for (int i = 0; i < Q; ++i) t[i] = t[i] + d[i];
+    }
+    // A:1857-1899 calRecoloringProcessM
+    const double gn = sqrt(gx * gx + gy * gy + gz * gz), tot = rR + rB;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const double un = i == 0 ? 0. : (i < 7 ? 1. : sqrt(2.));
+        double c = 0.;
+        if (gn > 1.0e-8 && un > 1.0e-8) c = edotv(CX[i], CY[i], CZ[i], gx, gy, gz) / (un * gn);
+        fr[(size_t)i * p.NS + n] = rR / tot * t[i] + p.beta * rR * rB / tot * wq(i) * c * un;
+        fb[(size_t)i * p.NS + n] = rB / tot * t[i] - p.beta * rR * rB / tot * wq(i) * c * un;
+    }
+}
+
+// host-layout views of the populations: out_pdf [2][N][19], out_rho [2][N], out_u [3][N] (REC only), out_phi [N] (REC only).
+// REC = false: the arrays as a completed step leaves them (streamed, densities re-summed); REC = true: what the next step's first half
+// makes of them (boundary planes, velocity with half the force, phase field) -- what the reference records (RKD2Q9.py:1382-1393)
+template <bool FIRST, bool REC>
+__global__ __launch_bounds__(256) void csf3d_observe(CsfDev p, double *out_pdf, double *out_rho, double *out_u, double *out_phi)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    int x, y, z;
+    if (!cell_of(p, n, x, y, z)) return;
+    const bool fluid = p.meta[n] & 1u;
+    double fR[Q], fB[Q], rR = 0., rB = 0.;
+    if (fluid) cell_state<FIRST, REC>(p, x, y, z, fR, fB, rR, rB);
+    if (out_pdf) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            out_pdf[(size_t)n * Q + i] = fluid ? fR[i] : 0.;
+            out_pdf[((size_t)p.N + n) * Q + i] = fluid ? fB[i] : 0.;
+        }
+    }
+    out_rho[n] = rR; out_rho[(size_t)p.N + n] = rB;
+    if (REC) {
+        double mx = 0., my = 0., mz = 0.;
+        if (fluid) {
+#pragma unroll
+            for (int i = 1; i < Q; ++i) { const double t = fR[i] + fB[i]; addc(mx, CX[i], t); addc(my, CY[i], t); addc(mz, CZ[i], t); }
+            const double rs = rB + rR;
+            mx = (mx + 0.5 * p.F[n]) / rs; my = (my + 0.5 * p.F[p.NS + n]) / rs; mz = (mz + 0.5 * p.F[2 * p.NS + n]) / rs;
+        }
+        out_u[n] = mx; out_u[(size_t)p.N + n] = my; out_u[2 * (size_t)p.N + n] = mz;
+        out_phi[n] = fluid ? (rR - rB) / (rR + rB) : 0.;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ set-up
+__device__ __forceinline__ int wrapn(int v, int n) { v %= n; return v < 0 ? v + n : v; }
+
+// meta words (RKD2Q9.py:657-690, :741-763 on the D3Q19 neighbourhood) and the number of wetting solids
+__global__ __launch_bounds__(256) void csf3d_setup_meta(int nx, int ny, int nz, unsigned N, const uint8_t *dom, uint32_t *meta, unsigned *nwet)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    const unsigned pl = (unsigned)nx * (unsigned)ny;
+    const int z = (int)(n / pl), y = (int)((n - (unsigned)z * pl) / (unsigned)nx), x = (int)(n - (unsigned)z * pl - (unsigned)y * (unsigned)nx);
+    const bool fluid = dom[n] == 1;
+    uint32_t m = fluid ? 1u : 0u;
+    int other = 0;
+    for (int i = 1; i < Q; ++i) {
+        const size_t q = ((size_t)wrapn(z + CZ[i], nz) * ny + wrapn(y + CY[i], ny)) * nx + wrapn(x + CX[i], nx);
+        const bool f = dom[q] == 1;
+        if (f) m |= 1u << i;
+        if (f != fluid) ++other;
+    }
+    const unsigned kind = fluid ? (other ? 3u : 1u) : (other ? 2u : 0u);
+    meta[n] = m | (kind << KIND_SHIFT);
+    if (kind == 2u) atomicAdd(nwet, 1u);
+}
+__global__ __launch_bounds__(256) void csf3d_setup_wetlist(unsigned N, const uint32_t *meta, uint32_t *wetlist, unsigned *cursor)
+{
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    if (((meta[n] >> KIND_SHIFT) & 3u) == 2u) wetlist[atomicAdd(cursor, 1u)] = n;
+}
+__device__ __forceinline__ double e8w(int c2)
+{   // the 3-D E8 stencil of Sbragaglia et al. 2007 by |c|^2; its sums along one axis are 4/21, 4/45, 1/60, 2/315, 1/5040 (RKD2Q9.py:811-885)
+    switch (c2) {
+    case 1: return 4. / 45.;
+    case 2: return 1. / 21.;
+    case 3: return 2. / 105.;
+    case 4: return 5. / 504.;
+    case 5: return 1. / 315.;
+    case 6: return 1. / 630.;
+    case 8: return 1. / 5040.;
+    default: return 0.;
+    }
+}
+// RKD2Q9.py:768-892 calVectorNormaltoSolid in three dimensions, at the fluid cells next to solid
+__global__ __launch_bounds__(256) void csf3d_setup_normals(int nx, int ny, int nz, unsigned N, size_t NS, const uint8_t *dom, const uint32_t *meta, double *ns)
+{
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    double ox = 0., oy = 0., oz = 0.;
+    if (((meta[n] >> KIND_SHIFT) & 3u) == 3u) {
+        const unsigned pl = (unsigned)nx * (unsigned)ny;
+        const int z = (int)(n / pl), y = (int)((n - (unsigned)z * pl) / (unsigned)nx), x = (int)(n - (unsigned)z * pl - (unsigned)y * (unsigned)nx);
+        double sx = 0., sy = 0., sz = 0.;
+        for (int dz = -2; dz <= 2; ++dz)
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const double w = e8w(dx * dx + dy * dy + dz * dz);
+                    if (w == 0.) continue;
+                    if (dom[((size_t)wrapn(z + dz, nz) * ny + wrapn(y + dy, ny)) * nx + wrapn(x + dx, nx)] == 1) continue;
+                    sx += w * dx; sy += w * dy; sz += w * dz;
+                }
+        const double nrm = sqrt(sx * sx + sy * sy + sz * sz);
+        ox = sx / nrm; oy = sy / nrm; oz = sz / nrm;
+    }
+    ns[n] = ox; ns[NS + n] = oy; ns[2 * NS + n] = oz;
+}
+
+// initial populations: f_c,i = rho_c w_i (1 + 3 e.u + 4.5 (e.u)^2 - 1.5 u^2) (RKD2Q9.py:577-601); host arrays dense [N], velocity may be absent
+__global__ __launch_bounds__(256) void csf3d_init(CsfDev p, double *f, const double *rho_r, const double *rho_b, const double *vx, const double *vy, const double *vz)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= p.N) return;
+    const bool fluid = p.meta[n] & 1u;
+    const double ux = vx ? vx[n] : 0., uy = vy ? vy[n] : 0., uz = vz ? vz[n] : 0.;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        f[(size_t)i * p.NS + n] = fluid ? feq(rho_r[n], i, CX[i], CY[i], CZ[i], ux, uy, uz) : 0.;
+        f[(size_t)(Q + i) * p.NS + n] = fluid ? feq(rho_b[n], i, CX[i], CY[i], CZ[i], ux, uy, uz) : 0.;
+    }
+}
+// populations given in the host layout [2][N][19] -> SoA
+__global__ __launch_bounds__(256) void csf3d_import(CsfDev p, double *f, const double *pdf)
+{
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= p.N) return;
+    const bool fluid = p.meta[n] & 1u;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        f[(size_t)i * p.NS + n] = fluid ? pdf[(size_t)n * Q + i] : 0.;
+        f[(size_t)(Q + i) * p.NS + n] = fluid ? pdf[((size_t)p.N + n) * Q + i] : 0.;
+    }
+}
+
+}  // namespace
+
+struct lbmpm_rk3dcsf {
+    lbmpm_rk3dcsf_config cfg;
+    int nx = 0, ny = 0, nz = 0;
+    size_t N = 0, NS = 0;
+    int64_t nfluid = 0, steps = 0, bytes = 0;
+    unsigned nwet = 0;
+    bool first = true, have_state = false, diag = false, diag_valid = false;
+    hipStream_t stream = nullptr;
+    uint8_t *dom = nullptr;
+    uint32_t *meta = nullptr, *wetlist = nullptr;
+    double *fA = nullptr, *fB = nullptr, *phi = nullptr, *G = nullptr, *nh = nullptr, *F = nullptr, *K = nullptr, *U = nullptr, *ns = nullptr;
+    double *obs = nullptr;         // staging of the observe kernel: pdf [2][N][19], rho [2][N], u [3][N], phi [N]
+    lbmpm::EventPool pool;
+    size_t timed_steps = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(lbmpm_rk3dcsf *c, T **ptr, size_t count)
+{
+    const hipError_t e = hipMalloc(reinterpret_cast<void **>(ptr), count * sizeof(T));
+    if (e != hipSuccess) { set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); return LBMPM_ERR_NOMEM; }
+    c->bytes += (int64_t)(count * sizeof(T));
+    return LBMPM_OK;
+}
+
+CsfDev make_dev(const lbmpm_rk3dcsf *c)
+{
+    CsfDev p;
+    p.nx = c->nx; p.ny = c->ny; p.nz = c->nz; p.N = (unsigned)c->N; p.NS = c->NS;
+    p.meta = c->meta; p.fin = c->fA; p.fout = c->fB;
+    p.phi = c->phi; p.G = c->G; p.nh = c->nh; p.F = c->F; p.K = c->K; p.U = c->U; p.ns = c->ns;
+    const double th = c->cfg.contact_angle_deg / 180. * M_PI;
+    p.sigma = c->cfg.surface_tension; p.cosT = cos(th); p.sinT = sin(th);
+    p.beta = c->cfg.beta; p.delta = c->cfg.delta; p.tauR = c->cfg.tau_r; p.tauB = c->cfg.tau_b;
+    p.vzIn = c->cfg.inlet_velocity_z; p.pInB = c->cfg.inlet_rho_b; p.pInR = c->cfg.inlet_rho_r; p.pOut = c->cfg.outlet_rho_total;
+    p.tauType = c->cfg.tau_type; p.inletP = c->cfg.inlet_type == LBMPM_INLET_PRESSURE; p.conv = c->cfg.outlet_type == LBMPM_OUTLET_CONVECTIVE;
+    p.wetting = c->cfg.wetting_type; p.nwet = (int)c->nwet;
+    bool any = false;
+    for (int i = 0; i < 6; ++i) any = any || c->cfg.mrt_rates[i] != 0.;
+    const double own[6] = {1.19, 1.4, 1.2, 1.4, 1.2, 0.};
+    for (int i = 0; i < 6; ++i) p.rate[i] = any ? c->cfg.mrt_rates[i] : own[i];
+    return p;
+}
+
+unsigned blocks_of(size_t n) { return (unsigned)((n + 255) / 256); }
+
+template <bool FIRST>
+int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
+{
+    const unsigned g = blocks_of(c->N);
+    csf3d_phase<FIRST><<<g, 256, 0, c->stream>>>(p);
+    if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist);
+    csf3d_gradient<<<g, 256, 0, c->stream>>>(p);
+    if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+    const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
+    if (mrt) { if (c->diag) csf3d_collide<FIRST, true, true><<<g, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, true, false><<<g, 256, 0, c->stream>>>(p); }
+    else { if (c->diag) csf3d_collide<FIRST, false, true><<<g, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, false, false><<<g, 256, 0, c->stream>>>(p); }
+    if (e1) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
+    LBMPM_HIP_TRY(hipGetLastError());
+    return LBMPM_OK;
+}
+
+int run_steps(lbmpm_rk3dcsf *c, int64_t nsteps, bool timed)
+{
+    if (!c->have_state) { set_error("lbmpm_rk3dcsf_step before set_macro / set_pdf"); return LBMPM_ERR_STATE; }
+    for (int64_t s = 0; s < nsteps; ++s) {
+        const CsfDev p = make_dev(c);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed && c->pool.take(&e0, &e1)) ++c->timed_steps;
+        const int rc = c->first ? launch_step<true>(c, p, e0, e1) : launch_step<false>(c, p, e0, e1);
+        if (rc != LBMPM_OK) return rc;
+        std::swap(c->fA, c->fB);
+        c->first = false;
+        ++c->steps;
+        c->diag_valid = c->diag;
+    }
+    return LBMPM_OK;
+}
+
+int upload(lbmpm_rk3dcsf *c, double *dst, const double *src, size_t count)
+{
+    LBMPM_HIP_TRY(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return LBMPM_OK;
+}
+
+}  // namespace
+
+extern "C" void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->dom, c->meta, c->wetlist, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    c->pool.destroy();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8_t *is_domain, lbmpm_rk3dcsf **out)
+{
+    LBMPM_REQUIRE(cfg && is_domain && out, "lbmpm_rk3dcsf_create: null argument");
+    LBMPM_REQUIRE(cfg->nx >= 1 && cfg->ny >= 1 && cfg->nz >= 8, "lbmpm_rk3dcsf_create: lattice %lld x %lld x %lld out of range (nz >= 8: two open planes and their ghosts at each end)",
+                  (long long)cfg->nx, (long long)cfg->ny, (long long)cfg->nz);
+    LBMPM_REQUIRE((double)cfg->nx * (double)cfg->ny * (double)cfg->nz < 2147483648., "lbmpm_rk3dcsf_create: more than 2^31 cells");
+    LBMPM_REQUIRE(cfg->relaxation == LBMPM_RELAX_SRT || cfg->relaxation == LBMPM_RELAX_MRT, "bad relaxation %d", cfg->relaxation);
+    LBMPM_REQUIRE(cfg->inlet_type == LBMPM_INLET_VELOCITY || cfg->inlet_type == LBMPM_INLET_PRESSURE, "bad inlet_type %d", cfg->inlet_type);
+    LBMPM_REQUIRE(cfg->outlet_type == LBMPM_OUTLET_PRESSURE || cfg->outlet_type == LBMPM_OUTLET_CONVECTIVE, "bad outlet_type %d", cfg->outlet_type);
+    LBMPM_REQUIRE(cfg->tau_type == 1 || cfg->tau_type == 2, "TauType must be 1 or 2");
+    LBMPM_REQUIRE(cfg->tau_r > 0.5 && cfg->tau_b > 0.5, "TauR, TauB must exceed 0.5");
+    if (cfg->wetting_type == 1) {
+        set_error("WettingType 1 (Xu et al. 2017, AcceleratedRKGPU2D.py:1639-1679) rotates the normal in the plane: a 2-D rule without a 3-D form; "
+                  "use WettingType 2 (Akai et al. 2018)");
+        return LBMPM_ERR_UNSUPPORTED;
+    }
+    LBMPM_REQUIRE(cfg->wetting_type == 2 || cfg->wetting_type == 0, "WettingType must be 2 (or 0: no correction at the walls)");
+    const size_t pl = (size_t)cfg->nx * cfg->ny, N = pl * (size_t)cfg->nz;
+    // the ghost planes copy the plane next to them cell by cell (the reference's kernels take the neighbour's index without looking)
+    auto same = [&](int64_t za, int64_t zb) {
+        for (size_t k = 0; k < pl; ++k) if ((is_domain[za * pl + k] == 1) != (is_domain[zb * pl + k] == 1)) return false;
+        return true;
+    };
+    LBMPM_REQUIRE(same(cfg->nz - 1, cfg->nz - 2), "lbmpm_rk3dcsf_create: the ghost plane nz-1 must have the mask of the inlet plane nz-2");
+    if (cfg->outlet_type == LBMPM_OUTLET_CONVECTIVE)
+        LBMPM_REQUIRE(same(0, 3) && same(1, 3) && same(2, 3), "lbmpm_rk3dcsf_create: the convective outlet copies plane 3 onto the planes 2, 1, 0: their masks must coincide");
+    else
+        LBMPM_REQUIRE(same(0, 1), "lbmpm_rk3dcsf_create: the ghost plane 0 must have the mask of the outlet plane 1");
+    LBMPM_HIP_TRY(hipSetDevice(cfg->device));
+    lbmpm_rk3dcsf *c = new (std::nothrow) lbmpm_rk3dcsf();
+    if (!c) { set_error("out of host memory"); return LBMPM_ERR_NOMEM; }
+    c->cfg = *cfg;
+    c->nx = (int)cfg->nx; c->ny = (int)cfg->ny; c->nz = (int)cfg->nz;
+    c->N = N; c->NS = (N + 15) / 16 * 16;
+    for (size_t k = 0; k < N; ++k) c->nfluid += is_domain[k] == 1;
+    if (c->nfluid == 0) { set_error("lbmpm_rk3dcsf_create: the domain has no fluid cell (is_domain == 1 marks fluid)"); delete c; return LBMPM_ERR_INVALID; }
+    {
+        const hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return LBMPM_ERR_HIP; }
+    }
+    int rc = LBMPM_OK;
+#define TRY_RC(e) do { rc = (e); if (rc != LBMPM_OK) { lbmpm_rk3dcsf_destroy(c); return rc; } } while (0)
+#define TRY_HIP(e) do { const hipError_t e_ = (e); if (e_ != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(e_)); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; } } while (0)
+    TRY_RC(dev_alloc(c, &c->dom, N));
+    TRY_RC(dev_alloc(c, &c->meta, N));
+    TRY_RC(dev_alloc(c, &c->fA, 2 * Q * c->NS));
+    TRY_RC(dev_alloc(c, &c->fB, 2 * Q * c->NS));
+    TRY_RC(dev_alloc(c, &c->phi, c->NS));
+    TRY_RC(dev_alloc(c, &c->G, 3 * c->NS));
+    TRY_RC(dev_alloc(c, &c->nh, 3 * c->NS));
+    TRY_RC(dev_alloc(c, &c->F, 3 * c->NS));
+    TRY_RC(dev_alloc(c, &c->ns, 3 * c->NS));
+    unsigned *counters = nullptr;
+    TRY_HIP(hipMalloc(reinterpret_cast<void **>(&counters), 2 * sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->dom, is_domain, N, hipMemcpyHostToDevice, c->stream);
+    for (double *q : {c->phi, c->G, c->nh, c->F}) if (e == hipSuccess) e = hipMemsetAsync(q, 0, (q == c->phi ? 1 : 3) * c->NS * sizeof(double), c->stream);
+    if (e == hipSuccess) {
+        csf3d_setup_meta<<<blocks_of(N), 256, 0, c->stream>>>(c->nx, c->ny, c->nz, (unsigned)N, c->dom, c->meta, counters);
+        csf3d_setup_normals<<<blocks_of(N), 256, 0, c->stream>>>(c->nx, c->ny, c->nz, (unsigned)N, c->NS, c->dom, c->meta, c->ns);
+        e = hipMemcpyAsync(&c->nwet, counters, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipFree(counters); set_error("set-up failed: %s", hipGetErrorString(e)); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; }
+    if (c->nwet) {
+        rc = dev_alloc(c, &c->wetlist, c->nwet);
+        if (rc != LBMPM_OK) { (void)hipFree(counters); lbmpm_rk3dcsf_destroy(c); return rc; }
+        csf3d_setup_wetlist<<<blocks_of(N), 256, 0, c->stream>>>((unsigned)N, c->meta, c->wetlist, counters + 1);
+        e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFree(counters); set_error("set-up failed: %s", hipGetErrorString(e)); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; }
+    }
+    (void)hipFree(counters);
+#undef TRY_RC
+#undef TRY_HIP
+    *out = c;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3dcsf_enable_diagnostics(lbmpm_rk3dcsf *c, int on)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if (on && !c->K) {
+        int rc = dev_alloc(c, &c->K, c->NS); if (rc) return rc;
+        rc = dev_alloc(c, &c->U, 3 * c->NS); if (rc) return rc;
+        LBMPM_HIP_TRY(hipMemsetAsync(c->K, 0, c->NS * sizeof(double), c->stream));
+        LBMPM_HIP_TRY(hipMemsetAsync(c->U, 0, 3 * c->NS * sizeof(double), c->stream));
+    }
+    c->diag = on != 0;
+    if (!on) c->diag_valid = false;
+    return LBMPM_OK;
+}
+
+static int reset_state(lbmpm_rk3dcsf *c, const double *fx, const double *fy, const double *fz)
+{
+    std::vector<double> tmp;
+    const double *src[3] = {fx, fy, fz};
+    for (int a = 0; a < 3; ++a) {
+        if (src[a]) { const int rc = upload(c, c->F + a * c->NS, src[a], c->N); if (rc) return rc; }
+        else LBMPM_HIP_TRY(hipMemsetAsync(c->F + a * c->NS, 0, c->NS * sizeof(double), c->stream));
+    }
+    LBMPM_HIP_TRY(hipMemsetAsync(c->G, 0, 3 * c->NS * sizeof(double), c->stream));
+    LBMPM_HIP_TRY(hipMemsetAsync(c->nh, 0, 3 * c->NS * sizeof(double), c->stream));
+    LBMPM_HIP_TRY(hipMemsetAsync(c->phi, 0, c->NS * sizeof(double), c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->first = true; c->have_state = true; c->steps = 0; c->diag_valid = false;
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3dcsf_set_macro(lbmpm_rk3dcsf *c, const double *rho_r, const double *rho_b, const double *vx, const double *vy, const double *vz)
+{
+    LBMPM_REQUIRE(c && rho_r && rho_b, "lbmpm_rk3dcsf_set_macro: null argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    // staged through the second population buffer (5 N doubles of its 38 N)
+    double *st = c->fB;
+    const double *src[5] = {rho_r, rho_b, vx, vy, vz};
+    for (int a = 0; a < 5; ++a) if (src[a]) { const int rc = upload(c, st + a * c->NS, src[a], c->N); if (rc) return rc; }
+    const CsfDev p = make_dev(c);
+    csf3d_init<<<blocks_of(c->N), 256, 0, c->stream>>>(p, c->fA, st, st + c->NS, vx ? st + 2 * c->NS : nullptr, vy ? st + 3 * c->NS : nullptr, vz ? st + 4 * c->NS : nullptr);
+    LBMPM_HIP_TRY(hipGetLastError());
+    return reset_state(c, nullptr, nullptr, nullptr);
+}
+
+extern "C" int lbmpm_rk3dcsf_set_pdf(lbmpm_rk3dcsf *c, const double *pdf_r, const double *pdf_b, const double *fx, const double *fy, const double *fz)
+{
+    LBMPM_REQUIRE(c && pdf_r && pdf_b, "lbmpm_rk3dcsf_set_pdf: null argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    double *st = c->fB;                          // [2][N][19] fits the 38 NS doubles of the buffer
+    int rc = upload(c, st, pdf_r, c->N * Q); if (rc) return rc;
+    rc = upload(c, st + c->N * Q, pdf_b, c->N * Q); if (rc) return rc;
+    const CsfDev p = make_dev(c);
+    csf3d_import<<<blocks_of(c->N), 256, 0, c->stream>>>(p, c->fA, st);
+    LBMPM_HIP_TRY(hipGetLastError());
+    return reset_state(c, fx, fy, fz);
+}
+
+extern "C" int lbmpm_rk3dcsf_step(lbmpm_rk3dcsf *c, int64_t nsteps)
+{
+    LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_rk3dcsf_step: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    return run_steps(c, nsteps, false);
+}
+
+extern "C" int lbmpm_rk3dcsf_step_timed(lbmpm_rk3dcsf *c, int64_t nsteps, double *ms_total, double *ms_dominant)
+{
+    LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_rk3dcsf_step_timed: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t pairs = (size_t)(nsteps < 4096 ? nsteps : 4096);
+    if (c->pool.reserve(pairs + 1) != LBMPM_OK) { set_error("hipEventCreate failed"); return LBMPM_ERR_HIP; }
+    c->pool.reset();
+    c->timed_steps = 0;
+    hipEvent_t t0, t1;
+    c->pool.take(&t0, &t1);
+    LBMPM_HIP_TRY(hipEventRecord(t0, c->stream));
+    const int rc = run_steps(c, nsteps, true);
+    if (rc != LBMPM_OK) return rc;
+    LBMPM_HIP_TRY(hipEventRecord(t1, c->stream));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    LBMPM_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+    if (ms_total) *ms_total = ms;
+    if (ms_dominant) {
+        double s = 0.0;
+        for (size_t k = 2; k + 1 < c->pool.used; k += 2) {
+            float m = 0.f;
+            LBMPM_HIP_TRY(hipEventElapsedTime(&m, c->pool.ev[k], c->pool.ev[k + 1]));
+            s += m;
+        }
+        *ms_dominant = c->timed_steps ? s * (double)nsteps / (double)c->timed_steps : 0.0;
+    }
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3dcsf_sync(lbmpm_rk3dcsf *c)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return LBMPM_OK;
+}
+
+static int observe(lbmpm_rk3dcsf *c, bool rec, bool with_pdf)
+{
+    const size_t need = (size_t)2 * c->N * Q + 6 * c->N;
+    if (!c->obs) { const int rc = dev_alloc(c, &c->obs, need); if (rc) return rc; }
+    const CsfDev p = make_dev(c);
+    double *pdf = c->obs, *rho = c->obs + 2 * c->N * Q, *u = rho + 2 * c->N, *phi = u + 3 * c->N;
+    const unsigned g = blocks_of(c->N);
+    if (c->first) { if (rec) csf3d_observe<true, true><<<g, 256, 0, c->stream>>>(p, with_pdf ? pdf : nullptr, rho, u, phi); else csf3d_observe<true, false><<<g, 256, 0, c->stream>>>(p, with_pdf ? pdf : nullptr, rho, u, phi); }
+    else { if (rec) csf3d_observe<false, true><<<g, 256, 0, c->stream>>>(p, with_pdf ? pdf : nullptr, rho, u, phi); else csf3d_observe<false, false><<<g, 256, 0, c->stream>>>(p, with_pdf ? pdf : nullptr, rho, u, phi); }
+    LBMPM_HIP_TRY(hipGetLastError());
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3dcsf_get_field(lbmpm_rk3dcsf *c, int field, double *out)
+{
+    LBMPM_REQUIRE(c && out, "lbmpm_rk3dcsf_get_field: null argument");
+    LBMPM_REQUIRE(c->have_state, "lbmpm_rk3dcsf_get_field before set_macro / set_pdf");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t N = c->N, NS = c->NS;
+    auto down = [&](const double *src, size_t count) -> int {
+        LBMPM_HIP_TRY(hipMemcpy(out, src, count * sizeof(double), hipMemcpyDeviceToHost));
+        return LBMPM_OK;
+    };
+    const bool rec = field >= LBMPM_RK3DCSF_REC_PDF_R;
+    switch (field) {
+    case LBMPM_RK3DCSF_PDF_R: case LBMPM_RK3DCSF_PDF_B: case LBMPM_RK3DCSF_RHO_R: case LBMPM_RK3DCSF_RHO_B:
+    case LBMPM_RK3DCSF_REC_PDF_R: case LBMPM_RK3DCSF_REC_PDF_B: case LBMPM_RK3DCSF_REC_RHO_R: case LBMPM_RK3DCSF_REC_RHO_B:
+    case LBMPM_RK3DCSF_REC_VX: case LBMPM_RK3DCSF_REC_VY: case LBMPM_RK3DCSF_REC_VZ: case LBMPM_RK3DCSF_REC_PHI: {
+        const int base = rec ? field - LBMPM_RK3DCSF_REC_PDF_R : field;
+        const int rc = observe(c, rec, base <= 1);
+        if (rc) return rc;
+        const double *pdf = c->obs, *rho = c->obs + 2 * N * Q, *u = rho + 2 * N, *phi = u + 3 * N;
+        if (base <= 1) return down(pdf + (size_t)base * N * Q, N * Q);
+        if (base <= 3) return down(rho + (size_t)(base - 2) * N, N);
+        if (field == LBMPM_RK3DCSF_REC_PHI) return down(phi, N);
+        return down(u + (size_t)(field - LBMPM_RK3DCSF_REC_VX) * N, N);
+    }
+    case LBMPM_RK3DCSF_PHI: return down(c->phi, N);
+    case LBMPM_RK3DCSF_GX: case LBMPM_RK3DCSF_GY: case LBMPM_RK3DCSF_GZ: return down(c->G + (size_t)(field - LBMPM_RK3DCSF_GX) * NS, N);
+    case LBMPM_RK3DCSF_FX: case LBMPM_RK3DCSF_FY: case LBMPM_RK3DCSF_FZ: return down(c->F + (size_t)(field - LBMPM_RK3DCSF_FX) * NS, N);
+    case LBMPM_RK3DCSF_NSX: case LBMPM_RK3DCSF_NSY: case LBMPM_RK3DCSF_NSZ: return down(c->ns + (size_t)(field - LBMPM_RK3DCSF_NSX) * NS, N);
+    case LBMPM_RK3DCSF_VX: case LBMPM_RK3DCSF_VY: case LBMPM_RK3DCSF_VZ: case LBMPM_RK3DCSF_K:
+        if (!c->diag_valid) { set_error("u and K of the last step are kept with lbmpm_rk3dcsf_enable_diagnostics(ctx, 1) before stepping"); return LBMPM_ERR_STATE; }
+        return field == LBMPM_RK3DCSF_K ? down(c->K, N) : down(c->U + (size_t)(field - LBMPM_RK3DCSF_VX) * NS, N);
+    case LBMPM_RK3DCSF_KIND: {
+        std::vector<uint32_t> m(N);
+        LBMPM_HIP_TRY(hipMemcpy(m.data(), c->meta, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < N; ++k) out[k] = (double)((m[k] >> KIND_SHIFT) & 3u);
+        return LBMPM_OK;
+    }
+    default:
+        set_error("unknown field id %d", field);
+        return LBMPM_ERR_INVALID;
+    }
+}
+
+extern "C" int64_t lbmpm_rk3dcsf_num_fluid_nodes(const lbmpm_rk3dcsf *c) { return c ? c->nfluid : 0; }
+extern "C" int64_t lbmpm_rk3dcsf_num_wetting_solids(const lbmpm_rk3dcsf *c) { return c ? (int64_t)c->nwet : 0; }
+extern "C" int64_t lbmpm_rk3dcsf_steps_done(const lbmpm_rk3dcsf *c) { return c ? c->steps : 0; }
+extern "C" int64_t lbmpm_rk3dcsf_device_bytes(const lbmpm_rk3dcsf *c) { return c ? c->bytes : 0; }
+extern "C" const char *lbmpm_rk3dcsf_dominant_kernel(const lbmpm_rk3dcsf *c) { (void)c; return "csf3d_collide"; }

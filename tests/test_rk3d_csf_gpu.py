@@ -1,0 +1,242 @@
+"""3-D CSF colour gradient on the GPU (lbmpm_rk3dcsf_*, csrc/rk3d_csf.hip) through the C ABI.
+
+* against oracle/rk3d_csf_oracle.c (pinned by reduction, tests/test_oracle_rk3d_csf.py) on 3-D samples without symmetry: every field the
+  loop keeps, 1e-10 field-relative, SRT and MRT, both inlets, both outlets, both tau types, with and without the wetting rule;
+* the reduction itself through the HIP kernels: a y-uniform lattice against the capture of the REAL 2-D driver (1e-9);
+* restart bit for bit; the record view; set-up tables; refusals; a static droplet's Laplace pressure."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_params, rel_err
+from oracle.rk import initial_densities
+from oracle.rk3dcsf import RK3DCSFOracle
+from test_oracle_rk3d_csf import blob3, extrude, params3, project_pdf, PAIRS
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+SCALARS = ("rhoR", "rhoB", "phi", "K")
+VECTORS = (("vx", "vy", "vz"), ("Gx", "Gy", "Gz"), ("Fx", "Fy", "Fz"))
+
+
+def solver(dom, par, **kw):
+    from openlbmpm_amd.rk3dcsf import RK3DCSFSolver
+    return RK3DCSFSolver(dom, par, diagnostics=True, **kw)
+
+
+def compare_all(s, o, what, tol=TOL):
+    fl = o.dom == 1
+    worst = 0.0
+    for f in SCALARS:
+        e = rel_err(s.get(f)[fl], o.field(f)[fl])
+        assert e < tol, "%s: %s %.3e" % (what, f, e)
+        worst = max(worst, e)
+    for vec in VECTORS:
+        scale = max(float(np.max(np.abs(o.field(c)[fl]))) for c in vec)
+        for c in vec:
+            e = rel_err(s.get(c)[fl], o.field(c)[fl], scale=max(scale, 1e-300))
+            assert e < tol, "%s: %s %.3e" % (what, c, e)
+            worst = max(worst, e)
+    for f in ("fR", "fB"):
+        a = s.get(f)
+        assert np.all(a[~fl] == 0.0)
+        e = rel_err(a[fl], o.field(f)[fl])
+        assert e < tol, "%s: %s %.3e" % (what, f, e)
+        worst = max(worst, e)
+    # phi on the wetting solids
+    wet = o.field("kind") == 2
+    if wet.any():
+        assert rel_err(s.get("phi")[wet], o.field("phi")[wet]) < tol, what
+    return worst
+
+
+VARIANTS = {
+    "MRT": dict(relax="MRT"),
+    "SRT": dict(relax="SRT"),
+    "MRT pressure inlet": dict(relax="MRT", inlet="Dirichlet"),
+    "SRT convective outlet": dict(relax="SRT", outlet="Convective"),
+    "MRT convective outlet, pressure inlet": dict(relax="MRT", outlet="Convective", inlet="Dirichlet"),
+    "MRT tau type 1": dict(relax="MRT", tautype=1, tauB=0.7),
+    "SRT no wetting rule": dict(relax="SRT", wetting=0),
+    "MRT theta 140": dict(relax="MRT", theta=140.0, tauB=0.8),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_against_the_oracle_on_a_sample_without_symmetry(name):
+    dom, rR, rB = blob3()
+    par = dict(theta=50.0, tauB=0.8); par.update(VARIANTS[name])
+    s = solver(dom, par)
+    s.set_macro(rR, rB)
+    o = RK3DCSFOracle(dom, rR, rB, par)
+    assert s.num_wetting_solids == o.W and s.num_fluid_nodes == int(dom.sum())
+    done = 0
+    for k in (1, 2, 30):
+        s.step(k - done); o.run(k - done)
+        done = k
+        compare_all(s, o, "%s, step %d" % (name, k))
+    assert np.max(np.abs(o.field("K"))) > 1e-3
+    s.close()
+
+
+def test_setup_tables():
+    dom, rR, rB = blob3()
+    s = solver(dom, dict(theta=50.0))
+    s.set_macro(rR, rB)
+    o = RK3DCSFOracle(dom, rR, rB, dict(theta=50.0))
+    assert np.array_equal(s.get("kind").astype(np.uint8), o.field("kind"))
+    for c in ("nsx", "nsy", "nsz"):
+        assert rel_err(s.get(c), o.field(c)) < 1e-15, c
+    near = o.field("kind") == 3
+    n2 = s.get("nsx") ** 2 + s.get("nsy") ** 2 + s.get("nsz") ** 2
+    assert np.allclose(n2[near], 1.0, atol=1e-14) and np.all(n2[~near] == 0.0)
+    s.close()
+
+
+ODD = {(13, 7, 11): (slice(4, 7), slice(2, 5), slice(3, 8)), (5, 1, 16): (slice(6, 9), slice(0, 1), slice(0, 2)),
+       (1, 6, 12): (slice(5, 7), slice(0, 2), slice(0, 1)), (70, 3, 9): (slice(3, 6), slice(1, 2), slice(10, 50))}
+
+
+@pytest.mark.parametrize("nx,ny,nz", sorted(ODD))
+def test_odd_sizes(nx, ny, nz):
+    """sizes that are no multiple of anything, one-cell-wide periodic directions (every neighbour along them is the cell itself)"""
+    dom = np.ones((nz, ny, nx), dtype=np.uint8)
+    dom[ODD[(nx, ny, nz)]] = 0              # one solid box: no cell sits between two symmetric walls (its solid normal would be 0 / 0, as in the reference)
+    zz = np.mgrid[0:nz, 0:ny, 0:nx][0]
+    rR = np.where((dom == 1) & (zz < nz // 2), 1.0, 0.02 * (dom == 1)); rB = np.where((dom == 1) & (zz >= nz // 2), 1.0, 0.03 * (dom == 1))
+    par = dict(relax="MRT", theta=70.0)
+    s = solver(dom, par); s.set_macro(rR, rB); s.step(12)
+    o = RK3DCSFOracle(dom, rR, rB, par).run(12)
+    assert np.all(np.isfinite(o.field("vz"))) and o.W > 0
+    compare_all(s, o, "%d x %d x %d" % (nx, ny, nz))
+    s.close()
+
+
+def test_initial_velocity_and_the_record_view():
+    dom, rR, rB = blob3()
+    rng = np.random.default_rng(4)
+    v = [1e-3 * rng.standard_normal(dom.shape) * (dom == 1) for _ in range(3)]
+    par = dict(relax="MRT", theta=50.0)
+    s = solver(dom, par); s.set_macro(rR, rB, *v)
+    o = RK3DCSFOracle(dom, rR, rB, par, velocity=v)
+    fl = dom == 1
+    assert rel_err(s.get("fR")[fl], o.field("fR")[fl]) < 1e-15 and rel_err(s.get("rhoB")[fl], o.field("rhoB")[fl]) < 1e-15
+    umax = 1e-3
+
+    def check_record(orc, what):
+        rec = {f: s.get("rec_" + f) for f in ("fR", "fB", "rhoR", "rhoB", "vx", "vy", "vz", "phi")}
+        orc.step_a()                     # the first half of the next step: what the reference records (RKD2Q9.py:1382-1393)
+        for f, a in rec.items():
+            e = rel_err(a[fl], orc.field(f)[fl], scale=umax if f[0] == "v" else None)
+            assert e < TOL, "record view %s: %s %.3e" % (what, f, e)
+
+    check_record(RK3DCSFOracle(dom, rR, rB, par, velocity=v), "of the initial state")
+    s.step(7); o.run(7)
+    compare_all(s, o, "step 7")
+    check_record(o, "after 7 steps")
+    s.close()
+
+
+@pytest.mark.parametrize("relax", ["SRT", "MRT"])
+def test_restart_is_exact(relax):
+    dom, rR, rB = blob3()
+    par = dict(relax=relax, theta=50.0, tauB=0.8)
+    a = solver(dom, par); a.set_macro(rR, rB); a.step(40)
+    b = solver(dom, par); b.set_macro(rR, rB); b.step(20)
+    state = (b.get("fR"), b.get("fB"), (b.get("Fx"), b.get("Fy"), b.get("Fz")))
+    b.close()
+    c = solver(dom, par); c.set_pdf(*state); c.step(20)
+    for f in ("fR", "fB", "rhoR", "rhoB", "phi", "Fx", "Fy", "Fz", "K", "vz"):
+        assert np.array_equal(a.get(f), c.get(f)), f
+    a.close(); c.close()
+
+
+@pytest.mark.parametrize("ny", [1, 4])
+def test_reduces_to_the_capture_of_the_real_2d_driver(ny):
+    d = np.load(os.path.join(GOLDEN, "rk_csf_srt_capillary.npz"))
+    p = load_params(d)
+    dom2 = d["isDomain"]
+    rR2, rB2 = initial_densities(dom2, False, p["nbuf"])
+    par = params3(p)
+    s = solver(extrude(dom2, ny), par); s.set_macro(extrude(rR2, ny), extrude(rB2, ny))
+    fl = dom2 == 1
+    done = 0
+    for k in d["snaps"]:
+        s.step(int(k) - done); done = int(k)
+        ref = {}
+        for f in ("rhoR", "rhoB", "phi", "vx", "vy", "Gx", "Gy", "Fx", "Fy", "K", "fR", "fB"):
+            a = d["s%d_%s" % (k, f)]
+            out = np.zeros((dom2.size,) + a.shape[1:]); out[d["fluidNodes"]] = a
+            ref[f] = out.reshape(dom2.shape + a.shape[1:])
+        scales = dict(v=max(np.max(np.abs(ref["vx"])), np.max(np.abs(ref["vy"]))), G=max(np.max(np.abs(ref["Gx"])), np.max(np.abs(ref["Gy"]))),
+                      F=max(np.max(np.abs(ref["Fx"])), np.max(np.abs(ref["Fy"]))))
+        for f3, f2 in PAIRS:
+            a = s.get(f3)
+            e = rel_err(a[:, 0, :][fl], ref[f2][fl], scale=scales.get(f3[0]))
+            assert e < 1e-9, "step %d: %s vs the reference's %s: %.3e" % (k, f3, f2, e)
+            assert np.max(np.abs(a - a[:, :1, :])) <= 1e-12 * max(np.max(np.abs(a)), 1e-300)
+        for f in ("fR", "fB"):
+            assert rel_err(project_pdf(s.get(f))[fl], ref[f][fl]) < 1e-9, f
+    s.close()
+
+
+def test_porous_sample_against_the_oracle():
+    from openlbmpm_amd.geometry import porous_spheres, initial_densities_rk3d
+    dom = porous_spheres(40, 24, 36, porosity=0.7, rmin=3.0, rmax=6.0, seed=7, nbuf=5)
+    dom[0] = dom[1]; dom[-1] = dom[-2]
+    rR, rB = initial_densities_rk3d(dom, 5)
+    par = dict(relax="MRT", theta=40.0, tauB=0.8)
+    s = solver(dom, par); s.set_macro(rR, rB); s.step(25)
+    o = RK3DCSFOracle(dom, rR, rB, par).run(25)
+    compare_all(s, o, "porous 40 x 24 x 36")
+    assert s.dominant_kernel == "csf3d_collide"
+    s.close()
+
+
+def test_refusals():
+    from openlbmpm_amd._lib import LbmpmError, ERR_UNSUPPORTED, ERR_INVALID, ERR_STATE
+    dom, rR, rB = blob3()
+    with pytest.raises(LbmpmError) as e:
+        solver(dom, dict(wetting=1))
+    assert e.value.status == ERR_UNSUPPORTED and "WettingType 1" in str(e.value)
+    bad = dom.copy(); bad[-1, 3, 3] = 0
+    with pytest.raises(LbmpmError) as e:
+        solver(bad, None)
+    assert e.value.status == ERR_INVALID and "ghost plane" in str(e.value)
+    with pytest.raises(LbmpmError) as e:
+        solver(dom[:6], None)
+    assert e.value.status == ERR_INVALID
+    s = solver(dom, None)
+    with pytest.raises(LbmpmError) as e:
+        s.step(1)
+    assert e.value.status == ERR_STATE
+    s.close()
+
+
+def test_static_droplet_obeys_laplace():
+    """a red sphere at rest in blue between the open planes (zero inlet velocity, the outlet at the ambient density): the pressure
+    jump (rho_in - rho_out) / 3 approaches 2 sigma / R; two radii share the constant"""
+    nx = ny = 48; nz = 64
+    sigma = 0.02
+    out = []
+    for R in (9.0, 13.0):
+        dom = np.ones((nz, ny, nx), dtype=np.uint8)
+        zz, yy, xx = np.mgrid[0:nz, 0:ny, 0:nx]
+        red = (zz - nz / 2) ** 2 + (yy - ny / 2) ** 2 + (xx - nx / 2) ** 2 <= R * R
+        par = dict(relax="MRT", sigma=sigma, beta=0.7, velocityZR=0.0, velocityZB=0.0, densityBL=1.0, densityRL=0.0, theta=90.0)
+        s = solver(dom, par); s.set_macro(np.where(red, 1.0, 0.0), np.where(red, 0.0, 1.0)); s.step(4000)
+        rho = s.get("rhoR") + s.get("rhoB")
+        assert np.all(np.isfinite(rho))
+        pin = rho[nz // 2 - 2:nz // 2 + 2, ny // 2 - 2:ny // 2 + 2, nx // 2 - 2:nx // 2 + 2].mean() / 3.
+        pout = rho[nz // 2 - 2:nz // 2 + 2, 2:5, 2:5].mean() / 3.
+        # effective radius from the red volume
+        vol = float((s.get("phi") > 0).sum())
+        Reff = (3. * vol / (4. * np.pi)) ** (1. / 3.)
+        out.append((pin - pout) * Reff / (2. * sigma))
+        umax = max(float(np.max(np.abs(s.get(c)))) for c in ("vx", "vy", "vz"))
+        assert umax < 5e-4, "spurious currents %.2e" % umax
+        s.close()
+    assert abs(out[0] - 1.0) < 0.12 and abs(out[1] - 1.0) < 0.12, out
+    assert abs(out[0] - out[1]) < 0.06, out
