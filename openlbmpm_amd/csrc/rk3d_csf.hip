@@ -47,8 +47,12 @@ constexpr unsigned KIND_SHIFT = 20;
 struct CsfDev {
     int nx, ny, nz;
     unsigned N;                  // cells
-    size_t NS;                   // stride between the planes of a SoA array (N rounded up to 16: 128-byte lines start on plane boundaries)
+    size_t NS;                   // stride between the planes of a dense SoA array (N rounded up to 16)
+    size_t FS;                   // stride between the 38 population planes: fluid cells only, numbered in lattice order (x fastest)
     const uint32_t *meta;
+    const uint32_t *cidx;        // [N] number of a fluid cell among the fluid cells
+    const uint32_t *cells;       // [NF] its inverse: the lattice cell of fluid cell j
+    unsigned NF;
     const double *fin;
     double *fout;
     double *phi, *G, *nh, *F, *K, *U;
@@ -111,15 +115,22 @@ __device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z,
     const Nb nb = make_nb(p, x, y, zs);
     const unsigned own = at(nb, 0, 0, 0);
     const uint32_t m = p.meta[own];
-    const double *fr = p.fin, *fb = p.fin + (size_t)Q * p.NS;
+    const unsigned oj = p.cidx[own];
+    const double *fr = p.fin, *fb = p.fin + (size_t)Q * p.FS;
+    // the numbers of the source cells first (one dependent load each), then the 38 population loads
+    unsigned sj[Q];
+#pragma unroll
+    for (int i = 1; i < Q; ++i) {
+        const bool from_fluid = !FIRST && ((m >> OPP[i]) & 1u);          // the cell the population comes from, x - e_i
+        sj[i] = from_fluid ? p.cidx[at(nb, -CX[i], -CY[i], -CZ[i])] : oj;
+    }
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
         if (FIRST || i == 0) {
-            fR[i] = fr[(size_t)i * p.NS + own]; fB[i] = fb[(size_t)i * p.NS + own];
+            fR[i] = fr[(size_t)i * p.FS + oj]; fB[i] = fb[(size_t)i * p.FS + oj];
         } else {
-            const bool from_fluid = (m >> OPP[i]) & 1u;                 // the cell the population comes from, x - e_i
-            const unsigned src = from_fluid ? at(nb, -CX[i], -CY[i], -CZ[i]) : own;
-            const size_t off = (size_t)(from_fluid ? i : OPP[i]) * p.NS + src;      // half-way bounce-back: the cell's own opposite population
+            const bool from_fluid = (m >> OPP[i]) & 1u;
+            const size_t off = (size_t)(from_fluid ? i : OPP[i]) * p.FS + sj[i];     // off a solid: half-way bounce-back, the cell's own opposite population
             fR[i] = fr[off]; fB[i] = fb[off];
         }
     }
@@ -190,13 +201,29 @@ __device__ __forceinline__ bool cell_of(const CsfDev &p, unsigned n, int &x, int
     return true;
 }
 
+// The step's kernels run one thread per FLUID cell (no idle lanes in a porous medium; a wave's 64 cells are 512 consecutive bytes of
+// every population plane).  Workgroups go to the XCDs round robin (workgroup b to XCD b % 8); numbered like this, every XCD walks ONE
+// contiguous eighth of the fluid cells in lattice order: the cells a workgroup's neighbours in y read are then in the same L2.
+__device__ __forceinline__ bool fluid_cell(const CsfDev &p, unsigned &j, unsigned &n, int &x, int &y, int &z)
+{
+    const unsigned per = (gridDim.x + 7u) / 8u;          // gridDim.x is a multiple of 8
+    j = ((blockIdx.x & 7u) * per + (blockIdx.x >> 3)) * 256u + threadIdx.x;
+    if (j >= p.NF) return false;
+    n = p.cells[j];
+    const unsigned pl = (unsigned)p.nx * (unsigned)p.ny;
+    z = (int)(n / pl);
+    const unsigned r = n - (unsigned)z * pl;
+    y = (int)(r / (unsigned)p.nx);
+    x = (int)(r - (unsigned)y * (unsigned)p.nx);
+    return true;
+}
+
 template <bool FIRST>
 __global__ __launch_bounds__(256) void csf3d_phase(CsfDev p)
 {
-    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    unsigned j, n;
     int x, y, z;
-    if (!cell_of(p, n, x, y, z)) return;
-    if (!(p.meta[n] & 1u)) return;
+    if (!fluid_cell(p, j, n, x, y, z)) return;
     double fR[Q], fB[Q], rR, rB;
     cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
     p.phi[n] = (rR - rB) / (rR + rB);
@@ -224,11 +251,10 @@ __global__ __launch_bounds__(256) void csf3d_solid_phi(CsfDev p, const uint32_t 
 __global__ __launch_bounds__(256) void csf3d_gradient(CsfDev p)
 {
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
-    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    unsigned j, n;
     int x, y, z;
-    if (!cell_of(p, n, x, y, z)) return;
+    if (!fluid_cell(p, j, n, x, y, z)) return;
     const uint32_t m = p.meta[n];
-    if (!(m & 1u)) return;
     const Nb nb = make_nb(p, x, y, z);
     double gx = 0., gy = 0., gz = 0.;
 #pragma unroll
@@ -355,25 +381,11 @@ template <bool FIRST, bool MRT, bool DIAG>
 __global__ __launch_bounds__(256) void csf3d_collide(CsfDev p)
 {
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
-    const unsigned n = blockIdx.x * 256u + threadIdx.x;
-    int x = 0, y = 0, z = 0;
-    const bool inside = cell_of(p, n, x, y, z);
-    const uint32_t m = inside ? p.meta[n] : 0u;
-    const bool fluid = m & 1u;
-    double *fr = p.fout, *fb = p.fout + (size_t)Q * p.NS;
-    // a solid cell whose 128-byte line (16 cells) holds fluid writes zeros: partially written lines cost a read-modify-write
-    {
-        const unsigned long long fl = __ballot(fluid);
-        const unsigned lane = threadIdx.x & 63u;
-        const bool line = ((fl >> (lane & ~15u)) & 0xFFFFull) != 0ull;
-        if (!fluid) {
-            if (inside && line) {
-#pragma unroll
-                for (int i = 0; i < Q; ++i) { fr[(size_t)i * p.NS + n] = 0.; fb[(size_t)i * p.NS + n] = 0.; }
-            }
-            return;
-        }
-    }
+    unsigned j, n;
+    int x, y, z;
+    if (!fluid_cell(p, j, n, x, y, z)) return;
+    const uint32_t m = p.meta[n];
+    double *fr = p.fout + j, *fb = p.fout + (size_t)Q * p.FS + j;
     double fR[Q], fB[Q], rR, rB;
     cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
     double t[Q];
@@ -447,8 +459,9 @@ __global__ __launch_bounds__(256) void csf3d_collide(CsfDev p)
         const double un = i == 0 ? 0. : (i < 7 ? 1. : sqrt(2.));
         double c = 0.;
         if (gn > 1.0e-8 && un > 1.0e-8) c = edotv(CX[i], CY[i], CZ[i], gx, gy, gz) / (un * gn);
-        fr[(size_t)i * p.NS + n] = rR / tot * t[i] + p.beta * rR * rB / tot * wq(i) * c * un;
-        fb[(size_t)i * p.NS + n] = rB / tot * t[i] - p.beta * rR * rB / tot * wq(i) * c * un;
+        // streaming stores: these lines are not read again before the next step
+        __builtin_nontemporal_store(rR / tot * t[i] + p.beta * rR * rB / tot * wq(i) * c * un, fr + (size_t)i * p.FS);
+        __builtin_nontemporal_store(rB / tot * t[i] - p.beta * rR * rB / tot * wq(i) * c * un, fb + (size_t)i * p.FS);
     }
 }
 
@@ -559,12 +572,13 @@ __global__ __launch_bounds__(256) void csf3d_init(CsfDev p, double *f, const dou
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
     const unsigned n = blockIdx.x * 256u + threadIdx.x;
     if (n >= p.N) return;
-    const bool fluid = p.meta[n] & 1u;
+    if (!(p.meta[n] & 1u)) return;
+    const unsigned j = p.cidx[n];
     const double ux = vx ? vx[n] : 0., uy = vy ? vy[n] : 0., uz = vz ? vz[n] : 0.;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
-        f[(size_t)i * p.NS + n] = fluid ? feq(rho_r[n], i, CX[i], CY[i], CZ[i], ux, uy, uz) : 0.;
-        f[(size_t)(Q + i) * p.NS + n] = fluid ? feq(rho_b[n], i, CX[i], CY[i], CZ[i], ux, uy, uz) : 0.;
+        f[(size_t)i * p.FS + j] = feq(rho_r[n], i, CX[i], CY[i], CZ[i], ux, uy, uz);
+        f[(size_t)(Q + i) * p.FS + j] = feq(rho_b[n], i, CX[i], CY[i], CZ[i], ux, uy, uz);
     }
 }
 // populations given in the host layout [2][N][19] -> SoA
@@ -572,11 +586,12 @@ __global__ __launch_bounds__(256) void csf3d_import(CsfDev p, double *f, const d
 {
     const unsigned n = blockIdx.x * 256u + threadIdx.x;
     if (n >= p.N) return;
-    const bool fluid = p.meta[n] & 1u;
+    if (!(p.meta[n] & 1u)) return;
+    const unsigned j = p.cidx[n];
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
-        f[(size_t)i * p.NS + n] = fluid ? pdf[(size_t)n * Q + i] : 0.;
-        f[(size_t)(Q + i) * p.NS + n] = fluid ? pdf[((size_t)p.N + n) * Q + i] : 0.;
+        f[(size_t)i * p.FS + j] = pdf[(size_t)n * Q + i];
+        f[(size_t)(Q + i) * p.FS + j] = pdf[((size_t)p.N + n) * Q + i];
     }
 }
 
@@ -585,15 +600,15 @@ __global__ __launch_bounds__(256) void csf3d_import(CsfDev p, double *f, const d
 struct lbmpm_rk3dcsf {
     lbmpm_rk3dcsf_config cfg;
     int nx = 0, ny = 0, nz = 0;
-    size_t N = 0, NS = 0;
+    size_t N = 0, NS = 0, FS = 0;
     int64_t nfluid = 0, steps = 0, bytes = 0;
     unsigned nwet = 0;
     bool first = true, have_state = false, diag = false, diag_valid = false;
     hipStream_t stream = nullptr;
     uint8_t *dom = nullptr;
-    uint32_t *meta = nullptr, *wetlist = nullptr;
+    uint32_t *meta = nullptr, *wetlist = nullptr, *cidx = nullptr, *cells = nullptr;
     double *fA = nullptr, *fB = nullptr, *phi = nullptr, *G = nullptr, *nh = nullptr, *F = nullptr, *K = nullptr, *U = nullptr, *ns = nullptr;
-    double *obs = nullptr;         // staging of the observe kernel: pdf [2][N][19], rho [2][N], u [3][N], phi [N]
+    double *obs = nullptr;         // staging of the observe kernel: rho [2][N], u [3][N], phi [N] (the populations [2][N][19] come and go with the call)
     lbmpm::EventPool pool;
     size_t timed_steps = 0;
 };
@@ -613,7 +628,7 @@ CsfDev make_dev(const lbmpm_rk3dcsf *c)
 {
     CsfDev p;
     p.nx = c->nx; p.ny = c->ny; p.nz = c->nz; p.N = (unsigned)c->N; p.NS = c->NS;
-    p.meta = c->meta; p.fin = c->fA; p.fout = c->fB;
+    p.FS = c->FS; p.meta = c->meta; p.cidx = c->cidx; p.cells = c->cells; p.NF = (unsigned)c->nfluid; p.fin = c->fA; p.fout = c->fB;
     p.phi = c->phi; p.G = c->G; p.nh = c->nh; p.F = c->F; p.K = c->K; p.U = c->U; p.ns = c->ns;
     const double th = c->cfg.contact_angle_deg / 180. * M_PI;
     p.sigma = c->cfg.surface_tension; p.cosT = cos(th); p.sinT = sin(th);
@@ -629,11 +644,12 @@ CsfDev make_dev(const lbmpm_rk3dcsf *c)
 }
 
 unsigned blocks_of(size_t n) { return (unsigned)((n + 255) / 256); }
+unsigned blocks8(size_t n) { return (blocks_of(n) + 7u) / 8u * 8u; }      // fluid_cell(): eight XCDs
 
 template <bool FIRST>
 int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
 {
-    const unsigned g = blocks_of(c->N);
+    const unsigned g = blocks8((size_t)c->nfluid);
     csf3d_phase<FIRST><<<g, 256, 0, c->stream>>>(p);
     if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist);
     csf3d_gradient<<<g, 256, 0, c->stream>>>(p);
@@ -676,7 +692,7 @@ extern "C" void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->dom, c->meta, c->wetlist, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
+    void *ptrs[] = {c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     c->pool.destroy();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -717,7 +733,20 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
     c->cfg = *cfg;
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny; c->nz = (int)cfg->nz;
     c->N = N; c->NS = (N + 15) / 16 * 16;
-    for (size_t k = 0; k < N; ++k) c->nfluid += is_domain[k] == 1;
+    // the populations are kept for fluid cells only, numbered in lattice order (a dense layout streams the solid cells of every
+    // 128-byte line that holds a fluid cell: counted 1.5 x the bytes on the bench's porous medium)
+    std::vector<uint32_t> hidx(N);
+    std::vector<uint32_t> hcells;
+    hcells.reserve(N);
+    for (size_t k = 0; k < N; ++k) {
+        const bool fl = is_domain[k] == 1;
+        hidx[k] = fl ? (uint32_t)hcells.size() : 0xFFFFFFFFu;
+        if (fl) hcells.push_back((uint32_t)k);
+    }
+    c->nfluid = (int64_t)hcells.size();
+    c->FS = ((size_t)c->nfluid + 15) / 16 * 16;
+    // 38 planes a power of two apart would sit in the same HBM channels and cache sets cell by cell: an odd stride
+    if ((c->FS * sizeof(double)) % 16384 == 0) c->FS += 1168;
     if (c->nfluid == 0) { set_error("lbmpm_rk3dcsf_create: the domain has no fluid cell (is_domain == 1 marks fluid)"); delete c; return LBMPM_ERR_INVALID; }
     {
         const hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -728,8 +757,10 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
 #define TRY_HIP(e) do { const hipError_t e_ = (e); if (e_ != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(e_)); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; } } while (0)
     TRY_RC(dev_alloc(c, &c->dom, N));
     TRY_RC(dev_alloc(c, &c->meta, N));
-    TRY_RC(dev_alloc(c, &c->fA, 2 * Q * c->NS));
-    TRY_RC(dev_alloc(c, &c->fB, 2 * Q * c->NS));
+    TRY_RC(dev_alloc(c, &c->cidx, N));
+    TRY_RC(dev_alloc(c, &c->cells, (size_t)c->nfluid));
+    TRY_RC(dev_alloc(c, &c->fA, 2 * Q * c->FS));
+    TRY_RC(dev_alloc(c, &c->fB, 2 * Q * c->FS));
     TRY_RC(dev_alloc(c, &c->phi, c->NS));
     TRY_RC(dev_alloc(c, &c->G, 3 * c->NS));
     TRY_RC(dev_alloc(c, &c->nh, 3 * c->NS));
@@ -739,6 +770,8 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
     TRY_HIP(hipMalloc(reinterpret_cast<void **>(&counters), 2 * sizeof(unsigned)));
     hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->dom, is_domain, N, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->cidx, hidx.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->cells, hcells.data(), hcells.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
     for (double *q : {c->phi, c->G, c->nh, c->F}) if (e == hipSuccess) e = hipMemsetAsync(q, 0, (q == c->phi ? 1 : 3) * c->NS * sizeof(double), c->stream);
     if (e == hipSuccess) {
         csf3d_setup_meta<<<blocks_of(N), 256, 0, c->stream>>>(c->nx, c->ny, c->nz, (unsigned)N, c->dom, c->meta, counters);
@@ -798,12 +831,12 @@ extern "C" int lbmpm_rk3dcsf_set_macro(lbmpm_rk3dcsf *c, const double *rho_r, co
 {
     LBMPM_REQUIRE(c && rho_r && rho_b, "lbmpm_rk3dcsf_set_macro: null argument");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
-    // staged through the second population buffer (5 N doubles of its 38 N)
-    double *st = c->fB;
+    // staged through the gradient and normal arrays (3 NS doubles each; reset_state clears them)
+    double *st[5] = {c->G, c->G + c->NS, c->G + 2 * c->NS, c->nh, c->nh + c->NS};
     const double *src[5] = {rho_r, rho_b, vx, vy, vz};
-    for (int a = 0; a < 5; ++a) if (src[a]) { const int rc = upload(c, st + a * c->NS, src[a], c->N); if (rc) return rc; }
+    for (int a = 0; a < 5; ++a) if (src[a]) { const int rc = upload(c, st[a], src[a], c->N); if (rc) return rc; }
     const CsfDev p = make_dev(c);
-    csf3d_init<<<blocks_of(c->N), 256, 0, c->stream>>>(p, c->fA, st, st + c->NS, vx ? st + 2 * c->NS : nullptr, vy ? st + 3 * c->NS : nullptr, vz ? st + 4 * c->NS : nullptr);
+    csf3d_init<<<blocks_of(c->N), 256, 0, c->stream>>>(p, c->fA, st[0], st[1], vx ? st[2] : nullptr, vy ? st[3] : nullptr, vz ? st[4] : nullptr);
     LBMPM_HIP_TRY(hipGetLastError());
     return reset_state(c, nullptr, nullptr, nullptr);
 }
@@ -812,13 +845,19 @@ extern "C" int lbmpm_rk3dcsf_set_pdf(lbmpm_rk3dcsf *c, const double *pdf_r, cons
 {
     LBMPM_REQUIRE(c && pdf_r && pdf_b, "lbmpm_rk3dcsf_set_pdf: null argument");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
-    double *st = c->fB;                          // [2][N][19] fits the 38 NS doubles of the buffer
-    int rc = upload(c, st, pdf_r, c->N * Q); if (rc) return rc;
-    rc = upload(c, st + c->N * Q, pdf_b, c->N * Q); if (rc) return rc;
-    const CsfDev p = make_dev(c);
-    csf3d_import<<<blocks_of(c->N), 256, 0, c->stream>>>(p, c->fA, st);
-    LBMPM_HIP_TRY(hipGetLastError());
-    return reset_state(c, fx, fy, fz);
+    double *st = nullptr;                        // [2][N][19] in the host's layout, for the length of the call
+    LBMPM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st), 2 * c->N * Q * sizeof(double)));
+    int rc = upload(c, st, pdf_r, c->N * Q);
+    if (rc == LBMPM_OK) rc = upload(c, st + c->N * Q, pdf_b, c->N * Q);
+    if (rc == LBMPM_OK) {
+        const CsfDev p = make_dev(c);
+        csf3d_import<<<blocks_of(c->N), 256, 0, c->stream>>>(p, c->fA, st);
+        if (hipGetLastError() != hipSuccess) { set_error("csf3d_import did not launch"); rc = LBMPM_ERR_HIP; }
+    }
+    if (rc == LBMPM_OK) rc = reset_state(c, fx, fy, fz);        // (synchronises the stream)
+    else (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(st);
+    return rc;
 }
 
 extern "C" int lbmpm_rk3dcsf_step(lbmpm_rk3dcsf *c, int64_t nsteps)
@@ -865,15 +904,14 @@ extern "C" int lbmpm_rk3dcsf_sync(lbmpm_rk3dcsf *c)
     return LBMPM_OK;
 }
 
-static int observe(lbmpm_rk3dcsf *c, bool rec, bool with_pdf)
+static int observe(lbmpm_rk3dcsf *c, bool rec, double *pdf)
 {
-    const size_t need = (size_t)2 * c->N * Q + 6 * c->N;
-    if (!c->obs) { const int rc = dev_alloc(c, &c->obs, need); if (rc) return rc; }
+    if (!c->obs) { const int rc = dev_alloc(c, &c->obs, 6 * c->N); if (rc) return rc; }
     const CsfDev p = make_dev(c);
-    double *pdf = c->obs, *rho = c->obs + 2 * c->N * Q, *u = rho + 2 * c->N, *phi = u + 3 * c->N;
+    double *rho = c->obs, *u = rho + 2 * c->N, *phi = u + 3 * c->N;
     const unsigned g = blocks_of(c->N);
-    if (c->first) { if (rec) csf3d_observe<true, true><<<g, 256, 0, c->stream>>>(p, with_pdf ? pdf : nullptr, rho, u, phi); else csf3d_observe<true, false><<<g, 256, 0, c->stream>>>(p, with_pdf ? pdf : nullptr, rho, u, phi); }
-    else { if (rec) csf3d_observe<false, true><<<g, 256, 0, c->stream>>>(p, with_pdf ? pdf : nullptr, rho, u, phi); else csf3d_observe<false, false><<<g, 256, 0, c->stream>>>(p, with_pdf ? pdf : nullptr, rho, u, phi); }
+    if (c->first) { if (rec) csf3d_observe<true, true><<<g, 256, 0, c->stream>>>(p, pdf, rho, u, phi); else csf3d_observe<true, false><<<g, 256, 0, c->stream>>>(p, pdf, rho, u, phi); }
+    else { if (rec) csf3d_observe<false, true><<<g, 256, 0, c->stream>>>(p, pdf, rho, u, phi); else csf3d_observe<false, false><<<g, 256, 0, c->stream>>>(p, pdf, rho, u, phi); }
     LBMPM_HIP_TRY(hipGetLastError());
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     return LBMPM_OK;
@@ -896,10 +934,13 @@ extern "C" int lbmpm_rk3dcsf_get_field(lbmpm_rk3dcsf *c, int field, double *out)
     case LBMPM_RK3DCSF_REC_PDF_R: case LBMPM_RK3DCSF_REC_PDF_B: case LBMPM_RK3DCSF_REC_RHO_R: case LBMPM_RK3DCSF_REC_RHO_B:
     case LBMPM_RK3DCSF_REC_VX: case LBMPM_RK3DCSF_REC_VY: case LBMPM_RK3DCSF_REC_VZ: case LBMPM_RK3DCSF_REC_PHI: {
         const int base = rec ? field - LBMPM_RK3DCSF_REC_PDF_R : field;
-        const int rc = observe(c, rec, base <= 1);
-        if (rc) return rc;
-        const double *pdf = c->obs, *rho = c->obs + 2 * N * Q, *u = rho + 2 * N, *phi = u + 3 * N;
-        if (base <= 1) return down(pdf + (size_t)base * N * Q, N * Q);
+        double *pdf = nullptr;                   // [2][N][19] in the host's layout, for the length of the call
+        if (base <= 1) LBMPM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&pdf), 2 * N * Q * sizeof(double)));
+        int rc = observe(c, rec, pdf);
+        if (rc == LBMPM_OK && base <= 1) rc = down(pdf + (size_t)base * N * Q, N * Q);
+        if (pdf) (void)hipFree(pdf);
+        if (rc != LBMPM_OK || base <= 1) return rc;
+        const double *rho = c->obs, *u = rho + 2 * N, *phi = u + 3 * N;
         if (base <= 3) return down(rho + (size_t)(base - 2) * N, N);
         if (field == LBMPM_RK3DCSF_REC_PHI) return down(phi, N);
         return down(u + (size_t)(field - LBMPM_RK3DCSF_REC_VX) * N, N);
