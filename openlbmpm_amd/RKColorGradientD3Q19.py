@@ -14,6 +14,11 @@ planes and blue in them (RKD2Q9.py:511-531 carried to 3-D), records densities an
 Beyond the reference: checkpoint() / restart_from= keep the solver's stored state (lbmpm_rk3d_get_state / set_state): a run
 continued from a checkpoint equals the uninterrupted one bit for bit, on any number of ranks.
 
+[SurfaceTension] SurfaceTensionType = 'CSF' (the section of RKtwophasesetup2D.ini added to the 3-D file): the 2-D CSF loop carried to
+D3Q19 (openlbmpm_amd/rk3dcsf.py, lbmpm_rk3dcsf_*) instead of the perturbation loop -- surface tension, contact angle (wetting rule 2),
+DeltaValue, TauType from the ini; one GPU; records hold what the reference records (the lattice after the next step's boundary
+planes, RKD2Q9.py:1382-1393); IsCycle and checkpoints as above (a checkpoint keeps the streamed populations and the last force).
+
 One process per GPU: when torch.distributed is initialised with world size > 1 the lattice is cut
 into z-slabs (openlbmpm_amd/rk3d.py: RK3DDistributed, halos over xGMI) and rank 0 writes ONE result file with the
 whole lattice's arrays, gathered at the record cadence (gather_records = False: every rank its own planes in its own file);
@@ -31,6 +36,47 @@ from .rk3d import RK3DSlab, RK3DDistributed
 PARAM_KEYS = ("AkR", "AkB", "beta", "tauR", "tauB", "SolidRhoR", "SolidRhoB", "velocityZR", "velocityZB",
               "densityRL", "densityBL", "relax", "inlet", "densityRH", "densityBH", "outlet")
 GROUPS = (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocity", "MacroVelocity"))
+
+
+class _CSFSlab:
+    """RK3DCSFSolver behind the calls this driver makes on a slab of the perturbation model"""
+
+    def __init__(self, dom, par, device):
+        from .rk3dcsf import RK3DCSFSolver
+        q = dict(sigma=par["sigma"], theta=par["theta"], wetting=par["wetting"], beta=par["beta"], delta=par["delta"], tauR=par["tauR"], tauB=par["tauB"],
+                 tautype=par["tautype"], relax=par["relax"], inlet=par["inlet"], outlet=par["outlet"], velocityZR=par["velocityZR"],
+                 velocityZB=par["velocityZB"], densityBH=par["densityBH"], densityRH=par["densityRH"], densityBL=par["densityBL"], densityRL=par["densityRL"])
+        self.solver = RK3DCSFSolver(dom, q, device=device)
+        self.step_single, self.sync, self.close = self.solver.step, self.solver.sync, self.solver.close
+
+    num_fluid_nodes = property(lambda self: self.solver.num_fluid_nodes)
+    dominant_kernel = property(lambda self: self.solver.dominant_kernel)
+
+    def set_density(self, rR, rB):
+        self.solver.set_macro(rR, rB)
+
+    def set_macro(self, rR, rB, vx, vy, vz):
+        self.solver.set_macro(rR, rB, vx, vy, vz)
+
+    def set_pdf(self, fR, fB, post_collision=True):
+        self.solver.set_pdf(fR, fB)          # the recorded arrays are the loop's arrays at its top: streamed populations
+
+    def get(self, name):
+        return self.solver.get("rec_" + name)
+
+    def get_pdf(self):
+        return self.solver.get("rec_fR"), self.solver.get("rec_fB")
+
+    def get_state(self):
+        s = self.solver
+        st = np.concatenate([s.get("fR"), s.get("fB")] + [s.get(c)[..., None] for c in ("Fx", "Fy", "Fz")], axis=-1)
+        return st, dict(doubles_per_cell=41, steps=s.steps_done, post_collision=False)
+
+    def set_state(self, st, steps, post_collision):
+        st = np.asarray(st)
+        if st.shape[-1] != 41:
+            raise config.ConfigError("restart_from: this checkpoint is not one of the 3-D CSF model (41 doubles per cell: f_R, f_B, F)")
+        self.solver.set_pdf(st[..., :19], st[..., 19:38], force=tuple(np.ascontiguousarray(st[..., 38 + a]) for a in range(3)))
 
 
 def duct(nx, ny, nz):
@@ -195,7 +241,13 @@ class RKColorGradient3D:
         par = {k: p[k] for k in PARAM_KEYS}
         name, rank = "SimulationResultsRK3D", 0
         self._gather = lambda a: a
-        if self._distributed():
+        if p["tension_type"] == "CSF":
+            if self._distributed():
+                raise config.ConfigError("SurfaceTensionType 'CSF' in 3-D runs on one GPU (the curvature reaches two cells: no slab decomposition of this model)")
+            slab = sim = _CSFSlab(self.isDomain, p, self.device)
+            step, observe = slab.step_single, (lambda: None)
+            self.z0, self.nzl = 0, self.zDomain
+        elif self._distributed():
             import torch.distributed as dist
             rank = dist.get_rank()
             sim = RK3DDistributed(self.isDomain, par, device=self.device)

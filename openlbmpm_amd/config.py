@@ -135,12 +135,31 @@ def read_rk3d(ini_dir):
             import warnings
             warnings.warn("[RKParameters] %s = %g has no effect, as in the reference's perturbation kernels "
                           "(AcceleratedRKGPU2D.py:1125-1267 load the rest weights and do not use them)" % (k, p[k]))
-    p["AkR"] = c.float("RKParameters", "AkR"); p["AkB"] = c.float("RKParameters", "AkB")
+    # [SurfaceTension] is not in the shipped 3-D file (its parameters are the perturbation loop's AkR / AkB); with the 2-D file's section
+    # (RKtwophasesetup2D.ini, RKD2Q9.py:72-101) the 3-D driver runs the CSF loop carried to D3Q19 (lbmpm_rk3dcsf_*)
+    p["tension_type"] = c.str("SurfaceTension", "SurfaceTensionType", default="'Perturbation'")
+    if p["tension_type"] not in ("CSF", "Perturbation"):
+        raise ConfigError("SurfaceTensionType must be 'CSF' or 'Perturbation'")
+    if p["tension_type"] == "CSF":
+        p["sigma"] = c.float("SurfaceTension", "SurfaceTensionValue", "SurfaceTension")
+        p["theta"] = c.float("SurfaceTension", "ContactAngle")
+        p["wetting"] = c.int("SurfaceTension", "WettingType", default=2)
+        if p["wetting"] != 2:
+            raise ConfigError("3-D CSF: WettingType 2 (Akai et al. 2018); WettingType 1 (AcceleratedRKGPU2D.py:1639-1679) rotates the normal in the plane "
+                              "and has no 3-D form")
+        p["delta"] = c.float("RKParameters", "DeltaValue")
+        p["tautype"] = c.int("FluidParameters", "TauType", default=2)
+        if p["tautype"] not in (1, 2):
+            raise ConfigError("[FluidParameters] TauType must be 1 or 2")
+        p["AkR"] = c.float("RKParameters", "AkR", default=0.0); p["AkB"] = c.float("RKParameters", "AkB", default=0.0)      # read, unused by the CSF loop
+    else:
+        p["AkR"] = c.float("RKParameters", "AkR"); p["AkB"] = c.float("RKParameters", "AkB")
     p["beta"] = c.float("RKParameters", "BetaThickness")
     p["tauR"] = c.float("FluidParameters", "TauR"); p["tauB"] = c.float("FluidParameters", "TauB")
     p["rho0R"] = c.float("FluidParameters", "InitialRhoR", default=1.0)
     p["rho0B"] = c.float("FluidParameters", "InitialRhoB", default=1.0)
-    p["SolidRhoR"] = c.float("BoundariesSetup", "SolidRhoR"); p["SolidRhoB"] = c.float("BoundariesSetup", "SolidRhoB")
+    csf = p["tension_type"] == "CSF"      # (the CSF loop takes phi on the walls from the fluid next to them, AcceleratedRKGPU2D.py:1560-1581)
+    p["SolidRhoR"] = c.float("BoundariesSetup", "SolidRhoR", default=0.5 if csf else None); p["SolidRhoB"] = c.float("BoundariesSetup", "SolidRhoB", default=0.5 if csf else None)
     if p["SolidRhoR"] + p["SolidRhoB"] == 0.0:
         raise ConfigError("[BoundariesSetup] SolidRhoR + SolidRhoB must not be zero")
     p["inlet"] = c.str("BoundaryCondition", "BoundaryTypeInlet")

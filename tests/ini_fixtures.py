@@ -249,6 +249,23 @@ LastStep = 350
 """
 
 
+# the [SurfaceTension] section of RKtwophasesetup2D.ini (:14-18) and its TauType: with them the 3-D driver runs the CSF loop
+RK3D_CSF_EXTRA = """
+[SurfaceTension]
+SurfaceTensionType = 'CSF'
+SurfaceTension = {sigma}
+ContactAngle = {theta}
+WettingType = {wetting}
+"""
+
+
+def write_rk3d_csf(d, sigma=0.05, theta=60.0, wetting=2, **kw):
+    import os
+    write_rk3d(d, **kw)
+    with open(os.path.join(d, "RKtwophasesetup3D.ini"), "a") as fh:
+        fh.write(RK3D_CSF_EXTRA.format(sigma=sigma, theta=theta, wetting=wetting))
+
+
 def write_rk3d(d, nx=32, ny=32, nz=96, steps=1000, relax="SRT", alpha="0."):
     import os
     with open(os.path.join(d, "RKtwophasesetup3D.ini"), "w") as fh:

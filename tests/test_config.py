@@ -115,3 +115,17 @@ def test_rk3d_ini(tmp_path):
     write_rk3d(str(tmp_path), relax="TRT")
     with pytest.raises(config.ConfigError):
         config.read_rk3d(str(tmp_path))
+
+
+def test_rk3d_ini_with_the_2d_files_surface_tension_section(tmp_path):
+    """[SurfaceTension] SurfaceTensionType = 'CSF' in the 3-D file selects the CSF loop carried to D3Q19 (lbmpm_rk3dcsf_*)"""
+    from ini_fixtures import write_rk3d, write_rk3d_csf
+    write_rk3d(str(tmp_path))
+    assert config.read_rk3d(str(tmp_path))["tension_type"] == "Perturbation"          # the shipped file has no such section
+    write_rk3d_csf(str(tmp_path), sigma=0.03, theta=35.0, relax="MRT")
+    p = config.read_rk3d(str(tmp_path))
+    assert p["tension_type"] == "CSF" and p["sigma"] == 0.03 and p["theta"] == 35.0 and p["wetting"] == 2
+    assert p["delta"] == 0.98 and p["tautype"] == 2 and p["relax"] == "MRT"
+    write_rk3d_csf(str(tmp_path), wetting=1)
+    with pytest.raises(config.ConfigError, match="WettingType"):
+        config.read_rk3d(str(tmp_path))
