@@ -643,6 +643,28 @@ def main():
                                                                   "initial": "initial state"}[state], args.relax), args.relax, state, 40))
                     other = "SRT" if args.relax == "MRT" else "MRT"
                     sec.append(c5_leg("c5 with %s relaxation" % other, other, args.c5_state, 30))
+                    # the same lattice under the OTHER surface-tension model of the 2-D ini: the CSF loop carried to D3Q19 (a17's "CSF kappa = -div n in 3-D")
+                    from openlbmpm_amd.rk3dcsf import RK3DCSFSolver
+                    d2 = dom.copy(); d2[0] = d2[1]; d2[-1] = d2[-2]
+                    r2, b2 = c5_state(dom, 0, nz, "initial")
+                    sc3 = RK3DCSFSolver(d2, dict(relax=args.relax, tauB=0.8), device=local_rank)
+                    sc3.set_macro(r2, b2)
+                    del r2, b2, d2
+                    sc3.step(3); sc3.sync()
+                    kc = 20
+                    t1 = time.perf_counter(); mtc, mdc = sc3.step_timed(kc); sc3.sync(); wc = time.perf_counter() - t1
+                    nfc = sc3.num_fluid_nodes
+                    sec.append({"workload": "c5 lattice, [SurfaceTension] SurfaceTensionType = 'CSF' (%s): the 2-D CSF loop (RKD2Q9.py:1295-1490) carried to D3Q19, "
+                                            "RKtwophasesetup2D.ini's parameters (sigma 0.1, contact angle 60, wetting rule 2, TauType 2)" % args.relax,
+                                "value": round(nfc * kc / wc / 1e6, 2), "unit": "MLUPS", "ms_per_step": round(wc * 1e3 / kc, 5), "steps": kc, "fluid_nodes": nfc,
+                                "wetting_solids": sc3.num_wetting_solids, "kernel": sc3.dominant_kernel, "kernel_ms": round(mdc / kc, 5),
+                                "roofline_frac_by_survey_balg": round(B_ALG["c5"] * nfc / (mtc / kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "not a BASELINE config (the 3-D ini carries the perturbation parameters).  Four launches per step -- phase field (pull 38), "
+                                        "solid phi, gradient + wetting rule, collide (pull 38, store 38) -- because the curvature needs the normal one cell "
+                                        "around and the normal the phase field one cell around that: ~ 1.06 kB per fluid cell and step against B_alg = 608 B; "
+                                        "roofline_frac_by_survey_balg is over the whole step.  Parity: oracle/rk3d_csf_oracle.c at 1e-10, pinned by reduction to "
+                                        "the capture of the real 2-D driver (tests/test_rk3d_csf_gpu.py)"})
+                    sc3.close()
                 out["secondary"] = sec
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_c5(args.relax)
