@@ -17,7 +17,7 @@
 //
 // Schedule of one time step (four launches; populations q-major SoA, two buffers, pull):
 //   csf3d_phase     pull + boundary planes -> rho_R, rho_B -> phi                                 38 reads, 1 write per fluid cell
-//   csf3d_solid_phi phi of the wetting solids (compact list)
+//   csf3d_solid_phi phi of the wetting solids
 //   csf3d_gradient  G (18 cached phi reads), wetting rule on the cells next to solid, n = -G / |G|   6 writes
 //   csf3d_collide   pull + boundary planes again (bit-identical to the first pass), curvature from the neighbours' n, force, collision,
 //                   recolouring -> the other buffer                                                38 reads, 41 writes
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void csf3d_phase(CsfDev p)
     p.phi[n] = (rR - rB) / (rR + rB);
 }
 
-// A:1560-1581 calColorValueOnSolid over the list of wetting solids
+// A:1560-1581 calColorValueOnSolid over the list of wetting solids (in lattice order: neighbouring solids read neighbouring phi)
 __global__ __launch_bounds__(256) void csf3d_solid_phi(CsfDev p, const uint32_t *wetlist)
 {
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
@@ -377,8 +377,11 @@ __device__ __forceinline__ double tau_of(const CsfDev &p, double Phi, double rR,
 
 // second half of the loop for one cell: curvature and force, collision with the Guo source, recolouring; stores the post-collision
 // populations (the next step pulls them).  DIAG: also keep u and K of the step.
+#ifndef CSF_MRT_WAVES
+#define CSF_MRT_WAVES 2
+#endif
 template <bool FIRST, bool MRT, bool DIAG>
-__global__ __launch_bounds__(256) void csf3d_collide(CsfDev p)
+__global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(CsfDev p)
 {
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
     unsigned j, n;
@@ -523,11 +526,29 @@ __global__ __launch_bounds__(256) void csf3d_setup_meta(int nx, int ny, int nz, 
     meta[n] = m | (kind << KIND_SHIFT);
     if (kind == 2u) atomicAdd(nwet, 1u);
 }
-__global__ __launch_bounds__(256) void csf3d_setup_wetlist(unsigned N, const uint32_t *meta, uint32_t *wetlist, unsigned *cursor)
+// the wetting solids in lattice order: per workgroup of 256 cells a count, scanned on the host, then every workgroup writes its own stretch
+__global__ __launch_bounds__(256) void csf3d_setup_wetcount(unsigned N, const uint32_t *meta, uint32_t *count)
 {
+    __shared__ unsigned wsum[4];
     const unsigned n = blockIdx.x * 256u + threadIdx.x;
-    if (n >= N) return;
-    if (((meta[n] >> KIND_SHIFT) & 3u) == 2u) wetlist[atomicAdd(cursor, 1u)] = n;
+    const bool wet = n < N && ((meta[n] >> KIND_SHIFT) & 3u) == 2u;
+    const unsigned long long b = __ballot(wet);
+    if ((threadIdx.x & 63u) == 0u) wsum[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void csf3d_setup_wetlist(unsigned N, const uint32_t *meta, const uint32_t *first, uint32_t *wetlist)
+{
+    __shared__ unsigned wsum[4];
+    const unsigned n = blockIdx.x * 256u + threadIdx.x;
+    const bool wet = n < N && ((meta[n] >> KIND_SHIFT) & 3u) == 2u;
+    const unsigned long long b = __ballot(wet);
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (lane == 0u) wsum[w] = (unsigned)__popcll(b);
+    __syncthreads();
+    unsigned base = first[blockIdx.x];
+    for (unsigned k = 0; k < w; ++k) base += wsum[k];
+    if (wet) wetlist[base + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = n;
 }
 __device__ __forceinline__ double e8w(int c2)
 {   // the 3-D E8 stencil of Sbragaglia et al. 2007 by |c|^2; its sums along one axis are 4/21, 4/45, 1/60, 2/315, 1/5040 (RKD2Q9.py:811-885)
@@ -782,12 +803,28 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { (void)hipFree(counters); set_error("set-up failed: %s", hipGetErrorString(e)); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; }
     if (c->nwet) {
+        const unsigned nb = blocks_of(N);
+        uint32_t *cnt = nullptr;
+        std::vector<uint32_t> h(nb);
         rc = dev_alloc(c, &c->wetlist, c->nwet);
+        if (rc == LBMPM_OK && hipMalloc(reinterpret_cast<void **>(&cnt), nb * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc failed"); rc = LBMPM_ERR_NOMEM; }
+        if (rc == LBMPM_OK) {
+            csf3d_setup_wetcount<<<nb, 256, 0, c->stream>>>((unsigned)N, c->meta, cnt);
+            e = hipMemcpyAsync(h.data(), cnt, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            uint32_t run = 0;
+            for (unsigned k = 0; k < nb; ++k) { const uint32_t v = h[k]; h[k] = run; run += v; }
+            if (e == hipSuccess && run != c->nwet) { set_error("set-up: %u wetting solids counted, %u listed", c->nwet, run); rc = LBMPM_ERR_STATE; }
+            if (e == hipSuccess && rc == LBMPM_OK) e = hipMemcpyAsync(cnt, h.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess && rc == LBMPM_OK) {
+                csf3d_setup_wetlist<<<nb, 256, 0, c->stream>>>((unsigned)N, c->meta, cnt, c->wetlist);
+                e = hipStreamSynchronize(c->stream);
+                if (e == hipSuccess) e = hipGetLastError();
+            }
+            if (e != hipSuccess) { set_error("set-up failed: %s", hipGetErrorString(e)); rc = LBMPM_ERR_HIP; }
+        }
+        if (cnt) (void)hipFree(cnt);
         if (rc != LBMPM_OK) { (void)hipFree(counters); lbmpm_rk3dcsf_destroy(c); return rc; }
-        csf3d_setup_wetlist<<<blocks_of(N), 256, 0, c->stream>>>((unsigned)N, c->meta, c->wetlist, counters + 1);
-        e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) { (void)hipFree(counters); set_error("set-up failed: %s", hipGetErrorString(e)); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; }
     }
     (void)hipFree(counters);
 #undef TRY_RC
