@@ -532,6 +532,8 @@ typedef struct lbmpm_rk3dcsf_config {
     int32_t inlet_type;        /* LBMPM_INLET_VELOCITY | LBMPM_INLET_PRESSURE               */
     int32_t outlet_type;       /* LBMPM_OUTLET_PRESSURE | LBMPM_OUTLET_CONVECTIVE           */
     int32_t device;
+    int32_t variant;           /* 0: blocks of 256 fluid cells deep inside one colour skip the phase-field pull, the gradient and the curvature
+                                * (exact: phi = +-1, G = n = K = F = 0 there, bit for bit); 1: every cell takes the full path (cross-check) */
     double mrt_rates[6];       /* all 0: the model's own; else s_e, s_eps, s_q, s_pi, s_m, rate of the conserved moments */
 } lbmpm_rk3dcsf_config;
 
@@ -573,6 +575,8 @@ int lbmpm_rk3dcsf_enable_diagnostics(lbmpm_rk3dcsf *ctx, int on);
 int lbmpm_rk3dcsf_get_field(lbmpm_rk3dcsf *ctx, int field, double *out);
 int64_t lbmpm_rk3dcsf_num_fluid_nodes(const lbmpm_rk3dcsf *ctx);
 int64_t lbmpm_rk3dcsf_num_wetting_solids(const lbmpm_rk3dcsf *ctx);
+/* fluid cells whose block took the bulk path in the last step (variant 0; see lbmpm_rk3dcsf_config.variant) */
+int64_t lbmpm_rk3dcsf_bulk_cells(lbmpm_rk3dcsf *ctx);
 int64_t lbmpm_rk3dcsf_steps_done(const lbmpm_rk3dcsf *ctx);
 int64_t lbmpm_rk3dcsf_device_bytes(const lbmpm_rk3dcsf *ctx);
 const char *lbmpm_rk3dcsf_dominant_kernel(const lbmpm_rk3dcsf *ctx);

@@ -80,7 +80,7 @@ class RK3DCSFConfig(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("nx", "ny", "nz")] + \
                [(n, C.c_double) for n in ("surface_tension", "contact_angle_deg", "beta", "delta", "tau_r", "tau_b", "inlet_velocity_z",
                                           "inlet_rho_r", "inlet_rho_b", "outlet_rho_total")] + \
-               [(n, C.c_int32) for n in ("wetting_type", "tau_type", "relaxation", "inlet_type", "outlet_type", "device")] + \
+               [(n, C.c_int32) for n in ("wetting_type", "tau_type", "relaxation", "inlet_type", "outlet_type", "device", "variant")] + \
                [("mrt_rates", C.c_double * 6)]
 
 
@@ -180,6 +180,7 @@ _SIGNATURES = {
     "lbmpm_rk3dcsf_get_field": (C.c_int, [C.c_void_p, C.c_int, F64P]),
     "lbmpm_rk3dcsf_num_fluid_nodes": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk3dcsf_num_wetting_solids": (C.c_int64, [C.c_void_p]),
+    "lbmpm_rk3dcsf_bulk_cells": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk3dcsf_steps_done": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk3dcsf_device_bytes": (C.c_int64, [C.c_void_p]),
     "lbmpm_rk3dcsf_dominant_kernel": (C.c_char_p, [C.c_void_p]),

@@ -62,6 +62,14 @@ struct CsfDev {
     double sigma, cosT, sinT, beta, delta, tauR, tauB, vzIn, pInB, pInR, pOut;
     int tauType, inletP, conv, wetting, nwet;
     double rate[6];
+    // bulk skip (see deep_colour): per block of 256 fluid cells
+    unsigned nblk;
+    int skip;
+    uint8_t *pure;               // [nblk] after a step: 1 every cell of the block holds red only (rho_B == 0 exactly), 2 blue only, 0 else
+    uint8_t *deep_prev;          // [nblk] deep_colour of the step before
+    const uint8_t *bcblk;        // [nblk] the block holds cells of the open planes or their ghosts: always the full path
+    const uint32_t *rng;         // [2][nblk] first / last block that holds a cell within two cells of this block's cells
+    const uint32_t *pfx;         // [2][nblk + 1] number of blocks before k whose `pure` is not 1 / not 2
 };
 
 struct Nb { unsigned xo[3], yo[3], zo[3]; };
@@ -206,10 +214,29 @@ __device__ __forceinline__ bool cell_of(const CsfDev &p, unsigned n, int &x, int
 // The step's kernels run one thread per FLUID cell (no idle lanes in a porous medium; a wave's 64 cells are 512 consecutive bytes of
 // every population plane).  Workgroups go to the XCDs round robin (workgroup b to XCD b % 8); numbered like this, every XCD walks ONE
 // contiguous eighth of the fluid cells in lattice order: the cells a workgroup's neighbours in y read are then in the same L2.
-__device__ __forceinline__ bool fluid_cell(const CsfDev &p, unsigned &j, unsigned &n, int &x, int &y, int &z)
+__device__ __forceinline__ unsigned block_of()
 {
     const unsigned per = (gridDim.x + 7u) / 8u;          // gridDim.x is a multiple of 8
-    j = ((blockIdx.x & 7u) * per + (blockIdx.x >> 3)) * 256u + threadIdx.x;
+    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+// The bulk of a phase.  A cell whose every source cell held one colour only after the last step (rho of the other colour exactly 0:
+// the recolouring then hands on exact zeros) holds that colour only now: phi = +-1 exactly; if that is true two cells around, its
+// gradient, normal, curvature and force are exact zeros.  Decided per block of 256 fluid cells: the blocks between the first and the
+// last one that holds a cell within two cells of this block's (`rng`, a whole stretch of the lattice order: conservative) all `pure` of one
+// colour -- a difference of two prefix counts.  Such a block skips the phase-field pull, the gradient and the curvature: bit-equal to
+// the full path (tests/test_rk3d_csf_gpu.py), 79 instead of 136 doubles per cell and step.  The open planes always take the full path.
+__device__ __forceinline__ int deep_colour(const CsfDev &p, unsigned b)
+{
+    if (!p.skip || b >= p.nblk || p.bcblk[b]) return 0;
+    const unsigned lo = p.rng[b], hi = p.rng[p.nblk + b];
+    const uint32_t *pr = p.pfx, *pb = p.pfx + (p.nblk + 1u);
+    if (pr[hi + 1u] - pr[lo] == 0u) return 1;
+    if (pb[hi + 1u] - pb[lo] == 0u) return 2;
+    return 0;
+}
+__device__ __forceinline__ bool fluid_cell(const CsfDev &p, unsigned &j, unsigned &n, int &x, int &y, int &z)
+{
+    j = block_of() * 256u + threadIdx.x;
     if (j >= p.NF) return false;
     n = p.cells[j];
     const unsigned pl = (unsigned)p.nx * (unsigned)p.ny;
@@ -226,6 +253,11 @@ __global__ __launch_bounds__(256) void csf3d_phase(CsfDev p)
     unsigned j, n;
     int x, y, z;
     if (!fluid_cell(p, j, n, x, y, z)) return;
+    const int deep = deep_colour(p, block_of());
+    if (deep) {                                  // (rho - 0) / (rho + 0) = 1 exactly
+        if (p.deep_prev[block_of()] != deep) p.phi[n] = deep == 1 ? 1. : -1.;
+        return;
+    }
     double fR[Q], fB[Q], rR, rB;
     cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
     p.phi[n] = (rR - rB) / (rR + rB);
@@ -256,6 +288,13 @@ __global__ __launch_bounds__(256) void csf3d_gradient(CsfDev p)
     unsigned j, n;
     int x, y, z;
     if (!fluid_cell(p, j, n, x, y, z)) return;
+    if (deep_colour(p, block_of())) {            // phi is the same constant one cell around, phi_s of the walls included: sums of +-w that cancel exactly
+        if (!p.deep_prev[block_of()]) {
+            p.G[n] = 0.; p.G[p.NS + n] = 0.; p.G[2 * p.NS + n] = 0.;
+            p.nh[n] = 0.; p.nh[p.NS + n] = 0.; p.nh[2 * p.NS + n] = 0.;
+        }
+        return;
+    }
     const uint32_t m = p.meta[n];
     const Nb nb = make_nb(p, x, y, z);
     double gx = 0., gy = 0., gz = 0.;
@@ -388,11 +427,17 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
     unsigned j, n;
     int x, y, z;
-    if (!fluid_cell(p, j, n, x, y, z)) return;
+    const bool active = fluid_cell(p, j, n, x, y, z);
+    const unsigned blk = block_of();
+    const int deep = deep_colour(p, blk);
+    const bool was_deep = p.skip && blk < p.nblk && p.deep_prev[blk] != 0;     // the arrays G, n, F of this block hold zeros
+    bool only_red = true, only_blue = true;
+    if (active) {
     const uint32_t m = p.meta[n];
     double *fr = p.fout + j, *fb = p.fout + (size_t)Q * p.FS + j;
     double fR[Q], fB[Q], rR, rB;
     cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
+    only_red = rB == 0.; only_blue = rR == 0.;
     double t[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) t[i] = fR[i] + fB[i];
@@ -401,11 +446,14 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
 #pragma unroll
     for (int i = 1; i < Q; ++i) { addc(mx, CX[i], t[i]); addc(my, CY[i], t[i]); addc(mz, CZ[i], t[i]); }
     const double rs = rB + rR;
-    const double vx = (mx + 0.5 * p.F[n]) / rs, vy = (my + 0.5 * p.F[p.NS + n]) / rs, vz = (mz + 0.5 * p.F[2 * p.NS + n]) / rs;
+    const double pfx_ = was_deep ? 0. : p.F[n], pfy_ = was_deep ? 0. : p.F[p.NS + n], pfz_ = was_deep ? 0. : p.F[2 * p.NS + n];
+    const double vx = (mx + 0.5 * pfx_) / rs, vy = (my + 0.5 * pfy_) / rs, vz = (mz + 0.5 * pfz_) / rs;
     const double phi = (rR - rB) / (rR + rB);
     // A:2499-2551: derivatives of n over the fluid neighbours, K = -(I - n n) : grad n
+    double gx = 0., gy = 0., gz = 0., k = 0., fx = 0., fy = 0., fz = 0.;
+    if (!deep) {                                 // (deep: G = 0, so n = 0, so K = 0 whatever the neighbours' normals are, so F = 0)
     const Nb nb = make_nb(p, x, y, z);
-    const double gx = p.G[n], gy = p.G[p.NS + n], gz = p.G[2 * p.NS + n];
+    gx = p.G[n]; gy = p.G[p.NS + n]; gz = p.G[2 * p.NS + n];
     const double ux = p.nh[n], uy = p.nh[p.NS + n], uz = p.nh[2 * p.NS + n];
     double dxx = 0., dxy = 0., dxz = 0., dyx = 0., dyy = 0., dyz = 0., dzx = 0., dzy = 0., dzz = 0.;     // d<a><b> = d_a n_b
 #pragma unroll
@@ -417,10 +465,11 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
         addc(dyx, CY[i], qx); addc(dyy, CY[i], qy); addc(dyz, CY[i], qz);
         addc(dzx, CZ[i], qx); addc(dzy, CZ[i], qy); addc(dzz, CZ[i], qz);
     }
-    const double k = ux * uy * (dyx + dxy) + ux * uz * (dzx + dxz) + uy * uz * (dzy + dyz)
-                     - (uy * uy + uz * uz) * dxx - (ux * ux + uz * uz) * dyy - (ux * ux + uy * uy) * dzz;
-    const double fx = -0.5 * p.sigma * k * gx, fy = -0.5 * p.sigma * k * gy, fz = -0.5 * p.sigma * k * gz;
-    p.F[n] = fx; p.F[p.NS + n] = fy; p.F[2 * p.NS + n] = fz;
+    k = ux * uy * (dyx + dxy) + ux * uz * (dzx + dxz) + uy * uz * (dzy + dyz)
+        - (uy * uy + uz * uz) * dxx - (ux * ux + uz * uz) * dyy - (ux * ux + uy * uy) * dzz;
+    fx = -0.5 * p.sigma * k * gx; fy = -0.5 * p.sigma * k * gy; fz = -0.5 * p.sigma * k * gz;
+    }
+    if (!(deep && was_deep)) { p.F[n] = fx; p.F[p.NS + n] = fy; p.F[2 * p.NS + n] = fz; }
     if (DIAG) { p.K[n] = k; p.U[n] = vx; p.U[p.NS + n] = vy; p.U[2 * p.NS + n] = vz; }
     const double tau = tau_of(p, phi, rR, rB);
     if (!MRT) {
@@ -468,6 +517,77 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
         __builtin_nontemporal_store(rR / tot * t[i] + p.beta * rR * rB / tot * wq(i) * c * un, fr + (size_t)i * p.FS);
         __builtin_nontemporal_store(rB / tot * t[i] - p.beta * rR * rB / tot * wq(i) * c * un, fb + (size_t)i * p.FS);
     }
+    }   // active
+    if (p.skip) {                                // what the block hands on, for the next step's deep_colour
+        const int allr = __syncthreads_and(only_red), allb = __syncthreads_and(only_blue);
+        if (threadIdx.x == 0 && blk < p.nblk) { p.pure[blk] = allr ? 1 : (allb ? 2 : 0); p.deep_prev[blk] = (uint8_t)deep; }
+    }
+}
+
+// pfx[0][k] / pfx[1][k] = number of blocks before k that are not purely red / not purely blue (one workgroup; nblk ~ 3e5 at 512^3)
+__global__ __launch_bounds__(1024) void csf3d_scan_pure(unsigned nblk, const uint8_t *pure, uint32_t *pfx)
+{
+    __shared__ unsigned part[2][1024];
+    const unsigned t = threadIdx.x, chunk = (nblk + 1023u) / 1024u, k0 = t * chunk, k1 = min(nblk, k0 + chunk);
+    unsigned a = 0, b = 0;
+    for (unsigned k = k0; k < k1; ++k) { const unsigned v = pure[k]; a += v != 1u; b += v != 2u; }
+    part[0][t] = a; part[1][t] = b;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024u; d <<= 1) {   // inclusive scan of the 1024 partial counts
+        const unsigned va = t >= d ? part[0][t - d] : 0u, vb = t >= d ? part[1][t - d] : 0u;
+        __syncthreads();
+        part[0][t] += va; part[1][t] += vb;
+        __syncthreads();
+    }
+    a = part[0][t] - a; b = part[1][t] - b;      // exclusive: blocks before k0
+    for (unsigned k = k0; k < k1; ++k) {
+        pfx[k] = a; pfx[nblk + 1u + k] = b;
+        const unsigned v = pure[k]; a += v != 1u; b += v != 2u;
+    }
+    if (t == 1023u) { pfx[nblk] = part[0][1023]; pfx[2u * nblk + 1u] = part[1][1023]; }
+}
+
+// set-up of the bulk skip: first / last fluid cell any cell of a block reads its state from (pass 0), then first / last block over the
+// blocks of those cells' own ranges (pass 1: covers two cells around); blocks that hold cells of the open planes or their ghosts
+__global__ __launch_bounds__(256) void csf3d_setup_ranges(CsfDev p, int pass, uint32_t *lo, uint32_t *hi, const uint32_t *lo0, const uint32_t *hi0, uint8_t *bcblk)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= p.NF) return;
+    const unsigned n = p.cells[j], b = j >> 8;
+    int x, y, z;
+    cell_of(p, n, x, y, z);
+    int zs = z;
+    bool open = z >= p.nz - 2 || z <= 1;
+    if (z == p.nz - 1) zs = p.nz - 2;
+    else if (p.conv) { if (z <= 2) zs = 3; open = open || z <= 3; }
+    else if (z == 0) zs = 1;
+    const Nb nb = make_nb(p, x, y, zs);
+    const unsigned own = at(nb, 0, 0, 0);
+    const uint32_t m = p.meta[own];
+    unsigned mn = j, mx = j;
+    auto take = [&](unsigned q) {
+        if (pass == 0) { mn = min(mn, q); mx = max(mx, q); }
+        else { mn = min(mn, lo0[q >> 8]); mx = max(mx, hi0[q >> 8]); }
+    };
+    take(j);
+    take(p.cidx[own]);
+#pragma unroll 1
+    for (int i = 1; i < Q; ++i) {
+        const unsigned q = at(nb, CX[i], CY[i], CZ[i]);
+        if ((m >> i) & 1u) { take(p.cidx[q]); continue; }
+        // a wall cell next to this one: its phi is the mean over ITS fluid neighbours (up to two cells from here, possibly across the wall)
+        const uint32_t ms = p.meta[q];
+        if (((ms >> KIND_SHIFT) & 3u) != 2u) continue;
+        const unsigned pl = (unsigned)p.nx * (unsigned)p.ny;
+        const int qz = (int)(q / pl), qy = (int)((q - (unsigned)qz * pl) / (unsigned)p.nx), qx = (int)(q - (unsigned)qz * pl - (unsigned)qy * (unsigned)p.nx);
+        const Nb nq = make_nb(p, qx, qy, qz);
+        for (int k = 1; k < Q; ++k)
+            if ((ms >> k) & 1u) take(p.cidx[at(nq, CX[k], CY[k], CZ[k])]);
+    }
+    atomicMin(&lo[b], mn);
+    atomicMax(&hi[b], mx);
+    if (pass == 0 && open) bcblk[b] = 1;
 }
 
 // host-layout views of the populations: out_pdf [2][N][19], out_rho [2][N], out_u [3][N] (REC only), out_phi [N] (REC only).
@@ -629,7 +749,10 @@ struct lbmpm_rk3dcsf {
     bool first = true, have_state = false, diag = false, diag_valid = false;
     hipStream_t stream = nullptr;
     uint8_t *dom = nullptr;
-    uint32_t *meta = nullptr, *wetlist = nullptr, *cidx = nullptr, *cells = nullptr;
+    uint32_t *meta = nullptr, *wetlist = nullptr, *cidx = nullptr, *cells = nullptr, *rng = nullptr, *pfx = nullptr;
+    uint8_t *pure = nullptr, *deep_prev = nullptr, *bcblk = nullptr;
+    unsigned nblk = 0;
+    bool skip = true;
     double *fA = nullptr, *fB = nullptr, *phi = nullptr, *G = nullptr, *nh = nullptr, *F = nullptr, *K = nullptr, *U = nullptr, *ns = nullptr;
     double *obs = nullptr;         // staging of the observe kernel: rho [2][N], u [3][N], phi [N] (the populations [2][N][19] come and go with the call)
     lbmpm::EventPool pool;
@@ -663,6 +786,7 @@ CsfDev make_dev(const lbmpm_rk3dcsf *c)
     for (int i = 0; i < 6; ++i) any = any || c->cfg.mrt_rates[i] != 0.;
     const double own[6] = {1.19, 1.4, 1.2, 1.4, 1.2, 0.};
     for (int i = 0; i < 6; ++i) p.rate[i] = any ? c->cfg.mrt_rates[i] : own[i];
+    p.nblk = c->nblk; p.skip = c->skip ? 1 : 0; p.pure = c->pure; p.deep_prev = c->deep_prev; p.bcblk = c->bcblk; p.rng = c->rng; p.pfx = c->pfx;
     return p;
 }
 
@@ -673,6 +797,7 @@ template <bool FIRST>
 int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
 {
     const unsigned g = blocks8((size_t)c->nfluid);
+    if (c->skip) csf3d_scan_pure<<<1, 1024, 0, c->stream>>>(c->nblk, c->pure, c->pfx);
     csf3d_phase<FIRST><<<g, 256, 0, c->stream>>>(p);
     if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist);
     csf3d_gradient<<<g, 256, 0, c->stream>>>(p);
@@ -715,7 +840,7 @@ extern "C" void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
+    void *ptrs[] = {c->rng, c->pfx, c->pure, c->deep_prev, c->bcblk, c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     c->pool.destroy();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -739,6 +864,7 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
         return LBMPM_ERR_UNSUPPORTED;
     }
     LBMPM_REQUIRE(cfg->wetting_type == 2 || cfg->wetting_type == 0, "WettingType must be 2 (or 0: no correction at the walls)");
+    LBMPM_REQUIRE(cfg->variant == 0 || cfg->variant == 1, "variant must be 0 or 1");
     const size_t pl = (size_t)cfg->nx * cfg->ny, N = pl * (size_t)cfg->nz;
     // the ghost planes copy the plane next to them cell by cell (the reference's kernels take the neighbour's index without looking)
     auto same = [&](int64_t za, int64_t zb) {
@@ -828,6 +954,41 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
         if (cnt) (void)hipFree(cnt);
         if (rc != LBMPM_OK) { (void)hipFree(counters); lbmpm_rk3dcsf_destroy(c); return rc; }
     }
+    {   // the bulk skip's tables
+        c->skip = cfg->variant == 0;
+        c->nblk = blocks_of((size_t)c->nfluid);
+        const unsigned nb = c->nblk;
+        uint32_t *lo0 = nullptr, *hi0 = nullptr, *lo1 = nullptr, *hi1 = nullptr;
+        rc = dev_alloc(c, &c->pure, nb);
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->deep_prev, nb);
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->bcblk, nb);
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->rng, 2 * (size_t)nb);
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->pfx, 2 * ((size_t)nb + 1));
+        if (rc == LBMPM_OK && hipMalloc(reinterpret_cast<void **>(&lo0), 4 * (size_t)nb * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc failed"); rc = LBMPM_ERR_NOMEM; }
+        if (rc == LBMPM_OK) {
+            hi0 = lo0 + nb; lo1 = hi0 + nb; hi1 = lo1 + nb;
+            const CsfDev p = make_dev(c);
+            e = hipMemsetAsync(lo0, 0xFF, nb * sizeof(uint32_t), c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(hi0, 0, nb * sizeof(uint32_t), c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(lo1, 0xFF, nb * sizeof(uint32_t), c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(hi1, 0, nb * sizeof(uint32_t), c->stream);
+            for (uint8_t *q : {c->pure, c->deep_prev, c->bcblk}) if (e == hipSuccess) e = hipMemsetAsync(q, 0, nb, c->stream);
+            if (e == hipSuccess) {
+                csf3d_setup_ranges<<<nb, 256, 0, c->stream>>>(p, 0, lo0, hi0, nullptr, nullptr, c->bcblk);
+                csf3d_setup_ranges<<<nb, 256, 0, c->stream>>>(p, 1, lo1, hi1, lo0, hi0, c->bcblk);
+                std::vector<uint32_t> h(2 * (size_t)nb);
+                e = hipMemcpyAsync(h.data(), lo1, 2 * (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                for (uint32_t &v : h) v >>= 8;          // cells -> blocks
+                if (e == hipSuccess) e = hipMemcpyAsync(c->rng, h.data(), 2 * (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e == hipSuccess) e = hipGetLastError();
+            }
+            if (e != hipSuccess) { set_error("set-up failed: %s", hipGetErrorString(e)); rc = LBMPM_ERR_HIP; }
+        }
+        if (lo0) (void)hipFree(lo0);
+        if (rc != LBMPM_OK) { (void)hipFree(counters); lbmpm_rk3dcsf_destroy(c); return rc; }
+    }
     (void)hipFree(counters);
 #undef TRY_RC
 #undef TRY_HIP
@@ -861,6 +1022,8 @@ static int reset_state(lbmpm_rk3dcsf *c, const double *fx, const double *fy, con
     LBMPM_HIP_TRY(hipMemsetAsync(c->G, 0, 3 * c->NS * sizeof(double), c->stream));
     LBMPM_HIP_TRY(hipMemsetAsync(c->nh, 0, 3 * c->NS * sizeof(double), c->stream));
     LBMPM_HIP_TRY(hipMemsetAsync(c->phi, 0, c->NS * sizeof(double), c->stream));
+    LBMPM_HIP_TRY(hipMemsetAsync(c->pure, 0, c->nblk, c->stream));          // nothing is known about the new state: the first step takes the full path
+    LBMPM_HIP_TRY(hipMemsetAsync(c->deep_prev, 0, c->nblk, c->stream));
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
     c->first = true; c->have_state = true; c->steps = 0; c->diag_valid = false;
     return LBMPM_OK;
@@ -1005,6 +1168,16 @@ extern "C" int lbmpm_rk3dcsf_get_field(lbmpm_rk3dcsf *c, int field, double *out)
 
 extern "C" int64_t lbmpm_rk3dcsf_num_fluid_nodes(const lbmpm_rk3dcsf *c) { return c ? c->nfluid : 0; }
 extern "C" int64_t lbmpm_rk3dcsf_num_wetting_solids(const lbmpm_rk3dcsf *c) { return c ? (int64_t)c->nwet : 0; }
+extern "C" int64_t lbmpm_rk3dcsf_bulk_cells(lbmpm_rk3dcsf *c)
+{
+    if (!c || !c->skip || !c->nblk) return 0;
+    if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    std::vector<uint8_t> h(c->nblk);
+    if (hipMemcpy(h.data(), c->deep_prev, c->nblk, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int64_t n = 0;
+    for (unsigned k = 0; k < c->nblk; ++k) if (h[k]) n += k + 1 < c->nblk ? 256 : c->nfluid - 256 * (int64_t)k;
+    return n;
+}
 extern "C" int64_t lbmpm_rk3dcsf_steps_done(const lbmpm_rk3dcsf *c) { return c ? c->steps : 0; }
 extern "C" int64_t lbmpm_rk3dcsf_device_bytes(const lbmpm_rk3dcsf *c) { return c ? c->bytes : 0; }
 extern "C" const char *lbmpm_rk3dcsf_dominant_kernel(const lbmpm_rk3dcsf *c) { (void)c; return "csf3d_collide"; }

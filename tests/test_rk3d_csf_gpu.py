@@ -240,3 +240,66 @@ def test_static_droplet_obeys_laplace():
         s.close()
     assert abs(out[0] - 1.0) < 0.12 and abs(out[1] - 1.0) < 0.12, out
     assert abs(out[0] - out[1]) < 0.06, out
+
+
+@pytest.mark.parametrize("theta", [60.0, 120.0])
+def test_sessile_droplet_takes_the_prescribed_contact_angle(theta):
+    """a red cap on a side wall (x = 0) in blue at rest: Akai's rule with the 3-D E8 solid normals turns the interface to the ini's ContactAngle --
+    measured through BLUE with wetting rule 2 (n = -G / |G|), as the reference's 2-D kernel does it (tests/test_physics_gpu.py::
+    test_d2q9_contact_angle: the red cap shows 180 - theta); spherical cap: angle = 2 atan(height / base radius)"""
+    nx, ny, nz = 40, 56, 64
+    dom = np.ones((nz, ny, nx), dtype=np.uint8)
+    dom[:, :, 0] = 0
+    zz, yy, xx = np.mgrid[0:nz, 0:ny, 0:nx]
+    red = (zz - nz / 2) ** 2 + (yy - ny / 2) ** 2 + (xx - 1.0) ** 2 <= 14.0 ** 2
+    fl = dom == 1
+    par = dict(relax="MRT", sigma=0.03, beta=0.7, theta=theta, velocityZR=0.0, velocityZB=0.0, densityBL=1.0, densityRL=0.0)
+    s = solver(dom, par)
+    s.set_macro(np.where(red & fl, 1.0, 0.0), np.where(~red & fl, 1.0, 0.0))
+    s.step(12000)
+    phi = s.get("phi")
+    assert np.all(np.isfinite(phi))
+    inside = (phi > 0) & fl
+    # height above the wall along x through the cap's axis, base radius from the wetted area of the first fluid layer (x = 1);
+    # the interface is found where phi crosses zero (linear interpolation along the axis)
+    axis = phi[nz // 2, ny // 2, 1:]
+    k = int(np.argmax(axis <= 0))
+    h = 0.5 + (k - 1) + axis[k - 1] / (axis[k - 1] - axis[k])          # the wall sits half a cell below the first fluid cell
+    a = np.sqrt(float(inside[:, :, 1].sum()) / np.pi)
+    got = np.degrees(2. * np.arctan(h / a))
+    assert abs(got - (180. - theta)) < 6.0, "red cap's angle %.1f for ContactAngle %.0f (h %.2f, a %.2f)" % (got, theta, h, a)
+    assert max(float(np.max(np.abs(s.get(c)[fl]))) for c in ("vx", "vy", "vz")) < 2e-3
+    s.close()
+
+
+@pytest.mark.parametrize("relax,over", [("MRT", {}), ("SRT", dict(outlet="Convective")), ("MRT", dict(inlet="Dirichlet", densityBH=1.0, densityRH=1e-8))])
+def test_the_bulk_skip_is_exact(relax, over):
+    """blocks of 256 fluid cells deep inside one colour skip the phase-field pull, the gradient and the curvature (phi = +-1, G = n = K = F = 0
+    there): bit-equal to the build that sends every cell through the full path, while a front moves through the lattice and the set of
+    skipping blocks changes; and equal to the oracle"""
+    from openlbmpm_amd.RKColorGradientD3Q19 import duct
+    dom = duct(34, 30, 120)
+    dom[40:60, 8:20, 10:24] = 0                       # an obstacle with wetting walls inside the red bulk
+    zz = np.mgrid[0:120, 0:30, 0:34][0]
+    fl = dom == 1
+    rR, rB = np.where(fl & (zz < 84), 1.0, 0.0), np.where(fl & (zz >= 84), 1.0, 0.0)
+    par = dict(relax=relax, theta=60.0, tauB=0.8, velocityZR=0.0, velocityZB=-4.0e-3, sigma=0.05); par.update(over)
+    a = solver(dom, par); b = solver(dom, dict(par, variant=1))
+    a.set_macro(rR, rB); b.set_macro(rR, rB)
+    seen = []
+    for k in (1, 2, 3, 40, 41, 160):
+        a.step(k - a.steps_done); b.step(k - b.steps_done)
+        seen.append(a.bulk_cells)
+        assert b.bulk_cells == 0
+        for f in ("fR", "fB", "rhoR", "rhoB", "phi", "Gx", "Gy", "Gz", "Fx", "Fy", "Fz", "K", "vx", "vy", "vz", "rec_vz", "rec_phi"):
+            assert np.array_equal(a.get(f), b.get(f)), (k, f)
+    assert seen[0] == 0 and seen[1] > 0.3 * a.num_fluid_nodes, seen          # the first step knows nothing yet; then most of the lattice is bulk
+    assert len(set(seen[1:])) > 1, seen                                      # the front moved: the set of bulk blocks changed
+    o = RK3DCSFOracle(dom, rR, rB, par).run(160)
+    compare_all(a, o, "bulk skip vs oracle")
+    # a restart in the middle of it
+    c = solver(dom, par); c.set_pdf(a.get("fR"), a.get("fB"), force=(a.get("Fx"), a.get("Fy"), a.get("Fz")))
+    a.step(30); c.step(30)
+    for f in ("fR", "fB", "phi", "Fz", "K"):
+        assert np.array_equal(a.get(f), c.get(f)), f
+    a.close(); b.close(); c.close()
