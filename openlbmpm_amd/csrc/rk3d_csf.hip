@@ -112,8 +112,8 @@ __device__ __forceinline__ double sum_inplane(const double f[Q]) { return f[0] +
 // given by set_macro / set_pdf has been streamed already), then the boundary-plane rule of the cell's plane.  BC = false: the pull alone
 // (what the reference's arrays hold after a step).
 template <bool FIRST, bool BC>
-__device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z, double fR[Q], double fB[Q], double &rR, double &rB)
-{
+__device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z, double fR[Q], double fB[Q], double &rR, double &rB, int only = 0)
+{   // only = 1 / 2: every source cell holds red / blue alone (deep_colour): the other colour's populations are exact zeros and are not read
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ, OPP[Q] = CSF_OPP;
     constexpr int UP[5] = {5, 11, 14, 15, 18}, DN[5] = {6, 12, 13, 16, 17};
     int zs = z;                                   // the plane whose streamed populations this cell takes
@@ -136,13 +136,13 @@ __device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z,
     }
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
-        if (FIRST || i == 0) {
-            fR[i] = fr[(size_t)i * p.FS + oj]; fB[i] = fb[(size_t)i * p.FS + oj];
-        } else {
+        size_t off = (size_t)i * p.FS + oj;
+        if (!(FIRST || i == 0)) {
             const bool from_fluid = (m >> OPP[i]) & 1u;
-            const size_t off = (size_t)(from_fluid ? i : OPP[i]) * p.FS + sj[i];     // off a solid: half-way bounce-back, the cell's own opposite population
-            fR[i] = fr[off]; fB[i] = fb[off];
+            off = (size_t)(from_fluid ? i : OPP[i]) * p.FS + sj[i];     // off a solid: half-way bounce-back, the cell's own opposite population
         }
+        fR[i] = only == 2 ? 0. : fr[off];
+        fB[i] = only == 1 ? 0. : fb[off];
     }
     rR = sum19(fR); rB = sum19(fB);
     if (!BC) return;
@@ -430,13 +430,60 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     const bool active = fluid_cell(p, j, n, x, y, z);
     const unsigned blk = block_of();
     const int deep = deep_colour(p, blk);
-    const bool was_deep = p.skip && blk < p.nblk && p.deep_prev[blk] != 0;     // the arrays G, n, F of this block hold zeros
+    const int prev_deep = p.skip && blk < p.nblk ? (int)p.deep_prev[blk] : 0;
+    const bool was_deep = prev_deep != 0;       // the arrays G, n, F of this block hold zeros
+    const bool same_deep = deep != 0 && prev_deep == deep;
     bool only_red = true, only_blue = true;
-    if (active) {
+    if (active && deep) {
+        // One colour alone, no gradient, no force: what the full path below computes then, term by term -- the absent colour's equilibrium
+        // and populations are exact zeros, the Guo source is a sum of products by F = 0, cos(theta_i) = 0, rho_c / rho = 1 exactly -- so
+        // the present colour's populations are the relaxed f_tot and the other colour's are zeros, bit for bit.
+        double *fr = p.fout + j, *fb = p.fout + (size_t)Q * p.FS + j;
+        double fR[Q], fB[Q], rR, rB;
+        cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB, deep);
+        only_red = rB == 0.; only_blue = rR == 0.;
+        double t[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) t[i] = fR[i] + fB[i];
+        double mx = 0., my = 0., mz = 0.;
+#pragma unroll
+        for (int i = 1; i < Q; ++i) { addc(mx, CX[i], t[i]); addc(my, CY[i], t[i]); addc(mz, CZ[i], t[i]); }
+        const double rs = rB + rR;
+        const double pfx_ = was_deep ? 0. : p.F[n], pfy_ = was_deep ? 0. : p.F[p.NS + n], pfz_ = was_deep ? 0. : p.F[2 * p.NS + n];
+        const double vx = (mx + 0.5 * pfx_) / rs, vy = (my + 0.5 * pfy_) / rs, vz = (mz + 0.5 * pfz_) / rs;
+        const double phi = (rR - rB) / (rR + rB);
+        if (!was_deep) { p.F[n] = 0.; p.F[p.NS + n] = 0.; p.F[2 * p.NS + n] = 0.; }
+        if (DIAG) { p.K[n] = 0.; p.U[n] = vx; p.U[p.NS + n] = vy; p.U[2 * p.NS + n] = vz; }
+        const double tau = tau_of(p, phi, rR, rB);
+        const double rc = deep == 1 ? rR : rB;           // (the absent colour's equilibrium is 0 * ... = +0: adding it changes nothing)
+        if (!MRT) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                const double eT = feq(rc, i, CX[i], CY[i], CZ[i], vx, vy, vz);
+                t[i] = -1. / tau * (t[i] - eT) + t[i];
+            }
+        } else {
+            const double it = 1. / tau;
+            const double S[Q] = {p.rate[5], p.rate[0], p.rate[1], p.rate[5], p.rate[2], p.rate[5], p.rate[2], p.rate[5], p.rate[2], it, p.rate[3], it, p.rate[3],
+                                 it, it, it, p.rate[4], p.rate[4], p.rate[4]};
+            double d[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) d[i] = t[i] - feq(rc, i, CX[i], CY[i], CZ[i], vx, vy, vz);
+            mrt_apply(S, d);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) t[i] = -d[i] + t[i];
+        }
+        double *present = deep == 1 ? fr : fb, *absent = deep == 1 ? fb : fr;      // rho_c / rho = 1 exactly: the present colour takes f_tot as it is
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            __builtin_nontemporal_store(t[i], present + (size_t)i * p.FS);
+            if (!same_deep) __builtin_nontemporal_store(0., absent + (size_t)i * p.FS);
+        }
+    } else if (active) {
     const uint32_t m = p.meta[n];
     double *fr = p.fout + j, *fb = p.fout + (size_t)Q * p.FS + j;
     double fR[Q], fB[Q], rR, rB;
-    cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
+    cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB, deep);
     only_red = rB == 0.; only_blue = rR == 0.;
     double t[Q];
 #pragma unroll
@@ -514,8 +561,10 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
         double c = 0.;
         if (gn > 1.0e-8 && un > 1.0e-8) c = edotv(CX[i], CY[i], CZ[i], gx, gy, gz) / (un * gn);
         // streaming stores: these lines are not read again before the next step
-        __builtin_nontemporal_store(rR / tot * t[i] + p.beta * rR * rB / tot * wq(i) * c * un, fr + (size_t)i * p.FS);
-        __builtin_nontemporal_store(rB / tot * t[i] - p.beta * rR * rB / tot * wq(i) * c * un, fb + (size_t)i * p.FS);
+        // a block that was deep in the same colour a step ago finds the other colour's zeros in place (this buffer was written two steps
+        // ago, when the block held that colour alone already): they are not written again
+        if (!(same_deep && deep == 2)) __builtin_nontemporal_store(rR / tot * t[i] + p.beta * rR * rB / tot * wq(i) * c * un, fr + (size_t)i * p.FS);
+        if (!(same_deep && deep == 1)) __builtin_nontemporal_store(rB / tot * t[i] - p.beta * rR * rB / tot * wq(i) * c * un, fb + (size_t)i * p.FS);
     }
     }   // active
     if (p.skip) {                                // what the block hands on, for the next step's deep_colour
