@@ -70,6 +70,8 @@ struct CsfDev {
     const uint8_t *bcblk;        // [nblk] the block holds cells of the open planes or their ghosts: always the full path
     const uint32_t *rng;         // [2][nblk] first / last block that holds a cell within two cells of this block's cells
     const uint32_t *pfx;         // [2][nblk + 1] number of blocks before k whose `pure` is not 1 / not 2
+    const uint8_t *deep_now;     // [nblk] deep_colour of this step (csf3d_deep_mark)
+    const uint32_t *work;        // the blocks that are not deep, in order; work[nblk] = their number
 };
 
 struct Nb { unsigned xo[3], yo[3], zo[3]; };
@@ -234,9 +236,9 @@ __device__ __forceinline__ int deep_colour(const CsfDev &p, unsigned b)
     if (pb[hi + 1u] - pb[lo] == 0u) return 2;
     return 0;
 }
-__device__ __forceinline__ bool fluid_cell(const CsfDev &p, unsigned &j, unsigned &n, int &x, int &y, int &z)
+__device__ __forceinline__ bool fluid_cell(const CsfDev &p, unsigned blk, unsigned &j, unsigned &n, int &x, int &y, int &z)
 {
-    j = block_of() * 256u + threadIdx.x;
+    j = blk * 256u + threadIdx.x;
     if (j >= p.NF) return false;
     n = p.cells[j];
     const unsigned pl = (unsigned)p.nx * (unsigned)p.ny;
@@ -247,20 +249,33 @@ __device__ __forceinline__ bool fluid_cell(const CsfDev &p, unsigned &j, unsigne
     return true;
 }
 
+// csf3d_phase and csf3d_gradient run over the blocks that have something to do: all of them without the bulk skip, else the list
+// p.work of the blocks that are not deep or have just become so (a launch of one workgroup per block spends ~ 1 ms at 512^3 on
+// workgroups that only find out that they may leave).  A fixed grid; the workgroups of an XCD share one contiguous stretch of the list.
+__device__ __forceinline__ void work_range(const CsfDev &p, unsigned &k, unsigned &end, unsigned &step)
+{
+    const unsigned cnt = p.skip ? p.work[p.nblk] : p.nblk, x = blockIdx.x & 7u;
+    k = (unsigned)(((unsigned long long)cnt * x) >> 3) + (blockIdx.x >> 3);
+    end = (unsigned)(((unsigned long long)cnt * (x + 1u)) >> 3);
+    step = gridDim.x >> 3;
+}
+
 template <bool FIRST>
 __global__ __launch_bounds__(256) void csf3d_phase(CsfDev p)
 {
-    unsigned j, n;
-    int x, y, z;
-    if (!fluid_cell(p, j, n, x, y, z)) return;
-    const int deep = deep_colour(p, block_of());
-    if (deep) {                                  // (rho - 0) / (rho + 0) = 1 exactly
-        if (p.deep_prev[block_of()] != deep) p.phi[n] = deep == 1 ? 1. : -1.;
-        return;
+    unsigned k, end, step;
+    work_range(p, k, end, step);
+    for (; k < end; k += step) {
+        const unsigned blk = p.skip ? p.work[k] : k;
+        unsigned j, n;
+        int x, y, z;
+        if (!fluid_cell(p, blk, j, n, x, y, z)) continue;
+        const int deep = p.skip ? (int)p.deep_now[blk] : 0;
+        if (deep) { p.phi[n] = deep == 1 ? 1. : -1.; continue; }       // (rho - 0) / (rho + 0) = 1 exactly; listed: the block has just become deep
+        double fR[Q], fB[Q], rR, rB;
+        cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
+        p.phi[n] = (rR - rB) / (rR + rB);
     }
-    double fR[Q], fB[Q], rR, rB;
-    cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB);
-    p.phi[n] = (rR - rB) / (rR + rB);
 }
 
 // A:1560-1581 calColorValueOnSolid over the list of wetting solids (in lattice order: neighbouring solids read neighbouring phi)
@@ -285,15 +300,17 @@ __global__ __launch_bounds__(256) void csf3d_solid_phi(CsfDev p, const uint32_t 
 __global__ __launch_bounds__(256) void csf3d_gradient(CsfDev p)
 {
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    unsigned k, end, step;
+    work_range(p, k, end, step);
+    for (; k < end; k += step) {
+    const unsigned blk = p.skip ? p.work[k] : k;
     unsigned j, n;
     int x, y, z;
-    if (!fluid_cell(p, j, n, x, y, z)) return;
-    if (deep_colour(p, block_of())) {            // phi is the same constant one cell around, phi_s of the walls included: sums of +-w that cancel exactly
-        if (!p.deep_prev[block_of()]) {
-            p.G[n] = 0.; p.G[p.NS + n] = 0.; p.G[2 * p.NS + n] = 0.;
-            p.nh[n] = 0.; p.nh[p.NS + n] = 0.; p.nh[2 * p.NS + n] = 0.;
-        }
-        return;
+    if (!fluid_cell(p, blk, j, n, x, y, z)) continue;
+    if (p.skip && p.deep_now[blk]) {             // phi is the same constant one cell around, phi_s of the walls included: sums of +-w that cancel exactly
+        p.G[n] = 0.; p.G[p.NS + n] = 0.; p.G[2 * p.NS + n] = 0.;       // (listed: the block has just become deep)
+        p.nh[n] = 0.; p.nh[p.NS + n] = 0.; p.nh[2 * p.NS + n] = 0.;
+        continue;
     }
     const uint32_t m = p.meta[n];
     const Nb nb = make_nb(p, x, y, z);
@@ -330,6 +347,7 @@ __global__ __launch_bounds__(256) void csf3d_gradient(CsfDev p)
     double hx = 0., hy = 0., hz = 0.;
     if (gn > 1.0e-8) { hx = -gx / gn; hy = -gy / gn; hz = -gz / gn; }
     p.nh[n] = hx; p.nh[p.NS + n] = hy; p.nh[2 * p.NS + n] = hz;
+    }
 }
 
 // rows of the D3Q19 moment basis of d'Humieres et al. 2002:
@@ -427,9 +445,9 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
     unsigned j, n;
     int x, y, z;
-    const bool active = fluid_cell(p, j, n, x, y, z);
     const unsigned blk = block_of();
-    const int deep = deep_colour(p, blk);
+    const bool active = fluid_cell(p, blk, j, n, x, y, z);
+    const int deep = p.skip && blk < p.nblk ? (int)p.deep_now[blk] : 0;
     const int prev_deep = p.skip && blk < p.nblk ? (int)p.deep_prev[blk] : 0;
     const bool was_deep = prev_deep != 0;       // the arrays G, n, F of this block hold zeros
     const bool same_deep = deep != 0 && prev_deep == deep;
@@ -573,27 +591,71 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     }
 }
 
-// pfx[0][k] / pfx[1][k] = number of blocks before k that are not purely red / not purely blue (one workgroup; nblk ~ 3e5 at 512^3)
-__global__ __launch_bounds__(1024) void csf3d_scan_pure(unsigned nblk, const uint8_t *pure, uint32_t *pfx)
+// Per step, before the phase field: four small launches of ceil(nblk / 1024) workgroups.
+//   csf3d_tile_count<0>  per tile of 1024 blocks: how many are not purely red / not purely blue
+//   csf3d_tile_rank<0>   pfx[0][k] / pfx[1][k] = number of such blocks before k (tile offsets summed on the fly)
+//   csf3d_tile_count<1>  deep_now[b] = deep_colour(b); per tile: how many blocks have something to do in csf3d_phase / csf3d_gradient
+//   csf3d_tile_rank<1>   work[] = those blocks in order, work[nblk] = their number
+__device__ __forceinline__ unsigned block_sum(unsigned v, unsigned *lds)         // sum over the 1024 threads, to every thread
 {
-    __shared__ unsigned part[2][1024];
-    const unsigned t = threadIdx.x, chunk = (nblk + 1023u) / 1024u, k0 = t * chunk, k1 = min(nblk, k0 + chunk);
-    unsigned a = 0, b = 0;
-    for (unsigned k = k0; k < k1; ++k) { const unsigned v = pure[k]; a += v != 1u; b += v != 2u; }
-    part[0][t] = a; part[1][t] = b;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63u) == 0u) lds[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (unsigned d = 1; d < 1024u; d <<= 1) {   // inclusive scan of the 1024 partial counts
-        const unsigned va = t >= d ? part[0][t - d] : 0u, vb = t >= d ? part[1][t - d] : 0u;
-        __syncthreads();
-        part[0][t] += va; part[1][t] += vb;
-        __syncthreads();
+    unsigned t = 0;
+    for (int w = 0; w < 16; ++w) t += lds[w];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ unsigned block_rank(bool flag, unsigned *lds, unsigned &total)      // number of set flags in lower threads
+{
+    const unsigned long long b = __ballot(flag);
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (lane == 0u) lds[w] = (unsigned)__popcll(b);
+    __syncthreads();
+    unsigned before = 0; total = 0;
+    for (unsigned k = 0; k < 16u; ++k) { if (k < w) before += lds[k]; total += lds[k]; }
+    __syncthreads();
+    return before + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+}
+template <int WHAT>
+__global__ __launch_bounds__(1024) void csf3d_tile_count(CsfDev p, uint8_t *deep_now, uint32_t *tcnt)
+{
+    __shared__ unsigned lds[16];
+    const unsigned b = blockIdx.x * 1024u + threadIdx.x, ntile = gridDim.x;
+    if (WHAT == 0) {
+        const unsigned v = b < p.nblk ? p.pure[b] : 1u, w = b < p.nblk ? p.pure[b] : 2u;
+        const unsigned a = block_sum(v != 1u, lds), c = block_sum(w != 2u, lds);
+        if (threadIdx.x == 0) { tcnt[blockIdx.x] = a; tcnt[ntile + blockIdx.x] = c; }
+    } else {
+        int d = 0;
+        bool todo = false;
+        if (b < p.nblk) { d = deep_colour(p, b); deep_now[b] = (uint8_t)d; todo = !(d != 0 && p.deep_prev[b] == d); }
+        const unsigned a = block_sum(todo, lds);
+        if (threadIdx.x == 0) tcnt[blockIdx.x] = a;
     }
-    a = part[0][t] - a; b = part[1][t] - b;      // exclusive: blocks before k0
-    for (unsigned k = k0; k < k1; ++k) {
-        pfx[k] = a; pfx[nblk + 1u + k] = b;
-        const unsigned v = pure[k]; a += v != 1u; b += v != 2u;
+}
+template <int WHAT>
+__global__ __launch_bounds__(1024) void csf3d_tile_rank(CsfDev p, const uint8_t *deep_now, const uint32_t *tcnt, uint32_t *out)
+{
+    __shared__ unsigned lds[16];
+    const unsigned b = blockIdx.x * 1024u + threadIdx.x, ntile = gridDim.x;
+    for (int arr = 0; arr < (WHAT == 0 ? 2 : 1); ++arr) {
+        unsigned mine = 0;
+        for (unsigned s = threadIdx.x; s < blockIdx.x; s += 1024u) mine += tcnt[arr * ntile + s];
+        const unsigned off = block_sum(mine, lds);
+        bool flag;
+        if (WHAT == 0) flag = b < p.nblk && p.pure[b] != (arr == 0 ? 1u : 2u);
+        else flag = b < p.nblk && !(deep_now[b] != 0 && p.deep_prev[b] == deep_now[b]);
+        unsigned total;
+        const unsigned r = off + block_rank(flag, lds, total);
+        if (WHAT == 0) {
+            if (b < p.nblk) out[arr * (p.nblk + 1u) + b] = r;
+            if (blockIdx.x == ntile - 1u && threadIdx.x == 0) out[arr * (p.nblk + 1u) + p.nblk] = off + total;
+        } else {
+            if (flag) out[r] = b;
+            if (blockIdx.x == ntile - 1u && threadIdx.x == 0) out[p.nblk] = off + total;
+        }
     }
-    if (t == 1023u) { pfx[nblk] = part[0][1023]; pfx[2u * nblk + 1u] = part[1][1023]; }
 }
 
 // set-up of the bulk skip: first / last fluid cell any cell of a block reads its state from (pass 0), then first / last block over the
@@ -799,7 +861,8 @@ struct lbmpm_rk3dcsf {
     hipStream_t stream = nullptr;
     uint8_t *dom = nullptr;
     uint32_t *meta = nullptr, *wetlist = nullptr, *cidx = nullptr, *cells = nullptr, *rng = nullptr, *pfx = nullptr;
-    uint8_t *pure = nullptr, *deep_prev = nullptr, *bcblk = nullptr;
+    uint8_t *pure = nullptr, *deep_prev = nullptr, *bcblk = nullptr, *deep_now = nullptr;
+    uint32_t *work = nullptr, *tcnt = nullptr;
     unsigned nblk = 0;
     bool skip = true;
     double *fA = nullptr, *fB = nullptr, *phi = nullptr, *G = nullptr, *nh = nullptr, *F = nullptr, *K = nullptr, *U = nullptr, *ns = nullptr;
@@ -835,7 +898,7 @@ CsfDev make_dev(const lbmpm_rk3dcsf *c)
     for (int i = 0; i < 6; ++i) any = any || c->cfg.mrt_rates[i] != 0.;
     const double own[6] = {1.19, 1.4, 1.2, 1.4, 1.2, 0.};
     for (int i = 0; i < 6; ++i) p.rate[i] = any ? c->cfg.mrt_rates[i] : own[i];
-    p.nblk = c->nblk; p.skip = c->skip ? 1 : 0; p.pure = c->pure; p.deep_prev = c->deep_prev; p.bcblk = c->bcblk; p.rng = c->rng; p.pfx = c->pfx;
+    p.nblk = c->nblk; p.skip = c->skip ? 1 : 0; p.pure = c->pure; p.deep_prev = c->deep_prev; p.bcblk = c->bcblk; p.rng = c->rng; p.pfx = c->pfx; p.deep_now = c->deep_now; p.work = c->work;
     return p;
 }
 
@@ -845,11 +908,17 @@ unsigned blocks8(size_t n) { return (blocks_of(n) + 7u) / 8u * 8u; }      // flu
 template <bool FIRST>
 int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
 {
-    const unsigned g = blocks8((size_t)c->nfluid);
-    if (c->skip) csf3d_scan_pure<<<1, 1024, 0, c->stream>>>(c->nblk, c->pure, c->pfx);
-    csf3d_phase<FIRST><<<g, 256, 0, c->stream>>>(p);
+    const unsigned g = blocks8((size_t)c->nfluid), gw = g < 4096u ? g : 4096u;        // (both multiples of 8)
+    if (c->skip) {
+        const unsigned nt = (c->nblk + 1023u) / 1024u;
+        csf3d_tile_count<0><<<nt, 1024, 0, c->stream>>>(p, c->deep_now, c->tcnt);
+        csf3d_tile_rank<0><<<nt, 1024, 0, c->stream>>>(p, c->deep_now, c->tcnt, c->pfx);
+        csf3d_tile_count<1><<<nt, 1024, 0, c->stream>>>(p, c->deep_now, c->tcnt);
+        csf3d_tile_rank<1><<<nt, 1024, 0, c->stream>>>(p, c->deep_now, c->tcnt, c->work);
+    }
+    csf3d_phase<FIRST><<<gw, 256, 0, c->stream>>>(p);
     if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist);
-    csf3d_gradient<<<g, 256, 0, c->stream>>>(p);
+    csf3d_gradient<<<gw, 256, 0, c->stream>>>(p);
     if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
     const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
     if (mrt) { if (c->diag) csf3d_collide<FIRST, true, true><<<g, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, true, false><<<g, 256, 0, c->stream>>>(p); }
@@ -889,7 +958,7 @@ extern "C" void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->rng, c->pfx, c->pure, c->deep_prev, c->bcblk, c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
+    void *ptrs[] = {c->rng, c->pfx, c->pure, c->deep_prev, c->bcblk, c->deep_now, c->work, c->tcnt, c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     c->pool.destroy();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1013,6 +1082,9 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->bcblk, nb);
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->rng, 2 * (size_t)nb);
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->pfx, 2 * ((size_t)nb + 1));
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->deep_now, nb);
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->work, (size_t)nb + 1);
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->tcnt, 2 * ((size_t)nb / 1024 + 1));
         if (rc == LBMPM_OK && hipMalloc(reinterpret_cast<void **>(&lo0), 4 * (size_t)nb * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc failed"); rc = LBMPM_ERR_NOMEM; }
         if (rc == LBMPM_OK) {
             hi0 = lo0 + nb; lo1 = hi0 + nb; hi1 = lo1 + nb;
