@@ -45,6 +45,8 @@ __device__ __host__ __forceinline__ constexpr double wq(int i) { return i == 0 ?
 // meta word of a cell: bit 0 fluid, bits 1 .. 18 "the neighbour in direction i is fluid", bits 20 - 21 kind
 // (0 solid, 1 fluid, 2 wetting solid: >= 1 fluid among its 18 neighbours, 3 fluid with >= 1 solid among them)
 constexpr unsigned KIND_SHIFT = 20;
+constexpr unsigned SRC_WALL = 0xFFFFFFFFu;
+enum { L_TODO = 0, L_FULL = 1, L_DEEP = 2 };
 
 struct CsfDev {
     int nx, ny, nz;
@@ -71,7 +73,9 @@ struct CsfDev {
     const uint32_t *rng;         // [2][nblk] first / last block that holds a cell within two cells of this block's cells
     const uint32_t *pfx;         // [2][nblk + 1] number of blocks before k whose `pure` is not 1 / not 2
     const uint8_t *deep_now;     // [nblk] deep_colour of this step (csf3d_deep_mark)
-    const uint32_t *work;        // the blocks that are not deep, in order; work[nblk] = their number
+    const uint32_t *work;        // [3][nblk + 1] lists of blocks in order, each followed by its length: L_TODO the blocks csf3d_phase / csf3d_gradient
+                                 // have something to do in (not deep, or deep since this step), L_FULL the blocks that are not deep, L_DEEP those that are
+    const uint32_t *src;         // [18][FS] number of the fluid cell x - e_i (the cell direction i is pulled from), SRC_WALL off a solid
 };
 
 struct Nb { unsigned xo[3], yo[3], zo[3]; };
@@ -252,9 +256,10 @@ __device__ __forceinline__ bool fluid_cell(const CsfDev &p, unsigned blk, unsign
 // csf3d_phase and csf3d_gradient run over the blocks that have something to do: all of them without the bulk skip, else the list
 // p.work of the blocks that are not deep or have just become so (a launch of one workgroup per block spends ~ 1 ms at 512^3 on
 // workgroups that only find out that they may leave).  A fixed grid; the workgroups of an XCD share one contiguous stretch of the list.
-__device__ __forceinline__ void work_range(const CsfDev &p, unsigned &k, unsigned &end, unsigned &step)
+__device__ __forceinline__ const uint32_t *list_of(const CsfDev &p, int which) { return p.work + (size_t)which * (p.nblk + 1u); }
+__device__ __forceinline__ void work_range(const CsfDev &p, int which, unsigned &k, unsigned &end, unsigned &step)
 {
-    const unsigned cnt = p.skip ? p.work[p.nblk] : p.nblk, x = blockIdx.x & 7u;
+    const unsigned cnt = p.skip ? list_of(p, which)[p.nblk] : p.nblk, x = blockIdx.x & 7u;
     k = (unsigned)(((unsigned long long)cnt * x) >> 3) + (blockIdx.x >> 3);
     end = (unsigned)(((unsigned long long)cnt * (x + 1u)) >> 3);
     step = gridDim.x >> 3;
@@ -264,9 +269,9 @@ template <bool FIRST>
 __global__ __launch_bounds__(256) void csf3d_phase(CsfDev p)
 {
     unsigned k, end, step;
-    work_range(p, k, end, step);
+    work_range(p, L_TODO, k, end, step);
     for (; k < end; k += step) {
-        const unsigned blk = p.skip ? p.work[k] : k;
+        const unsigned blk = p.skip ? list_of(p, L_TODO)[k] : k;
         unsigned j, n;
         int x, y, z;
         if (!fluid_cell(p, blk, j, n, x, y, z)) continue;
@@ -301,9 +306,9 @@ __global__ __launch_bounds__(256) void csf3d_gradient(CsfDev p)
 {
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
     unsigned k, end, step;
-    work_range(p, k, end, step);
+    work_range(p, L_TODO, k, end, step);
     for (; k < end; k += step) {
-    const unsigned blk = p.skip ? p.work[k] : k;
+    const unsigned blk = p.skip ? list_of(p, L_TODO)[k] : k;
     unsigned j, n;
     int x, y, z;
     if (!fluid_cell(p, blk, j, n, x, y, z)) continue;
@@ -443,61 +448,18 @@ template <bool FIRST, bool MRT, bool DIAG>
 __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(CsfDev p)
 {
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    unsigned kk, kend, kstep;
+    work_range(p, L_FULL, kk, kend, kstep);
+    for (; kk < kend; kk += kstep) {
+    const unsigned blk = p.skip ? list_of(p, L_FULL)[kk] : kk;
     unsigned j, n;
     int x, y, z;
-    const unsigned blk = block_of();
     const bool active = fluid_cell(p, blk, j, n, x, y, z);
-    const int deep = p.skip && blk < p.nblk ? (int)p.deep_now[blk] : 0;
-    const int prev_deep = p.skip && blk < p.nblk ? (int)p.deep_prev[blk] : 0;
-    const bool was_deep = prev_deep != 0;       // the arrays G, n, F of this block hold zeros
-    const bool same_deep = deep != 0 && prev_deep == deep;
+    constexpr int deep = 0;                       // (the deep blocks go through csf3d_collide_deep)
+    const bool was_deep = p.skip && p.deep_prev[blk] != 0;       // the arrays G, n, F of this block hold zeros
+    constexpr bool same_deep = false;
     bool only_red = true, only_blue = true;
-    if (active && deep) {
-        // One colour alone, no gradient, no force: what the full path below computes then, term by term -- the absent colour's equilibrium
-        // and populations are exact zeros, the Guo source is a sum of products by F = 0, cos(theta_i) = 0, rho_c / rho = 1 exactly -- so
-        // the present colour's populations are the relaxed f_tot and the other colour's are zeros, bit for bit.
-        double *fr = p.fout + j, *fb = p.fout + (size_t)Q * p.FS + j;
-        double fR[Q], fB[Q], rR, rB;
-        cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB, deep);
-        only_red = rB == 0.; only_blue = rR == 0.;
-        double t[Q];
-#pragma unroll
-        for (int i = 0; i < Q; ++i) t[i] = fR[i] + fB[i];
-        double mx = 0., my = 0., mz = 0.;
-#pragma unroll
-        for (int i = 1; i < Q; ++i) { addc(mx, CX[i], t[i]); addc(my, CY[i], t[i]); addc(mz, CZ[i], t[i]); }
-        const double rs = rB + rR;
-        const double pfx_ = was_deep ? 0. : p.F[n], pfy_ = was_deep ? 0. : p.F[p.NS + n], pfz_ = was_deep ? 0. : p.F[2 * p.NS + n];
-        const double vx = (mx + 0.5 * pfx_) / rs, vy = (my + 0.5 * pfy_) / rs, vz = (mz + 0.5 * pfz_) / rs;
-        const double phi = (rR - rB) / (rR + rB);
-        if (!was_deep) { p.F[n] = 0.; p.F[p.NS + n] = 0.; p.F[2 * p.NS + n] = 0.; }
-        if (DIAG) { p.K[n] = 0.; p.U[n] = vx; p.U[p.NS + n] = vy; p.U[2 * p.NS + n] = vz; }
-        const double tau = tau_of(p, phi, rR, rB);
-        const double rc = deep == 1 ? rR : rB;           // (the absent colour's equilibrium is 0 * ... = +0: adding it changes nothing)
-        if (!MRT) {
-#pragma unroll
-            for (int i = 0; i < Q; ++i) {
-                const double eT = feq(rc, i, CX[i], CY[i], CZ[i], vx, vy, vz);
-                t[i] = -1. / tau * (t[i] - eT) + t[i];
-            }
-        } else {
-            const double it = 1. / tau;
-            const double S[Q] = {p.rate[5], p.rate[0], p.rate[1], p.rate[5], p.rate[2], p.rate[5], p.rate[2], p.rate[5], p.rate[2], it, p.rate[3], it, p.rate[3],
-                                 it, it, it, p.rate[4], p.rate[4], p.rate[4]};
-            double d[Q];
-#pragma unroll
-            for (int i = 0; i < Q; ++i) d[i] = t[i] - feq(rc, i, CX[i], CY[i], CZ[i], vx, vy, vz);
-            mrt_apply(S, d);
-#pragma unroll
-            for (int i = 0; i < Q; ++i) t[i] = -d[i] + t[i];
-        }
-        double *present = deep == 1 ? fr : fb, *absent = deep == 1 ? fb : fr;      // rho_c / rho = 1 exactly: the present colour takes f_tot as it is
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            __builtin_nontemporal_store(t[i], present + (size_t)i * p.FS);
-            if (!same_deep) __builtin_nontemporal_store(0., absent + (size_t)i * p.FS);
-        }
-    } else if (active) {
+    if (active) {
     const uint32_t m = p.meta[n];
     double *fr = p.fout + j, *fb = p.fout + (size_t)Q * p.FS + j;
     double fR[Q], fB[Q], rR, rB;
@@ -587,15 +549,102 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     }   // active
     if (p.skip) {                                // what the block hands on, for the next step's deep_colour
         const int allr = __syncthreads_and(only_red), allb = __syncthreads_and(only_blue);
-        if (threadIdx.x == 0 && blk < p.nblk) { p.pure[blk] = allr ? 1 : (allb ? 2 : 0); p.deep_prev[blk] = (uint8_t)deep; }
+        if (threadIdx.x == 0) { p.pure[blk] = allr ? 1 : (allb ? 2 : 0); p.deep_prev[blk] = 0; }
     }
+    }   // blocks of the list
+}
+
+// The deep blocks' collision (deep_colour): one colour alone, no gradient, no force.  What the full path computes then, term by term --
+// the absent colour's populations and equilibrium are exact zeros, the Guo source is a sum of products by F = 0, cos(theta_i) = 0,
+// rho_c / rho = 1 exactly -- so the present colour's populations are the relaxed f_tot and the other colour's are zeros, bit for bit
+// (tests: variant 1 runs every block through csf3d_collide).  19 loads through the table of source cells (no lattice coordinates, no
+// meta words: the open planes are never deep), 19 stores; the absent colour is not read, and not written again once its zeros are in
+// place (a block deep since the step before: this buffer was written two steps ago, when the block held that colour alone already).
+template <bool MRT, bool DIAG>
+__global__ __launch_bounds__(256) void csf3d_collide_deep(CsfDev p)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ, OPP[Q] = CSF_OPP;
+    unsigned kk, kend, kstep;
+    work_range(p, L_DEEP, kk, kend, kstep);
+    for (; kk < kend; kk += kstep) {
+        const unsigned blk = list_of(p, L_DEEP)[kk];
+        const int deep = (int)p.deep_now[blk];
+        const bool same_deep = (int)p.deep_prev[blk] == deep, was_deep = p.deep_prev[blk] != 0;
+        const unsigned j = blk * 256u + threadIdx.x;
+        if (j < p.NF) {
+            const size_t colour = deep == 1 ? 0 : (size_t)Q * p.FS;
+            const double *f = p.fin + colour;
+            double t[Q];
+            t[0] = f[j];
+#pragma unroll
+            for (int i = 1; i < Q; ++i) {
+                const unsigned q = p.src[(size_t)(i - 1) * p.FS + j];
+                t[i] = f[q != SRC_WALL ? (size_t)i * p.FS + q : (size_t)OPP[i] * p.FS + j];
+            }
+            const double rc = sum19(t);
+            double mx = 0., my = 0., mz = 0.;
+#pragma unroll
+            for (int i = 1; i < Q; ++i) { addc(mx, CX[i], t[i]); addc(my, CY[i], t[i]); addc(mz, CZ[i], t[i]); }
+            const double rR = deep == 1 ? rc : 0., rB = deep == 1 ? 0. : rc;
+            const double rs = rB + rR;
+            unsigned n = 0;
+            if (!was_deep || DIAG) n = p.cells[j];
+            const double pfx_ = was_deep ? 0. : p.F[n], pfy_ = was_deep ? 0. : p.F[p.NS + n], pfz_ = was_deep ? 0. : p.F[2 * p.NS + n];
+            const double vx = (mx + 0.5 * pfx_) / rs, vy = (my + 0.5 * pfy_) / rs, vz = (mz + 0.5 * pfz_) / rs;
+            const double phi = (rR - rB) / (rR + rB);
+            if (!was_deep) { p.F[n] = 0.; p.F[p.NS + n] = 0.; p.F[2 * p.NS + n] = 0.; }
+            if (DIAG) { p.K[n] = 0.; p.U[n] = vx; p.U[p.NS + n] = vy; p.U[2 * p.NS + n] = vz; }
+            const double tau = tau_of(p, phi, rR, rB);
+            if (!MRT) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
+                    const double eT = feq(rc, i, CX[i], CY[i], CZ[i], vx, vy, vz);      // (+ the absent colour's 0 * ... = +0)
+                    t[i] = -1. / tau * (t[i] - eT) + t[i];
+                }
+            } else {
+                const double it = 1. / tau;
+                const double S[Q] = {p.rate[5], p.rate[0], p.rate[1], p.rate[5], p.rate[2], p.rate[5], p.rate[2], p.rate[5], p.rate[2], it, p.rate[3], it, p.rate[3],
+                                     it, it, it, p.rate[4], p.rate[4], p.rate[4]};
+                double d[Q];
+#pragma unroll
+                for (int i = 0; i < Q; ++i) d[i] = t[i] - feq(rc, i, CX[i], CY[i], CZ[i], vx, vy, vz);
+                mrt_apply(S, d);
+#pragma unroll
+                for (int i = 0; i < Q; ++i) t[i] = -d[i] + t[i];
+            }
+            double *present = p.fout + colour + j, *absent = p.fout + ((size_t)Q * p.FS - colour) + j;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                __builtin_nontemporal_store(t[i], present + (size_t)i * p.FS);
+                if (!same_deep) __builtin_nontemporal_store(0., absent + (size_t)i * p.FS);
+            }
+        }
+        __syncthreads();                         // (every wave has read deep_prev)
+        if (threadIdx.x == 0) { p.pure[blk] = (uint8_t)deep; p.deep_prev[blk] = (uint8_t)deep; }     // (sums of exact zeros: the absent colour stays absent)
+    }
+}
+
+// set-up: the table of source cells
+__global__ __launch_bounds__(256) void csf3d_setup_src(CsfDev p, uint32_t *src)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ, OPP[Q] = CSF_OPP;
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= p.NF) return;
+    const unsigned n = p.cells[j];
+    int x, y, z;
+    cell_of(p, n, x, y, z);
+    const Nb nb = make_nb(p, x, y, z);
+    const uint32_t m = p.meta[n];
+#pragma unroll
+    for (int i = 1; i < Q; ++i)
+        src[(size_t)(i - 1) * p.FS + j] = ((m >> OPP[i]) & 1u) ? p.cidx[at(nb, -CX[i], -CY[i], -CZ[i])] : SRC_WALL;
 }
 
 // Per step, before the phase field: four small launches of ceil(nblk / 1024) workgroups.
 //   csf3d_tile_count<0>  per tile of 1024 blocks: how many are not purely red / not purely blue
 //   csf3d_tile_rank<0>   pfx[0][k] / pfx[1][k] = number of such blocks before k (tile offsets summed on the fly)
-//   csf3d_tile_count<1>  deep_now[b] = deep_colour(b); per tile: how many blocks have something to do in csf3d_phase / csf3d_gradient
-//   csf3d_tile_rank<1>   work[] = those blocks in order, work[nblk] = their number
+//   csf3d_tile_count<1>  deep_now[b] = deep_colour(b); per tile: how many blocks belong to each of the three lists (L_TODO, L_FULL, L_DEEP)
+//   csf3d_tile_rank<1>   the lists, each in order and followed by its length
 __device__ __forceinline__ unsigned block_sum(unsigned v, unsigned *lds)         // sum over the 1024 threads, to every thread
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -617,6 +666,8 @@ __device__ __forceinline__ unsigned block_rank(bool flag, unsigned *lds, unsigne
     __syncthreads();
     return before + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
 }
+// the three lists' membership of block b (L_TODO, L_FULL, L_DEEP)
+__device__ __forceinline__ bool listed(int which, int deep, int prev) { return which == L_TODO ? !(deep != 0 && prev == deep) : (which == L_FULL ? deep == 0 : deep != 0); }
 template <int WHAT>
 __global__ __launch_bounds__(1024) void csf3d_tile_count(CsfDev p, uint8_t *deep_now, uint32_t *tcnt)
 {
@@ -627,11 +678,12 @@ __global__ __launch_bounds__(1024) void csf3d_tile_count(CsfDev p, uint8_t *deep
         const unsigned a = block_sum(v != 1u, lds), c = block_sum(w != 2u, lds);
         if (threadIdx.x == 0) { tcnt[blockIdx.x] = a; tcnt[ntile + blockIdx.x] = c; }
     } else {
-        int d = 0;
-        bool todo = false;
-        if (b < p.nblk) { d = deep_colour(p, b); deep_now[b] = (uint8_t)d; todo = !(d != 0 && p.deep_prev[b] == d); }
-        const unsigned a = block_sum(todo, lds);
-        if (threadIdx.x == 0) tcnt[blockIdx.x] = a;
+        int d = 0, prev = 0;
+        if (b < p.nblk) { d = deep_colour(p, b); deep_now[b] = (uint8_t)d; prev = p.deep_prev[b]; }
+        for (int which = 0; which < 3; ++which) {
+            const unsigned a = block_sum(b < p.nblk && listed(which, d, prev), lds);
+            if (threadIdx.x == 0) tcnt[which * ntile + blockIdx.x] = a;
+        }
     }
 }
 template <int WHAT>
@@ -639,22 +691,22 @@ __global__ __launch_bounds__(1024) void csf3d_tile_rank(CsfDev p, const uint8_t 
 {
     __shared__ unsigned lds[16];
     const unsigned b = blockIdx.x * 1024u + threadIdx.x, ntile = gridDim.x;
-    for (int arr = 0; arr < (WHAT == 0 ? 2 : 1); ++arr) {
+    for (int arr = 0; arr < (WHAT == 0 ? 2 : 3); ++arr) {
         unsigned mine = 0;
         for (unsigned s = threadIdx.x; s < blockIdx.x; s += 1024u) mine += tcnt[arr * ntile + s];
         const unsigned off = block_sum(mine, lds);
         bool flag;
         if (WHAT == 0) flag = b < p.nblk && p.pure[b] != (arr == 0 ? 1u : 2u);
-        else flag = b < p.nblk && !(deep_now[b] != 0 && p.deep_prev[b] == deep_now[b]);
+        else flag = b < p.nblk && listed(arr, deep_now[b], p.deep_prev[b]);
         unsigned total;
         const unsigned r = off + block_rank(flag, lds, total);
+        uint32_t *o = out + (size_t)arr * (p.nblk + 1u);
         if (WHAT == 0) {
-            if (b < p.nblk) out[arr * (p.nblk + 1u) + b] = r;
-            if (blockIdx.x == ntile - 1u && threadIdx.x == 0) out[arr * (p.nblk + 1u) + p.nblk] = off + total;
+            if (b < p.nblk) o[b] = r;
         } else {
-            if (flag) out[r] = b;
-            if (blockIdx.x == ntile - 1u && threadIdx.x == 0) out[p.nblk] = off + total;
+            if (flag) o[r] = b;
         }
+        if (blockIdx.x == ntile - 1u && threadIdx.x == 0) o[p.nblk] = off + total;
     }
 }
 
@@ -862,7 +914,7 @@ struct lbmpm_rk3dcsf {
     uint8_t *dom = nullptr;
     uint32_t *meta = nullptr, *wetlist = nullptr, *cidx = nullptr, *cells = nullptr, *rng = nullptr, *pfx = nullptr;
     uint8_t *pure = nullptr, *deep_prev = nullptr, *bcblk = nullptr, *deep_now = nullptr;
-    uint32_t *work = nullptr, *tcnt = nullptr;
+    uint32_t *work = nullptr, *tcnt = nullptr, *src = nullptr;
     unsigned nblk = 0;
     bool skip = true;
     double *fA = nullptr, *fB = nullptr, *phi = nullptr, *G = nullptr, *nh = nullptr, *F = nullptr, *K = nullptr, *U = nullptr, *ns = nullptr;
@@ -898,7 +950,7 @@ CsfDev make_dev(const lbmpm_rk3dcsf *c)
     for (int i = 0; i < 6; ++i) any = any || c->cfg.mrt_rates[i] != 0.;
     const double own[6] = {1.19, 1.4, 1.2, 1.4, 1.2, 0.};
     for (int i = 0; i < 6; ++i) p.rate[i] = any ? c->cfg.mrt_rates[i] : own[i];
-    p.nblk = c->nblk; p.skip = c->skip ? 1 : 0; p.pure = c->pure; p.deep_prev = c->deep_prev; p.bcblk = c->bcblk; p.rng = c->rng; p.pfx = c->pfx; p.deep_now = c->deep_now; p.work = c->work;
+    p.nblk = c->nblk; p.skip = c->skip ? 1 : 0; p.pure = c->pure; p.deep_prev = c->deep_prev; p.bcblk = c->bcblk; p.rng = c->rng; p.pfx = c->pfx; p.deep_now = c->deep_now; p.work = c->work; p.src = c->src;
     return p;
 }
 
@@ -921,8 +973,12 @@ int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
     csf3d_gradient<<<gw, 256, 0, c->stream>>>(p);
     if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
     const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
-    if (mrt) { if (c->diag) csf3d_collide<FIRST, true, true><<<g, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, true, false><<<g, 256, 0, c->stream>>>(p); }
-    else { if (c->diag) csf3d_collide<FIRST, false, true><<<g, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, false, false><<<g, 256, 0, c->stream>>>(p); }
+    if (mrt) { if (c->diag) csf3d_collide<FIRST, true, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, true, false><<<gw, 256, 0, c->stream>>>(p); }
+    else { if (c->diag) csf3d_collide<FIRST, false, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, false, false><<<gw, 256, 0, c->stream>>>(p); }
+    if (c->skip && !FIRST) {                     // (nothing is deep in the first step after a set_*)
+        if (mrt) { if (c->diag) csf3d_collide_deep<true, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide_deep<true, false><<<gw, 256, 0, c->stream>>>(p); }
+        else { if (c->diag) csf3d_collide_deep<false, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide_deep<false, false><<<gw, 256, 0, c->stream>>>(p); }
+    }
     if (e1) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     LBMPM_HIP_TRY(hipGetLastError());
     return LBMPM_OK;
@@ -958,7 +1014,7 @@ extern "C" void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->rng, c->pfx, c->pure, c->deep_prev, c->bcblk, c->deep_now, c->work, c->tcnt, c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
+    void *ptrs[] = {c->rng, c->pfx, c->pure, c->deep_prev, c->bcblk, c->deep_now, c->work, c->tcnt, c->src, c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     c->pool.destroy();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1083,8 +1139,9 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->rng, 2 * (size_t)nb);
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->pfx, 2 * ((size_t)nb + 1));
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->deep_now, nb);
-        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->work, (size_t)nb + 1);
-        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->tcnt, 2 * ((size_t)nb / 1024 + 1));
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->work, 3 * ((size_t)nb + 1));
+        if (rc == LBMPM_OK) rc = dev_alloc(c, &c->tcnt, 3 * ((size_t)nb / 1024 + 1));
+        if (rc == LBMPM_OK && c->skip) rc = dev_alloc(c, &c->src, 18 * c->FS);
         if (rc == LBMPM_OK && hipMalloc(reinterpret_cast<void **>(&lo0), 4 * (size_t)nb * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc failed"); rc = LBMPM_ERR_NOMEM; }
         if (rc == LBMPM_OK) {
             hi0 = lo0 + nb; lo1 = hi0 + nb; hi1 = lo1 + nb;
@@ -1097,6 +1154,7 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
             if (e == hipSuccess) {
                 csf3d_setup_ranges<<<nb, 256, 0, c->stream>>>(p, 0, lo0, hi0, nullptr, nullptr, c->bcblk);
                 csf3d_setup_ranges<<<nb, 256, 0, c->stream>>>(p, 1, lo1, hi1, lo0, hi0, c->bcblk);
+                if (c->src) csf3d_setup_src<<<nb, 256, 0, c->stream>>>(p, c->src);
                 std::vector<uint32_t> h(2 * (size_t)nb);
                 e = hipMemcpyAsync(h.data(), lo1, 2 * (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
