@@ -457,14 +457,12 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     const bool active = fluid_cell(p, blk, j, n, x, y, z);
     constexpr int deep = 0;                       // (the deep blocks go through csf3d_collide_deep)
     const bool was_deep = p.skip && p.deep_prev[blk] != 0;       // the arrays G, n, F of this block hold zeros
-    constexpr bool same_deep = false;
     bool only_red = true, only_blue = true;
     if (active) {
     const uint32_t m = p.meta[n];
     double *fr = p.fout + j, *fb = p.fout + (size_t)Q * p.FS + j;
     double fR[Q], fB[Q], rR, rB;
     cell_state<FIRST, true>(p, x, y, z, fR, fB, rR, rB, deep);
-    only_red = rB == 0.; only_blue = rR == 0.;
     double t[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) t[i] = fR[i] + fB[i];
@@ -535,16 +533,21 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     }
     // A:1857-1899 calRecoloringProcessM
     const double gn = sqrt(gx * gx + gy * gy + gz * gz), tot = rR + rB;
+    // "One colour alone" as a crisp property of a cell (the bulk skip rests on it, as the row flags of rk3dq.h do): a colour whose density
+    // is within the rounding of the total (|rho_c| <= 2^-51 rho: absent, or the far end of the other colour's tail, which would otherwise
+    // creep outwards one cell per step as ever smaller numbers) is absent -- it hands on exact zeros, the other colour takes f_tot.
+    // The oracle keeps the tail; the difference is below 1e-15 of the density fields (tests: 1e-10).
+    const double tiny = 0x1p-51 * tot;
+    only_red = fabs(rB) <= tiny; only_blue = !only_red && fabs(rR) <= tiny;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
         const double un = i == 0 ? 0. : (i < 7 ? 1. : sqrt(2.));
         double c = 0.;
         if (gn > 1.0e-8 && un > 1.0e-8) c = edotv(CX[i], CY[i], CZ[i], gx, gy, gz) / (un * gn);
+        const double a = rR / tot * t[i] + p.beta * rR * rB / tot * wq(i) * c * un, b = rB / tot * t[i] - p.beta * rR * rB / tot * wq(i) * c * un;
         // streaming stores: these lines are not read again before the next step
-        // a block that was deep in the same colour a step ago finds the other colour's zeros in place (this buffer was written two steps
-        // ago, when the block held that colour alone already): they are not written again
-        if (!(same_deep && deep == 2)) __builtin_nontemporal_store(rR / tot * t[i] + p.beta * rR * rB / tot * wq(i) * c * un, fr + (size_t)i * p.FS);
-        if (!(same_deep && deep == 1)) __builtin_nontemporal_store(rB / tot * t[i] - p.beta * rR * rB / tot * wq(i) * c * un, fb + (size_t)i * p.FS);
+        __builtin_nontemporal_store(only_red ? t[i] : (only_blue ? 0. : a), fr + (size_t)i * p.FS);
+        __builtin_nontemporal_store(only_blue ? t[i] : (only_red ? 0. : b), fb + (size_t)i * p.FS);
     }
     }   // active
     if (p.skip) {                                // what the block hands on, for the next step's deep_colour

@@ -17,6 +17,11 @@ from test_oracle_rk3d_csf import blob3, extrude, params3, project_pdf, PAIRS
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
+# K alone is held to 1e-7: where |G| sits at the kernel's threshold of 1e-8 (the far tail of the interface) the unit normal -G / |G| turns a
+# perturbation eps of the populations into eps / |G|, and the library drops a colour whose density is below 2^-51 of the total (the crisp
+# "one colour alone" its bulk skip rests on; the oracle keeps that tail).  What K feeds, F = -1/2 sigma K G, carries |G| as a factor and is held
+# to 1e-9 of the largest force; densities, phase field, velocity, gradient and populations to 1e-10.
+TOL_K, TOL_F = 1e-7, 1e-9
 SCALARS = ("rhoR", "rhoB", "phi", "K")
 VECTORS = (("vx", "vy", "vz"), ("Gx", "Gy", "Gz"), ("Fx", "Fy", "Fz"))
 
@@ -31,13 +36,13 @@ def compare_all(s, o, what, tol=TOL):
     worst = 0.0
     for f in SCALARS:
         e = rel_err(s.get(f)[fl], o.field(f)[fl])
-        assert e < tol, "%s: %s %.3e" % (what, f, e)
+        assert e < (max(tol, TOL_K) if f == "K" else tol), "%s: %s %.3e" % (what, f, e)
         worst = max(worst, e)
     for vec in VECTORS:
         scale = max(float(np.max(np.abs(o.field(c)[fl]))) for c in vec)
         for c in vec:
             e = rel_err(s.get(c)[fl], o.field(c)[fl], scale=max(scale, 1e-300))
-            assert e < tol, "%s: %s %.3e" % (what, c, e)
+            assert e < (max(tol, TOL_F) if c[0] == "F" else tol), "%s: %s %.3e" % (what, c, e)
             worst = max(worst, e)
     for f in ("fR", "fB"):
         a = s.get(f)
@@ -175,7 +180,7 @@ def test_reduces_to_the_capture_of_the_real_2d_driver(ny):
         for f3, f2 in PAIRS:
             a = s.get(f3)
             e = rel_err(a[:, 0, :][fl], ref[f2][fl], scale=scales.get(f3[0]))
-            assert e < 1e-9, "step %d: %s vs the reference's %s: %.3e" % (k, f3, f2, e)
+            assert e < (TOL_K if f3 == "K" else 1e-9), "step %d: %s vs the reference's %s: %.3e" % (k, f3, f2, e)
             assert np.max(np.abs(a - a[:, :1, :])) <= 1e-12 * max(np.max(np.abs(a)), 1e-300)
         for f in ("fR", "fB"):
             assert rel_err(project_pdf(s.get(f))[fl], ref[f][fl]) < 1e-9, f
