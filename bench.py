@@ -659,11 +659,14 @@ def main():
                                 "value": round(nfc * kc / wc / 1e6, 2), "unit": "MLUPS", "ms_per_step": round(wc * 1e3 / kc, 5), "steps": kc, "fluid_nodes": nfc,
                                 "wetting_solids": sc3.num_wetting_solids, "kernel": sc3.dominant_kernel, "kernel_ms": round(mdc / kc, 5),
                                 "roofline_frac_by_survey_balg": round(B_ALG["c5"] * nfc / (mtc / kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "note": "not a BASELINE config (the 3-D ini carries the perturbation parameters).  Four launches per step -- phase field (pull 38), "
-                                        "solid phi, gradient + wetting rule, collide (pull 38, store 38) -- because the curvature needs the normal one cell "
-                                        "around and the normal the phase field one cell around that: ~ 1.06 kB per fluid cell and step against B_alg = 608 B; "
-                                        "roofline_frac_by_survey_balg is over the whole step.  Parity: oracle/rk3d_csf_oracle.c at 1e-10, pinned by reduction to "
-                                        "the capture of the real 2-D driver (tests/test_rk3d_csf_gpu.py)"})
+                                "bulk_cells": sc3.bulk_cells,
+                                "note": "not a BASELINE config (the 3-D ini carries the perturbation parameters).  Where two colours meet: phase field (pull 38), "
+                                        "solid phi, gradient + wetting rule, collide (pull 38, store 38) -- the curvature needs the normal one cell around and the "
+                                        "normal the phase field one cell around that.  Blocks of 256 fluid cells deep inside one colour (bulk_cells of fluid_nodes "
+                                        "in the last step) skip phase field and gradient and collide the present colour alone through a table of source cells "
+                                        "(19 loads, 19 stores): exact, bit-equal to the full path.  roofline_frac_by_survey_balg is over the whole step (608 B per "
+                                        "update, which the bulk path does not move: it may exceed the bandwidth fraction; counted: DESIGN.md section 4).  Parity: "
+                                        "oracle/rk3d_csf_oracle.c at 1e-10, pinned by reduction to the capture of the real 2-D driver (tests/test_rk3d_csf_gpu.py)"})
                     sc3.close()
                 out["secondary"] = sec
             if world == 1 and not args.no_cpu_baseline:

@@ -15,16 +15,17 @@
 // The parity oracle is oracle/rk3d_csf_oracle.c (pinned by reduction to the capture of the real 2-D driver, tests/test_oracle_rk3d_csf.py);
 // the arithmetic below keeps that file's evaluation order (no FMA contraction in this file), so the two agree to rounding.
 //
-// Schedule of one time step (four launches; populations q-major SoA for FLUID cells only in lattice order, two buffers, pull; one thread
-// per fluid cell):
-//   csf3d_phase     pull + boundary planes -> rho_R, rho_B -> phi                                 38 reads, 1 write per fluid cell
-//   csf3d_solid_phi phi of the wetting solids (list in lattice order)
-//   csf3d_gradient  G (18 cached phi reads), wetting rule on the cells next to solid, n = -G / |G|   6 writes
-//   csf3d_collide   pull + boundary planes again (bit-identical to the first pass), curvature from the neighbours' n, force, collision,
-//                   recolouring -> the other buffer                                                38 reads, 41 writes
-// The curvature needs n one cell around and n needs phi one cell around that: two global dependencies per step, hence the two
-// passes over the populations (136 doubles per cell and step by the schedule's own count, 1.37 kB counted on the bench's porous
-// medium, against the perturbation model's 0.30 - 0.37 kB in rk3dq_fused).  Measured: DESIGN.md section 4.
+// Schedule of one time step (populations q-major SoA for FLUID cells only in lattice order, two buffers, pull; one thread per fluid
+// cell, blocks of 256 cells, fixed grids over lists of blocks):
+//   csf3d_tile_count / _rank   which blocks are deep inside one colour (deep_colour), the three lists
+//   csf3d_phase      pull + boundary planes -> rho_R, rho_B -> phi                                38 reads, 1 write per cell   } blocks that
+//   csf3d_solid_phi  phi of the wetting solids (list in lattice order)                                                          } are not deep
+//   csf3d_gradient   G (18 cached phi reads), wetting rule on the cells next to solid, n = -G / |G|   6 writes                   }
+//   csf3d_collide    pull + boundary planes again (bit-identical to the first pass), curvature from the neighbours' n, force,   }
+//                    collision, recolouring -> the other buffer                                   38 reads, 41 writes           }
+//   csf3d_collide_deep   the deep blocks: the present colour alone through a table of source cells 19 reads, 19 writes
+// The curvature needs n one cell around and n needs phi one cell around that: two global dependencies per step, hence the two passes
+// over the populations where colours meet (136 doubles per cell and step).  Measured: DESIGN.md section 4.
 #include "lbmpm_common.h"
 
 #include <cmath>
