@@ -657,7 +657,7 @@ def main():
                     sec.append({"workload": "c5 lattice, [SurfaceTension] SurfaceTensionType = 'CSF' (%s): the 2-D CSF loop (RKD2Q9.py:1295-1490) carried to D3Q19, "
                                             "RKtwophasesetup2D.ini's parameters (sigma 0.1, contact angle 60, wetting rule 2, TauType 2)" % args.relax,
                                 "value": round(nfc * kc / wc / 1e6, 2), "unit": "MLUPS", "ms_per_step": round(wc * 1e3 / kc, 5), "steps": kc, "fluid_nodes": nfc,
-                                "wetting_solids": sc3.num_wetting_solids, "kernel": sc3.dominant_kernel, "kernel_ms": round(mdc / kc, 5),
+                                "wetting_solids": sc3.num_wetting_solids, "kernel": "csf3d_collide_deep", "collide_ms": round(mdc / kc, 5),
                                 "roofline_frac_by_survey_balg": round(B_ALG["c5"] * nfc / (mtc / kc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                 "bulk_cells": sc3.bulk_cells,
                                 "note": "not a BASELINE config (the 3-D ini carries the perturbation parameters).  Where two colours meet: phase field (pull 38), "
@@ -667,6 +667,16 @@ def main():
                                         "(19 loads, 19 stores): exact, bit-equal to the full path.  roofline_frac_by_survey_balg is over the whole step (608 B per "
                                         "update, which the bulk path does not move: it may exceed the bandwidth fraction; counted: DESIGN.md section 4).  Parity: "
                                         "oracle/rk3d_csf_oracle.c at 1e-10, pinned by reduction to the capture of the real 2-D driver (tests/test_rk3d_csf_gpu.py)"})
+                    # ... and with both colours in every cell: every block on the full path
+                    r2, b2 = c5_state(dom, 0, nz, "mixed")
+                    sc3.set_macro(r2, b2)
+                    del r2, b2
+                    sc3.step(3); sc3.sync()
+                    t1 = time.perf_counter(); mtm, mdm = sc3.step_timed(10); sc3.sync(); wm = time.perf_counter() - t1
+                    sec.append({"workload": "c5 lattice, SurfaceTensionType = 'CSF' (%s), two colours in every cell" % args.relax, "value": round(nfc * 10 / wm / 1e6, 2),
+                                "unit": "MLUPS", "ms_per_step": round(wm * 1e2, 5), "steps": 10, "fluid_nodes": nfc, "kernel": "csf3d_collide", "bulk_cells": sc3.bulk_cells,
+                                "roofline_frac_by_survey_balg": round(B_ALG["c5"] * nfc / (mtm / 10 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "the full path everywhere: 136 doubles per cell and step by the schedule's own count (1.37 kB counted) against B_alg = 608 B"})
                     sc3.close()
                 out["secondary"] = sec
             if world == 1 and not args.no_cpu_baseline:

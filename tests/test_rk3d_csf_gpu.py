@@ -309,3 +309,26 @@ def test_the_bulk_skip_is_exact(relax, over):
     for f in ("fR", "fB", "phi", "Fz", "K"):
         assert np.array_equal(a.get(f), c.get(f)), f
     a.close(); b.close(); c.close()
+
+
+def test_without_diagnostics_the_state_is_the_same():
+    """the instances that do not keep u and K (what bench.py times) leave the same populations, forces and phase field, bit for bit"""
+    from openlbmpm_amd.rk3dcsf import RK3DCSFSolver
+    from openlbmpm_amd.RKColorGradientD3Q19 import duct
+    dom = duct(30, 26, 90)
+    zz = np.mgrid[0:90, 0:26, 0:30][0]
+    fl = dom == 1
+    rR, rB = np.where(fl & (zz < 60), 1.0, 0.0), np.where(fl & (zz >= 60), 1.0, 0.0)
+    for relax in ("SRT", "MRT"):
+        par = dict(relax=relax, theta=70.0, velocityZB=-2.0e-3, velocityZR=0.0)
+        a = RK3DCSFSolver(dom, par, diagnostics=True); b = RK3DCSFSolver(dom, par, diagnostics=False)
+        a.set_macro(rR, rB); b.set_macro(rR, rB)
+        a.step(50); b.step(50)
+        assert a.bulk_cells == b.bulk_cells > 0
+        for f in ("fR", "fB", "phi", "Gz", "Fz", "rec_vz"):
+            assert np.array_equal(a.get(f), b.get(f)), (relax, f)
+        from openlbmpm_amd._lib import LbmpmError, ERR_STATE
+        with pytest.raises(LbmpmError) as e:
+            b.get("K")
+        assert e.value.status == ERR_STATE
+        a.close(); b.close()
