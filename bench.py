@@ -304,6 +304,25 @@ def cpu_baseline_c5(relax, edge=128, target_seconds=12.0):
                           edge, n, team["cores"], el), **team)
 
 
+def cpu_baseline_csf3d(relax, edge=96, target_seconds=8.0):
+    """the 3-D CSF model's oracle (oracle/rk3d_csf_oracle.c, OpenMP) on a bounded sample of the leg's workload"""
+    from oracle.rk3dcsf import RK3DCSFOracle
+    from openlbmpm_amd.geometry import porous_spheres
+    dom = porous_spheres(edge, edge, edge, porosity=0.65, rmin=6.0, rmax=20.0, seed=SEED, nbuf=10)
+    dom[0] = dom[1]; dom[-1] = dom[-2]
+    rR, rB = c5_densities(dom, 0, edge)
+    team = cpu_team()
+    o = RK3DCSFOracle(dom, rR, rB, dict(relax=relax, tauB=0.8))
+    nfl = int(dom.sum())
+    o.run(1)
+    t0 = time.perf_counter(); o.run(1); dt = time.perf_counter() - t0
+    n = max(1, min(2000, int(target_seconds / max(dt, 1e-6))))
+    t0 = time.perf_counter(); o.run(n); el = time.perf_counter() - t0
+    return dict(value=round(nfl * n / el / 1e6, 3), unit="MLUPS", kind="port",
+                sample="3-D CSF model (%s) on a %d^3 porous sample (same generator / parameters), %d steps of oracle/rk3d_csf_oracle.c "
+                       "(OpenMP, %d threads; MRT by 19 x 19 products as the reference's 2-D kernel does it), %.1f s" % (relax, edge, n, team["cores"], el), **team)
+
+
 def cpu_baseline_simple_d2q9(target_seconds=6.0):
     """the 'repo's own CPU path' line: configs[0] in the shape of the reference's SimpleD2Q9 (whole-array NumPy,
     one thread), see oracle/simple_d2q9.py"""
@@ -682,6 +701,8 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_c5(args.relax)
                 out["cpu_baseline_reference_shape"] = cpu_baseline_simple_d2q9()
+                if not args.no_secondary and not args.no_c5_legs:
+                    out["cpu_baseline_csf3d"] = cpu_baseline_csf3d(args.relax)
             for fn in deferred:          # the counter passes: nothing is timed after this point
                 fn()
     else:
