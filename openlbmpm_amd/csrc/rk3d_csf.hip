@@ -1062,9 +1062,9 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
     c->N = N; c->NS = (N + 15) / 16 * 16;
     // the populations are kept for fluid cells only, numbered in lattice order (a dense layout streams the solid cells of every
     // 128-byte line that holds a fluid cell: counted 1.5 x the bytes on the bench's porous medium)
-    std::vector<uint32_t> hidx(N);
-    std::vector<uint32_t> hcells;
-    hcells.reserve(N);
+    std::vector<uint32_t> hidx, hcells;
+    try { hidx.resize(N); hcells.reserve(N); }
+    catch (const std::bad_alloc &) { set_error("lbmpm_rk3dcsf_create: out of host memory (8 bytes per lattice cell for the set-up tables)"); delete c; return LBMPM_ERR_NOMEM; }
     for (size_t k = 0; k < N; ++k) {
         const bool fl = is_domain[k] == 1;
         hidx[k] = fl ? (uint32_t)hcells.size() : 0xFFFFFFFFu;
