@@ -314,10 +314,9 @@ int64_t lbmpm_sc2d_device_bytes(const lbmpm_sc2d *ctx);
  * recolouring, velocity inlet and pressure outlet as z planes with their ghost planes -- everything IniFiles/RKtwophasesetup3D.ini
  * parametrises -- plus, since round 6, the loop's other two boundary kernels as z-plane rules: the pressure INLET per colour
  * (AcceleratedRKGPU2D.py:925-962, inlet_type) and the convective OUTLET (:700-784, outlet_type), each pinned by reduction to the 2-D fused
- * loop, whose kernels are pinned to the reference's one by one; and state in / out and restart (below).  NOT built (there is no field
- * for them in this struct, and the 3-D ini has no key that would ask for them):
- *   - [SurfaceTension] SurfaceTensionType = 'CSF' in 3-D is a model of its own: lbmpm_rk3dcsf_* at the end of this header;
- *   - body force: read and never used by the reference's colour-gradient loops.
+ * loop, whose kernels are pinned to the reference's one by one; and state in / out and restart (below).
+ * [SurfaceTension] SurfaceTensionType = 'CSF' in 3-D (curvature force + wetting rule) is a model of its own: lbmpm_rk3dcsf_* at the end of this
+ * header.  Not in either: body force (read and never used by the reference's colour-gradient loops).
  * ---------------------------------------------------------------------------------- */
 typedef struct lbmpm_rk3d_config {
     int64_t nx, ny, nz_local, nz_global, z_offset;
