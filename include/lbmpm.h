@@ -566,8 +566,8 @@ int lbmpm_rk3dcsf_set_macro(lbmpm_rk3dcsf *ctx, const double *rho_r, const doubl
  * them, and the force of the last step (LBMPM_RK3DCSF_F*; NULL = 0): a run continued from them equals the uninterrupted run bit for bit */
 int lbmpm_rk3dcsf_set_pdf(lbmpm_rk3dcsf *ctx, const double *pdf_r, const double *pdf_b, const double *fx, const double *fy, const double *fz);
 int lbmpm_rk3dcsf_step(lbmpm_rk3dcsf *ctx, int64_t nsteps);
-/* ms_total: HIP events around the steps; ms_dominant: sum over the collision launches (csf3d_collide for the blocks on the full path +
- * csf3d_collide_deep for the bulk) */
+/* ms_total: HIP events around the steps; ms_dominant: the steps without their bookkeeping launches -- csf3d_collide_deep for the bulk on a
+ * second stream beside phase field, solid phi, gradient and csf3d_collide for the blocks on the full path */
 int lbmpm_rk3dcsf_step_timed(lbmpm_rk3dcsf *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);
 int lbmpm_rk3dcsf_sync(lbmpm_rk3dcsf *ctx);
 /* keep u and K of every step (four more stores per cell) */

@@ -914,7 +914,8 @@ struct lbmpm_rk3dcsf {
     int64_t nfluid = 0, steps = 0, bytes = 0;
     unsigned nwet = 0;
     bool first = true, have_state = false, diag = false, diag_valid = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;        // stream2: the deep blocks' collision beside the full path's four launches
+    hipEvent_t ev_lists = nullptr, ev_deep = nullptr;
     uint8_t *dom = nullptr;
     uint32_t *meta = nullptr, *wetlist = nullptr, *cidx = nullptr, *cells = nullptr, *rng = nullptr, *pfx = nullptr;
     uint8_t *pure = nullptr, *deep_prev = nullptr, *bcblk = nullptr, *deep_now = nullptr;
@@ -972,17 +973,24 @@ int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
         csf3d_tile_count<1><<<nt, 1024, 0, c->stream>>>(p, c->deep_now, c->tcnt);
         csf3d_tile_rank<1><<<nt, 1024, 0, c->stream>>>(p, c->deep_now, c->tcnt, c->work);
     }
+    const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
+    const bool deep_launch = c->skip && !FIRST;      // (nothing is deep in the first step after a set_*)
+    if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
+    if (deep_launch) {
+        // the deep blocks' collision reads the last step's populations and its own flags, and writes its own blocks only: it runs on a
+        // second stream beside the four launches of the full path (small, latency-bound launches when most of the lattice is bulk)
+        LBMPM_HIP_TRY(hipEventRecord(c->ev_lists, c->stream));
+        LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_lists, 0));
+        if (mrt) { if (c->diag) csf3d_collide_deep<true, true><<<gw, 256, 0, c->stream2>>>(p); else csf3d_collide_deep<true, false><<<gw, 256, 0, c->stream2>>>(p); }
+        else { if (c->diag) csf3d_collide_deep<false, true><<<gw, 256, 0, c->stream2>>>(p); else csf3d_collide_deep<false, false><<<gw, 256, 0, c->stream2>>>(p); }
+        LBMPM_HIP_TRY(hipEventRecord(c->ev_deep, c->stream2));
+    }
     csf3d_phase<FIRST><<<gw, 256, 0, c->stream>>>(p);
     if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist);
     csf3d_gradient<<<gw, 256, 0, c->stream>>>(p);
-    if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
-    const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
     if (mrt) { if (c->diag) csf3d_collide<FIRST, true, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, true, false><<<gw, 256, 0, c->stream>>>(p); }
     else { if (c->diag) csf3d_collide<FIRST, false, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, false, false><<<gw, 256, 0, c->stream>>>(p); }
-    if (c->skip && !FIRST) {                     // (nothing is deep in the first step after a set_*)
-        if (mrt) { if (c->diag) csf3d_collide_deep<true, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide_deep<true, false><<<gw, 256, 0, c->stream>>>(p); }
-        else { if (c->diag) csf3d_collide_deep<false, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide_deep<false, false><<<gw, 256, 0, c->stream>>>(p); }
-    }
+    if (deep_launch) LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_deep, 0));
     if (e1) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     LBMPM_HIP_TRY(hipGetLastError());
     return LBMPM_OK;
@@ -1021,6 +1029,9 @@ extern "C" void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *c)
     void *ptrs[] = {c->rng, c->pfx, c->pure, c->deep_prev, c->bcblk, c->deep_now, c->work, c->tcnt, c->src, c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     c->pool.destroy();
+    if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
+    if (c->ev_deep) (void)hipEventDestroy(c->ev_deep);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1078,6 +1089,8 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
     {
         const hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return LBMPM_ERR_HIP; }
+        if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_lists, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_deep, hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate / hipEventCreate failed"); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; }
     }
     int rc = LBMPM_OK;
 #define TRY_RC(e) do { rc = (e); if (rc != LBMPM_OK) { lbmpm_rk3dcsf_destroy(c); return rc; } } while (0)
