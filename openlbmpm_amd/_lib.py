@@ -81,7 +81,7 @@ class RK3DCSFConfig(C.Structure):
                [(n, C.c_double) for n in ("surface_tension", "contact_angle_deg", "beta", "delta", "tau_r", "tau_b", "inlet_velocity_z",
                                           "inlet_rho_r", "inlet_rho_b", "outlet_rho_total")] + \
                [(n, C.c_int32) for n in ("wetting_type", "tau_type", "relaxation", "inlet_type", "outlet_type", "device", "variant")] + \
-               [("mrt_rates", C.c_double * 6)]
+               [("mrt_rates", C.c_double * 6), ("bulk_epsilon", C.c_double)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # lbmpm_rk3d_exchange_fn

@@ -65,6 +65,7 @@ struct CsfDev {
     double sigma, cosT, sinT, beta, delta, tauR, tauB, vzIn, pInB, pInR, pOut;
     int tauType, inletP, conv, wetting, nwet;
     double rate[6];
+    double eps;                  // a colour below eps * rho is absent (0x1p-51 unless the caller asks for more)
     // bulk skip (see deep_colour): per block of 256 fluid cells
     unsigned nblk;
     int skip;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     // is within the rounding of the total (|rho_c| <= 2^-51 rho: absent, or the far end of the other colour's tail, which would otherwise
     // creep outwards one cell per step as ever smaller numbers) is absent -- it hands on exact zeros, the other colour takes f_tot.
     // The oracle keeps the tail; the difference is below 1e-15 of the density fields (tests: 1e-10).
-    const double tiny = 0x1p-51 * tot;
+    const double tiny = p.eps * tot;
     only_red = fabs(rB) <= tiny; only_blue = !only_red && fabs(rR) <= tiny;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -955,6 +956,7 @@ CsfDev make_dev(const lbmpm_rk3dcsf *c)
     for (int i = 0; i < 6; ++i) any = any || c->cfg.mrt_rates[i] != 0.;
     const double own[6] = {1.19, 1.4, 1.2, 1.4, 1.2, 0.};
     for (int i = 0; i < 6; ++i) p.rate[i] = any ? c->cfg.mrt_rates[i] : own[i];
+    p.eps = c->cfg.bulk_epsilon > 0. ? c->cfg.bulk_epsilon : 0x1p-51;
     p.nblk = c->nblk; p.skip = c->skip ? 1 : 0; p.pure = c->pure; p.deep_prev = c->deep_prev; p.bcblk = c->bcblk; p.rng = c->rng; p.pfx = c->pfx; p.deep_now = c->deep_now; p.work = c->work; p.src = c->src;
     return p;
 }
@@ -1054,6 +1056,7 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
     }
     LBMPM_REQUIRE(cfg->wetting_type == 2 || cfg->wetting_type == 0, "WettingType must be 2 (or 0: no correction at the walls)");
     LBMPM_REQUIRE(cfg->variant == 0 || cfg->variant == 1, "variant must be 0 or 1");
+    LBMPM_REQUIRE(cfg->bulk_epsilon >= 0. && cfg->bulk_epsilon <= 1.0e-3, "bulk_epsilon must lie in [0, 1e-3]");
     const size_t pl = (size_t)cfg->nx * cfg->ny, N = pl * (size_t)cfg->nz;
     // the ghost planes copy the plane next to them cell by cell (the reference's kernels take the neighbour's index without looking)
     auto same = [&](int64_t za, int64_t zb) {

@@ -17,7 +17,7 @@ _PDF_FIELDS = {"fR", "fB", "rec_fR", "rec_fB"}
 # the 2-D ini's parameters (IniFiles/RKtwophasesetup2D.ini) under the 3-D ini's key names for the flow axis (RKtwophasesetup3D.ini:27-38)
 DEFAULT_PARAMS = dict(sigma=0.1, theta=60.0, wetting=2, beta=0.7, delta=0.98, tauR=1.0, tauB=1.0, tautype=2, relax="MRT",
                       inlet="Neumann", outlet="Dirichlet", velocityZR=-1.0e-4, velocityZB=0.0, densityBH=5e-8, densityRH=1.00536,
-                      densityBL=1.0, densityRL=5e-8, rates=None, variant=0)
+                      densityBL=1.0, densityRL=5e-8, rates=None, variant=0, bulk_epsilon=0.0)
 
 
 def _f64(a):
@@ -58,6 +58,7 @@ class RK3DCSFSolver:
         cfg.outlet_type = 0 if p["outlet"] == "Dirichlet" else 1
         cfg.device = int(device)
         cfg.variant = int(p["variant"])        # 1: no bulk skip (cross-check)
+        cfg.bulk_epsilon = float(p["bulk_epsilon"])      # 0: exact (2^-51); opt-in: cut a colour's tail below this fraction of the density
         if p["rates"] is not None:
             if len(p["rates"]) != 6:
                 raise ValueError("rates = (s_e, s_eps, s_q, s_pi, s_m, rate of the conserved moments)")
