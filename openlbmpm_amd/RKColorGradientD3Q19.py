@@ -41,11 +41,12 @@ GROUPS = (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocit
 class _CSFSlab:
     """RK3DCSFSolver behind the calls this driver makes on a slab of the perturbation model"""
 
-    def __init__(self, dom, par, device):
+    def __init__(self, dom, par, device, bulk_epsilon=0.0):
         from .rk3dcsf import RK3DCSFSolver
         q = dict(sigma=par["sigma"], theta=par["theta"], wetting=par["wetting"], beta=par["beta"], delta=par["delta"], tauR=par["tauR"], tauB=par["tauB"],
                  tautype=par["tautype"], relax=par["relax"], inlet=par["inlet"], outlet=par["outlet"], velocityZR=par["velocityZR"],
-                 velocityZB=par["velocityZB"], densityBH=par["densityBH"], densityRH=par["densityRH"], densityBL=par["densityBL"], densityRL=par["densityRL"])
+                 velocityZB=par["velocityZB"], densityBH=par["densityBH"], densityRH=par["densityRH"], densityBL=par["densityBL"], densityRL=par["densityRL"],
+                 bulk_epsilon=float(bulk_epsilon))
         self.solver = RK3DCSFSolver(dom, q, device=device)
         self.step_single, self.sync, self.close = self.solver.step, self.solver.sync, self.solver.close
 
@@ -89,7 +90,7 @@ def duct(nx, ny, nz):
 
 class RKColorGradient3D:
     def __init__(self, pathIniFile, output_dir=None, domain=None, device=0, record_every=None, num_buffering_layers=10,
-                 structure_path=None, initial_dir=None, record_pdf=False, restart_from=None, checkpoint_every=0):
+                 structure_path=None, initial_dir=None, record_pdf=False, restart_from=None, checkpoint_every=0, csf_bulk_epsilon=0.0):
         self.pathIni = pathIniFile
         self.par = config.read_rk3d(pathIniFile)
         self.output_dir = output_dir or os.path.expanduser("~/LBMResults3D")       # main.py:28
@@ -100,6 +101,7 @@ class RKColorGradient3D:
         self.timeInterval = record_every or self.par["interval"] or max(1, self.timeSteps // 10)
         self.record_pdf = bool(record_pdf)          # /FluidPDF/FluidPDFRat<k>, ...Bat<k> [nz][ny][nx][19] with every record (38 doubles per cell)
         self.restart_from, self.checkpoint_every = restart_from, int(checkpoint_every)
+        self.csf_bulk_epsilon = float(csf_bulk_epsilon)      # 3-D CSF only, opt-in (include/lbmpm.h: lbmpm_rk3dcsf_config.bulk_epsilon; 0 = exact)
         self.gather_records = True
         self.records = 0
         self.physicalVX = self.physicalVY = self.physicalVZ = None
@@ -244,7 +246,7 @@ class RKColorGradient3D:
         if p["tension_type"] == "CSF":
             if self._distributed():
                 raise config.ConfigError("SurfaceTensionType 'CSF' in 3-D runs on one GPU (the curvature reaches two cells: no slab decomposition of this model)")
-            slab = sim = _CSFSlab(self.isDomain, p, self.device)
+            slab = sim = _CSFSlab(self.isDomain, p, self.device, self.csf_bulk_epsilon)
             step, observe = slab.step_single, (lambda: None)
             self.z0, self.nzl = 0, self.zDomain
         elif self._distributed():
