@@ -286,11 +286,18 @@ __global__ __launch_bounds__(256) void csf3d_phase(CsfDev p)
 }
 
 // A:1560-1581 calColorValueOnSolid over the list of wetting solids (in lattice order: neighbouring solids read neighbouring phi)
-__global__ __launch_bounds__(256) void csf3d_solid_phi(CsfDev p, const uint32_t *wetlist)
+// (a wall cell whose first fluid neighbour's block has been deep for two steps keeps its value: deep means that every fluid neighbour of
+// the walls next to that block has phi = the block's colour, this step and the last)
+__global__ __launch_bounds__(256) void csf3d_solid_phi(CsfDev p, const uint32_t *wetlist, const uint32_t *wethome)
 {
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
     const unsigned k = blockIdx.x * 256u + threadIdx.x;
     if (k >= (unsigned)p.nwet) return;
+    if (p.skip) {
+        const unsigned hb = wethome[k];
+        const uint8_t d = p.deep_now[hb];
+        if (d != 0 && p.deep_prev[hb] == d) return;
+    }
     const unsigned n = wetlist[k];
     int x, y, z;
     cell_of(p, n, x, y, z);
@@ -840,6 +847,23 @@ __global__ __launch_bounds__(256) void csf3d_setup_wetlist(unsigned N, const uin
     for (unsigned k = 0; k < w; ++k) base += wsum[k];
     if (wet) wetlist[base + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = n;
 }
+// the block of a wall cell's first fluid neighbour
+__global__ __launch_bounds__(256) void csf3d_setup_wethome(CsfDev p, const uint32_t *wetlist, uint32_t *wethome)
+{
+    constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= (unsigned)p.nwet) return;
+    const unsigned n = wetlist[k];
+    int x, y, z;
+    cell_of(p, n, x, y, z);
+    const Nb nb = make_nb(p, x, y, z);
+    const uint32_t m = p.meta[n];
+    unsigned hb = 0;
+#pragma unroll 1
+    for (int i = Q - 1; i >= 1; --i)
+        if ((m >> i) & 1u) hb = p.cidx[at(nb, CX[i], CY[i], CZ[i])] >> 8;
+    wethome[k] = hb;
+}
 __device__ __forceinline__ double e8w(int c2)
 {   // the 3-D E8 stencil of Sbragaglia et al. 2007 by |c|^2; its sums along one axis are 4/21, 4/45, 1/60, 2/315, 1/5040 (RKD2Q9.py:811-885)
     switch (c2) {
@@ -918,7 +942,7 @@ struct lbmpm_rk3dcsf {
     hipStream_t stream = nullptr, stream2 = nullptr;        // stream2: the deep blocks' collision beside the full path's four launches
     hipEvent_t ev_lists = nullptr, ev_deep = nullptr;
     uint8_t *dom = nullptr;
-    uint32_t *meta = nullptr, *wetlist = nullptr, *cidx = nullptr, *cells = nullptr, *rng = nullptr, *pfx = nullptr;
+    uint32_t *meta = nullptr, *wetlist = nullptr, *wethome = nullptr, *cidx = nullptr, *cells = nullptr, *rng = nullptr, *pfx = nullptr;
     uint8_t *pure = nullptr, *deep_prev = nullptr, *bcblk = nullptr, *deep_now = nullptr;
     uint32_t *work = nullptr, *tcnt = nullptr, *src = nullptr;
     unsigned nblk = 0;
@@ -988,7 +1012,7 @@ int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
         LBMPM_HIP_TRY(hipEventRecord(c->ev_deep, c->stream2));
     }
     csf3d_phase<FIRST><<<gw, 256, 0, c->stream>>>(p);
-    if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist);
+    if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist, c->wethome);
     csf3d_gradient<<<gw, 256, 0, c->stream>>>(p);
     if (mrt) { if (c->diag) csf3d_collide<FIRST, true, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, true, false><<<gw, 256, 0, c->stream>>>(p); }
     else { if (c->diag) csf3d_collide<FIRST, false, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, false, false><<<gw, 256, 0, c->stream>>>(p); }
@@ -1028,7 +1052,7 @@ extern "C" void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->rng, c->pfx, c->pure, c->deep_prev, c->bcblk, c->deep_now, c->work, c->tcnt, c->src, c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
+    void *ptrs[] = {c->wethome, c->rng, c->pfx, c->pure, c->deep_prev, c->bcblk, c->deep_now, c->work, c->tcnt, c->src, c->dom, c->meta, c->wetlist, c->cidx, c->cells, c->fA, c->fB, c->phi, c->G, c->nh, c->F, c->K, c->U, c->ns, c->obs};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     c->pool.destroy();
     if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
@@ -1162,6 +1186,7 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->work, 3 * ((size_t)nb + 1));
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->tcnt, 3 * ((size_t)nb / 1024 + 1));
         if (rc == LBMPM_OK && c->skip) rc = dev_alloc(c, &c->src, 18 * c->FS);
+        if (rc == LBMPM_OK && c->nwet) rc = dev_alloc(c, &c->wethome, c->nwet);
         if (rc == LBMPM_OK && hipMalloc(reinterpret_cast<void **>(&lo0), 4 * (size_t)nb * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc failed"); rc = LBMPM_ERR_NOMEM; }
         if (rc == LBMPM_OK) {
             hi0 = lo0 + nb; lo1 = hi0 + nb; hi1 = lo1 + nb;
@@ -1175,6 +1200,7 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
                 csf3d_setup_ranges<<<nb, 256, 0, c->stream>>>(p, 0, lo0, hi0, nullptr, nullptr, c->bcblk);
                 csf3d_setup_ranges<<<nb, 256, 0, c->stream>>>(p, 1, lo1, hi1, lo0, hi0, c->bcblk);
                 if (c->src) csf3d_setup_src<<<nb, 256, 0, c->stream>>>(p, c->src);
+                if (c->nwet) csf3d_setup_wethome<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist, c->wethome);
                 std::vector<uint32_t> h(2 * (size_t)nb);
                 e = hipMemcpyAsync(h.data(), lo1, 2 * (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
