@@ -669,8 +669,8 @@ def main():
                     sc3 = RK3DCSFSolver(d2, dict(relax=args.relax, tauB=0.8), device=local_rank)
                     sc3.set_macro(r2, b2)
                     del r2, b2, d2
-                    sc3.step(3); sc3.sync()
-                    kc = 20
+                    sc3.step(10); sc3.sync()
+                    kc = 100                    # (like the primary line: 10 + 100 steps from the drainage's initial state)
                     t1 = time.perf_counter(); mtc, mdc = sc3.step_timed(kc); sc3.sync(); wc = time.perf_counter() - t1
                     nfc = sc3.num_fluid_nodes
                     sec.append({"workload": "c5 lattice, [SurfaceTension] SurfaceTensionType = 'CSF' (%s): the 2-D CSF loop (RKD2Q9.py:1295-1490) carried to D3Q19, "
