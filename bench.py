@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-B_ALG = {"c1": 288.0, "c2": 288.0, "c2p": 288.0, "c3": 288.0, "c4": 368.0, "c5": 608.0}   # algorithmic bytes / lattice update
+B_ALG = {"c1": 288.0, "c2": 288.0, "c2p": 288.0, "c3": 288.0, "c4": 368.0, "c5": 608.0, "csf3d": 608.0}   # algorithmic bytes / lattice update
 SEED = 20260928
 
 
@@ -204,6 +204,17 @@ def build_c1(nx, ny, device):
     return s, float((r0 + r1).sum()), None
 
 
+def build_csf3d(size, device, relax, state="initial"):
+    """the c5 lattice under the 3-D CSF model (lbmpm_rk3dcsf_*), RKtwophasesetup2D.ini's surface-tension parameters"""
+    from openlbmpm_amd.rk3dcsf import RK3DCSFSolver
+    dom = c5_domain(size)
+    dom[0] = dom[1]; dom[-1] = dom[-2]
+    rR, rB = c5_state(dom, 0, size[2], state)
+    s = RK3DCSFSolver(dom, dict(relax=relax, tauB=0.8), device=device)
+    s.set_macro(rR, rB)
+    return s, None, None
+
+
 def c5_domain(n):
     from openlbmpm_amd.geometry import porous_spheres
     nx, ny, nz = n
@@ -346,7 +357,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c5", choices=["c5", "c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c5", choices=["c5", "c2", "c3", "c4", "csf3d"],
+                    help="csf3d: the c5 lattice under the 3-D CSF model (not a BASELINE config; one GPU)")
     ap.add_argument("--size", type=int, nargs="+", default=None, help="c5: NX NY NZ; c2/c3: NX NY")
     ap.add_argument("--relax", default="MRT", choices=["MRT", "SRT"],
                     help="c5 relaxation: BASELINE.json names the MRT configuration; the shipped ini says 'SRT' with ';;MRT' beside it")
@@ -686,6 +698,17 @@ def main():
                                         "(19 loads, 19 stores): exact, bit-equal to the full path.  roofline_frac_by_survey_balg is over the whole step (608 B per "
                                         "update, which the bulk path does not move: it may exceed the bandwidth fraction; counted: DESIGN.md section 4).  Parity: "
                                         "oracle/rk3d_csf_oracle.c at 1e-10, pinned by reduction to the capture of the real 2-D driver (tests/test_rk3d_csf_gpu.py)"})
+                    csf_leg = sec[-1]
+                    if not args.no_live_traffic:
+                        def csf_live(leg=csf_leg, ms=mdc / kc):
+                            # bytes the bulk's collision moves, counted in a child of this run (csf3d_collide_deep runs beside the full path's
+                            # launches: its own time is not separable by events; the fraction below is over the step's time, all launches)
+                            lv = live_pmc_traffic("csf3d_collide_deep", ["--workload", "csf3d", "--steps", "6", "--warmup", "12", "--no-cpu-baseline", "--relax", args.relax,
+                                                                         "--size"] + [str(v) for v in size])
+                            if lv:
+                                leg["bulk_collision_counted"] = dict(lv, GBs_over_the_step=round(lv["traffic"] / (ms * 1e-3) / 1e9, 1),
+                                                                     frac_over_the_step=round(lv["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                        deferred.append(csf_live)
                     # ... and with both colours in every cell: every block on the full path
                     r2, b2 = c5_state(dom, 0, nz, "mixed")
                     sc3.set_macro(r2, b2)
@@ -706,10 +729,13 @@ def main():
             for fn in deferred:          # the counter passes: nothing is timed after this point
                 fn()
     else:
-        size = tuple(args.size) if args.size else ((1024, 1024) if wl == "c2" else (2048, 2048))
-        steps = args.steps if args.steps is not None else (2000 if wl == "c2" else 500)
+        size = tuple(args.size) if args.size else ((512, 512, 512) if wl == "csf3d" else ((1024, 1024) if wl == "c2" else (2048, 2048)))
+        steps = args.steps if args.steps is not None else (100 if wl == "csf3d" else (2000 if wl == "c2" else 500))
         warmup = args.warmup if args.warmup is not None else steps // 10
-        solver, m0, mass = {"c2": build_c2, "c3": build_c3, "c4": build_c4}[wl](size[0], size[1], local_rank)
+        if wl == "csf3d":
+            solver, m0, mass = build_csf3d(size, local_rank, args.relax, args.c5_state)
+        else:
+            solver, m0, mass = {"c2": build_c2, "c3": build_c3, "c4": build_c4}[wl](size[0], size[1], local_rank)
         nfluid = solver.num_fluid_nodes
         solver.step(warmup)
         solver.sync(); barrier()
@@ -732,18 +758,19 @@ def main():
                     "c3": "c3: explicit-forcing Shan-Chen D2Q9 MRT (efs2D.ini parameters), %dx%d synthetic "
                           "porous image (discs r 6-20, porosity 0.65)",
                     "c4": "c4: CSF colour-gradient D2Q9 MRT + one D2Q5-MRT tracer, %dx%d synthetic porous "
-                          "image (discs r 6-20, porosity 0.65)"}[wl] % size
+                          "image (discs r 6-20, porosity 0.65)",
+                    "csf3d": "not a BASELINE config: the c5 lattice %dx%dx%d under the 3-D CSF model (" + args.relax + ", state " + args.c5_state + ")"}[wl] % size
             out = {
                 "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid * steps * world / wall / 1e6, 2),
                 "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
                 "ms_per_step": round(wall * 1e3 / steps, 6), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": desc, "fluid_nodes": nfluid, "lattice_nodes": size[0] * size[1],
+                "config": {"workload": desc, "fluid_nodes": nfluid, "lattice_nodes": int(np.prod(size)),
                            "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
                            "kernel_schedule": "fused", "device_ms_per_step_hip_events": round(ms_total / steps, 6)},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
-                             "traffic": pmc_traffic(solver.dominant_kernel, "%s %dx%d" % ((wl,) + size)),
+                             "traffic": pmc_traffic(solver.dominant_kernel, "%s %s" % (wl, "x".join(str(v) for v in size))),
                              "traffic_source": "profiles/pmc_traffic.json (rocprofv3 counter passes of tools/profile_round.sh, committed; not measured in this run)",
                              "measured_stream_ceiling": measured_hbm(local_rank),
                              "kernel": solver.dominant_kernel, "avg_launch_ms": round(per_launch_ms, 6),
@@ -751,6 +778,24 @@ def main():
             }
             if world == 1 and not args.no_cpu_baseline and wl == "c2":
                 out["cpu_baseline"] = cpu_baseline_c2(*size)
+            if wl == "csf3d":
+                out["config"]["kernel_schedule"] = ("per step: bookkeeping of the bulk skip, phase field / solid phi / gradient / collision of the blocks on the full "
+                                                    "path, and beside them csf3d_collide_deep for the blocks deep inside one colour (19 loads through a table of source cells, 19 stores)")
+                out["config"]["bulk_cells"] = solver.bulk_cells
+                out["roofline"].update(kernel="csf3d_collide_deep", achieved_is="B_alg (608 B) x fluid nodes / step time: NOT a bandwidth fraction -- the bulk path does not move "
+                                       "608 B per cell; counted bytes below when this run could count them", frac_by_survey_balg=out["roofline"]["frac"])
+                lv = None if (args.no_live_traffic or world != 1) else live_pmc_traffic(
+                    "csf3d_collide_deep", ["--workload", "csf3d", "--steps", "6", "--warmup", "12", "--no-cpu-baseline", "--no-live-traffic", "--relax", args.relax,
+                                           "--c5-state", args.c5_state, "--size"] + [str(v) for v in size])
+                if lv:
+                    gbs = lv["traffic"] / (per_launch_ms * 1e-3) / 1e9
+                    out["roofline"].update(traffic=lv["traffic"], traffic_live=lv, achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+                                           achieved_is="bytes csf3d_collide_deep moved per launch (hardware counters) / the step's time (HIP events)",
+                                           traffic_source="measured in THIS run: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE) over a child process; bytes of "
+                                                          "csf3d_collide_deep per launch over the step's time by HIP events (that kernel runs beside the full path's "
+                                                          "launches; alone it takes ~ 0.85 of the step)")
+                if world == 1 and not args.no_cpu_baseline:
+                    out["cpu_baseline"] = cpu_baseline_csf3d(args.relax)
         solver.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
