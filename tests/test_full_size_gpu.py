@@ -77,3 +77,31 @@ def test_c5_512_cubed_storage_layouts_agree_and_mass_bounded(monkeypatch):
     rho = out[0]["rhoR"] + out[0]["rhoB"]
     assert np.isfinite(rho).all()
     assert abs(float(rho.sum()) - m0) / m0 < 4.0 * 1.0e-4 * 512 * 512 * 3 / m0
+
+
+def test_c5_lattice_under_the_3d_csf_model_bulk_path_equals_full_path():
+    """the bench's 512^3 porous lattice under the 3-D CSF model (bench.py's CSF legs): the bulk path (variant 0) against every cell on the
+    full path (variant 1), bit for bit after 12 steps -- phase field, colour densities of the next record, force; total mass moves only
+    by the inlet flux; most of the lattice is on the bulk path"""
+    from openlbmpm_amd.rk3dcsf import RK3DCSFSolver
+    size = (512, 512, 512)
+    dom = bench.c5_domain(size)
+    dom[0] = dom[1]; dom[-1] = dom[-2]
+    rR, rB = bench.c5_densities(dom, 0, size[2])
+    m0 = float((rR + rB).sum())
+    out = []
+    for variant in (0, 1):
+        s = RK3DCSFSolver(dom, dict(relax="MRT", tauB=0.8, variant=variant))
+        s.set_macro(rR, rB)
+        s.step(12)
+        out.append({f: s.get(f) for f in ("phi", "rec_rhoR", "rec_rhoB", "Fz")})
+        if variant == 0:
+            assert s.bulk_cells > 0.8 * s.num_fluid_nodes
+        else:
+            assert s.bulk_cells == 0
+        s.close()
+    for f in out[0]:
+        assert np.array_equal(out[0][f], out[1][f]), f
+    rho = out[0]["rec_rhoR"] + out[0]["rec_rhoB"]
+    assert np.isfinite(rho).all()
+    assert abs(float(rho.sum()) - m0) / m0 < 4.0 * 1.0e-4 * 512 * 512 * 12 / m0
