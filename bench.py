@@ -707,7 +707,12 @@ def main():
                                                                          "--size"] + [str(v) for v in size])
                             if lv:
                                 leg["bulk_collision_counted"] = dict(lv, GBs_over_the_step=round(lv["traffic"] / (ms * 1e-3) / 1e9, 1),
-                                                                     frac_over_the_step=round(lv["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                                                                     frac_over_the_step=round(lv["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                                     note="an upper bound: FETCH_SIZE's factor is calibrated on aligned 128-byte requests, the "
+                                                                          "pulls of the fluid-cells-only numbering are unaligned; by the kernel's own count a bulk "
+                                                                          "cell moves 376 B (19 loads, 18 table words, 19 stores)",
+                                                                     own_count_bytes=376 * leg["bulk_cells"],
+                                                                     own_count_frac_over_the_step=round(376 * leg["bulk_cells"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
                         deferred.append(csf_live)
                     # ... and with both colours in every cell: every block on the full path
                     r2, b2 = c5_state(dom, 0, nz, "mixed")
@@ -790,7 +795,9 @@ def main():
                 if lv:
                     gbs = lv["traffic"] / (per_launch_ms * 1e-3) / 1e9
                     out["roofline"].update(traffic=lv["traffic"], traffic_live=lv, achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
-                                           achieved_is="bytes csf3d_collide_deep moved per launch (hardware counters) / the step's time (HIP events)",
+                                           achieved_is="bytes csf3d_collide_deep moved per launch (hardware counters; an upper bound: the FETCH_SIZE factor is "
+                                                       "calibrated on aligned 128-byte requests, these pulls are unaligned) / the step's time (HIP events)",
+                                           own_count_bytes=376 * solver.bulk_cells, own_count_frac=round(376 * solver.bulk_cells / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                            traffic_source="measured in THIS run: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE) over a child process; bytes of "
                                                           "csf3d_collide_deep per launch over the step's time by HIP events (that kernel runs beside the full path's "
                                                           "launches; alone it takes ~ 0.85 of the step)")
