@@ -60,15 +60,15 @@ def under_rocprof():
 _LIVE = {"ok": True}        # one failed or overrunning counter pass and this run asks for no further one (the committed profile serves)
 
 
-def live_pmc_traffic(kernel, child_args, timeout=150):
+def live_pmc_traffic(kernel, child_args, timeout=150, calib="calib_pull19_b64"):
     if not _LIVE["ok"]:
         return None
-    out = _live_pmc_traffic(kernel, child_args, timeout)
+    out = _live_pmc_traffic(kernel, child_args, timeout, calib)
     _LIVE["ok"] = out is not None
     return out
 
 
-def _live_pmc_traffic(kernel, child_args, timeout):
+def _live_pmc_traffic(kernel, child_args, timeout, calib="calib_pull19_b64"):
     """HBM bytes per launch of `kernel` counted IN THIS RUN: two short rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`, then
     `--pmc WRITE_SIZE`: one counter group per pass and no other trace domain beside it, as the guide's HBM section prescribes) over a few
     steps of this same workload in a child process.  FETCH_SIZE is scaled by the factor the SAME pass measures on the calibration kernel
@@ -108,7 +108,7 @@ def _live_pmc_traffic(kernel, child_args, timeout):
             if not lattice:
                 return None
             got[counter] = {"launches": sum(n for n, _ in lattice), "kb": sum(n * a for n, a in lattice) / sum(n for n, _ in lattice),
-                            "calib_kb": next((a for name, _n, a in rows if "calib_pull19_b64" in name), None)}
+                            "calib_kb": next((a for name, _n, a in rows if calib in name), None)}
     except (OSError, sqlite3.Error):
         return None
     finally:
@@ -118,7 +118,7 @@ def _live_pmc_traffic(kernel, child_args, timeout):
     factor = true_calib / (ck * 1024.0) if ck else 2.0
     return {"traffic": factor * got["FETCH_SIZE"]["kb"] * 1024.0 + got["WRITE_SIZE"]["kb"] * 1024.0,
             "fetch_size_kb": round(got["FETCH_SIZE"]["kb"], 1), "write_size_kb": round(got["WRITE_SIZE"]["kb"], 1),
-            "fetch_factor": round(factor, 4), "fetch_factor_from": "calib_pull19_b64 in the same pass" if ck else "the guide's gfx950 correction (no calibration row)",
+            "fetch_factor": round(factor, 4), "fetch_factor_from": calib + " in the same pass" if ck else "the guide's gfx950 correction (no calibration row)",
             "launches_counted": got["FETCH_SIZE"]["launches"]}
 
 
@@ -704,13 +704,14 @@ def main():
                             # bytes the bulk's collision moves, counted in a child of this run (csf3d_collide_deep runs beside the full path's
                             # launches: its own time is not separable by events; the fraction below is over the step's time, all launches)
                             lv = live_pmc_traffic("csf3d_collide_deep", ["--workload", "csf3d", "--steps", "6", "--warmup", "12", "--no-cpu-baseline", "--relax", args.relax,
-                                                                         "--size"] + [str(v) for v in size])
+                                                                         "--size"] + [str(v) for v in size], calib="calib_shift19_b64")
                             if lv:
                                 leg["bulk_collision_counted"] = dict(lv, GBs_over_the_step=round(lv["traffic"] / (ms * 1e-3) / 1e9, 1),
                                                                      frac_over_the_step=round(lv["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                                     note="an upper bound: FETCH_SIZE's factor is calibrated on aligned 128-byte requests, the "
-                                                                          "pulls of the fluid-cells-only numbering are unaligned; by the kernel's own count a bulk "
-                                                                          "cell moves 376 B (19 loads, 18 table words, 19 stores)",
+                                                                     note="FETCH_SIZE x the factor the same pass measures on calib_shift19_b64 (19 planes pulled "
+                                                                          "through windows that do not start on a line, like the pulls of the fluid-cells-only "
+                                                                          "numbering); by the kernel's own count a bulk cell moves 376 B (19 loads, 18 table words, "
+                                                                          "19 stores)",
                                                                      own_count_bytes=376 * leg["bulk_cells"],
                                                                      own_count_frac_over_the_step=round(376 * leg["bulk_cells"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
                         deferred.append(csf_live)
@@ -791,12 +792,12 @@ def main():
                                        "608 B per cell; counted bytes below when this run could count them", frac_by_survey_balg=out["roofline"]["frac"])
                 lv = None if (args.no_live_traffic or world != 1) else live_pmc_traffic(
                     "csf3d_collide_deep", ["--workload", "csf3d", "--steps", "6", "--warmup", "12", "--no-cpu-baseline", "--no-live-traffic", "--relax", args.relax,
-                                           "--c5-state", args.c5_state, "--size"] + [str(v) for v in size])
+                                           "--c5-state", args.c5_state, "--size"] + [str(v) for v in size], calib="calib_shift19_b64")
                 if lv:
                     gbs = lv["traffic"] / (per_launch_ms * 1e-3) / 1e9
                     out["roofline"].update(traffic=lv["traffic"], traffic_live=lv, achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
-                                           achieved_is="bytes csf3d_collide_deep moved per launch (hardware counters; an upper bound: the FETCH_SIZE factor is "
-                                                       "calibrated on aligned 128-byte requests, these pulls are unaligned) / the step's time (HIP events)",
+                                           achieved_is="bytes csf3d_collide_deep moved per launch (hardware counters; FETCH_SIZE x the factor of calib_shift19_b64, "
+                                                       "the calibration kernel with unaligned windows, in the same pass) / the step's time (HIP events)",
                                            own_count_bytes=376 * solver.bulk_cells, own_count_frac=round(376 * solver.bulk_cells / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                            traffic_source="measured in THIS run: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE) over a child process; bytes of "
                                                           "csf3d_collide_deep per launch over the step's time by HIP events (that kernel runs beside the full path's "

@@ -152,6 +152,20 @@ __global__ __launch_bounds__(256) void calib_pull19_b64(const double *__restrict
 #pragma unroll
     for (int q = 0; q < 19; ++q) b[(size_t)q * n + i] = v[q] + 1.;
 }
+// the same with every plane's window shifted by an odd number of elements (2 q + 1, wrapping at the plane's end: every element is still
+// read exactly once): waves whose 512 bytes do not start on a line -- the pulls of a fluid-cells-only numbering (csf3d_*, rk3d_csf.hip)
+__global__ __launch_bounds__(256) void calib_shift19_b64(const double *__restrict__ a, double *__restrict__ b)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = CALIB_PLANE / sizeof(double);
+    double v[19];
+#pragma unroll
+    for (int q = 0; q < 19; ++q) {
+        const size_t k = i + (size_t)(2 * q + 1);
+        v[q] = a[(size_t)q * n + (k < n ? k : k - n)];
+    }
+#pragma unroll
+    for (int q = 0; q < 19; ++q) b[(size_t)q * n + i] = v[q] + 1.;
+}
 }  // namespace
 
 extern "C" int lbmpm_hbm_stream_test(int device, int64_t bytes_per_buffer, int reps, double *copy_gbs, double *read_gbs, double *inplace_gbs)
@@ -189,6 +203,7 @@ extern "C" int lbmpm_hbm_stream_test(int device, int64_t bytes_per_buffer, int r
             calib_read_b128<<<dim3((unsigned)(CALIB_BYTES / 16 / 256)), block, 0, st>>>(a, bd);
             calib_copy_b128<<<dim3((unsigned)(CALIB_BYTES / 16 / 256)), block, 0, st>>>(a, b);
             calib_pull19_b64<<<dim3((unsigned)(CALIB_PLANE / 8 / 256)), block, 0, st>>>(ad, bd);
+            calib_shift19_b64<<<dim3((unsigned)(CALIB_PLANE / 8 / 256)), block, 0, st>>>(ad, bd);
         }
         e = hipStreamSynchronize(st);
         if (e == hipSuccess) e = hipGetLastError();
