@@ -519,7 +519,8 @@ int64_t lbmpm_rk3d_device_bytes(const lbmpm_rk3d *ctx);
 typedef struct lbmpm_rk3dcsf_config {
     int64_t nx, ny, nz;        /* xDomain, yDomain, zDomain (incl. the ghost planes 0 and nz-1); nz >= 8 */
     double surface_tension;    /* [SurfaceTension] SurfaceTensionValue                      */
-    double contact_angle_deg;  /* [SurfaceTension] ContactAngle                             */
+    double contact_angle_deg;  /* [SurfaceTension] ContactAngle (measured through the blue fluid with rule 2; at exactly 0 or 180 the rule's two
+                                * candidates coincide and its choice -- AcceleratedRKGPU2D.py:2488-2492 -- is decided by rounding, as in the reference) */
     double beta, delta;        /* [RKParameters] BetaThickness, DeltaValue                  */
     double tau_r, tau_b;       /* [FluidParameters] TauR, TauB                              */
     double inlet_velocity_z;   /* velocityZR + velocityZB (2-D: RKD2Q9.py:1300)             */

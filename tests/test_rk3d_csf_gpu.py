@@ -66,6 +66,15 @@ VARIANTS = {
     "MRT tau type 1": dict(relax="MRT", tautype=1, tauB=0.7),
     "SRT no wetting rule": dict(relax="SRT", wetting=0),
     "MRT theta 140": dict(relax="MRT", theta=140.0, tauB=0.8),
+    "SRT tau type 1": dict(relax="SRT", tautype=1, tauB=0.65),
+    # (not 0 / 180 degrees: sin(theta) is then 1e-16, the rule's two candidates coincide to the last bit or two, and whether their distances
+    # compare <, > or == -- the last leaves the gradient untouched, A:2488-2492 -- is decided by rounding: the reference's rule itself is a
+    # coin toss there, and two correct implementations differ by 4e-2 after 30 steps)
+    "MRT theta 10": dict(relax="MRT", theta=10.0),
+    "MRT theta 170": dict(relax="MRT", theta=170.0),
+    "MRT no tension": dict(relax="MRT", sigma=0.0),
+    "SRT pressure inlet, convective outlet": dict(relax="SRT", inlet="Dirichlet", outlet="Convective", densityRH=1.0, densityBH=1.0e-8),
+    "MRT thin interface (beta 1)": dict(relax="MRT", beta=1.0, delta=0.9),
 }
 
 
