@@ -694,3 +694,33 @@ def test_rk3d_csf_cycle_restart_from_the_last_record(tmp_path):
     fl = dom == 1
     for name, f in (("FluidMacro/FluidDensityRin1", "rhoR"), ("FluidMacro/FluidDensityBin1", "rhoB"), ("FluidVelocity/FluidVelocityZAt1", "vz")):
         assert rel_err(res["/" + name][fl], o.field(f)[fl], scale=1e-4 if f == "vz" else None) < 1e-9, name
+
+
+def test_rk3d_csf_image_cycle_takes_the_populations_over_with_the_colours_swapped(tmp_path):
+    """the image branch of IsCycle = 'yes' (RKD2Q9.py:532-556 in 3-D) with the CSF model: cycleInitialRK3D written from a finished run, taken over
+    with the colours swapped in the top buffer planes; the run starts from exactly those populations (record 0 below the open planes)"""
+    from ini_fixtures import write_rk3d_csf
+    from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D
+    from openlbmpm_amd.geometry import porous_spheres, voxel_domain
+    from openlbmpm_amd.results import load_results
+    write_rk3d_csf(str(tmp_path), steps=30, relax="MRT", sigma=0.05, theta=60.0)
+    vox = porous_spheres(40, 18, 30, porosity=0.7, rmin=2.0, rmax=5.0, seed=8, nbuf=0, walls=False)
+    init = tmp_path / "LBMInitial"
+    a = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "a"), domain=voxel_domain(vox, 6), record_every=30, num_buffering_layers=6)
+    a.runRKColorGradient3D()
+    assert a.solver.dominant_kernel == "csf3d_collide"
+    path = a.write_cycle_initial(str(init))
+    stored = load_results(path)
+    fR, fB = a.solver.get_pdf()
+    assert np.array_equal(stored["/FluidPDF/FluidPDFR"], fR) and fR.shape == a._domain.shape + (19,)
+    _set_cycle(str(tmp_path), 0)
+    b = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "b"), domain=a._domain, record_every=6, num_buffering_layers=6, initial_dir=str(init))
+    b.timeSteps = 6
+    b.initializeDomainBorder(); b.initializeDomainCondition()
+    assert np.array_equal(b.fluidPDFR[:-6], fR[:-6]) and np.array_equal(b.fluidPDFB[-6:], fR[-6:]) and np.array_equal(b.fluidPDFR[-6:], fB[-6:])
+    res = load_results(b.runRKColorGradient3D())
+    z = slice(2, a._domain.shape[0] - 8)         # record 0 = the densities of the populations taken over (away from the open planes and the swapped buffer)
+    want = stored["/FluidPDF/FluidPDFR"].sum(axis=-1)
+    assert rel_err(res["/FluidMacro/FluidDensityRin0"][z], want[z]) < 1e-13
+    assert np.all(np.isfinite(res["/FluidVelocity/FluidVelocityZAt1"]))
+    assert res["/FluidMacro/FluidDensityBin0"][-4:-2].sum() < 1e-2 * res["/FluidMacro/FluidDensityRin0"][-4:-2].sum()
