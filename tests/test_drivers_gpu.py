@@ -325,6 +325,9 @@ def test_cli_runs(tmp_path):
     from ini_fixtures import write_rk3d
     write_rk3d(str(tmp_path), nx=16, ny=12, nz=24, steps=10)
     assert main(["rk3d", str(tmp_path), "--out", str(tmp_path / "o3")]) == 0
+    from ini_fixtures import write_rk3d_csf
+    write_rk3d_csf(str(tmp_path), nx=16, ny=12, nz=24, steps=10)            # the same entry with [SurfaceTension] SurfaceTensionType = 'CSF'
+    assert main(["rk3d", str(tmp_path), "--out", str(tmp_path / "o3c")]) == 0
 
 
 @pytest.mark.parametrize("calibrate,gather,ranks", [(False, True, 2), (True, True, 2), (False, False, 2), (False, True, 8)],
