@@ -66,6 +66,11 @@ typedef struct {
     double rates[6];             /* MRT: s_e, s_eps, s_q, s_pi, s_m, and the rate of the conserved moments (0 in the model, as S[0] = S[3] = S[5] = 0 in
                                     RKD2Q9.py:338-340; the BGK-limit test sets all six to 1/tau: the velocity carries half the force of the step BEFORE,
                                     so the momentum of f - feq does not cancel against the source's and its rate matters) */
+    double crisp;                /* 0: the loop as the reference writes it.  > 0 (the library's rule, include/lbmpm.h bulk_epsilon; its default
+                                    2^-51): a colour whose density is below crisp * rho after the collision is absent -- it hands on exact zeros and
+                                    the other colour takes f_tot.  Exists so that the HIP kernels can be compared with this file on K as well,
+                                    which turns any last-bit difference into 1e-8 where |G| sits at its threshold (tests/test_rk3d_csf_gpu.py); that
+                                    the rule itself moves the other fields by 1e-15 is a CPU test (tests/test_oracle_rk3d_csf.py) */
 } rk3dcsf_sim;
 
 static i64 wrap(i64 v, i64 n) { v %= n; return v < 0 ? v + n : v; }      /* any offset, any n >= 1 */
@@ -423,6 +428,11 @@ void rk3dcsf_step_b(rk3dcsf_sim *s)
             else c = 0.;
             s->fR[Q * n + i] = rR / tot * t[i] + s->beta * rR * rB / tot * WT(i) * c * un;
             s->fB[Q * n + i] = rB / tot * t[i] - s->beta * rR * rB / tot * WT(i) * c * un;
+            if (s->crisp > 0.) {
+                const int noB = fabs(rB) <= s->crisp * tot, noR = !noB && fabs(rR) <= s->crisp * tot;
+                if (noB) { s->fR[Q * n + i] = t[i]; s->fB[Q * n + i] = 0.; }
+                else if (noR) { s->fR[Q * n + i] = 0.; s->fB[Q * n + i] = t[i]; }
+            }
         }
     }
     /* A:340-417 streaming: push + half-way bounce-back; direction 0 stays where it is */

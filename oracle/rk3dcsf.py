@@ -18,13 +18,13 @@ class _Sim(C.Structure):
                [(n, C.c_double) for n in ("sigma", "cosT", "sinT", "beta", "delta", "tauR", "tauB", "vzIn", "pInB", "pInR", "pOutTotal")] + \
                [(n, C.c_int) for n in ("tauType", "mrt", "inletType", "outletType", "wetting")] + \
                [(n, F64P) for n in _F19 + _F1] + \
-               [("kind", U8P), ("W", C.c_int64), ("rates", C.c_double * 6)]
+               [("kind", U8P), ("W", C.c_int64), ("rates", C.c_double * 6), ("crisp", C.c_double)]
 
 
 # the 2-D ini's parameters (RKtwophasesetup2D.ini) under the 3-D ini's key names for the flow axis
 DEFAULT_PARAMS = dict(sigma=0.1, theta=60.0, wetting=2, beta=0.7, delta=0.98, tauR=1.0, tauB=1.0, tautype=2, relax="MRT",
                       inlet="Neumann", outlet="Dirichlet", velocityZR=-1.0e-4, velocityZB=0.0, densityBH=5e-8, densityRH=1.00536,
-                      densityBL=1.0, densityRL=5e-8, rates=(1.19, 1.4, 1.2, 1.4, 1.2, 0.0))
+                      densityBL=1.0, densityRL=5e-8, rates=(1.19, 1.4, 1.2, 1.4, 1.2, 0.0), crisp=0.0)
 
 
 class RK3DCSFOracle:
@@ -55,6 +55,7 @@ class RK3DCSFOracle:
         s.wetting = int(p["wetting"])
         for i, r in enumerate(p["rates"]):
             s.rates[i] = float(r)
+        s.crisp = float(p["crisp"])
         for name in _F19 + _F1:
             setattr(s, name, getattr(self, "_" + name).ctypes.data_as(F64P))
         s.kind = self._kind.ctypes.data_as(U8P)

@@ -11,19 +11,26 @@ import pytest
 
 from helpers import GOLDEN, load_params, rel_err
 from oracle.rk import initial_densities
-from oracle.rk3dcsf import RK3DCSFOracle
+from oracle.rk3dcsf import RK3DCSFOracle as _Oracle
 from test_oracle_rk3d_csf import blob3, extrude, params3, project_pdf, PAIRS
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
-# K alone is held to 1e-7: where |G| sits at the kernel's threshold of 1e-8 (the far tail of the interface) the unit normal -G / |G| turns a
-# perturbation eps of the populations into eps / |G|, and the library drops a colour whose density is below 2^-51 of the total (the crisp
-# "one colour alone" its bulk skip rests on; the oracle keeps that tail).  What K feeds, F = -1/2 sigma K G, carries |G| as a factor and is held
-# to 1e-9 of the largest force; densities, phase field, velocity, gradient and populations to 1e-10.
-TOL_K, TOL_F = 1e-7, 1e-9
+# The library drops a colour whose density is below 2^-51 of the total (the crisp "one colour alone" its bulk skip rests on).  The oracle can
+# do the same (`crisp`; tests/test_oracle_rk3d_csf.py: that moves its densities, phase field and velocity by 1e-13 at most), and against that
+# oracle every field is held to 1e-10, K included.  Against the loop as the reference writes it (the capture of the real 2-D driver) K alone is
+# held to 1e-7: where |G| sits at the kernel's threshold of 1e-8 the unit normal -G / |G| turns ANY last-bit difference into eps / |G|.
+CRISP = 2.0 ** -51
+TOL_K, TOL_F = 1e-10, 1e-10
+TOL_K_CAPTURE = 1e-7
 SCALARS = ("rhoR", "rhoB", "phi", "K")
 VECTORS = (("vx", "vy", "vz"), ("Gx", "Gy", "Gz"), ("Fx", "Fy", "Fz"))
+
+
+def RK3DCSFOracle(dom, rR, rB, par=None, **kw):
+    """the oracle with the library's crisp rule (see above)"""
+    return _Oracle(dom, rR, rB, dict(par or {}, crisp=CRISP), **kw)
 
 
 def solver(dom, par, **kw):
@@ -189,7 +196,7 @@ def test_reduces_to_the_capture_of_the_real_2d_driver(ny):
         for f3, f2 in PAIRS:
             a = s.get(f3)
             e = rel_err(a[:, 0, :][fl], ref[f2][fl], scale=scales.get(f3[0]))
-            assert e < (TOL_K if f3 == "K" else 1e-9), "step %d: %s vs the reference's %s: %.3e" % (k, f3, f2, e)
+            assert e < (TOL_K_CAPTURE if f3 == "K" else 1e-9), "step %d: %s vs the reference's %s: %.3e" % (k, f3, f2, e)
             assert np.max(np.abs(a - a[:, :1, :])) <= 1e-12 * max(np.max(np.abs(a)), 1e-300)
         for f in ("fR", "fB"):
             assert rel_err(project_pdf(s.get(f))[fl], ref[f][fl]) < 1e-9, f
