@@ -514,7 +514,12 @@ int64_t lbmpm_rk3d_device_bytes(const lbmpm_rk3d *ctx);
  *     Hecht & Harting 2010 (their 2-D image is the 1/2 (f_1 - f_3) of :943-944),
  *   - MRT: moment basis of d'Humieres et al. 2002, rates s_e 1.19, s_eps = s_pi 1.4, s_q = s_m 1.2 (as lbmpm_rk3d_config), stress
  *     moments at 1/tau, conserved moments 0; Guo source in moment space M^-1 (I - S/2) M (:2027-2113).  mrt_rates overrides (tests).
- * One context = one GPU (the curvature reaches two cells: no slab decomposition of this model yet).
+ * Slabs along z (one context per GPU / rank): ghost_lo = ghost_hi = 2 make the two planes at either end of the context's lattice images of
+ * the neighbouring slabs' edge planes.  The curvature reads n one cell around and n reads phi one cell around that, so a step has three
+ * face messages instead of the perturbation model's one: phi of two planes (after the phase field), n of one plane (after the gradient),
+ * the five populations per colour that cross the face (after the collision).  lbmpm_rk3dcsf_stage runs a third of a step;
+ * lbmpm_rk3dcsf_face_copy hands a message to a context of the same process, lbmpm_rk3dcsf_face_pack / _unpack go through a device buffer
+ * the caller sends (RCCL / MPI / torch.distributed).  Bit-equal to the undivided lattice (tests/test_rk3d_csf_gpu.py).
  * ---------------------------------------------------------------------------------- */
 typedef struct lbmpm_rk3dcsf_config {
     int64_t nx, ny, nz;        /* xDomain, yDomain, zDomain (incl. the ghost planes 0 and nz-1); nz >= 8 */
@@ -542,6 +547,12 @@ typedef struct lbmpm_rk3dcsf_config {
                                 * bulk_epsilon the bulk path keeps its share in long runs (1e-10: + 35 % after 2 000 steps of the 512^3 drainage).
                                 * The cut is a sink at the tail's end: after 3 000 steps densities, phi, u differ from the exact loop by 8e-8 at
                                 * 1e-10 and 5e-5 at 1e-7 (tests/test_rk3d_csf_gpu.py, profiles/r06_soak_csf3d.txt) */
+    int32_t ghost_lo, ghost_hi; /* 0, 0: the undivided lattice.  2, 2: a slab of it -- the planes 0, 1 and nz-2, nz-1 of this context are images of
+                                * the neighbouring slabs' edge planes; is_domain and the arrays of set_macro / set_pdf / get_field carry them like any
+                                * other plane (cut from the undivided lattice).  The slabs form a RING: the loop wraps z like x and y (the walls of
+                                * the ghost plane 0 average phi over the plane nz-1), so the first slab's low face is the last slab's high face */
+    int64_t slab_z0, global_nz; /* a slab: its first own plane (this context's plane 2) and the number of planes of the undivided lattice; the open
+                                * planes are the undivided lattice's 0, 1 (0 .. 3 convective) and nz-2, nz-1; >= 4 own planes per slab */
 } lbmpm_rk3dcsf_config;
 
 typedef struct lbmpm_rk3dcsf lbmpm_rk3dcsf;
@@ -573,7 +584,24 @@ int lbmpm_rk3dcsf_set_macro(lbmpm_rk3dcsf *ctx, const double *rho_r, const doubl
 /* restart ([CyclesSetup] IsCycle, RKD2Q9.py:491-559): streamed populations [nz][ny][nx][19] per colour as LBMPM_RK3DCSF_PDF_* returns
  * them, and the force of the last step (LBMPM_RK3DCSF_F*; NULL = 0): a run continued from them equals the uninterrupted run bit for bit */
 int lbmpm_rk3dcsf_set_pdf(lbmpm_rk3dcsf *ctx, const double *pdf_r, const double *pdf_b, const double *fx, const double *fy, const double *fz);
-int lbmpm_rk3dcsf_step(lbmpm_rk3dcsf *ctx, int64_t nsteps);
+int lbmpm_rk3dcsf_step(lbmpm_rk3dcsf *ctx, int64_t nsteps);          /* undivided lattices only (ghost_lo = ghost_hi = 0) */
+/* One third of a time step, in order 0, 1, 2: (0) the blocks' lists, the bulk's collision on its own stream, the phase field;
+ * (1) phi on the wetting solids, gradient, n; (2) the collision of the full path, buffers swapped.  Between them the face messages:
+ * LBMPM_CSF_MSG_PHI after stage 0, LBMPM_CSF_MSG_NORMAL after stage 1, LBMPM_CSF_MSG_PDF after stage 2.  face: 0 = low z, 1 = high z. */
+enum { LBMPM_CSF_MSG_PDF = 0, LBMPM_CSF_MSG_PHI = 1, LBMPM_CSF_MSG_NORMAL = 2 };
+int lbmpm_rk3dcsf_stage(lbmpm_rk3dcsf *ctx, int stage);
+/* doubles of a message through that face (0 for the undivided lattice); the two sides of a face must agree (same mask on both) */
+int64_t lbmpm_rk3dcsf_face_doubles(const lbmpm_rk3dcsf *ctx, int msg, int face);
+/* ... of the message that comes in through that face (the populations travel for the fluid cells of the sender's edge plane only: the
+ * plane this context holds an image of, not the one it sends) */
+int64_t lbmpm_rk3dcsf_face_doubles_in(const lbmpm_rk3dcsf *ctx, int msg, int face);
+/* the message this context sends through `face` into / the message it receives through `face` out of a DEVICE buffer of face_doubles
+ * doubles, on the context's stream (lbmpm_rk3dcsf_sync before the buffer leaves; unpack before the next stage) */
+int lbmpm_rk3dcsf_face_pack(lbmpm_rk3dcsf *ctx, int msg, int face, double *device_buffer);
+int lbmpm_rk3dcsf_face_unpack(lbmpm_rk3dcsf *ctx, int msg, int face, const double *device_buffer);
+/* same process: src's message through src_face straight into dst's ghost planes at the opposite face (ordered by events against both
+ * contexts' streams; nothing to wait for on the host) */
+int lbmpm_rk3dcsf_face_copy(lbmpm_rk3dcsf *src, int src_face, lbmpm_rk3dcsf *dst, int msg);
 /* ms_total: HIP events around the steps; ms_dominant: the steps without their bookkeeping launches -- csf3d_collide_deep for the bulk on a
  * second stream beside phase field, solid phi, gradient and csf3d_collide for the blocks on the full path */
 int lbmpm_rk3dcsf_step_timed(lbmpm_rk3dcsf *ctx, int64_t nsteps, double *ms_total, double *ms_dominant);

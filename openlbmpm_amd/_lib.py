@@ -81,7 +81,8 @@ class RK3DCSFConfig(C.Structure):
                [(n, C.c_double) for n in ("surface_tension", "contact_angle_deg", "beta", "delta", "tau_r", "tau_b", "inlet_velocity_z",
                                           "inlet_rho_r", "inlet_rho_b", "outlet_rho_total")] + \
                [(n, C.c_int32) for n in ("wetting_type", "tau_type", "relaxation", "inlet_type", "outlet_type", "device", "variant")] + \
-               [("mrt_rates", C.c_double * 6), ("bulk_epsilon", C.c_double)]
+               [("mrt_rates", C.c_double * 6), ("bulk_epsilon", C.c_double), ("ghost_lo", C.c_int32), ("ghost_hi", C.c_int32),
+                ("slab_z0", C.c_int64), ("global_nz", C.c_int64)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)      # lbmpm_rk3d_exchange_fn
@@ -175,6 +176,12 @@ _SIGNATURES = {
     "lbmpm_rk3dcsf_set_pdf": (C.c_int, [C.c_void_p, F64P, F64P, F64P, F64P, F64P]),
     "lbmpm_rk3dcsf_step": (C.c_int, [C.c_void_p, C.c_int64]),
     "lbmpm_rk3dcsf_step_timed": (C.c_int, [C.c_void_p, C.c_int64, F64P, F64P]),
+    "lbmpm_rk3dcsf_stage": (C.c_int, [C.c_void_p, C.c_int]),
+    "lbmpm_rk3dcsf_face_doubles": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "lbmpm_rk3dcsf_face_doubles_in": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "lbmpm_rk3dcsf_face_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lbmpm_rk3dcsf_face_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lbmpm_rk3dcsf_face_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "lbmpm_rk3dcsf_sync": (C.c_int, [C.c_void_p]),
     "lbmpm_rk3dcsf_enable_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
     "lbmpm_rk3dcsf_get_field": (C.c_int, [C.c_void_p, C.c_int, F64P]),

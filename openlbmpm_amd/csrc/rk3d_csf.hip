@@ -51,6 +51,8 @@ enum { L_TODO = 0, L_FULL = 1, L_DEEP = 2 };
 
 struct CsfDev {
     int nx, ny, nz;
+    int glo, ghi;                // ghost planes at the low / high end of z (0: the undivided lattice; 2: images of the neighbouring slab's edge planes)
+    int zoff, nzg;               // plane z of this lattice is plane z + zoff of the undivided lattice of nzg planes (its own planes: 0 <= z + zoff < nzg)
     unsigned N;                  // cells
     size_t NS;                   // stride between the planes of a dense SoA array (N rounded up to 16)
     size_t FS;                   // stride between the 38 population planes: fluid cells only, numbered in lattice order (x fastest)
@@ -125,10 +127,15 @@ __device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z,
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ, OPP[Q] = CSF_OPP;
     constexpr int UP[5] = {5, 11, 14, 15, 18}, DN[5] = {6, 12, 13, 16, 17};
     int zs = z;                                   // the plane whose streamed populations this cell takes
-    if (BC) {
-        if (z == p.nz - 1) zs = p.nz - 2;
-        else if (p.conv) { if (z <= 2) zs = 3; }
-        else if (z == 0) zs = 1;
+    bool top = false, bot = false;                // the inlet's / the pressure outlet's rule applies
+    if (BC && z >= p.glo && z < p.nz - p.ghi) {   // (a slab's own planes; the open planes are planes of the undivided lattice)
+        const int zg = z + p.zoff;
+        int zsg = zg;
+        if (zg == p.nzg - 1) zsg = p.nzg - 2;
+        else if (p.conv) { if (zg <= 2) zsg = 3; }
+        else if (zg == 0) zsg = 1;
+        zs = z + (zsg - zg);
+        top = zsg == p.nzg - 2; bot = !p.conv && zsg == 1;
     }
     const Nb nb = make_nb(p, x, y, zs);
     const unsigned own = at(nb, 0, 0, 0);
@@ -154,7 +161,7 @@ __device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z,
     }
     rR = sum19(fR); rB = sum19(fB);
     if (!BC) return;
-    if (zs == p.nz - 2) {
+    if (top) {
         if (!p.inletP) {                         // A:2348-2412 constantTotalVelocityInlet
             double t[Q];
 #pragma unroll
@@ -172,7 +179,7 @@ __device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z,
             rB = ratioB * rho;
 #pragma unroll
             for (int a = 0; a < 5; ++a) fB[DN[a]] = ratioB * t[DN[a]];
-            if (z == p.nz - 1) { rR = sum19(fR); rB = sum19(fB); }          // A:607-650: the ghost plane re-sums
+            if (zs != z) { rR = sum19(fR); rB = sum19(fB); }          // A:607-650: the ghost plane re-sums
         } else {                                 // A:925-962 calConstPressureInletGPU; the ghost plane copies the densities too (A:968-1002)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -189,7 +196,7 @@ __device__ __forceinline__ void cell_state(const CsfDev &p, int x, int y, int z,
             }
             rB = p.pInB; rR = p.pInR;
         }
-    } else if (!p.conv && zs == 1) {             // A:2560-2590 calConstPressureLowerGPUTotal; ghost plane 0: A:1045-1081
+    } else if (bot) {                            // A:2560-2590 calConstPressureLowerGPUTotal; ghost plane 0: A:1045-1081
         double t[Q];
 #pragma unroll
         for (int i = 0; i < Q; ++i) t[i] = fR[i] + fB[i];
@@ -252,7 +259,7 @@ __device__ __forceinline__ bool fluid_cell(const CsfDev &p, unsigned blk, unsign
     const unsigned r = n - (unsigned)z * pl;
     y = (int)(r / (unsigned)p.nx);
     x = (int)(r - (unsigned)y * (unsigned)p.nx);
-    return true;
+    return z >= p.glo && z < p.nz - p.ghi;       // (a slab's ghost planes are images of the neighbour's cells: received, not computed)
 }
 
 // csf3d_phase and csf3d_gradient run over the blocks that have something to do: all of them without the bulk skip, else the list
@@ -301,6 +308,7 @@ __global__ __launch_bounds__(256) void csf3d_solid_phi(CsfDev p, const uint32_t 
     const unsigned n = wetlist[k];
     int x, y, z;
     cell_of(p, n, x, y, z);
+    if ((p.glo && z < 1) || (p.ghi && z > p.nz - 2)) return;       // the outer ghost plane's walls: their neighbours are not all here, nobody reads them
     const Nb nb = make_nb(p, x, y, z);
     const uint32_t m = p.meta[n];
     double sum = 0., sw = 0.;
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     }   // active
     if (p.skip) {                                // what the block hands on, for the next step's deep_colour
         const int allr = __syncthreads_and(only_red), allb = __syncthreads_and(only_blue);
-        if (threadIdx.x == 0) { p.pure[blk] = allr ? 1 : (allb ? 2 : 0); p.deep_prev[blk] = 0; }
+        if (threadIdx.x == 0) { p.pure[blk] = (p.bcblk[blk] & 2) ? 0 : (allr ? 1 : (allb ? 2 : 0)); p.deep_prev[blk] = 0; }      // (bit 1: ghost cells, whose colours this slab does not know)
     }
     }   // blocks of the list
 }
@@ -733,10 +741,17 @@ __global__ __launch_bounds__(256) void csf3d_setup_ranges(CsfDev p, int pass, ui
     int x, y, z;
     cell_of(p, n, x, y, z);
     int zs = z;
-    bool open = z >= p.nz - 2 || z <= 1;
-    if (z == p.nz - 1) zs = p.nz - 2;
-    else if (p.conv) { if (z <= 2) zs = 3; open = open || z <= 3; }
-    else if (z == 0) zs = 1;
+    const bool ghost = z < p.glo || z >= p.nz - p.ghi;
+    bool open = false;
+    if (!ghost) {
+        const int zg = z + p.zoff;
+        int zsg = zg;
+        open = zg >= p.nzg - 2 || zg <= 1;
+        if (zg == p.nzg - 1) zsg = p.nzg - 2;
+        else if (p.conv) { if (zg <= 2) zsg = 3; open = open || zg <= 3; }
+        else if (zg == 0) zsg = 1;
+        zs = z + (zsg - zg);
+    }
     const Nb nb = make_nb(p, x, y, zs);
     const unsigned own = at(nb, 0, 0, 0);
     const uint32_t m = p.meta[own];
@@ -763,6 +778,7 @@ __global__ __launch_bounds__(256) void csf3d_setup_ranges(CsfDev p, int pass, ui
     atomicMin(&lo[b], mn);
     atomicMax(&hi[b], mx);
     if (pass == 0 && open) bcblk[b] = 1;
+    if (pass == 1 && ghost) bcblk[b] = 3;        // (a launch of its own after pass 0: every writer stores the same value)
 }
 
 // host-layout views of the populations: out_pdf [2][N][19], out_rho [2][N], out_u [3][N] (REC only), out_phi [N] (REC only).
@@ -941,6 +957,10 @@ struct lbmpm_rk3dcsf {
     bool first = true, have_state = false, diag = false, diag_valid = false;
     hipStream_t stream = nullptr, stream2 = nullptr;        // stream2: the deep blocks' collision beside the full path's four launches
     hipEvent_t ev_lists = nullptr, ev_deep = nullptr;
+    hipEvent_t ev_stage = nullptr, ev_sent[2] = {nullptr, nullptr};      // slabs: this context's last stage is queued / a face message of its is
+    std::vector<uint32_t> pfirst;  // [nz + 1] fluid cells before plane z
+    int next_stage = 0;
+    int zoff = 0, nzg = 0;         // CsfDev
     uint8_t *dom = nullptr;
     uint32_t *meta = nullptr, *wetlist = nullptr, *wethome = nullptr, *cidx = nullptr, *cells = nullptr, *rng = nullptr, *pfx = nullptr;
     uint8_t *pure = nullptr, *deep_prev = nullptr, *bcblk = nullptr, *deep_now = nullptr;
@@ -968,6 +988,8 @@ CsfDev make_dev(const lbmpm_rk3dcsf *c)
 {
     CsfDev p;
     p.nx = c->nx; p.ny = c->ny; p.nz = c->nz; p.N = (unsigned)c->N; p.NS = c->NS;
+    p.glo = c->cfg.ghost_lo; p.ghi = c->cfg.ghost_hi;
+    p.zoff = c->zoff; p.nzg = c->nzg;
     p.FS = c->FS; p.meta = c->meta; p.cidx = c->cidx; p.cells = c->cells; p.NF = (unsigned)c->nfluid; p.fin = c->fA; p.fout = c->fB;
     p.phi = c->phi; p.G = c->G; p.nh = c->nh; p.F = c->F; p.K = c->K; p.U = c->U; p.ns = c->ns;
     const double th = c->cfg.contact_angle_deg / 180. * M_PI;
@@ -988,11 +1010,12 @@ CsfDev make_dev(const lbmpm_rk3dcsf *c)
 unsigned blocks_of(size_t n) { return (unsigned)((n + 255) / 256); }
 unsigned blocks8(size_t n) { return (blocks_of(n) + 7u) / 8u * 8u; }      // fluid_cell(): eight XCDs
 
+// stages: bit 0 lists, bulk collision, phase field | bit 1 solid phi, gradient | bit 2 collision of the full path (7: a whole step)
 template <bool FIRST>
-int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
+int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1, int stages = 7)
 {
     const unsigned g = blocks8((size_t)c->nfluid), gw = g < 4096u ? g : 4096u;        // (both multiples of 8)
-    if (c->skip) {
+    if (c->skip && (stages & 1)) {
         const unsigned nt = (c->nblk + 1023u) / 1024u;
         csf3d_tile_count<0><<<nt, 1024, 0, c->stream>>>(p, c->deep_now, c->tcnt);
         csf3d_tile_rank<0><<<nt, 1024, 0, c->stream>>>(p, c->deep_now, c->tcnt, c->pfx);
@@ -1002,7 +1025,7 @@ int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
     const bool mrt = c->cfg.relaxation == LBMPM_RELAX_MRT;
     const bool deep_launch = c->skip && !FIRST;      // (nothing is deep in the first step after a set_*)
     if (e0) LBMPM_HIP_TRY(hipEventRecord(e0, c->stream));
-    if (deep_launch) {
+    if (deep_launch && (stages & 1)) {
         // the deep blocks' collision reads the last step's populations and its own flags, and writes its own blocks only: it runs on a
         // second stream beside the four launches of the full path (small, latency-bound launches when most of the lattice is bulk)
         LBMPM_HIP_TRY(hipEventRecord(c->ev_lists, c->stream));
@@ -1011,12 +1034,16 @@ int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
         else { if (c->diag) csf3d_collide_deep<false, true><<<gw, 256, 0, c->stream2>>>(p); else csf3d_collide_deep<false, false><<<gw, 256, 0, c->stream2>>>(p); }
         LBMPM_HIP_TRY(hipEventRecord(c->ev_deep, c->stream2));
     }
-    csf3d_phase<FIRST><<<gw, 256, 0, c->stream>>>(p);
-    if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist, c->wethome);
-    csf3d_gradient<<<gw, 256, 0, c->stream>>>(p);
-    if (mrt) { if (c->diag) csf3d_collide<FIRST, true, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, true, false><<<gw, 256, 0, c->stream>>>(p); }
-    else { if (c->diag) csf3d_collide<FIRST, false, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, false, false><<<gw, 256, 0, c->stream>>>(p); }
-    if (deep_launch) LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_deep, 0));
+    if (stages & 1) csf3d_phase<FIRST><<<gw, 256, 0, c->stream>>>(p);
+    if (stages & 2) {
+        if (c->nwet) csf3d_solid_phi<<<blocks_of(c->nwet), 256, 0, c->stream>>>(p, c->wetlist, c->wethome);
+        csf3d_gradient<<<gw, 256, 0, c->stream>>>(p);
+    }
+    if (stages & 4) {
+        if (mrt) { if (c->diag) csf3d_collide<FIRST, true, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, true, false><<<gw, 256, 0, c->stream>>>(p); }
+        else { if (c->diag) csf3d_collide<FIRST, false, true><<<gw, 256, 0, c->stream>>>(p); else csf3d_collide<FIRST, false, false><<<gw, 256, 0, c->stream>>>(p); }
+        if (deep_launch) LBMPM_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_deep, 0));
+    }
     if (e1) LBMPM_HIP_TRY(hipEventRecord(e1, c->stream));
     LBMPM_HIP_TRY(hipGetLastError());
     return LBMPM_OK;
@@ -1025,6 +1052,7 @@ int launch_step(lbmpm_rk3dcsf *c, const CsfDev &p, hipEvent_t e0, hipEvent_t e1)
 int run_steps(lbmpm_rk3dcsf *c, int64_t nsteps, bool timed)
 {
     if (!c->have_state) { set_error("lbmpm_rk3dcsf_step before set_macro / set_pdf"); return LBMPM_ERR_STATE; }
+    if (c->cfg.ghost_lo || c->cfg.ghost_hi) { set_error("lbmpm_rk3dcsf_step: a slab with ghost planes steps by lbmpm_rk3dcsf_stage, the face messages in between"); return LBMPM_ERR_STATE; }
     for (int64_t s = 0; s < nsteps; ++s) {
         const CsfDev p = make_dev(c);
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1057,6 +1085,7 @@ extern "C" void lbmpm_rk3dcsf_destroy(lbmpm_rk3dcsf *c)
     c->pool.destroy();
     if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
     if (c->ev_deep) (void)hipEventDestroy(c->ev_deep);
+    for (hipEvent_t e : {c->ev_stage, c->ev_sent[0], c->ev_sent[1]}) if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1081,33 +1110,55 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
     LBMPM_REQUIRE(cfg->wetting_type == 2 || cfg->wetting_type == 0, "WettingType must be 2 (or 0: no correction at the walls)");
     LBMPM_REQUIRE(cfg->variant == 0 || cfg->variant == 1, "variant must be 0 or 1");
     LBMPM_REQUIRE(cfg->bulk_epsilon >= 0. && cfg->bulk_epsilon <= 1.0e-3, "bulk_epsilon must lie in [0, 1e-3]");
+    const bool slab = cfg->ghost_lo != 0 || cfg->ghost_hi != 0;
+    LBMPM_REQUIRE(!slab || (cfg->ghost_lo == 2 && cfg->ghost_hi == 2), "ghost_lo, ghost_hi must be 0, 0 (the undivided lattice) or 2, 2 (a slab)");
+    LBMPM_REQUIRE(cfg->nz - cfg->ghost_lo - cfg->ghost_hi >= 4, "lbmpm_rk3dcsf_create: a slab keeps at least 4 planes of its own between its ghost planes");
+    const int64_t own_nz = cfg->nz - cfg->ghost_lo - cfg->ghost_hi;
+    LBMPM_REQUIRE(!slab || (cfg->slab_z0 >= 0 && cfg->slab_z0 + own_nz <= cfg->global_nz && cfg->global_nz >= 8 && own_nz < cfg->global_nz),
+                  "lbmpm_rk3dcsf_create: slab_z0 %lld + %lld planes of its own within global_nz %lld", (long long)cfg->slab_z0, (long long)own_nz, (long long)cfg->global_nz);
+    const int64_t zoff = slab ? cfg->slab_z0 - cfg->ghost_lo : 0, nzg = slab ? cfg->global_nz : cfg->nz;
     const size_t pl = (size_t)cfg->nx * cfg->ny, N = pl * (size_t)cfg->nz;
     // the ghost planes copy the plane next to them cell by cell (the reference's kernels take the neighbour's index without looking)
     auto same = [&](int64_t za, int64_t zb) {
         for (size_t k = 0; k < pl; ++k) if ((is_domain[za * pl + k] == 1) != (is_domain[zb * pl + k] == 1)) return false;
         return true;
     };
-    LBMPM_REQUIRE(same(cfg->nz - 1, cfg->nz - 2), "lbmpm_rk3dcsf_create: the ghost plane nz-1 must have the mask of the inlet plane nz-2");
-    if (cfg->outlet_type == LBMPM_OUTLET_CONVECTIVE)
-        LBMPM_REQUIRE(same(0, 3) && same(1, 3) && same(2, 3), "lbmpm_rk3dcsf_create: the convective outlet copies plane 3 onto the planes 2, 1, 0: their masks must coincide");
-    else
-        LBMPM_REQUIRE(same(0, 1), "lbmpm_rk3dcsf_create: the ghost plane 0 must have the mask of the outlet plane 1");
+    // (planes of the undivided lattice; a slab checks the ones it owns: the open planes and the planes they copy lie in one slab, >= 4 planes)
+    auto owns = [&](int64_t zg) { return zg - zoff >= cfg->ghost_lo && zg - zoff < cfg->nz - cfg->ghost_hi; };
+    if (owns(nzg - 1)) {
+        LBMPM_REQUIRE(owns(nzg - 2), "lbmpm_rk3dcsf_create: the inlet plane and its ghost plane belong to one slab");
+        LBMPM_REQUIRE(same(nzg - 1 - zoff, nzg - 2 - zoff), "lbmpm_rk3dcsf_create: the ghost plane nz-1 must have the mask of the inlet plane nz-2");
+    }
+    if (owns(0)) {
+        if (cfg->outlet_type == LBMPM_OUTLET_CONVECTIVE) {
+            LBMPM_REQUIRE(owns(3), "lbmpm_rk3dcsf_create: the planes 0 .. 3 of the convective outlet belong to one slab");
+            LBMPM_REQUIRE(same(0 - zoff, 3 - zoff) && same(1 - zoff, 3 - zoff) && same(2 - zoff, 3 - zoff), "lbmpm_rk3dcsf_create: the convective outlet copies plane 3 onto the planes 2, 1, 0: their masks must coincide");
+        } else {
+            LBMPM_REQUIRE(owns(1), "lbmpm_rk3dcsf_create: the outlet plane and its ghost plane belong to one slab");
+            LBMPM_REQUIRE(same(0 - zoff, 1 - zoff), "lbmpm_rk3dcsf_create: the ghost plane 0 must have the mask of the outlet plane 1");
+        }
+    }
     LBMPM_HIP_TRY(hipSetDevice(cfg->device));
     lbmpm_rk3dcsf *c = new (std::nothrow) lbmpm_rk3dcsf();
     if (!c) { set_error("out of host memory"); return LBMPM_ERR_NOMEM; }
     c->cfg = *cfg;
     c->nx = (int)cfg->nx; c->ny = (int)cfg->ny; c->nz = (int)cfg->nz;
+    c->zoff = (int)zoff; c->nzg = (int)nzg;
     c->N = N; c->NS = (N + 15) / 16 * 16;
     // the populations are kept for fluid cells only, numbered in lattice order (a dense layout streams the solid cells of every
     // 128-byte line that holds a fluid cell: counted 1.5 x the bytes on the bench's porous medium)
     std::vector<uint32_t> hidx, hcells;
     try { hidx.resize(N); hcells.reserve(N); }
     catch (const std::bad_alloc &) { set_error("lbmpm_rk3dcsf_create: out of host memory (8 bytes per lattice cell for the set-up tables)"); delete c; return LBMPM_ERR_NOMEM; }
+    try { c->pfirst.assign((size_t)cfg->nz + 1, 0u); }
+    catch (const std::bad_alloc &) { set_error("lbmpm_rk3dcsf_create: out of host memory"); delete c; return LBMPM_ERR_NOMEM; }
     for (size_t k = 0; k < N; ++k) {
+        if (k % pl == 0) c->pfirst[k / pl] = (uint32_t)hcells.size();
         const bool fl = is_domain[k] == 1;
         hidx[k] = fl ? (uint32_t)hcells.size() : 0xFFFFFFFFu;
         if (fl) hcells.push_back((uint32_t)k);
     }
+    c->pfirst[(size_t)cfg->nz] = (uint32_t)hcells.size();
     c->nfluid = (int64_t)hcells.size();
     c->FS = ((size_t)c->nfluid + 15) / 16 * 16;
     // 38 planes a power of two apart would sit in the same HBM channels and cache sets cell by cell: an odd stride
@@ -1117,7 +1168,8 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
         const hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return LBMPM_ERR_HIP; }
         if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_lists, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_deep, hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate / hipEventCreate failed"); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; }
+            hipEventCreateWithFlags(&c->ev_deep, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_sent[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_sent[1], hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate / hipEventCreate failed"); lbmpm_rk3dcsf_destroy(c); return LBMPM_ERR_HIP; }
     }
     int rc = LBMPM_OK;
 #define TRY_RC(e) do { rc = (e); if (rc != LBMPM_OK) { lbmpm_rk3dcsf_destroy(c); return rc; } } while (0)
@@ -1250,7 +1302,7 @@ static int reset_state(lbmpm_rk3dcsf *c, const double *fx, const double *fy, con
     LBMPM_HIP_TRY(hipMemsetAsync(c->pure, 0, c->nblk, c->stream));          // nothing is known about the new state: the first step takes the full path
     LBMPM_HIP_TRY(hipMemsetAsync(c->deep_prev, 0, c->nblk, c->stream));
     LBMPM_HIP_TRY(hipStreamSynchronize(c->stream));
-    c->first = true; c->have_state = true; c->steps = 0; c->diag_valid = false;
+    c->first = true; c->have_state = true; c->steps = 0; c->diag_valid = false; c->next_stage = 0;
     return LBMPM_OK;
 }
 
@@ -1292,6 +1344,118 @@ extern "C" int lbmpm_rk3dcsf_step(lbmpm_rk3dcsf *c, int64_t nsteps)
     LBMPM_REQUIRE(c && nsteps >= 0, "lbmpm_rk3dcsf_step: bad argument");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     return run_steps(c, nsteps, false);
+}
+
+extern "C" int lbmpm_rk3dcsf_stage(lbmpm_rk3dcsf *c, int stage)
+{
+    LBMPM_REQUIRE(c, "null context");
+    LBMPM_REQUIRE(stage >= 0 && stage <= 2, "lbmpm_rk3dcsf_stage: stage %d", stage);
+    if (!c->have_state) { set_error("lbmpm_rk3dcsf_stage before set_macro / set_pdf"); return LBMPM_ERR_STATE; }
+    if (stage != c->next_stage) { set_error("lbmpm_rk3dcsf_stage: stage %d is next, not %d", c->next_stage, stage); return LBMPM_ERR_STATE; }
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    const CsfDev p = make_dev(c);
+    const int rc = c->first ? launch_step<true>(c, p, nullptr, nullptr, 1 << stage) : launch_step<false>(c, p, nullptr, nullptr, 1 << stage);
+    if (rc != LBMPM_OK) return rc;
+    if (stage == 2) {
+        std::swap(c->fA, c->fB);
+        c->first = false;
+        ++c->steps;
+        c->diag_valid = c->diag;
+    }
+    c->next_stage = (stage + 1) % 3;
+    LBMPM_HIP_TRY(hipEventRecord(c->ev_stage, c->stream));
+    return LBMPM_OK;
+}
+
+namespace {
+// A face message as runs of doubles inside the context's arrays: what this context SENDS through `face` (recv = false: its edge planes)
+// or where what comes through `face` lands (recv = true: its ghost planes).  The two sides list their runs in the same order.
+struct Run { double *ptr; size_t count; };
+int face_runs(lbmpm_rk3dcsf *c, int msg, int face, bool recv, Run runs[10])
+{
+    const int g = face == 0 ? c->cfg.ghost_lo : c->cfg.ghost_hi;
+    if (g == 0) return 0;
+    const size_t pl = (size_t)c->nx * c->ny;
+    const int lo = c->cfg.ghost_lo, top = c->nz - c->cfg.ghost_hi;       // own planes: lo .. top - 1
+    if (msg == LBMPM_CSF_MSG_PDF) {
+        // the populations that cross the face, of the plane next to it: moving down (c_z < 0) through the low face, up through the high one;
+        // the receiver pulls them out of its first ghost plane.  Fluid cells of a plane are one stretch of every population plane.
+        static const int DN[5] = {6, 12, 13, 16, 17}, UP[5] = {5, 11, 14, 15, 18};
+        const int z = face == 0 ? (recv ? lo - 1 : lo) : (recv ? top : top - 1);
+        const int *dir = (face == 0) != recv ? DN : UP;      // sent through the low face: down; received through the low face: up
+        const size_t first = c->pfirst[(size_t)z], count = c->pfirst[(size_t)z + 1] - first;
+        for (int col = 0; col < 2; ++col)
+            for (int a = 0; a < 5; ++a) runs[col * 5 + a] = Run{c->fA + ((size_t)col * Q + (size_t)dir[a]) * c->FS + first, count};
+        return 10;
+    }
+    if (msg == LBMPM_CSF_MSG_PHI) {              // two planes, ascending z on both sides
+        const int z = face == 0 ? (recv ? 0 : lo) : (recv ? top : top - 2);
+        runs[0] = Run{c->phi + (size_t)z * pl, 2 * pl};
+        return 1;
+    }
+    const int z = face == 0 ? (recv ? lo - 1 : lo) : (recv ? top : top - 1);
+    for (int a = 0; a < 3; ++a) runs[a] = Run{c->nh + (size_t)a * c->NS + (size_t)z * pl, pl};
+    return 3;
+}
+bool msg_ok(int msg, int face) { return msg >= 0 && msg <= 2 && (face == 0 || face == 1); }
+}  // namespace
+
+static int64_t face_total(const lbmpm_rk3dcsf *c, int msg, int face, bool recv)
+{
+    if (!c || !msg_ok(msg, face)) return 0;
+    Run runs[10];
+    const int n = face_runs(const_cast<lbmpm_rk3dcsf *>(c), msg, face, recv, runs);
+    int64_t t = 0;
+    for (int k = 0; k < n; ++k) t += (int64_t)runs[k].count;
+    return t;
+}
+extern "C" int64_t lbmpm_rk3dcsf_face_doubles(const lbmpm_rk3dcsf *c, int msg, int face) { return face_total(c, msg, face, false); }
+extern "C" int64_t lbmpm_rk3dcsf_face_doubles_in(const lbmpm_rk3dcsf *c, int msg, int face) { return face_total(c, msg, face, true); }
+
+extern "C" int lbmpm_rk3dcsf_face_pack(lbmpm_rk3dcsf *c, int msg, int face, double *buf)
+{
+    LBMPM_REQUIRE(c && buf && msg_ok(msg, face), "lbmpm_rk3dcsf_face_pack: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    Run runs[10];
+    const int n = face_runs(c, msg, face, false, runs);
+    for (int k = 0; k < n; ++k) {
+        if (runs[k].count) LBMPM_HIP_TRY(hipMemcpyAsync(buf, runs[k].ptr, runs[k].count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        buf += runs[k].count;
+    }
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3dcsf_face_unpack(lbmpm_rk3dcsf *c, int msg, int face, const double *buf)
+{
+    LBMPM_REQUIRE(c && buf && msg_ok(msg, face), "lbmpm_rk3dcsf_face_unpack: bad argument");
+    LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    Run runs[10];
+    const int n = face_runs(c, msg, face, true, runs);
+    for (int k = 0; k < n; ++k) {
+        if (runs[k].count) LBMPM_HIP_TRY(hipMemcpyAsync(runs[k].ptr, buf, runs[k].count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        buf += runs[k].count;
+    }
+    return LBMPM_OK;
+}
+
+extern "C" int lbmpm_rk3dcsf_face_copy(lbmpm_rk3dcsf *src, int src_face, lbmpm_rk3dcsf *dst, int msg)
+{
+    LBMPM_REQUIRE(src && dst && src != dst && msg_ok(msg, src_face), "lbmpm_rk3dcsf_face_copy: bad argument");
+    Run out[10], in[10];
+    const int n = face_runs(src, msg, src_face, false, out), m = face_runs(dst, msg, 1 - src_face, true, in);
+    if (n == 0 || n != m) { set_error("lbmpm_rk3dcsf_face_copy: the two contexts do not share that face"); return LBMPM_ERR_INVALID; }
+    for (int k = 0; k < n; ++k)
+        if (out[k].count != in[k].count) { set_error("lbmpm_rk3dcsf_face_copy: the masks of the two sides of the face differ (%zu / %zu cells)", out[k].count, in[k].count); return LBMPM_ERR_INVALID; }
+    // on the sender's stream, once the receiver's last stage (which may read the planes written here) has run; the receiver's stream then waits
+    LBMPM_HIP_TRY(hipSetDevice(src->cfg.device));
+    LBMPM_HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_stage, 0));
+    for (int k = 0; k < n; ++k)
+        if (out[k].count) LBMPM_HIP_TRY(hipMemcpyAsync(in[k].ptr, out[k].ptr, out[k].count * sizeof(double), hipMemcpyDefault, src->stream));
+    LBMPM_HIP_TRY(hipEventRecord(src->ev_sent[src_face], src->stream));
+    LBMPM_HIP_TRY(hipSetDevice(dst->cfg.device));
+    LBMPM_HIP_TRY(hipStreamWaitEvent(dst->stream, src->ev_sent[src_face], 0));
+    // (the sender's next stage must not overwrite its planes before the copy has run: it is queued behind it on the same stream)
+    return LBMPM_OK;
 }
 
 extern "C" int lbmpm_rk3dcsf_step_timed(lbmpm_rk3dcsf *c, int64_t nsteps, double *ms_total, double *ms_dominant)

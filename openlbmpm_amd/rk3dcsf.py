@@ -25,7 +25,10 @@ def _f64(a):
 
 
 class RK3DCSFSolver:
-    def __init__(self, is_domain, params=None, device=0, diagnostics=False):
+    def __init__(self, is_domain, params=None, device=0, diagnostics=False, slab=None):
+        """slab = (z0, global_nz): this lattice is a slab of an undivided lattice of global_nz planes -- its planes 2 .. nz-3 are the planes
+        z0 .. of that lattice, its two planes at either end images of the neighbouring slabs' edge planes (cut from the undivided lattice,
+        wrapping around its ends, like the rest)"""
         L = _lib.lib()
         p = dict(DEFAULT_PARAMS)
         p.update(params or {})
@@ -59,6 +62,10 @@ class RK3DCSFSolver:
         cfg.device = int(device)
         cfg.variant = int(p["variant"])        # 1: no bulk skip (cross-check)
         cfg.bulk_epsilon = float(p["bulk_epsilon"])      # 0: exact (2^-51); opt-in: cut a colour's tail below this fraction of the density
+        self.ghost = (GHOST, GHOST) if slab else (0, 0)
+        cfg.ghost_lo, cfg.ghost_hi = self.ghost
+        if slab:
+            cfg.slab_z0, cfg.global_nz = int(slab[0]), int(slab[1])
         if p["rates"] is not None:
             if len(p["rates"]) != 6:
                 raise ValueError("rates = (s_e, s_eps, s_q, s_pi, s_m, rate of the conserved moments)")
@@ -110,6 +117,26 @@ class RK3DCSFSolver:
     def step(self, nsteps=1):
         check(self._L.lbmpm_rk3dcsf_step(self._h, int(nsteps)), "lbmpm_rk3dcsf_step")
 
+    def stage(self, k):
+        """a third of a step (0 phase field, 1 gradient, 2 collision); the face messages go in between (include/lbmpm.h)"""
+        check(self._L.lbmpm_rk3dcsf_stage(self._h, int(k)), "lbmpm_rk3dcsf_stage")
+
+    def face_doubles(self, msg, face):
+        return int(self._L.lbmpm_rk3dcsf_face_doubles(self._h, int(msg), int(face)))
+
+    def face_doubles_in(self, msg, face):
+        return int(self._L.lbmpm_rk3dcsf_face_doubles_in(self._h, int(msg), int(face)))
+
+    def face_pack(self, msg, face, device_ptr):
+        check(self._L.lbmpm_rk3dcsf_face_pack(self._h, int(msg), int(face), C.c_void_p(int(device_ptr))), "lbmpm_rk3dcsf_face_pack")
+
+    def face_unpack(self, msg, face, device_ptr):
+        check(self._L.lbmpm_rk3dcsf_face_unpack(self._h, int(msg), int(face), C.c_void_p(int(device_ptr))), "lbmpm_rk3dcsf_face_unpack")
+
+    def send_to(self, face, other, msg):
+        """same process: this slab's message through `face` into the ghost planes of the slab on the other side"""
+        check(self._L.lbmpm_rk3dcsf_face_copy(self._h, int(face), other._h, int(msg)), "lbmpm_rk3dcsf_face_copy")
+
     def step_timed(self, nsteps):
         """(ms_total, ms of the csf3d_collide launches) by HIP events on the solver's stream"""
         a, b = C.c_double(0), C.c_double(0)
@@ -148,3 +175,213 @@ class RK3DCSFSolver:
     @property
     def dominant_kernel(self):
         return self._L.lbmpm_rk3dcsf_dominant_kernel(self._h).decode()
+
+
+MSG_PDF, MSG_PHI, MSG_NORMAL = 0, 1, 2        # LBMPM_CSF_MSG_*
+_AFTER_STAGE = (MSG_PHI, MSG_NORMAL, MSG_PDF)  # the message that follows stage 0, 1, 2
+GHOST = 2
+
+
+def slab_cuts(nz, nslabs, weights=None):
+    """z0 of every slab + nz: equal shares of the planes (or of `weights`, one number per plane), at least 4 planes each"""
+    nslabs = int(nslabs)
+    if nslabs < 1 or nz < 4 * nslabs:
+        raise ValueError("%d planes do not make %d slabs of at least 4" % (nz, nslabs))
+    w = np.ones(nz) if weights is None else np.asarray(weights, dtype=np.float64)
+    acc = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for k in range(1, nslabs):
+        z = int(np.searchsorted(acc, acc[-1] * k / nslabs))
+        cuts.append(min(max(z, cuts[-1] + 4), nz - 4 * (nslabs - k)))
+    return cuts + [nz]
+
+
+class _SlabGeometry:
+    """the planes [z0, z1) of a lattice [nz][ny][nx] with the two ghost planes a slab of the CSF model carries at either end (the slabs
+    form a ring: the loop wraps z, so the first slab's low neighbour is the last slab)"""
+
+    def __init__(self, nz, z0, z1):
+        self.nz, self.z0, self.z1 = int(nz), int(z0), int(z1)
+        self.whole = self.z0 == 0 and self.z1 == self.nz
+        self.ghost = (0, 0) if self.whole else (GHOST, GHOST)
+        self.planes = np.arange(self.z0 - self.ghost[0], self.z1 + self.ghost[1]) % self.nz
+        self.slab = None if self.whole else (self.z0, self.nz)
+
+    def cut(self, a):
+        return None if a is None else np.ascontiguousarray(np.take(a, self.planes, axis=0))
+
+    def own(self, a):
+        return a[self.ghost[0]:a.shape[0] - self.ghost[1]]
+
+
+class RK3DCSFCluster:
+    """The 3-D CSF model cut into slabs along z, every slab a context of its own (devices[k]; all on one GPU: a rehearsal of the
+    decomposition, bit-equal to the undivided lattice).  One time step = three stages with a face message after each: phi (two planes),
+    n (one plane), the populations crossing the face (lbmpm_rk3dcsf_stage / _face_copy)."""
+
+    def __init__(self, is_domain, params=None, nslabs=2, devices=None, cuts=None, diagnostics=False):
+        dom = np.ascontiguousarray(is_domain, dtype=np.uint8)
+        self.shape = dom.shape
+        self.nz, self.ny, self.nx = dom.shape
+        self.cuts = list(cuts) if cuts is not None else slab_cuts(self.nz, nslabs)
+        n = len(self.cuts) - 1
+        devices = list(devices) if devices is not None else [0] * n
+        self.geo = [_SlabGeometry(self.nz, self.cuts[k], self.cuts[k + 1]) for k in range(n)]
+        self.slabs = [RK3DCSFSolver(g.cut(dom), params, device=devices[k], diagnostics=diagnostics, slab=g.slab) for k, g in enumerate(self.geo)]
+        self.params = self.slabs[0].params
+
+    def close(self):
+        for s in self.slabs:
+            s.close()
+
+    def set_macro(self, rhoR, rhoB, vx=None, vy=None, vz=None):
+        for s, g in zip(self.slabs, self.geo):
+            s.set_macro(*[g.cut(None if a is None else np.asarray(a, dtype=np.float64)) for a in (rhoR, rhoB, vx, vy, vz)])
+
+    def set_pdf(self, fR, fB, force=None):
+        for s, g in zip(self.slabs, self.geo):
+            s.set_pdf(g.cut(np.asarray(fR)), g.cut(np.asarray(fB)), None if force is None else tuple(g.cut(np.asarray(c)) for c in force))
+
+    def _exchange(self, msg):
+        n = len(self.slabs)
+        for k in range(n):                         # a ring: the last slab's high face is the first slab's low face
+            up = self.slabs[(k + 1) % n]
+            self.slabs[k].send_to(1, up, msg)
+            up.send_to(0, self.slabs[k], msg)
+
+    def step(self, nsteps=1):
+        if len(self.slabs) == 1:
+            return self.slabs[0].step(nsteps)
+        for _ in range(int(nsteps)):
+            for stage in range(3):
+                for s in self.slabs:
+                    s.stage(stage)
+                self._exchange(_AFTER_STAGE[stage])
+
+    def sync(self):
+        for s in self.slabs:
+            s.sync()
+
+    def get(self, name):
+        return np.concatenate([g.own(s.get(name)) for s, g in zip(self.slabs, self.geo)], axis=0)
+
+    num_fluid_nodes = property(lambda self: int(self.is_fluid_total))
+    steps_done = property(lambda self: self.slabs[0].steps_done)
+    dominant_kernel = property(lambda self: self.slabs[0].dominant_kernel)
+
+    @property
+    def is_fluid_total(self):
+        return sum(int((g.own(s.is_domain) == 1).sum()) for s, g in zip(self.slabs, self.geo))
+
+    @property
+    def bulk_cells(self):
+        return sum(s.bulk_cells for s in self.slabs)
+
+
+class RK3DCSFDistributed:
+    """One slab of the 3-D CSF model per rank of torch.distributed (launch: one process per GPU).  The face messages travel as device
+    tensors under the nccl (= RCCL) backend and through host memory under gloo; three per step and face (phi, n, populations: 2 + 3 +
+    10 doubles per cell of a plane), batched per stage."""
+
+    def __init__(self, is_domain, params=None, device=0, cuts=None, diagnostics=False):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        dom = np.ascontiguousarray(is_domain, dtype=np.uint8)
+        self.shape = dom.shape
+        self.nz = dom.shape[0]
+        self.cuts = list(cuts) if cuts is not None else slab_cuts(self.nz, self.world)
+        if len(self.cuts) != self.world + 1:
+            raise ValueError("one slab per rank: %d cuts for %d ranks" % (len(self.cuts) - 1, self.world))
+        self.geo = _SlabGeometry(self.nz, self.cuts[self.rank], self.cuts[self.rank + 1])
+        self.z0, self.nzl = self.geo.z0, self.geo.z1 - self.geo.z0
+        self.slab = RK3DCSFSolver(self.geo.cut(dom), params, device=device, diagnostics=diagnostics, slab=self.geo.slab)
+        self.params = self.slab.params
+        self._on_device = dist.get_backend() == "nccl"
+        dev = self._dev = torch.device("cuda", int(device))
+        self._buf = {}
+        for face in (0, 1):
+            if self.geo.ghost[face]:
+                for msg in (MSG_PDF, MSG_PHI, MSG_NORMAL):
+                    n, m = self.slab.face_doubles(msg, face), self.slab.face_doubles_in(msg, face)
+                    self._buf[(msg, face)] = (torch.empty(n, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.float64, device=dev))
+        # every rank cuts its slab out of the same undivided lattice
+        import zlib
+        mine = torch.tensor([zlib.crc32(dom.tobytes()), dom.shape[0], dom.shape[1], dom.shape[2]] + self.cuts, dtype=torch.int64)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        if self._on_device:
+            every = [t.to(dev) for t in every]
+            mine = mine.to(dev)
+        dist.all_gather(every, mine)
+        for r in range(self.world):
+            if not bool((every[r] == mine).all()):
+                raise ValueError("rank %d holds another lattice or other cuts than rank %d" % (r, self.rank))
+
+    def close(self):
+        self.slab.close()
+
+    def _exchange(self, msg):
+        torch, dist = self._torch, self._dist
+        if self.world == 1:
+            return
+        lo_peer, hi_peer = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        for face in (0, 1):
+            self.slab.face_pack(msg, face, self._buf[(msg, face)][0].data_ptr())
+        self.slab.sync()
+        staged = []
+        if self._on_device:
+            # (no tags under NCCL: between two ranks the messages pair up in the order posted -- with two ranks both faces join the same
+            # pair, so every rank sends low, high and receives high, low: the peer's low-face message is what arrives through my high face)
+            ops = [dist.P2POp(dist.isend, self._buf[(msg, 0)][0], lo_peer), dist.P2POp(dist.isend, self._buf[(msg, 1)][0], hi_peer),
+                   dist.P2POp(dist.irecv, self._buf[(msg, 1)][1], hi_peer), dist.P2POp(dist.irecv, self._buf[(msg, 0)][1], lo_peer)]
+            reqs = dist.batch_isend_irecv(ops)
+        else:
+            reqs = []
+            for face, peer in ((0, lo_peer), (1, hi_peer)):
+                out, inn = self._buf[(msg, face)]
+                o = out.cpu()
+                i = torch.empty(inn.shape, dtype=inn.dtype)
+                staged.append((inn, i))
+                # tag = the face of the RECEIVER the message enters through
+                reqs += [dist.isend(o, peer, tag=1 - face), dist.irecv(i, peer, tag=face)]
+        for w in reqs:
+            w.wait()
+        for inn, i in staged:
+            inn.copy_(i)
+        torch.cuda.synchronize(self._dev)        # the messages are in the buffers before the library's stream takes them
+        for face in (0, 1):
+            self.slab.face_unpack(msg, face, self._buf[(msg, face)][1].data_ptr())
+
+    def set_macro(self, rhoR, rhoB, vx=None, vy=None, vz=None):
+        """the undivided arrays [nz][ny][nx]; every rank takes its planes"""
+        self.slab.set_macro(*[self.geo.cut(None if a is None else np.asarray(a, dtype=np.float64)) for a in (rhoR, rhoB, vx, vy, vz)])
+
+    def set_pdf(self, fR, fB, force=None):
+        self.slab.set_pdf(self.geo.cut(np.asarray(fR)), self.geo.cut(np.asarray(fB)),
+                          None if force is None else tuple(self.geo.cut(np.asarray(c)) for c in force))
+
+    def step(self, nsteps=1):
+        if self.world == 1:
+            return self.slab.step(nsteps)
+        for _ in range(int(nsteps)):
+            for stage in range(3):
+                self.slab.stage(stage)
+                self._exchange(_AFTER_STAGE[stage])
+
+    def sync(self):
+        self.slab.sync()
+
+    def get(self, name):
+        """this rank's own planes"""
+        return np.ascontiguousarray(self.geo.own(self.slab.get(name)))
+
+    def gather(self, a):
+        """rank 0: the ranks' planes stacked along z (None elsewhere)"""
+        parts = [None] * self.world if self.rank == 0 else None
+        self._dist.gather_object(np.ascontiguousarray(a), parts, dst=0)
+        return np.concatenate(parts, axis=0) if self.rank == 0 else None
+
+    num_fluid_nodes = property(lambda self: int((self.geo.own(self.slab.is_domain) == 1).sum()))
+    steps_done = property(lambda self: self.slab.steps_done)
+    dominant_kernel = property(lambda self: self.slab.dominant_kernel)

@@ -399,3 +399,132 @@ def test_the_opt_in_cut_of_a_colours_tail(eps, bound):
     assert a.bulk_cells >= b.bulk_cells, (a.bulk_cells, b.bulk_cells, n)
     print("bulk_epsilon %g: worst field error %.2e after 3000 steps; bulk share %.2f against %.2f with the exact rule" % (eps, worst, a.bulk_cells / n, b.bulk_cells / n))
     a.close(); b.close()
+
+
+# ------------------------------------------------------------------------------------------------ slabs along z
+_SLAB_FIELDS = ("fR", "fB", "rhoR", "rhoB", "phi", "Gx", "Gy", "Gz", "Fx", "Fy", "Fz", "K", "vx", "vy", "vz", "rec_rhoR", "rec_rhoB", "rec_vz", "rec_phi")
+
+
+def _slab_case(nx=22, ny=18, nz=44, seed=5):
+    """a duct with obstacles that cross the cuts, a slanted interface that crosses them too"""
+    from openlbmpm_amd.RKColorGradientD3Q19 import duct
+    rng = np.random.default_rng(seed)
+    dom = duct(nx, ny, nz)
+    for _ in range(7):
+        z, y, x = rng.integers(5, nz - 9), rng.integers(2, ny - 5), rng.integers(2, nx - 6)
+        dom[z:z + 4, y:y + 3, x:x + 4] = 0
+    zz, yy, xx = np.mgrid[0:nz, 0:ny, 0:nx]
+    fl = dom == 1
+    red = zz + 0.3 * xx - 0.2 * yy < 0.55 * nz
+    return dom, np.where(fl & red, 1.0, 0.0), np.where(fl & ~red, 1.0, 0.0)
+
+
+@pytest.mark.parametrize("nslabs,relax,over", [(2, "MRT", {}), (3, "SRT", {}), (3, "MRT", dict(outlet="Convective")),
+                                               (4, "MRT", dict(inlet="Dirichlet", densityBH=1.0, densityRH=1e-8)), (2, "SRT", dict(variant=1))])
+def test_slabs_along_z_equal_the_undivided_lattice(nslabs, relax, over):
+    """RK3DCSFCluster (one context per slab; two ghost planes at a shared face; phi, n, crossing populations as face messages between the
+    three stages of a step) leaves every field of the undivided lattice bit for bit, walls and the interface crossing the cuts"""
+    from openlbmpm_amd.rk3dcsf import RK3DCSFCluster
+    dom, rR, rB = _slab_case()
+    par = dict(relax=relax, theta=55.0, tauB=0.8, velocityZR=0.0, velocityZB=-3.0e-3, sigma=0.06); par.update(over)
+    a = solver(dom, par)
+    c = RK3DCSFCluster(dom, par, nslabs=nslabs, diagnostics=True)
+    assert c.num_fluid_nodes == a.num_fluid_nodes and len(c.slabs) == nslabs
+    a.set_macro(rR, rB); c.set_macro(rR, rB)
+    for k in (1, 2, 3, 25, 60):
+        a.step(k - a.steps_done); c.step(k - c.steps_done)
+        for f in _SLAB_FIELDS:
+            assert np.array_equal(a.get(f), c.get(f)), (k, f, float(np.max(np.abs(a.get(f) - c.get(f)))))
+    assert np.all(np.isfinite(a.get("vz"))) and np.abs(a.get("Fz")).max() > 0
+    # a restart across a different cut
+    d = RK3DCSFCluster(dom, par, cuts=[0, 9, 30, dom.shape[0]], diagnostics=True)
+    d.set_pdf(c.get("fR"), c.get("fB"), force=(c.get("Fx"), c.get("Fy"), c.get("Fz")))
+    a.step(20); d.step(20)
+    for f in _SLAB_FIELDS:
+        assert np.array_equal(a.get(f), d.get(f)), ("restart", f)
+    a.close(); c.close(); d.close()
+
+
+def test_slabs_keep_the_bulk_path_away_from_their_faces():
+    """the bulk skip inside slabs: exact (equal to the undivided lattice), and most of a slab's cells stay on it"""
+    from openlbmpm_amd.rk3dcsf import RK3DCSFCluster
+    from openlbmpm_amd.RKColorGradientD3Q19 import duct
+    dom = duct(34, 30, 160)
+    zz = np.mgrid[0:160, 0:30, 0:34][0]
+    fl = dom == 1
+    rR, rB = np.where(fl & (zz < 100), 1.0, 0.0), np.where(fl & (zz >= 100), 1.0, 0.0)
+    par = dict(relax="MRT", theta=60.0, tauB=0.8, velocityZR=0.0, velocityZB=-4.0e-3, sigma=0.05)
+    a = solver(dom, par); c = RK3DCSFCluster(dom, par, nslabs=2, diagnostics=True)
+    a.set_macro(rR, rB); c.set_macro(rR, rB)
+    for k in (2, 50, 120):
+        a.step(k - a.steps_done); c.step(k - c.steps_done)
+        for f in ("fR", "fB", "phi", "Gz", "Fz", "K", "vz"):
+            assert np.array_equal(a.get(f), c.get(f)), (k, f)
+        assert 0.6 * a.bulk_cells < c.bulk_cells <= a.bulk_cells, (k, a.bulk_cells, c.bulk_cells)
+    a.close(); c.close()
+
+
+def test_slab_refusals():
+    from openlbmpm_amd.rk3dcsf import RK3DCSFSolver, slab_cuts
+    from openlbmpm_amd._lib import LbmpmError, ERR_STATE, ERR_INVALID
+    dom, rR, rB = _slab_case()
+    nz, pl = dom.shape[0], dom.shape[1] * dom.shape[2]
+    planes = np.arange(-2, 20) % nz                  # the planes 0 .. 17 of its own, two images at either end (the ring: 42, 43 below plane 0)
+    s = RK3DCSFSolver(dom[planes], None, slab=(0, nz))
+    s.set_macro(rR[planes], rB[planes])
+    with pytest.raises(LbmpmError) as e:
+        s.step(1)                                  # a slab steps by stages
+    assert e.value.status == ERR_STATE
+    with pytest.raises(LbmpmError) as e:
+        s.stage(1)                                 # in order
+    assert e.value.status == ERR_STATE
+    assert s.face_doubles(1, 1) == 2 * pl and s.face_doubles(2, 0) == 3 * pl
+    assert s.face_doubles(0, 1) == 10 * int((dom[17] == 1).sum()) and s.face_doubles(0, 0) == 10 * int((dom[0] == 1).sum())
+    assert s.face_doubles_in(0, 1) == 10 * int((dom[18] == 1).sum()) and s.face_doubles_in(0, 0) == 10 * int((dom[nz - 1] == 1).sum())
+    s.close()
+    with pytest.raises(LbmpmError) as e:
+        RK3DCSFSolver(dom[np.arange(8, 15)], None, slab=(10, nz))  # fewer than 4 planes of its own
+    assert e.value.status == ERR_INVALID
+    with pytest.raises(LbmpmError) as e:
+        RK3DCSFSolver(dom[np.arange(nz - 7, nz + 3) % nz], None, slab=(nz - 5, nz))  # own planes beyond the undivided lattice
+    assert e.value.status == ERR_INVALID
+    with pytest.raises(ValueError):
+        slab_cuts(10, 3)
+    assert slab_cuts(44, 4) == [0, 11, 22, 33, 44]
+
+
+def test_two_processes_over_torch_distributed_equal_the_undivided_lattice(tmp_path):
+    """RK3DCSFDistributed: one slab per rank, the face messages through torch.distributed (gloo here: both ranks share the one GPU, the
+    messages pass through host memory; nccl = RCCL hands the device buffers over as they are)"""
+    import subprocess
+    import sys
+    from test_rk3d_gpu import _free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from test_rk3d_csf_gpu import _slab_case
+from openlbmpm_amd.rk3dcsf import RK3DCSFDistributed
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+dom, rR, rB = _slab_case()
+d = RK3DCSFDistributed(dom, dict(relax="MRT", theta=55.0, tauB=0.8, velocityZR=0.0, velocityZB=-3.0e-3, sigma=0.06), device=0)
+d.set_macro(rR, rB)
+d.step(30)
+for f in ("fR", "phi", "Fz", "rec_rhoB", "rec_vz"):
+    g = d.gather(d.get(f))
+    if dist.get_rank() == 0:
+        np.save(os.path.join(%r, f + ".npy"), g)
+d.close(); dist.destroy_process_group()
+''' % (root, root, str(tmp_path)))
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], timeout=300)
+    dom, rR, rB = _slab_case()
+    from openlbmpm_amd.rk3dcsf import RK3DCSFSolver
+    a = RK3DCSFSolver(dom, dict(relax="MRT", theta=55.0, tauB=0.8, velocityZR=0.0, velocityZB=-3.0e-3, sigma=0.06))
+    a.set_macro(rR, rB); a.step(30)
+    for f in ("fR", "phi", "Fz", "rec_rhoB", "rec_vz"):
+        assert np.array_equal(a.get(f), np.load(tmp_path / (f + ".npy"))), f
+    a.close()
