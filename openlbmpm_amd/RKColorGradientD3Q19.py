@@ -41,13 +41,15 @@ GROUPS = (("FluidMacro", "MacroData"), ("FluidPDF", "MicroData"), ("FluidVelocit
 class _CSFSlab:
     """RK3DCSFSolver behind the calls this driver makes on a slab of the perturbation model"""
 
-    def __init__(self, dom, par, device, bulk_epsilon=0.0):
-        from .rk3dcsf import RK3DCSFSolver
+    def __init__(self, dom, par, device, bulk_epsilon=0.0, distributed=False):
+        from .rk3dcsf import RK3DCSFSolver, RK3DCSFDistributed
         q = dict(sigma=par["sigma"], theta=par["theta"], wetting=par["wetting"], beta=par["beta"], delta=par["delta"], tauR=par["tauR"], tauB=par["tauB"],
                  tautype=par["tautype"], relax=par["relax"], inlet=par["inlet"], outlet=par["outlet"], velocityZR=par["velocityZR"],
                  velocityZB=par["velocityZB"], densityBH=par["densityBH"], densityRH=par["densityRH"], densityBL=par["densityBL"], densityRL=par["densityRL"],
                  bulk_epsilon=float(bulk_epsilon))
-        self.solver = RK3DCSFSolver(dom, q, device=device)
+        # distributed: one slab per rank; set_* take the undivided arrays (a slab cuts its planes and the images of its neighbours' out of
+        # them), get* return the rank's own planes
+        self.solver = RK3DCSFDistributed(dom, q, device=device) if distributed else RK3DCSFSolver(dom, q, device=device)
         self.step_single, self.sync, self.close = self.solver.step, self.solver.sync, self.solver.close
 
     num_fluid_nodes = property(lambda self: self.solver.num_fluid_nodes)
@@ -243,12 +245,20 @@ class RKColorGradient3D:
         par = {k: p[k] for k in PARAM_KEYS}
         name, rank = "SimulationResultsRK3D", 0
         self._gather = lambda a: a
+        whole_arrays = False          # distributed 3-D CSF: the slabs carry images of their neighbours' planes and cut them out of the undivided arrays
         if p["tension_type"] == "CSF":
-            if self._distributed():
-                raise config.ConfigError("SurfaceTensionType 'CSF' in 3-D runs on one GPU (the curvature reaches two cells: no slab decomposition of this model)")
-            slab = sim = _CSFSlab(self.isDomain, p, self.device, self.csf_bulk_epsilon)
+            whole_arrays = self._distributed()
+            slab = sim = _CSFSlab(self.isDomain, p, self.device, self.csf_bulk_epsilon, distributed=whole_arrays)
             step, observe = slab.step_single, (lambda: None)
             self.z0, self.nzl = 0, self.zDomain
+            if whole_arrays:
+                import torch.distributed as dist
+                rank = dist.get_rank()
+                self.z0, self.nzl = sim.solver.z0, sim.solver.nzl
+                if self.gather_records:
+                    self._gather = sim.solver.gather
+                else:
+                    name += "_rank%d" % rank
         elif self._distributed():
             import torch.distributed as dist
             rank = dist.get_rank()
@@ -274,10 +284,11 @@ class RKColorGradient3D:
             self.z0, self.nzl = 0, self.zDomain
         self._slab, self._observe = slab, observe
         done = 0
+        z0, nzl = (0, self.zDomain) if whole_arrays else (self.z0, self.nzl)
         if self.restart_from:
-            done, self.records = self._load_checkpoint(slab, self.z0, self.nzl)
+            done, self.records = self._load_checkpoint(slab, z0, nzl)
         else:
-            self.initializeDomainCondition(self.z0, self.nzl)
+            self.initializeDomainCondition(z0, nzl)
             self._upload_initial_state(slab)
         writes = rank == 0 or not (self._distributed() and self.gather_records)
         out = ResultFile(self.output_dir, name, GROUPS) if writes else None

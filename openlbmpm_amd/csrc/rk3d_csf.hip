@@ -300,15 +300,15 @@ __global__ __launch_bounds__(256) void csf3d_solid_phi(CsfDev p, const uint32_t 
     constexpr int CX[Q] = CSF_CX, CY[Q] = CSF_CY, CZ[Q] = CSF_CZ;
     const unsigned k = blockIdx.x * 256u + threadIdx.x;
     if (k >= (unsigned)p.nwet) return;
-    if (p.skip) {
-        const unsigned hb = wethome[k];
-        const uint8_t d = p.deep_now[hb];
-        if (d != 0 && p.deep_prev[hb] == d) return;
-    }
     const unsigned n = wetlist[k];
     int x, y, z;
     cell_of(p, n, x, y, z);
     if ((p.glo && z < 1) || (p.ghi && z > p.nz - 2)) return;       // the outer ghost plane's walls: their neighbours are not all here, nobody reads them
+    if (p.skip && z >= p.glo && z < p.nz - p.ghi) {                // (the phi message overwrites the ghost planes' walls with the sender's values of the step before)
+        const unsigned hb = wethome[k];
+        const uint8_t d = p.deep_now[hb];
+        if (d != 0 && p.deep_prev[hb] == d) return;
+    }
     const Nb nb = make_nb(p, x, y, z);
     const uint32_t m = p.meta[n];
     double sum = 0., sw = 0.;
@@ -569,7 +569,9 @@ __global__ __launch_bounds__(256, MRT ? CSF_MRT_WAVES : 3) void csf3d_collide(Cs
     }   // active
     if (p.skip) {                                // what the block hands on, for the next step's deep_colour
         const int allr = __syncthreads_and(only_red), allb = __syncthreads_and(only_blue);
-        if (threadIdx.x == 0) { p.pure[blk] = (p.bcblk[blk] & 2) ? 0 : (allr ? 1 : (allb ? 2 : 0)); p.deep_prev[blk] = 0; }      // (bit 1: ghost cells, whose colours this slab does not know)
+        // (a block that holds ghost cells: what its own cells allow, bit 0 red / bit 1 blue -- both if it has none; the sender's flags for the
+        // ghost cells are ANDed in when the face message arrives, csf3d_face_flags)
+        if (threadIdx.x == 0) { p.pure[blk] = (p.bcblk[blk] & 2) ? (uint8_t)((allr ? 1 : 0) | (allb ? 2 : 0)) : (uint8_t)(allr ? 1 : (allb ? 2 : 0)); p.deep_prev[blk] = 0; }
     }
     }   // blocks of the list
 }
@@ -642,6 +644,42 @@ __global__ __launch_bounds__(256) void csf3d_collide_deep(CsfDev p)
         __syncthreads();                         // (every wave has read deep_prev)
         if (threadIdx.x == 0) { p.pure[blk] = (uint8_t)deep; p.deep_prev[blk] = (uint8_t)deep; }     // (sums of exact zeros: the absent colour stays absent)
     }
+}
+
+// Slabs: with the populations that cross a face travels, for the fluid cells of the sender's two edge planes, what their blocks handed on
+// (`pure`: 1 red alone, 2 blue alone, 0 both) -- the receiver's blocks of ghost cells AND it into theirs, so that a block next to a face
+// is deep when the cells two planes beyond the face allow it (without it every block within reach of a face would take the full path).
+__global__ __launch_bounds__(256) void csf3d_face_flags_pack(const uint8_t *pure, unsigned j0, unsigned count, uint8_t *out)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < count) out[i] = pure[(j0 + i) >> 8];
+}
+// flags != nullptr: the packed bytes; else the sender's own array (same process), its cells numbered from sj0.  One workgroup per block of
+// the receiver that holds some of the `count` cells numbered from j0: one atomic per block.
+__global__ __launch_bounds__(256) void csf3d_face_flags(const uint8_t *flags, const uint8_t *src_pure, unsigned sj0, uint8_t *pure, unsigned j0, unsigned count)
+{
+    const unsigned b = (j0 >> 8) + blockIdx.x, j = b * 256u + threadIdx.x;
+    const bool mine = j >= j0 && j < j0 + count;
+    unsigned f = 3u;
+    if (mine) {
+        f = flags ? flags[j - j0] : src_pure[(sj0 + (j - j0)) >> 8];
+        if (f > 2u) f = 0u;                      // (the sender's own blocks of ghost cells: a mask, not a colour)
+    }
+    const int red = __syncthreads_and((f & 1u) != 0u), blue = __syncthreads_and((f & 2u) != 0u);
+    if (threadIdx.x == 0) {
+        const unsigned m = (red ? 1u : 0u) | (blue ? 2u : 0u), sh = 8u * (b & 3u);   // the byte of block b: AND with m; the other three bytes of the word stay
+        atomicAnd(reinterpret_cast<unsigned *>(pure + (b & ~3u)), (m << sh) | ~(0xFFu << sh));
+    }
+}
+
+// the runs of a face message in one launch (blockIdx.y = the run)
+struct RunSet { const double *src[10]; double *dst[10]; unsigned count[10]; };
+__global__ __launch_bounds__(256) void csf3d_copy_runs(RunSet r)
+{
+    const unsigned k = blockIdx.y, n = r.count[k];
+    const double *s = r.src[k];
+    double *d = r.dst[k];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) d[i] = s[i];
 }
 
 // set-up: the table of source cells
@@ -762,10 +800,15 @@ __global__ __launch_bounds__(256) void csf3d_setup_ranges(CsfDev p, int pass, ui
     };
     take(j);
     take(p.cidx[own]);
+    // A slab's ghost cells are read, not computed; what matters is where THEIR phase field comes from (pass 1 of the cells that read it):
+    // the cells around them -- all here for the first ghost plane, beyond this lattice for the second one, whose phi (read through the
+    // walls of the first) therefore counts as unknown: the whole lattice, never one colour.
+    if ((p.glo && z < 1) || (p.ghi && z > p.nz - 2)) { mn = 0u; mx = p.NF - 1u; }
 #pragma unroll 1
     for (int i = 1; i < Q; ++i) {
         const unsigned q = at(nb, CX[i], CY[i], CZ[i]);
         if ((m >> i) & 1u) { take(p.cidx[q]); continue; }
+        if (ghost) continue;
         // a wall cell next to this one: its phi is the mean over ITS fluid neighbours (up to two cells from here, possibly across the wall)
         const uint32_t ms = p.meta[q];
         if (((ms >> KIND_SHIFT) & 3u) != 2u) continue;
@@ -1229,7 +1272,7 @@ extern "C" int lbmpm_rk3dcsf_create(const lbmpm_rk3dcsf_config *cfg, const uint8
         c->nblk = blocks_of((size_t)c->nfluid);
         const unsigned nb = c->nblk;
         uint32_t *lo0 = nullptr, *hi0 = nullptr, *lo1 = nullptr, *hi1 = nullptr;
-        rc = dev_alloc(c, &c->pure, nb);
+        rc = dev_alloc(c, &c->pure, (size_t)nb + 4);      // (csf3d_face_flags works on whole words)
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->deep_prev, nb);
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->bcblk, nb);
         if (rc == LBMPM_OK) rc = dev_alloc(c, &c->rng, 2 * (size_t)nb);
@@ -1398,6 +1441,38 @@ int face_runs(lbmpm_rk3dcsf *c, int msg, int face, bool recv, Run runs[10])
     return 3;
 }
 bool msg_ok(int msg, int face) { return msg >= 0 && msg <= 2 && (face == 0 || face == 1); }
+// n runs from `from` to `to` (either side a packed buffer when its runs are null: consecutive stretches of `buf`), one launch on `stream`
+int copy_runs(const Run *from, const Run *to, const double *buf_in, double *buf_out, const Run *shape, int n, hipStream_t stream)
+{
+    RunSet r;
+    unsigned most = 0;
+    size_t off = 0;
+    for (int k = 0; k < 10; ++k) {
+        r.count[k] = k < n ? (unsigned)shape[k].count : 0u;
+        r.src[k] = k < n ? (from ? from[k].ptr : buf_in + off) : nullptr;
+        r.dst[k] = k < n ? (to ? to[k].ptr : buf_out + off) : nullptr;
+        if (k < n) { off += shape[k].count; most = most > r.count[k] ? most : r.count[k]; }
+    }
+    if (n == 0 || most == 0) return LBMPM_OK;
+    unsigned gx = (most + 2047u) / 2048u;            // eight doubles per thread
+    if (gx > 1024u) gx = 1024u;
+    csf3d_copy_runs<<<dim3(gx, (unsigned)n), 256, 0, stream>>>(r);
+    LBMPM_HIP_TRY(hipGetLastError());
+    return LBMPM_OK;
+}
+// the fluid cells of the two planes next to a face (sent) / beyond it (received), as a stretch of the cells' numbers: the flags of csf3d_face_flags
+void flag_cells(const lbmpm_rk3dcsf *c, int face, bool recv, unsigned &j0, unsigned &count)
+{
+    const int lo = c->cfg.ghost_lo, top = c->nz - c->cfg.ghost_hi;
+    const int z = face == 0 ? (recv ? 0 : lo) : (recv ? top : top - 2);
+    j0 = c->pfirst[(size_t)z]; count = c->pfirst[(size_t)z + 2] - j0;
+}
+size_t flag_doubles(const lbmpm_rk3dcsf *c, int face, bool recv)
+{
+    unsigned j0, count;
+    flag_cells(c, face, recv, j0, count);
+    return ((size_t)count + 7) / 8;
+}
 }  // namespace
 
 static int64_t face_total(const lbmpm_rk3dcsf *c, int msg, int face, bool recv)
@@ -1407,6 +1482,7 @@ static int64_t face_total(const lbmpm_rk3dcsf *c, int msg, int face, bool recv)
     const int n = face_runs(const_cast<lbmpm_rk3dcsf *>(c), msg, face, recv, runs);
     int64_t t = 0;
     for (int k = 0; k < n; ++k) t += (int64_t)runs[k].count;
+    if (n && msg == LBMPM_CSF_MSG_PDF) t += (int64_t)flag_doubles(c, face, recv);      // one byte per fluid cell of two planes behind the populations
     return t;
 }
 extern "C" int64_t lbmpm_rk3dcsf_face_doubles(const lbmpm_rk3dcsf *c, int msg, int face) { return face_total(c, msg, face, false); }
@@ -1418,9 +1494,13 @@ extern "C" int lbmpm_rk3dcsf_face_pack(lbmpm_rk3dcsf *c, int msg, int face, doub
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     Run runs[10];
     const int n = face_runs(c, msg, face, false, runs);
-    for (int k = 0; k < n; ++k) {
-        if (runs[k].count) LBMPM_HIP_TRY(hipMemcpyAsync(buf, runs[k].ptr, runs[k].count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        buf += runs[k].count;
+    { const int rc = copy_runs(runs, nullptr, nullptr, buf, runs, n, c->stream); if (rc) return rc; }
+    for (int k = 0; k < n; ++k) buf += runs[k].count;
+    if (n && msg == LBMPM_CSF_MSG_PDF) {
+        unsigned j0, count;
+        flag_cells(c, face, false, j0, count);
+        if (count) csf3d_face_flags_pack<<<blocks_of(count), 256, 0, c->stream>>>(c->pure, j0, count, reinterpret_cast<uint8_t *>(buf));
+        LBMPM_HIP_TRY(hipGetLastError());
     }
     return LBMPM_OK;
 }
@@ -1431,9 +1511,13 @@ extern "C" int lbmpm_rk3dcsf_face_unpack(lbmpm_rk3dcsf *c, int msg, int face, co
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
     Run runs[10];
     const int n = face_runs(c, msg, face, true, runs);
-    for (int k = 0; k < n; ++k) {
-        if (runs[k].count) LBMPM_HIP_TRY(hipMemcpyAsync(runs[k].ptr, buf, runs[k].count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        buf += runs[k].count;
+    { const int rc = copy_runs(nullptr, runs, buf, nullptr, runs, n, c->stream); if (rc) return rc; }
+    for (int k = 0; k < n; ++k) buf += runs[k].count;
+    if (n && msg == LBMPM_CSF_MSG_PDF) {
+        unsigned j0, count;
+        flag_cells(c, face, true, j0, count);
+        if (count) csf3d_face_flags<<<((j0 + count - 1u) >> 8) - (j0 >> 8) + 1u, 256, 0, c->stream>>>(reinterpret_cast<const uint8_t *>(buf), nullptr, 0u, c->pure, j0, count);
+        LBMPM_HIP_TRY(hipGetLastError());
     }
     return LBMPM_OK;
 }
@@ -1449,8 +1533,21 @@ extern "C" int lbmpm_rk3dcsf_face_copy(lbmpm_rk3dcsf *src, int src_face, lbmpm_r
     // on the sender's stream, once the receiver's last stage (which may read the planes written here) has run; the receiver's stream then waits
     LBMPM_HIP_TRY(hipSetDevice(src->cfg.device));
     LBMPM_HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_stage, 0));
-    for (int k = 0; k < n; ++k)
-        if (out[k].count) LBMPM_HIP_TRY(hipMemcpyAsync(in[k].ptr, out[k].ptr, out[k].count * sizeof(double), hipMemcpyDefault, src->stream));
+    if (src->cfg.device == dst->cfg.device) {
+        const int rc = copy_runs(out, in, nullptr, nullptr, out, n, src->stream);
+        if (rc) return rc;
+    } else {
+        for (int k = 0; k < n; ++k)
+            if (out[k].count) LBMPM_HIP_TRY(hipMemcpyAsync(in[k].ptr, out[k].ptr, out[k].count * sizeof(double), hipMemcpyDefault, src->stream));
+    }
+    if (msg == LBMPM_CSF_MSG_PDF) {
+        unsigned sj0, scount, dj0, dcount;
+        flag_cells(src, src_face, false, sj0, scount);
+        flag_cells(dst, 1 - src_face, true, dj0, dcount);
+        if (scount != dcount) { set_error("lbmpm_rk3dcsf_face_copy: the masks of the two sides of the face differ"); return LBMPM_ERR_INVALID; }
+        if (scount) csf3d_face_flags<<<((dj0 + scount - 1u) >> 8) - (dj0 >> 8) + 1u, 256, 0, src->stream>>>(nullptr, src->pure, sj0, dst->pure, dj0, scount);
+        LBMPM_HIP_TRY(hipGetLastError());
+    }
     LBMPM_HIP_TRY(hipEventRecord(src->ev_sent[src_face], src->stream));
     LBMPM_HIP_TRY(hipSetDevice(dst->cfg.device));
     LBMPM_HIP_TRY(hipStreamWaitEvent(dst->stream, src->ev_sent[src_face], 0));

@@ -283,7 +283,9 @@ class RK3DCSFDistributed:
     tensors under the nccl (= RCCL) backend and through host memory under gloo; three per step and face (phi, n, populations: 2 + 3 +
     10 doubles per cell of a plane), batched per stage."""
 
-    def __init__(self, is_domain, params=None, device=0, cuts=None, diagnostics=False):
+    def __init__(self, is_domain, params=None, device=0, cuts=None, diagnostics=False, slab_factory=None):
+        """slab_factory: tests/test_slab_cpu.py puts a host stand-in with the library's stage / face calls in the solver's place (attribute
+        on_host: its buffers are host tensors) to run this class's orchestration under gloo without a GPU"""
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -296,10 +298,10 @@ class RK3DCSFDistributed:
             raise ValueError("one slab per rank: %d cuts for %d ranks" % (len(self.cuts) - 1, self.world))
         self.geo = _SlabGeometry(self.nz, self.cuts[self.rank], self.cuts[self.rank + 1])
         self.z0, self.nzl = self.geo.z0, self.geo.z1 - self.geo.z0
-        self.slab = RK3DCSFSolver(self.geo.cut(dom), params, device=device, diagnostics=diagnostics, slab=self.geo.slab)
+        self.slab = (slab_factory or RK3DCSFSolver)(self.geo.cut(dom), params, device=device, diagnostics=diagnostics, slab=self.geo.slab)
         self.params = self.slab.params
         self._on_device = dist.get_backend() == "nccl"
-        dev = self._dev = torch.device("cuda", int(device))
+        dev = self._dev = torch.device("cpu") if getattr(slab_factory, "on_host", False) else torch.device("cuda", int(device))
         self._buf = {}
         for face in (0, 1):
             if self.geo.ghost[face]:
@@ -308,7 +310,7 @@ class RK3DCSFDistributed:
                     self._buf[(msg, face)] = (torch.empty(n, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.float64, device=dev))
         # every rank cuts its slab out of the same undivided lattice
         import zlib
-        mine = torch.tensor([zlib.crc32(dom.tobytes()), dom.shape[0], dom.shape[1], dom.shape[2]] + self.cuts, dtype=torch.int64)
+        mine = torch.tensor([zlib.crc32(dom.tobytes())] + list(dom.shape) + self.cuts, dtype=torch.int64)
         every = [torch.zeros_like(mine) for _ in range(self.world)]
         if self._on_device:
             every = [t.to(dev) for t in every]
@@ -349,7 +351,8 @@ class RK3DCSFDistributed:
             w.wait()
         for inn, i in staged:
             inn.copy_(i)
-        torch.cuda.synchronize(self._dev)        # the messages are in the buffers before the library's stream takes them
+        if self._dev.type == "cuda":
+            torch.cuda.synchronize(self._dev)    # the messages are in the buffers before the library's stream takes them
         for face in (0, 1):
             self.slab.face_unpack(msg, face, self._buf[(msg, face)][1].data_ptr())
 
@@ -377,10 +380,10 @@ class RK3DCSFDistributed:
         return np.ascontiguousarray(self.geo.own(self.slab.get(name)))
 
     def gather(self, a):
-        """rank 0: the ranks' planes stacked along z (None elsewhere)"""
-        parts = [None] * self.world if self.rank == 0 else None
-        self._dist.gather_object(np.ascontiguousarray(a), parts, dst=0)
-        return np.concatenate(parts, axis=0) if self.rank == 0 else None
+        """rank 0: the ranks' planes stacked along z (None elsewhere); slab.gather_planes"""
+        from .slab import gather_planes
+        parts = [(self.cuts[r], self.cuts[r + 1] - self.cuts[r]) for r in range(self.world)]
+        return gather_planes(a, parts, self.rank, self.world, device=self._dev.index)
 
     num_fluid_nodes = property(lambda self: int((self.geo.own(self.slab.is_domain) == 1).sum()))
     steps_done = property(lambda self: self.slab.steps_done)

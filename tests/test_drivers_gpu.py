@@ -727,3 +727,46 @@ def test_rk3d_csf_image_cycle_takes_the_populations_over_with_the_colours_swappe
     assert rel_err(res["/FluidMacro/FluidDensityRin0"][z], want[z]) < 1e-13
     assert np.all(np.isfinite(res["/FluidVelocity/FluidVelocityZAt1"]))
     assert res["/FluidMacro/FluidDensityBin0"][-4:-2].sum() < 1e-2 * res["/FluidMacro/FluidDensityRin0"][-4:-2].sum()
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_rk3d_csf_driver_on_several_ranks_writes_the_single_process_record(tmp_path, ranks):
+    """RKColorGradient3D with SurfaceTensionType = 'CSF' under torchrun (the ranks share this GPU, gloo): one slab per rank, three face messages
+    per step (rk3dcsf.RK3DCSFDistributed); rank 0 writes ONE file equal to the single-process driver's bit for bit; the checkpoint the ranks
+    wrote together continues a single-process run to the same last record"""
+    import subprocess
+    import sys
+    from ini_fixtures import write_rk3d_csf
+    from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D
+    from openlbmpm_amd.results import load_results
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    write_rk3d_csf(str(tmp_path), nx=14, ny=12, nz=40, steps=24, relax="MRT", sigma=0.05, theta=60.0)
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from openlbmpm_amd.RKColorGradientD3Q19 import RKColorGradient3D
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+sim = RKColorGradient3D(%r, output_dir=%r, record_every=12, checkpoint_every=12, device=0)
+sim.runRKColorGradient3D()
+assert sim.solver.solver.world == %d and sim.nzl < 40
+dist.destroy_process_group()
+''' % (root, str(tmp_path), str(tmp_path / "out2"), ranks))
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)], env=dict(os.environ), timeout=600)
+    single = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out1"), record_every=12)
+    ref = load_results(single.runRKColorGradient3D())
+    files = sorted(os.listdir(tmp_path / "out2"))
+    rec = [f for f in files if f.startswith("SimulationResultsRK3D.")]
+    ck = [f for f in files if f.startswith("CheckpointRK3D.")]
+    assert len(rec) == 1 and len(ck) == 1, files
+    got = load_results(str(tmp_path / "out2" / rec[0]))
+    assert set(got) == set(ref)
+    for key in ref:
+        assert np.array_equal(got[key], ref[key]), key
+    again = RKColorGradient3D(str(tmp_path), output_dir=str(tmp_path / "out3"), record_every=12, restart_from=str(tmp_path / "out2" / ck[0]))
+    res = load_results(again.runRKColorGradient3D())
+    for key in ("/FluidMacro/FluidDensityRin2", "/FluidVelocity/FluidVelocityZAt2"):
+        assert np.array_equal(res[key], ref[key]), key

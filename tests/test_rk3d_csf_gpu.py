@@ -460,7 +460,7 @@ def test_slabs_keep_the_bulk_path_away_from_their_faces():
         a.step(k - a.steps_done); c.step(k - c.steps_done)
         for f in ("fR", "fB", "phi", "Gz", "Fz", "K", "vz"):
             assert np.array_equal(a.get(f), c.get(f)), (k, f)
-        assert 0.6 * a.bulk_cells < c.bulk_cells <= a.bulk_cells, (k, a.bulk_cells, c.bulk_cells)
+        assert 0.9 * a.bulk_cells < c.bulk_cells <= a.bulk_cells, (k, a.bulk_cells, c.bulk_cells)     # (only the blocks that hold ghost cells are kept off it)
     a.close(); c.close()
 
 
@@ -479,8 +479,10 @@ def test_slab_refusals():
         s.stage(1)                                 # in order
     assert e.value.status == ERR_STATE
     assert s.face_doubles(1, 1) == 2 * pl and s.face_doubles(2, 0) == 3 * pl
-    assert s.face_doubles(0, 1) == 10 * int((dom[17] == 1).sum()) and s.face_doubles(0, 0) == 10 * int((dom[0] == 1).sum())
-    assert s.face_doubles_in(0, 1) == 10 * int((dom[18] == 1).sum()) and s.face_doubles_in(0, 0) == 10 * int((dom[nz - 1] == 1).sum())
+    cells = lambda *zs: sum(int((dom[z % nz] == 1).sum()) for z in zs)
+    flags = lambda *zs: (cells(*zs) + 7) // 8       # a byte per fluid cell of two planes: what their blocks handed on (the bulk path next to a face)
+    assert s.face_doubles(0, 1) == 10 * cells(17) + flags(16, 17) and s.face_doubles(0, 0) == 10 * cells(0) + flags(0, 1)
+    assert s.face_doubles_in(0, 1) == 10 * cells(18) + flags(18, 19) and s.face_doubles_in(0, 0) == 10 * cells(-1) + flags(-2, -1)
     s.close()
     with pytest.raises(LbmpmError) as e:
         RK3DCSFSolver(dom[np.arange(8, 15)], None, slab=(10, nz))  # fewer than 4 planes of its own

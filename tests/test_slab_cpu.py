@@ -350,3 +350,130 @@ def test_transport_selection_is_agreed_on_by_all_ranks(want, fail, backend, expe
         assert all("sync(deadline)" in c for c in g[3] if c.startswith("sync"))        # no probe is waited for without a deadline
     if fail.get("sizes") is not None:
         assert all("disagree on the size" in g[4] for g in got) and all("rccl_connect" not in g[3] for g in got)
+
+
+# ------------------------------------------------------------------------------------------------ the 3-D CSF model's ring of slabs
+def test_csf_slab_cuts_and_ghost_planes():
+    """rk3dcsf.slab_cuts / _SlabGeometry: the slabs' own planes tile the lattice, every slab carries two images at either end, cut around
+    the ends of the lattice (the loop wraps z: the slabs form a ring)"""
+    from openlbmpm_amd.rk3dcsf import slab_cuts, _SlabGeometry
+    assert slab_cuts(40, 1) == [0, 40] and slab_cuts(12, 3) == [0, 4, 8, 12]
+    w = np.ones(64); w[:16] = 5.0                     # weights: the planes of the colour interface cost more
+    cuts = slab_cuts(64, 4, w)
+    assert cuts[0] == 0 and cuts[-1] == 64 and all(b - a >= 4 for a, b in zip(cuts, cuts[1:])) and cuts[1] < 16
+    with pytest.raises(ValueError):
+        slab_cuts(11, 3)
+    a = np.arange(40 * 2 * 3).reshape(40, 2, 3)
+    geo = [_SlabGeometry(40, z0, z1) for z0, z1 in zip([0, 14, 27], [14, 27, 40])]
+    assert np.array_equal(np.concatenate([g.own(g.cut(a)) for g in geo]), a)
+    assert list(geo[0].planes[:3]) == [38, 39, 0] and list(geo[2].planes[-3:]) == [39, 0, 1] and geo[1].slab == (14, 40)
+    whole = _SlabGeometry(40, 0, 40)
+    assert whole.ghost == (0, 0) and whole.slab is None and np.array_equal(whole.cut(a), a)
+
+
+class _HostSlab:
+    """A host stand-in with the library's slab calls (stage, face_pack / _unpack, face_doubles) and the CSF step's dependency pattern on a
+    periodic column of planes: the phase field reads the state one plane around, the 'normal' reads phi two planes around, the new state
+    reads n one plane around -- so the same three messages are needed, of two, one and one plane"""
+    on_host = True
+    W = 3
+
+    def __init__(self, a, params, device=0, diagnostics=False, slab=None):
+        self.params, self.slab = params, slab
+        self.nz = a.shape[0]
+        self.a = np.zeros((self.nz, self.W)); self.phi = np.zeros_like(self.a); self.n = np.zeros_like(self.a)
+        self.next, self.steps_done = 0, 0
+
+    def set_macro(self, a, *_):
+        self.a[:] = a
+
+    def stage(self, k):
+        assert k == self.next
+        own = slice(2, self.nz - 2)
+        z = np.arange(2, self.nz - 2)
+        if k == 0:
+            self.phi[own] = 0.25 * self.a[z - 1] + 0.5 * self.a[z] + 0.25 * self.a[z + 1]
+        elif k == 1:
+            self.n[own] = self.phi[z + 1] - self.phi[z - 1] + 0.1 * (self.phi[z + 2] - self.phi[z - 2])
+        else:
+            self.a[own] = self.phi[z] + 0.3 * (self.n[z + 1] - self.n[z - 1])
+            self.steps_done += 1
+        self.next = (k + 1) % 3
+
+    def _planes(self, msg, face, incoming):
+        arr = (self.a, self.phi, self.n)[msg]
+        k = 2 if msg == 1 else 1
+        if incoming:
+            return arr, (slice(2 - k, 2) if face == 0 else slice(self.nz - 2, self.nz - 2 + k))
+        return arr, (slice(2, 2 + k) if face == 0 else slice(self.nz - 2 - k, self.nz - 2))
+
+    def face_doubles(self, msg, face):
+        return (2 if msg == 1 else 1) * self.W
+
+    face_doubles_in = face_doubles
+
+    def _view(self, ptr, n):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_double * n).from_address(ptr))
+
+    def face_pack(self, msg, face, ptr):
+        arr, sl = self._planes(msg, face, False)
+        self._view(ptr, arr[sl].size)[:] = arr[sl].reshape(-1)
+
+    def face_unpack(self, msg, face, ptr):
+        arr, sl = self._planes(msg, face, True)
+        arr[sl] = self._view(ptr, arr[sl].size).reshape(arr[sl].shape)
+
+    def sync(self):
+        pass
+
+    def get(self, name):
+        return self.a.copy()
+
+    def close(self):
+        pass
+
+
+def _csf_ring_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openlbmpm_amd.rk3dcsf import RK3DCSFDistributed
+        nz = 29
+        full = np.random.default_rng(5).standard_normal((nz, _HostSlab.W))
+        d = RK3DCSFDistributed(full, dict(tag="host stand-in"), slab_factory=_HostSlab)
+        d.set_macro(full, full)
+        d.step(7)
+        ref = full.copy()
+        for _ in range(7):
+            phi = 0.25 * np.roll(ref, 1, 0) + 0.5 * ref + 0.25 * np.roll(ref, -1, 0)
+            n = np.roll(phi, -1, 0) - np.roll(phi, 1, 0) + 0.1 * (np.roll(phi, -2, 0) - np.roll(phi, 2, 0))
+            ref = phi + 0.3 * (np.roll(n, -1, 0) - np.roll(n, 1, 0))
+        mine = d.get("a")
+        ok = np.array_equal(mine, ref[d.z0:d.z0 + d.nzl]) and d.slab.steps_done == 7
+        whole = d.gather(mine)
+        ok = ok and ((whole is None) if rank else np.array_equal(whole, ref))
+        q.put((rank, bool(ok)))
+    except Exception as e:                           # (the parent does not wait for its time-out)
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_csf_ring_of_slabs_gloo(world):
+    """rk3dcsf.RK3DCSFDistributed's orchestration -- three stages per step, a face message after each, the ranks a ring (with two ranks both
+    faces join the same pair: told apart by tags) -- with a host stand-in for the solver: equal to the undivided periodic column"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_csf_ring_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]
