@@ -293,7 +293,8 @@ class RK3DCSFDistributed:
         dom = np.ascontiguousarray(is_domain, dtype=np.uint8)
         self.shape = dom.shape
         self.nz = dom.shape[0]
-        self.cuts = list(cuts) if cuts is not None else slab_cuts(self.nz, self.world)
+        # (default: equal shares of the fluid cells -- the same cuts on every rank, they hold the same mask)
+        self.cuts = list(cuts) if cuts is not None else slab_cuts(self.nz, self.world, weights=(dom.reshape(self.nz, -1) == 1).sum(axis=1) + 1.0e-3)
         if len(self.cuts) != self.world + 1:
             raise ValueError("one slab per rank: %d cuts for %d ranks" % (len(self.cuts) - 1, self.world))
         self.geo = _SlabGeometry(self.nz, self.cuts[self.rank], self.cuts[self.rank + 1])
@@ -352,7 +353,9 @@ class RK3DCSFDistributed:
         for inn, i in staged:
             inn.copy_(i)
         if self._dev.type == "cuda":
-            torch.cuda.synchronize(self._dev)    # the messages are in the buffers before the library's stream takes them
+            # the messages are in the buffers before the library's stream takes them; torch's stream only -- the bulk's collision keeps
+            # running on the library's second stream while phi and n travel
+            torch.cuda.current_stream(self._dev).synchronize()
         for face in (0, 1):
             self.slab.face_unpack(msg, face, self._buf[(msg, face)][1].data_ptr())
 

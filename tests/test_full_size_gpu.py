@@ -97,11 +97,21 @@ def test_c5_lattice_under_the_3d_csf_model_bulk_path_equals_full_path():
         out.append({f: s.get(f) for f in ("phi", "rec_rhoR", "rec_rhoB", "Fz")})
         if variant == 0:
             assert s.bulk_cells > 0.8 * s.num_fluid_nodes
+            bulk = s.bulk_cells
         else:
             assert s.bulk_cells == 0
         s.close()
     for f in out[0]:
         assert np.array_equal(out[0][f], out[1][f]), f
+    # ... and cut into 8 z-slabs (the node's rank count, here contexts of one process on this GPU): the same bits, the bulk path up to the faces
+    from openlbmpm_amd.rk3dcsf import RK3DCSFCluster
+    c = RK3DCSFCluster(dom, dict(relax="MRT", tauB=0.8), nslabs=8)
+    c.set_macro(rR, rB)
+    c.step(12)
+    for f in out[0]:
+        assert np.array_equal(out[0][f], c.get(f)), ("8 slabs", f)
+    assert c.bulk_cells > 0.97 * bulk
+    c.close()
     rho = out[0]["rec_rhoR"] + out[0]["rec_rhoB"]
     assert np.isfinite(rho).all()
     assert abs(float(rho.sum()) - m0) / m0 < 4.0 * 1.0e-4 * 512 * 512 * 12 / m0
