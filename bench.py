@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: MLUPS of the LBM time step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c5|c2|c3] [--size ...]
+    python bench.py --gpus N --steps K --warmup W [--workload c5|c2|c3|c4|csf3d] [--size ...]
 
 A "step" is one full lattice time step (stream + boundary planes + colour gradient / forces +
 collision + recolouring) over the whole synthetic domain.  MLUPS counts FLUID-node updates.
@@ -213,6 +213,29 @@ def build_csf3d(size, device, relax, state="initial"):
     s = RK3DCSFSolver(dom, dict(relax=relax, tauB=0.8), device=device)
     s.set_macro(rR, rB)
     return s, None, None
+
+
+class _CSF3DRanks:
+    """--workload csf3d --gpus N: the same lattice cut into one z-slab per rank (rk3dcsf.RK3DCSFDistributed: three face messages per step over
+    torch.distributed), strong scaling like the c5 line.  Timed by the wall clock between barriers; no per-kernel events."""
+
+    def __init__(self, size, device, relax, state):
+        from openlbmpm_amd.rk3dcsf import RK3DCSFDistributed
+        dom = c5_domain(size)
+        dom[0] = dom[1]; dom[-1] = dom[-2]
+        rR, rB = c5_state(dom, 0, size[2], state)
+        self.d = RK3DCSFDistributed(dom, dict(relax=relax, tauB=0.8), device=device)
+        self.d.set_macro(rR, rB)
+        self.num_fluid_nodes = int((dom == 1).sum())        # of the whole lattice
+        self.step, self.sync, self.close, self.dominant_kernel = self.d.step, self.d.sync, self.d.close, "csf3d_collide_deep"
+
+    def step_timed(self, n):
+        import time as _t
+        self.d.sync()
+        t0 = _t.perf_counter()
+        self.d.step(n); self.d.sync()
+        ms = (_t.perf_counter() - t0) * 1e3
+        return ms, ms
 
 
 def c5_domain(n):
@@ -738,7 +761,10 @@ def main():
         size = tuple(args.size) if args.size else ((512, 512, 512) if wl == "csf3d" else ((1024, 1024) if wl == "c2" else (2048, 2048)))
         steps = args.steps if args.steps is not None else (100 if wl == "csf3d" else (2000 if wl == "c2" else 500))
         warmup = args.warmup if args.warmup is not None else steps // 10
-        if wl == "csf3d":
+        csf_ranks = wl == "csf3d" and world > 1
+        if csf_ranks:
+            solver, m0, mass = _CSF3DRanks(size, local_rank, args.relax, args.c5_state), None, None
+        elif wl == "csf3d":
             solver, m0, mass = build_csf3d(size, local_rank, args.relax, args.c5_state)
         else:
             solver, m0, mass = {"c2": build_c2, "c3": build_c3, "c4": build_c4}[wl](size[0], size[1], local_rank)
@@ -767,12 +793,12 @@ def main():
                           "image (discs r 6-20, porosity 0.65)",
                     "csf3d": "not a BASELINE config: the c5 lattice %dx%dx%d under the 3-D CSF model (" + args.relax + ", state " + args.c5_state + ")"}[wl] % size
             out = {
-                "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid * steps * world / wall / 1e6, 2),
+                "metric": "MLUPS (million lattice updates/s)", "value": round(nfluid * steps * (1 if csf_ranks else world) / wall / 1e6, 2),
                 "unit": "MLUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
-                "ms_per_step": round(wall * 1e3 / steps, 6), "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": round(wall * 1e3 / steps, 6), "higher_is_better": True, "scaling": "strong" if csf_ranks else "weak",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": desc, "fluid_nodes": nfluid, "lattice_nodes": int(np.prod(size)),
-                           "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
+                           "parallelism": ("z-slabs x%d (a ring; phi, n, crossing populations as face messages)" % world if csf_ranks else "replicas x%d" % world) if world > 1 else "1 gpu",
                            "kernel_schedule": "fused", "device_ms_per_step_hip_events": round(ms_total / steps, 6)},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -787,7 +813,7 @@ def main():
             if wl == "csf3d":
                 out["config"]["kernel_schedule"] = ("per step: bookkeeping of the bulk skip, phase field / solid phi / gradient / collision of the blocks on the full "
                                                     "path, and beside them csf3d_collide_deep for the blocks deep inside one colour (19 loads through a table of source cells, 19 stores)")
-                out["config"]["bulk_cells"] = solver.bulk_cells
+                out["config"]["bulk_cells"] = None if csf_ranks else solver.bulk_cells
                 out["roofline"].update(kernel="csf3d_collide_deep", achieved_is="B_alg (608 B) x fluid nodes / step time: NOT a bandwidth fraction -- the bulk path does not move "
                                        "608 B per cell; counted bytes below when this run could count them", frac_by_survey_balg=out["roofline"]["frac"])
                 lv = None if (args.no_live_traffic or world != 1) else live_pmc_traffic(

@@ -530,3 +530,23 @@ d.close(); dist.destroy_process_group()
     for f in ("fR", "phi", "Fz", "rec_rhoB", "rec_vz"):
         assert np.array_equal(a.get(f), np.load(tmp_path / (f + ".npy"))), f
     a.close()
+
+
+def test_bench_line_of_the_csf_model_on_two_ranks():
+    """`bench.py --workload csf3d --gpus 2` (two ranks sharing this GPU over the gloo rehearsal transport): one z-slab per rank, one JSON line
+    from rank 0 with the whole lattice's rate, strong scaling"""
+    import json
+    import subprocess
+    import sys
+    from test_rk3d_gpu import _free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--workload", "csf3d", "--gpus", "2", "--steps", "6", "--warmup", "3",
+                          "--size", "96", "96", "96", "--no-cpu-baseline", "--no-live-traffic"],
+                         env=dict(os.environ, LBMPM_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "MLUPS"
+    assert "z-slabs x2" in d["config"]["parallelism"] and d["config"]["fluid_nodes"] > 0.5 * 96 ** 3
