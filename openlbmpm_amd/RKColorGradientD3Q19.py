@@ -16,7 +16,7 @@ continued from a checkpoint equals the uninterrupted one bit for bit, on any num
 
 [SurfaceTension] SurfaceTensionType = 'CSF' (the section of RKtwophasesetup2D.ini added to the 3-D file): the 2-D CSF loop carried to
 D3Q19 (openlbmpm_amd/rk3dcsf.py, lbmpm_rk3dcsf_*) instead of the perturbation loop -- surface tension, contact angle (wetting rule 2),
-DeltaValue, TauType from the ini; one GPU; records hold what the reference records (the lattice after the next step's boundary
+DeltaValue, TauType from the ini; one GPU or one z-slab per rank (rk3dcsf.RK3DCSFDistributed: three face messages per step); records hold what the reference records (the lattice after the next step's boundary
 planes, RKD2Q9.py:1382-1393); IsCycle and checkpoints as above (a checkpoint keeps the streamed populations and the last force).
 
 One process per GPU: when torch.distributed is initialised with world size > 1 the lattice is cut
