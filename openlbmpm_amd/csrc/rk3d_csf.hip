@@ -1532,14 +1532,13 @@ extern "C" int lbmpm_rk3dcsf_face_copy(lbmpm_rk3dcsf *src, int src_face, lbmpm_r
         if (out[k].count != in[k].count) { set_error("lbmpm_rk3dcsf_face_copy: the masks of the two sides of the face differ (%zu / %zu cells)", out[k].count, in[k].count); return LBMPM_ERR_INVALID; }
     // on the sender's stream, once the receiver's last stage (which may read the planes written here) has run; the receiver's stream then waits
     LBMPM_HIP_TRY(hipSetDevice(src->cfg.device));
-    LBMPM_HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_stage, 0));
-    if (src->cfg.device == dst->cfg.device) {
-        const int rc = copy_runs(out, in, nullptr, nullptr, out, n, src->stream);
-        if (rc) return rc;
-    } else {
-        for (int k = 0; k < n; ++k)
-            if (out[k].count) LBMPM_HIP_TRY(hipMemcpyAsync(in[k].ptr, out[k].ptr, out[k].count * sizeof(double), hipMemcpyDefault, src->stream));
+    if (src->cfg.device != dst->cfg.device) {    // two GPUs of one process: the sender's kernels write the receiver's memory
+        const hipError_t e = hipDeviceEnablePeerAccess(dst->cfg.device, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        else if (e != hipSuccess) { set_error("lbmpm_rk3dcsf_face_copy: device %d cannot reach device %d (%s); use face_pack / face_unpack", src->cfg.device, dst->cfg.device, hipGetErrorString(e)); return LBMPM_ERR_UNSUPPORTED; }
     }
+    LBMPM_HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_stage, 0));
+    { const int rc = copy_runs(out, in, nullptr, nullptr, out, n, src->stream); if (rc) return rc; }
     if (msg == LBMPM_CSF_MSG_PDF) {
         unsigned sj0, scount, dj0, dcount;
         flag_cells(src, src_face, false, sj0, scount);
