@@ -550,3 +550,21 @@ def test_bench_line_of_the_csf_model_on_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "MLUPS"
     assert "z-slabs x2" in d["config"]["parallelism"] and d["config"]["fluid_nodes"] > 0.5 * 96 ** 3
+
+
+@pytest.mark.parametrize("over", [dict(outlet="Convective"), dict(inlet="Dirichlet", densityBH=1.0, densityRH=1e-8)])
+def test_the_thinnest_slabs_hold_the_open_planes(over):
+    """slabs of four planes -- the least a slab may own: the convective outlet's planes 0 .. 3 make one slab, the inlet plane and its ghost
+    half of another, a four-plane slab sits between two others (its two faces two planes apart)"""
+    from openlbmpm_amd.rk3dcsf import RK3DCSFCluster
+    dom, rR, rB = _slab_case()
+    nz = dom.shape[0]
+    par = dict(relax="MRT", theta=55.0, tauB=0.8, velocityZR=0.0, velocityZB=-3.0e-3, sigma=0.06); par.update(over)
+    a = solver(dom, par)
+    c = RK3DCSFCluster(dom, par, cuts=[0, 4, 8, 12, nz - 4, nz], diagnostics=True)
+    a.set_macro(rR, rB); c.set_macro(rR, rB)
+    for k in (1, 2, 30):
+        a.step(k - a.steps_done); c.step(k - c.steps_done)
+        for f in _SLAB_FIELDS:
+            assert np.array_equal(a.get(f), c.get(f)), (k, f)
+    a.close(); c.close()
