@@ -771,6 +771,8 @@ def main():
         nfluid = solver.num_fluid_nodes
         solver.step(warmup)
         solver.sync(); barrier()
+        if csf_ranks:
+            solver.d.timing()                    # (the warm-up steps leave the per-stage clocks)
         t0 = time.perf_counter()
         ms_total, ms_dom = solver.step_timed(steps)
         solver.sync(); barrier()
@@ -782,6 +784,10 @@ def main():
             t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
+        per_rank_timing = None
+        if csf_ranks:
+            per_rank_timing = [None] * world
+            dist.all_gather_object(per_rank_timing, dict(solver.d.timing(), rank=rank))
         if rank == 0:
             per_launch_ms = ms_dom / steps
             achieved = B_ALG[wl] * nfluid / (per_launch_ms * 1e-3) / 1e9
@@ -814,6 +820,11 @@ def main():
                 out["config"]["kernel_schedule"] = ("per step: bookkeeping of the bulk skip, phase field / solid phi / gradient / collision of the blocks on the full "
                                                     "path, and beside them csf3d_collide_deep for the blocks deep inside one colour (19 loads through a table of source cells, 19 stores)")
                 out["config"]["bulk_cells"] = None if csf_ranks else solver.bulk_cells
+                if csf_ranks:
+                    out["multi_gpu"] = {"backend": dist.get_backend(), "world_size": world, "per_rank": per_rank_timing,
+                                        "note": "host clocks per step and stage: wait_stage = the stage's launches on the first stream + the pack have run; message = "
+                                                "both faces' messages sent, received and unpacked (phi and n travel while the bulk's collision runs on the second stream; "
+                                                "the populations' message is exposed)"}
                 out["roofline"].update(kernel="csf3d_collide_deep", achieved_is="B_alg (608 B) x fluid nodes / step time: NOT a bandwidth fraction -- the bulk path does not move "
                                        "608 B per cell; counted bytes below when this run could count them", frac_by_survey_balg=out["roofline"]["frac"])
                 lv = None if (args.no_live_traffic or world != 1) else live_pmc_traffic(

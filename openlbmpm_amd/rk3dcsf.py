@@ -303,6 +303,7 @@ class RK3DCSFDistributed:
         self.params = self.slab.params
         self._on_device = dist.get_backend() == "nccl"
         dev = self._dev = torch.device("cpu") if getattr(slab_factory, "on_host", False) else torch.device("cuda", int(device))
+        self._t_stage, self._t_msg, self._t_count = [0.0] * 3, [0.0] * 3, [0] * 3
         self._buf = {}
         for face in (0, 1):
             if self.geo.ghost[face]:
@@ -329,9 +330,12 @@ class RK3DCSFDistributed:
         if self.world == 1:
             return
         lo_peer, hi_peer = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        import time
+        t0 = time.perf_counter()
         for face in (0, 1):
             self.slab.face_pack(msg, face, self._buf[(msg, face)][0].data_ptr())
         self.slab.sync()
+        t1 = time.perf_counter()
         staged = []
         if self._on_device:
             # (no tags under NCCL: between two ranks the messages pair up in the order posted -- with two ranks both faces join the same
@@ -358,6 +362,24 @@ class RK3DCSFDistributed:
             torch.cuda.current_stream(self._dev).synchronize()
         for face in (0, 1):
             self.slab.face_unpack(msg, face, self._buf[(msg, face)][1].data_ptr())
+        t2 = time.perf_counter()
+        # host clock: [stage's launches on the first stream + pack] until they have run | the message (both faces) until it is unpacked
+        k = _AFTER_STAGE.index(msg)
+        self._t_stage[k] += t1 - t0
+        self._t_msg[k] += t2 - t1
+        self._t_count[k] += 1
+
+    def timing(self, reset=True):
+        """per step and stage, on this rank's host clock (ms): 'wait_stage' = from the stage's call to the moment its launches on the first
+        stream and the pack have run (the bulk's collision on the second stream is not waited for before stage 2), 'message' = from there
+        until both faces' messages are unpacked; names of the stages' messages: phi, normal, populations"""
+        n = [max(1, c) for c in self._t_count]
+        out = dict(steps=int(self._t_count[2]), wait_stage_ms=[round(1e3 * t / c, 4) for t, c in zip(self._t_stage, n)],
+                   message_ms=[round(1e3 * t / c, 4) for t, c in zip(self._t_msg, n)], messages=["phi", "normal", "populations"],
+                   bytes_per_face=[8 * self.slab.face_doubles(m, 1) for m in _AFTER_STAGE], planes=[self.z0, self.z0 + self.nzl])
+        if reset:
+            self._t_stage, self._t_msg, self._t_count = [0.0] * 3, [0.0] * 3, [0] * 3
+        return out
 
     def set_macro(self, rhoR, rhoB, vx=None, vy=None, vz=None):
         """the undivided arrays [nz][ny][nx]; every rank takes its planes"""
@@ -373,7 +395,7 @@ class RK3DCSFDistributed:
         for _ in range(int(nsteps)):
             for stage in range(3):
                 self.slab.stage(stage)
-                self._exchange(_AFTER_STAGE[stage])
+                self._exchange(_AFTER_STAGE[stage])       # (its clock starts right after the stage's launches are queued)
 
     def sync(self):
         self.slab.sync()

@@ -550,6 +550,11 @@ def test_bench_line_of_the_csf_model_on_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "MLUPS"
     assert "z-slabs x2" in d["config"]["parallelism"] and d["config"]["fluid_nodes"] > 0.5 * 96 ** 3
+    m = d["multi_gpu"]
+    assert m["backend"] == "gloo" and m["world_size"] == 2 and [r["rank"] for r in m["per_rank"]] == [0, 1]
+    for r in m["per_rank"]:
+        assert r["steps"] == 6 and len(r["wait_stage_ms"]) == 3 and all(v > 0 for v in r["message_ms"]) and r["bytes_per_face"][2] > r["bytes_per_face"][0] > 0
+    assert m["per_rank"][0]["planes"][1] == m["per_rank"][1]["planes"][0] and m["per_rank"][1]["planes"][1] == 96
 
 
 @pytest.mark.parametrize("over", [dict(outlet="Convective"), dict(inlet="Dirichlet", densityBH=1.0, densityRH=1e-8)])
