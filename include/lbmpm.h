@@ -516,7 +516,8 @@ int64_t lbmpm_rk3d_device_bytes(const lbmpm_rk3d *ctx);
  *     moments at 1/tau, conserved moments 0; Guo source in moment space M^-1 (I - S/2) M (:2027-2113).  mrt_rates overrides (tests).
  * Slabs along z (one context per GPU / rank): ghost_lo = ghost_hi = 2 make the two planes at either end of the context's lattice images of
  * the neighbouring slabs' edge planes.  The curvature reads n one cell around and n reads phi one cell around that, so a step has three
- * face messages instead of the perturbation model's one: phi of two planes (after the phase field), n of one plane (after the gradient),
+ * face messages instead of the perturbation model's one (all for fluid cells only; the receiver recomputes phi on the walls of its first
+ * ghost plane): phi of two planes (after the phase field), n of one plane (after the gradient),
  * the five populations per colour that cross the face (after the collision; behind them a byte per fluid cell of two planes: whether the
  * cell's block handed on one colour alone, so that the bulk path -- see `variant` -- runs up to the faces).  lbmpm_rk3dcsf_stage runs a third of a step;
  * lbmpm_rk3dcsf_face_copy hands a message to a context of the same process, lbmpm_rk3dcsf_face_pack / _unpack go through a device buffer

@@ -682,6 +682,18 @@ __global__ __launch_bounds__(256) void csf3d_copy_runs(RunSet r)
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) d[i] = s[i];
 }
 
+// phi / n of the fluid cells of a face's planes (dense arrays [ncomp][stride] indexed by lattice cell) to or from a packed stretch
+// [ncomp][count], or straight from one context's arrays into another's (blockIdx.y = the component)
+__global__ __launch_bounds__(256) void csf3d_copy_cells(const double *src, const uint32_t *scells, unsigned sj0, size_t sstride,
+                                                        double *dst, const uint32_t *dcells, unsigned dj0, size_t dstride, unsigned count)
+{
+    const unsigned a = blockIdx.y;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const double v = scells ? src[(size_t)a * sstride + scells[sj0 + i]] : src[(size_t)a * count + i];
+        if (dcells) dst[(size_t)a * dstride + dcells[dj0 + i]] = v; else dst[(size_t)a * count + i] = v;
+    }
+}
+
 // set-up: the table of source cells
 __global__ __launch_bounds__(256) void csf3d_setup_src(CsfDev p, uint32_t *src)
 {
@@ -1418,7 +1430,6 @@ int face_runs(lbmpm_rk3dcsf *c, int msg, int face, bool recv, Run runs[10])
 {
     const int g = face == 0 ? c->cfg.ghost_lo : c->cfg.ghost_hi;
     if (g == 0) return 0;
-    const size_t pl = (size_t)c->nx * c->ny;
     const int lo = c->cfg.ghost_lo, top = c->nz - c->cfg.ghost_hi;       // own planes: lo .. top - 1
     if (msg == LBMPM_CSF_MSG_PDF) {
         // the populations that cross the face, of the plane next to it: moving down (c_z < 0) through the low face, up through the high one;
@@ -1431,14 +1442,7 @@ int face_runs(lbmpm_rk3dcsf *c, int msg, int face, bool recv, Run runs[10])
             for (int a = 0; a < 5; ++a) runs[col * 5 + a] = Run{c->fA + ((size_t)col * Q + (size_t)dir[a]) * c->FS + first, count};
         return 10;
     }
-    if (msg == LBMPM_CSF_MSG_PHI) {              // two planes, ascending z on both sides
-        const int z = face == 0 ? (recv ? 0 : lo) : (recv ? top : top - 2);
-        runs[0] = Run{c->phi + (size_t)z * pl, 2 * pl};
-        return 1;
-    }
-    const int z = face == 0 ? (recv ? lo - 1 : lo) : (recv ? top : top - 1);
-    for (int a = 0; a < 3; ++a) runs[a] = Run{c->nh + (size_t)a * c->NS + (size_t)z * pl, pl};
-    return 3;
+    return 0;                                    // (phi and n: cell_msg)
 }
 bool msg_ok(int msg, int face) { return msg >= 0 && msg <= 2 && (face == 0 || face == 1); }
 // n runs from `from` to `to` (either side a packed buffer when its runs are null: consecutive stretches of `buf`), one launch on `stream`
@@ -1467,6 +1471,35 @@ void flag_cells(const lbmpm_rk3dcsf *c, int face, bool recv, unsigned &j0, unsig
     const int z = face == 0 ? (recv ? 0 : lo) : (recv ? top : top - 2);
     j0 = c->pfirst[(size_t)z]; count = c->pfirst[(size_t)z + 2] - j0;
 }
+// phi (two planes) and n (the plane next to the face / the first ghost plane) travel for fluid cells only: the receiver recomputes phi on
+// the walls of its first ghost plane itself (same inputs, same order), nobody reads the second one's walls or a wall's n
+struct CellMsg { double *base; size_t stride; unsigned ncomp, j0, count; };
+CellMsg cell_msg(const lbmpm_rk3dcsf *c, int msg, int face, bool recv)
+{
+    const int lo = c->cfg.ghost_lo, top = c->nz - c->cfg.ghost_hi;
+    CellMsg m;
+    if (msg == LBMPM_CSF_MSG_PHI) {
+        const int z = face == 0 ? (recv ? 0 : lo) : (recv ? top : top - 2);
+        m.base = c->phi; m.stride = 0; m.ncomp = 1;
+        m.j0 = c->pfirst[(size_t)z]; m.count = c->pfirst[(size_t)z + 2] - m.j0;
+    } else {
+        const int z = face == 0 ? (recv ? lo - 1 : lo) : (recv ? top : top - 1);
+        m.base = c->nh; m.stride = c->NS; m.ncomp = 3;
+        m.j0 = c->pfirst[(size_t)z]; m.count = c->pfirst[(size_t)z + 1] - m.j0;
+    }
+    return m;
+}
+int copy_cells(const CellMsg *from, const lbmpm_rk3dcsf *fc, const CellMsg *to, const lbmpm_rk3dcsf *tc, const double *buf_in, double *buf_out, hipStream_t stream)
+{
+    const CellMsg &shape = from ? *from : *to;
+    if (shape.count == 0) return LBMPM_OK;
+    unsigned gx = (shape.count + 1023u) / 1024u;
+    if (gx > 1024u) gx = 1024u;
+    csf3d_copy_cells<<<dim3(gx, shape.ncomp), 256, 0, stream>>>(from ? from->base : buf_in, from ? fc->cells : nullptr, from ? from->j0 : 0u, from ? from->stride : 0,
+                                                                 to ? to->base : buf_out, to ? tc->cells : nullptr, to ? to->j0 : 0u, to ? to->stride : 0, shape.count);
+    LBMPM_HIP_TRY(hipGetLastError());
+    return LBMPM_OK;
+}
 size_t flag_doubles(const lbmpm_rk3dcsf *c, int face, bool recv)
 {
     unsigned j0, count;
@@ -1478,6 +1511,11 @@ size_t flag_doubles(const lbmpm_rk3dcsf *c, int face, bool recv)
 static int64_t face_total(const lbmpm_rk3dcsf *c, int msg, int face, bool recv)
 {
     if (!c || !msg_ok(msg, face)) return 0;
+    if (msg != LBMPM_CSF_MSG_PDF) {
+        if ((face == 0 ? c->cfg.ghost_lo : c->cfg.ghost_hi) == 0) return 0;
+        const CellMsg m = cell_msg(c, msg, face, recv);
+        return (int64_t)m.ncomp * m.count;
+    }
     Run runs[10];
     const int n = face_runs(const_cast<lbmpm_rk3dcsf *>(c), msg, face, recv, runs);
     int64_t t = 0;
@@ -1492,6 +1530,8 @@ extern "C" int lbmpm_rk3dcsf_face_pack(lbmpm_rk3dcsf *c, int msg, int face, doub
 {
     LBMPM_REQUIRE(c && buf && msg_ok(msg, face), "lbmpm_rk3dcsf_face_pack: bad argument");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((face == 0 ? c->cfg.ghost_lo : c->cfg.ghost_hi) == 0) return LBMPM_OK;
+    if (msg != LBMPM_CSF_MSG_PDF) { const CellMsg m = cell_msg(c, msg, face, false); return copy_cells(&m, c, nullptr, nullptr, nullptr, buf, c->stream); }
     Run runs[10];
     const int n = face_runs(c, msg, face, false, runs);
     { const int rc = copy_runs(runs, nullptr, nullptr, buf, runs, n, c->stream); if (rc) return rc; }
@@ -1509,6 +1549,8 @@ extern "C" int lbmpm_rk3dcsf_face_unpack(lbmpm_rk3dcsf *c, int msg, int face, co
 {
     LBMPM_REQUIRE(c && buf && msg_ok(msg, face), "lbmpm_rk3dcsf_face_unpack: bad argument");
     LBMPM_HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((face == 0 ? c->cfg.ghost_lo : c->cfg.ghost_hi) == 0) return LBMPM_OK;
+    if (msg != LBMPM_CSF_MSG_PDF) { const CellMsg m = cell_msg(c, msg, face, true); return copy_cells(nullptr, nullptr, &m, c, buf, nullptr, c->stream); }
     Run runs[10];
     const int n = face_runs(c, msg, face, true, runs);
     { const int rc = copy_runs(nullptr, runs, buf, nullptr, runs, n, c->stream); if (rc) return rc; }
@@ -1526,10 +1568,21 @@ extern "C" int lbmpm_rk3dcsf_face_copy(lbmpm_rk3dcsf *src, int src_face, lbmpm_r
 {
     LBMPM_REQUIRE(src && dst && src != dst && msg_ok(msg, src_face), "lbmpm_rk3dcsf_face_copy: bad argument");
     Run out[10], in[10];
-    const int n = face_runs(src, msg, src_face, false, out), m = face_runs(dst, msg, 1 - src_face, true, in);
-    if (n == 0 || n != m) { set_error("lbmpm_rk3dcsf_face_copy: the two contexts do not share that face"); return LBMPM_ERR_INVALID; }
-    for (int k = 0; k < n; ++k)
-        if (out[k].count != in[k].count) { set_error("lbmpm_rk3dcsf_face_copy: the masks of the two sides of the face differ (%zu / %zu cells)", out[k].count, in[k].count); return LBMPM_ERR_INVALID; }
+    int n = 0;
+    CellMsg cm_out{}, cm_in{};
+    if ((src_face == 0 ? src->cfg.ghost_lo : src->cfg.ghost_hi) == 0 || (src_face == 0 ? dst->cfg.ghost_hi : dst->cfg.ghost_lo) == 0) {
+        set_error("lbmpm_rk3dcsf_face_copy: the two contexts do not share that face"); return LBMPM_ERR_INVALID;
+    }
+    if (msg == LBMPM_CSF_MSG_PDF) {
+        n = face_runs(src, msg, src_face, false, out);
+        const int m = face_runs(dst, msg, 1 - src_face, true, in);
+        if (n == 0 || n != m) { set_error("lbmpm_rk3dcsf_face_copy: the two contexts do not share that face"); return LBMPM_ERR_INVALID; }
+        for (int k = 0; k < n; ++k)
+            if (out[k].count != in[k].count) { set_error("lbmpm_rk3dcsf_face_copy: the masks of the two sides of the face differ (%zu / %zu cells)", out[k].count, in[k].count); return LBMPM_ERR_INVALID; }
+    } else {
+        cm_out = cell_msg(src, msg, src_face, false); cm_in = cell_msg(dst, msg, 1 - src_face, true);
+        if (cm_out.count != cm_in.count) { set_error("lbmpm_rk3dcsf_face_copy: the masks of the two sides of the face differ (%u / %u cells)", cm_out.count, cm_in.count); return LBMPM_ERR_INVALID; }
+    }
     // on the sender's stream, once the receiver's last stage (which may read the planes written here) has run; the receiver's stream then waits
     LBMPM_HIP_TRY(hipSetDevice(src->cfg.device));
     if (src->cfg.device != dst->cfg.device) {    // two GPUs of one process: the sender's kernels write the receiver's memory
@@ -1538,7 +1591,8 @@ extern "C" int lbmpm_rk3dcsf_face_copy(lbmpm_rk3dcsf *src, int src_face, lbmpm_r
         else if (e != hipSuccess) { set_error("lbmpm_rk3dcsf_face_copy: device %d cannot reach device %d (%s); use face_pack / face_unpack", src->cfg.device, dst->cfg.device, hipGetErrorString(e)); return LBMPM_ERR_UNSUPPORTED; }
     }
     LBMPM_HIP_TRY(hipStreamWaitEvent(src->stream, dst->ev_stage, 0));
-    { const int rc = copy_runs(out, in, nullptr, nullptr, out, n, src->stream); if (rc) return rc; }
+    if (msg == LBMPM_CSF_MSG_PDF) { const int rc = copy_runs(out, in, nullptr, nullptr, out, n, src->stream); if (rc) return rc; }
+    else { const int rc = copy_cells(&cm_out, src, &cm_in, dst, nullptr, nullptr, src->stream); if (rc) return rc; }
     if (msg == LBMPM_CSF_MSG_PDF) {
         unsigned sj0, scount, dj0, dcount;
         flag_cells(src, src_face, false, sj0, scount);

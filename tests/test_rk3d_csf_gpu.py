@@ -478,10 +478,11 @@ def test_slab_refusals():
     with pytest.raises(LbmpmError) as e:
         s.stage(1)                                 # in order
     assert e.value.status == ERR_STATE
-    assert s.face_doubles(1, 1) == 2 * pl and s.face_doubles(2, 0) == 3 * pl
     cells = lambda *zs: sum(int((dom[z % nz] == 1).sum()) for z in zs)
     flags = lambda *zs: (cells(*zs) + 7) // 8       # a byte per fluid cell of two planes: what their blocks handed on (the bulk path next to a face)
     assert s.face_doubles(0, 1) == 10 * cells(17) + flags(16, 17) and s.face_doubles(0, 0) == 10 * cells(0) + flags(0, 1)
+    assert s.face_doubles(1, 1) == cells(16, 17) and s.face_doubles_in(1, 1) == cells(18, 19)      # phi: the fluid cells of two planes
+    assert s.face_doubles(2, 0) == 3 * cells(0) and s.face_doubles_in(2, 0) == 3 * cells(-1)         # n: of one
     assert s.face_doubles_in(0, 1) == 10 * cells(18) + flags(18, 19) and s.face_doubles_in(0, 0) == 10 * cells(-1) + flags(-2, -1)
     s.close()
     with pytest.raises(LbmpmError) as e:
