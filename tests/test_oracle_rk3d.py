@@ -134,3 +134,30 @@ def test_mrt_without_the_matrix_products_is_the_same_operator():
         a, b = np.zeros(19), np.zeros(19)
         L.rk3d_mrt_relax_both_public(C.c_double(inv_tau), P(np.ascontiguousarray(d)), P(a), P(b))
         assert np.max(np.abs(a - b)) < 1e-14 * max(1.0, np.max(np.abs(a)))
+
+
+def test_mrt_equilibrium_moments_are_the_published_ones():
+    """known answer from the paper the basis is taken from (d'Humieres, Ginzburg, Krafczyk, Lallemand, Luo 2002, appendix A, D3Q19): the
+    moments of the second-order equilibrium the loop relaxes towards are  e = -11 rho + 19 j.j / rho,  eps = w_eps rho + w_epsj j.j / rho
+    with w_eps = 3, w_epsj = -11/2,  q = -2/3 j,  3 p_xx = (2 jx^2 - jy^2 - jz^2) / rho,  p_ww = (jy^2 - jz^2) / rho,  p_xy = jx jy / rho ...,
+    pi = w_xx p with w_xx = -1/2,  m = 0 -- the parameter set for which the paper's model is the BGK equilibrium (order of the rows:
+    rho, e, eps, jx, qx, jy, qy, jz, qz, 3pxx, 3pixx, pww, piww, pxy, pyz, pxz, mx, my, mz)"""
+    import ctypes as C
+    from oracle import lib
+    L = lib()
+    M = np.zeros((19, 19))
+    L.rk3d_mrt_basis_public(M.ctypes.data_as(C.POINTER(C.c_double)))
+    cx = np.array([0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 1, -1, 1, -1, 0, 0, 0, 0.])
+    cy = np.array([0, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 0, 0, 1, -1, 1, -1.])
+    cz = np.array([0, 0, 0, 0, 0, 1, -1, 0, 0, 0, 0, 1, -1, -1, 1, 1, -1, -1, 1.])
+    assert np.array_equal(M[3], cx) and np.array_equal(M[5], cy) and np.array_equal(M[7], cz)       # the direction order of the library
+    w = np.where(cx ** 2 + cy ** 2 + cz ** 2 == 0, 1 / 3, np.where(cx ** 2 + cy ** 2 + cz ** 2 == 1, 1 / 18, 1 / 36))
+    rho, ux, uy, uz = 1.37, 0.031, -0.052, 0.017
+    eu = cx * ux + cy * uy + cz * uz
+    feq = rho * w * (1 + 3 * eu + 4.5 * eu ** 2 - 1.5 * (ux * ux + uy * uy + uz * uz))
+    jx, jy, jz = rho * ux, rho * uy, rho * uz
+    jj = jx * jx + jy * jy + jz * jz
+    pxx3, pww = (2 * jx * jx - jy * jy - jz * jz) / rho, (jy * jy - jz * jz) / rho
+    want = [rho, -11 * rho + 19 * jj / rho, 3 * rho - 5.5 * jj / rho, jx, -2 / 3 * jx, jy, -2 / 3 * jy, jz, -2 / 3 * jz,
+            pxx3, -0.5 * pxx3, pww, -0.5 * pww, jx * jy / rho, jy * jz / rho, jx * jz / rho, 0.0, 0.0, 0.0]
+    assert np.allclose(M @ feq, want, rtol=0, atol=2e-15)
