@@ -330,6 +330,8 @@ static void mrt_basis(double M[Q][Q], double nrm[Q])
         nrm[k] = a;
     }
 }
+/* the rows, for tests/test_oracle_rk3d.py (the paper's equilibrium moments as a known answer) */
+void rk3dcsf_mrt_basis_public(double *M19x19) { double nrm[Q]; mrt_basis((double (*)[Q])M19x19, nrm); }
 /* d <- M^-1 diag(S) M d (rows of M mutually orthogonal) */
 static void mrt_apply(const double M[Q][Q], const double nrm[Q], const double S[Q], double d[Q])
 {

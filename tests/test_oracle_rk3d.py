@@ -3,6 +3,7 @@ reference code for this model; its pin is the reduction to the reference's 2-D l
 tests/test_rk3d_reduction.py.  Here the oracle is additionally held to physics:
 lattice symmetry, colour/mass bookkeeping, and a flat interface at rest staying at rest."""
 import numpy as np
+import pytest
 
 from oracle.rk3d import RK3DOracle
 
@@ -136,7 +137,8 @@ def test_mrt_without_the_matrix_products_is_the_same_operator():
         assert np.max(np.abs(a - b)) < 1e-14 * max(1.0, np.max(np.abs(a)))
 
 
-def test_mrt_equilibrium_moments_are_the_published_ones():
+@pytest.mark.parametrize("basis", ["rk3d_mrt_basis_public", "rk3dcsf_mrt_basis_public"])       # the perturbation model's oracle, the 3-D CSF model's
+def test_mrt_equilibrium_moments_are_the_published_ones(basis):
     """known answer from the paper the basis is taken from (d'Humieres, Ginzburg, Krafczyk, Lallemand, Luo 2002, appendix A, D3Q19): the
     moments of the second-order equilibrium the loop relaxes towards are  e = -11 rho + 19 j.j / rho,  eps = w_eps rho + w_epsj j.j / rho
     with w_eps = 3, w_epsj = -11/2,  q = -2/3 j,  3 p_xx = (2 jx^2 - jy^2 - jz^2) / rho,  p_ww = (jy^2 - jz^2) / rho,  p_xy = jx jy / rho ...,
@@ -146,7 +148,7 @@ def test_mrt_equilibrium_moments_are_the_published_ones():
     from oracle import lib
     L = lib()
     M = np.zeros((19, 19))
-    L.rk3d_mrt_basis_public(M.ctypes.data_as(C.POINTER(C.c_double)))
+    getattr(L, basis)(M.ctypes.data_as(C.POINTER(C.c_double)))
     cx = np.array([0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 1, -1, 1, -1, 0, 0, 0, 0.])
     cy = np.array([0, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 0, 0, 1, -1, 1, -1.])
     cz = np.array([0, 0, 0, 0, 0, 1, -1, 0, 0, 0, 0, 1, -1, -1, 1, 1, -1, -1, 1.])
